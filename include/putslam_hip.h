@@ -1,0 +1,227 @@
+/* putslam_hip.h -- C ABI of the MI355X-native PUTSLAM visual-odometry front end.
+ *
+ * One data-parallel path of LRMPUT/PUTSLAM, hand-written for gfx950 (CDNA4):
+ *   brute-force 256-bit Hamming matching with OpenCV cross-check semantics
+ *   -> depth filter -> 3-point RANSAC / USAC with a float Umeyama fit
+ *   -> inlier scoring (Euclidean / reprojection) -> refit -> acceptance gate,
+ * plus the double-precision N-point Kabsch fit behind TransformEst and the
+ * pinhole back-projection helper.
+ *
+ * Every entry point names the reference interface (file:line under the
+ * PUTSLAM tree) it replaces.  Signatures are plain C: pointers, sizes, PODs.
+ * All functions return PS_OK (0) or a negative PsStatus; on failure the
+ * reference's own fallback outputs (identity pose, zero inliers) are still
+ * written, because the reference path has no exceptions and no error codes
+ * (src/TransformEst/RANSAC.cpp:77-80,161-164,239-242).
+ *
+ * There is NO CPU fallback behind this ABI.  If no HIP device is usable the
+ * context constructor fails with PS_ERR_NO_DEVICE and every call fails loudly.
+ */
+#ifndef PUTSLAM_HIP_H_
+#define PUTSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_ABI_VERSION 1
+#define PS_DESC_BYTES 32          /* ORB (matcherOpenCV.cpp:90) and LDB (ldb.cpp:61,657) rows: 256 bit */
+#define PS_MAX_KPTS 16384         /* keypoints per frame handled by one launch (LDS-resident cross-check) */
+#define PS_MAX_HYPOTHESES (1 << 20)
+
+typedef enum PsStatus {
+    PS_OK = 0,
+    PS_ERR_BAD_ARG = -1,
+    PS_ERR_NO_DEVICE = -2,
+    PS_ERR_HIP = -3,
+    PS_ERR_ALLOC = -4,
+    PS_ERR_UNSUPPORTED = -5
+} PsStatus;
+
+/* cv::DMatch: same field order and size (16 B) as OpenCV's struct, so a
+ * std::vector<cv::DMatch>::data() can be passed straight through. */
+typedef struct PsDMatch {
+    int32_t queryIdx;   /* row of the PREVIOUS frame's descriptors (matcher.cpp:470-471) */
+    int32_t trainIdx;   /* row of the CURRENT frame's descriptors */
+    int32_t imgIdx;     /* always 0 */
+    float distance;     /* integer Hamming distance 0..256 as float */
+} PsDMatch;
+
+/* RANSAC::ERROR_VERSION, include/putslam/TransformEst/RANSAC.h:22 */
+typedef enum PsErrorVersion {
+    PS_EUCLIDEAN_ERROR = 0,
+    PS_REPROJECTION_ERROR = 1,
+    PS_EUCLIDEAN_AND_REPROJECTION_ERROR = 2,
+    PS_MAHALANOBIS_ERROR = 3,  /* dead in the reference (cov never set, RANSAC.cpp:301-303): scores 0 */
+    PS_ADAPTIVE_ERROR = 4
+} PsErrorVersion;
+
+/* RANSAC::parameters, include/putslam/TransformEst/RANSAC.h:23-31 (same fields, same order). */
+typedef struct PsRansacParams {
+    int32_t verbose;
+    int32_t errorVersion, errorVersionVO, errorVersionMap;
+    double inlierThresholdEuclidean, inlierThresholdReprojection, inlierThresholdMahalanobis;
+    double minimalInlierRatioThreshold;
+    int32_t minimalNumberOfMatches;
+    int32_t usedPairs;        /* only 3 is supported (the shipped value, putslammatcherOpenCVParameters.xml:37) */
+    int32_t iterationCount;   /* ignored on input, like the reference ctor (RANSAC.cpp:30) */
+} PsRansacParams;
+
+/* Which sequential selection rule is replayed over the per-hypothesis inlier counts. */
+typedef enum PsEstimator {
+    PS_EST_RANSAC = 0,  /* RANSAC.cpp:87-164: strict-> best ratio, adaptive iterationCount, refit, ratio gate */
+    PS_EST_USAC = 1,    /* USAC.h:326,409-414,944-971 + USAC_wrapper.cpp:104-151: best count, std stopping, no refit */
+    PS_EST_FIXED = 2    /* all H hypotheses, first best wins, then RANSAC's refit + gate (adaptive stop disabled) */
+} PsEstimator;
+
+/* Controls that have no counterpart in the reference because its sampling is
+ * srand(time(0)) + rand() (RANSAC.cpp:13,191): the sample stream is an input. */
+typedef struct PsRansacConfig {
+    int32_t estimator;        /* PsEstimator */
+    int32_t numHypotheses;    /* H: number of 3-point samples that may be consumed (>= the schedule's maximum) */
+    uint64_t seed;            /* counter-based stream: draw(h,j) = mix(seed,h,j) >> 33, index = draw % M, redraw on repeat */
+    const uint32_t *sampleIdx;/* optional HOST pointer, H x 3 raw draws replacing the seeded stream:
+                                 index_j = raw % M, a repeat is moved to the next free index (+1 mod M) */
+} PsRansacConfig;
+
+typedef struct PsRansacStats {
+    int32_t numMatchesIn;     /* matches handed in (cross-check survivors) */
+    int32_t numMatchesValid;  /* M after the depth filter RANSAC.cpp:65-74 */
+    int32_t bestHypothesis;   /* index of the selected sample, -1 if none */
+    int32_t bestInlierCount;  /* its inlier count inside the loop */
+    int32_t iterationsRun;    /* loop trips the sequential reference would have made */
+    int32_t numInliers;       /* final inliers (after refit re-selection and the ratio gate) */
+    int32_t accepted;         /* 0 => identity returned (too few matches or ratio gate) */
+    float bestInlierRatio;    /* float(count)/float(M) as in RANSAC.cpp:280 */
+    double pointInlierRatio;  /* RANSAC::pointInlierRatio, RANSAC.h:56-66 (NaN if no input matches) */
+} PsRansacStats;
+
+typedef struct PsContext PsContext;
+
+/* ---- context: one HIP stream + scratch arena per instance (reference threading
+ * contract: main-thread matcher and loop-closure matcher are separate instances,
+ * PUTSLAM.cpp:566,570; featuresMap.cpp:650-652,794). ------------------------- */
+int ps_context_create(int device, PsContext **out);
+void ps_context_destroy(PsContext *ctx);
+/* Use an externally owned hipStream_t (e.g. the caller's current stream); NULL restores the private stream. */
+int ps_context_set_stream(PsContext *ctx, void *hipStream);
+int ps_context_synchronize(PsContext *ctx);
+const char *ps_last_error(const PsContext *ctx);
+int ps_abi_version(void);
+/* Name of the device the context runs on, e.g. "gfx950". */
+const char *ps_device_arch(const PsContext *ctx);
+
+/* ---- A1: MatcherOpenCV::performMatching, src/Matcher/matcherOpenCV.cpp:198-206
+ * = cv::BFMatcher(NORM_HAMMING, crossCheck=true).match(query=prev, train=cur)
+ * (matcher object built at matcherOpenCV.cpp:100-105).  Host pointers; rows are
+ * 32 bytes wide with a row pitch of qstep/tstep bytes (cv::Mat::step).
+ * out must hold nq entries; *nout receives the number written (ascending queryIdx). */
+int ps_match_hamming256(PsContext *ctx,
+                        const uint8_t *query, int nq, size_t qstep,
+                        const uint8_t *train, int nt, size_t tstep,
+                        PsDMatch *out, int *nout);
+
+/* ---- A4-A9 / A11: RANSAC::estimateTransformation, src/TransformEst/RANSAC.cpp:50-174
+ * and RANSAC_USAC::estimateTransformation, src/USAC/USAC_wrapper.cpp:104-151.
+ * prev/cur: N x 3 floats, 12-byte stride (std::vector<Eigen::Vector3f> storage).
+ * K: row-major 3x3 float camera matrix (cv::Mat CV_32FC1, RGBD.cpp:93-96); may be NULL for
+ *    the Euclidean/adaptive modes.
+ * pose: column-major 4x4 float (Eigen::Matrix4f storage), maps current-frame points into
+ *    the previous frame (umeyama(src=cur,dst=prev), RANSAC.cpp:225-226).
+ * inliers (capacity m) / ninl: final inlier matches in input order; mask (m bytes, may be
+ *    NULL): 1 where matches[i] is a final inlier. stats may be NULL. */
+int ps_ransac_rigid3d(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
+                      const float *K,
+                      const float *prev, int nprev, const float *cur, int ncur,
+                      const PsDMatch *matches, int m,
+                      float *pose, PsDMatch *inliers, int *ninl, uint8_t *mask,
+                      PsRansacStats *stats);
+
+/* ---- A7: RANSAC::computeTransformationModel, RANSAC.cpp:207-244
+ * (Eigen::umeyama(src, dst, false) in float + the isnan(T(0,0)) check).
+ * nsets independent fits of k points each: src/dst are nsets x k x 3 floats.
+ * T: nsets x 16 column-major; valid: nsets flags (0 => identity written). */
+int ps_umeyama_f32(PsContext *ctx, const float *src, const float *dst, int k, int nsets,
+                   float *T, int32_t *valid);
+
+/* ---- A10: KabschEst::computeTransformation, src/TransformEst/kabschEst.cpp:24-68
+ * (interface include/putslam/TransformEst/transformEst.h:23).
+ * A, B: n x 3 doubles, COLUMN-major with leading dimension ld (Eigen::MatrixXd storage).
+ * T: column-major 4x4 double (Mat34 = Eigen::Transform<double,3,Affine>), maps A onto B. */
+int ps_kabsch_f64(PsContext *ctx, const double *A, const double *B, int n, int ld, double *T);
+
+/* ---- A3: RGBD::keypoints2Dto3D / point2Dto3D / roundSize, src/RGBD/RGBD.cpp:10-16,30-65.
+ * xy: n x 2 floats (cv::Point2f), depth: rows x cols uint16 with a pitch of depthStep BYTES,
+ * K row-major 3x3 float, out: n x 3 floats. */
+int ps_keypoints2Dto3D(PsContext *ctx, const float *xy, int n,
+                       const uint16_t *depth, int rows, int cols, size_t depthStep,
+                       const float *K, double depthImageScale, float *out);
+
+/* ---- A3: RGBD::point3Dto2D, src/RGBD/RGBD.cpp:92-98 (n points). */
+int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, float *uv);
+
+/* ---- A2 + A12: the data flow of Matcher::match (src/Matcher/matcher.cpp:470-515) for a
+ * whole batch of independent frame pairs, everything resident in HBM.  All pointers in
+ * PsFrameSet / PsPairResults are DEVICE pointers; nothing is copied to or from the host. */
+typedef struct PsFrameSet {
+    const uint8_t *desc;      /* numFrames x maxKpts x 32 B descriptors */
+    const float *pts;         /* numFrames x maxKpts x 3 floats, back-projected 3-D points */
+    const int32_t *nkpts;     /* numFrames keypoint counts (<= maxKpts) */
+    int32_t numFrames;
+    int32_t maxKpts;          /* row capacity per frame; also the capacity of per-pair outputs */
+} PsFrameSet;
+
+typedef struct PsPairResults {
+    PsDMatch *matches;        /* P x maxKpts: cross-check matches per pair, ascending queryIdx */
+    int32_t *numMatches;      /* P */
+    uint8_t *inlierMask;      /* P x maxKpts: 1 where matches[p][i] is a final inlier */
+    float *pose;              /* P x 16 column-major */
+    PsRansacStats *stats;     /* P */
+} PsPairResults;
+
+/* pairs: DEVICE array of P (prevFrame, curFrame) index pairs, int32 x 2 each.
+ * Hypothesis h of pair p draws from the seeded stream with seed cfg->seed + p
+ * (cfg->sampleIdx must be NULL). Asynchronous on the context's stream. */
+int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
+                       const float *K, const PsFrameSet *frames,
+                       const int32_t *pairs, int P, const PsPairResults *out);
+
+/* Algorithmic bytes one call of ps_vo_pairs_device moves per SURVEY.md section 8(d):
+ * computed from the per-pair stats already on the host (numMatchesIn, numMatchesValid). */
+uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int numHypotheses);
+
+/* Names of the kernels launched by ps_vo_pairs_device, in launch order, NUL separated,
+ * double-NUL terminated (used by the bench to pick rows out of rocprofv3 output). */
+const char *ps_kernel_names(void);
+
+/* Time the kernels of the most recent ps_vo_pairs_device call (HIP events recorded on the
+ * context's stream around every launch).  ms must hold 8 floats; returns the kernel count. */
+int ps_last_kernel_times_ms(PsContext *ctx, float *ms);
+int ps_context_enable_timing(PsContext *ctx, int enable);
+
+/* ---- diagnostics (used by the parity tests; no reference counterpart) -------------------- */
+/* ps_ransac_rigid3d's scoring stage only: counts[h] = inlier count kernel 3 produced for
+ * hypothesis h (0 for an invalid model); *numScored = hypotheses scored (<= cfg->numHypotheses:
+ * the RANSAC estimator never needs more than max(iterations(0.2), iterations(minRatio))). */
+int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
+                           const float *K, const float *prev, int nprev, const float *cur, int ncur,
+                           const PsDMatch *matches, int m, int32_t *counts, int *numScored);
+/* Device-side trip limit after a best model with c inliers out of M, for c = 1..M:
+ * min(H, iterations(minRatio), iterations(float(c)/float(M))) for PS_EST_RANSAC (RANSAC.cpp:450-461),
+ * min(H, updateStandardStopping(c, M, 3)) for PS_EST_USAC (USAC.h:944-971). */
+int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M, int32_t *out);
+/* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
+size_t ps_abi_sizeof_dmatch(void);
+size_t ps_abi_sizeof_params(void);
+size_t ps_abi_sizeof_config(void);
+size_t ps_abi_sizeof_stats(void);
+size_t ps_abi_sizeof_frameset(void);
+size_t ps_abi_sizeof_results(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PUTSLAM_HIP_H_ */

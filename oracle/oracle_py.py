@@ -1,0 +1,237 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libputslam_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by anything under putslam_amd/.  PARITY UNPINNED (see
+oracle/putslam_oracle.h): the reference cannot be compiled here (needs OpenCV + Eigen).
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+from putslam_amd._abi import (DMATCH_DTYPE, STATS_DTYPE, PsDMatch, PsFrameSet, PsPairResults,
+                              PsRansacConfig, PsRansacParams, PsRansacStats)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libputslam_oracle.so")
+
+
+def _cpu_stamp():
+    """-march=native code must not travel between hosts with different CPUs: key the build on the flags."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return hashlib.sha1(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds). Building the checker is not using it."""
+    srcs = [os.path.join(_HERE, f) for f in ("putslam_oracle.c", "putslam_oracle.h", "po_svd.inc")]
+    stamp_file = os.path.join(_HERE, "_build", "cpu.stamp")
+    stamp = _cpu_stamp()
+    fresh = (os.path.exists(_SO) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp
+             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs))
+    if not force and fresh:
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.po_hamming256.restype = C.c_int
+        L.po_round_size.restype = C.c_int
+        L.po_round_size.argtypes = [C.c_double, C.c_int]
+        L.po_ransac_iterations.restype = C.c_int
+        L.po_ransac_iterations.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.po_usac_stopping.restype = C.c_uint
+        L.po_usac_stopping.argtypes = [C.c_uint, C.c_uint, C.c_uint]
+        L.po_draw31.restype = C.c_uint32
+        L.po_draw31.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.po_point_inlier_ratio.restype = C.c_double
+        L.po_umeyama_f32.restype = C.c_int
+        L.po_is_inlier.restype = C.c_int
+        L.po_is_inlier.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def hamming256(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().po_hamming256(_p(a), _p(b))
+
+
+def match_hamming256(query, train):
+    """query (nq, >=32) / train (nt, >=32) uint8 arrays (row pitch taken from strides)."""
+    assert query.dtype == np.uint8 and train.dtype == np.uint8
+    nq, nt = query.shape[0], train.shape[0]
+    out = np.zeros(max(nq, 1), DMATCH_DTYPE)
+    n = C.c_int(0)
+    qs = query.strides[0] if nq else 32
+    ts = train.strides[0] if nt else 32
+    rc = lib().po_match_hamming256(_p(query), nq, C.c_size_t(qs), _p(train), nt, C.c_size_t(ts), _p(out), C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy()
+
+
+def round_size(x, size):
+    return lib().po_round_size(float(x), int(size))
+
+
+def keypoints2Dto3D(xy, depth, K, scale):
+    xy = np.ascontiguousarray(xy, np.float32)
+    K = np.ascontiguousarray(K, np.float32)
+    assert depth.dtype == np.uint16
+    out = np.zeros((xy.shape[0], 3), np.float32)
+    lib().po_keypoints2Dto3D(_p(xy), xy.shape[0], _p(depth), depth.shape[0], depth.shape[1],
+                             C.c_size_t(depth.strides[0]), _p(K), C.c_double(scale), _p(out))
+    return out
+
+
+def points3Dto2D(xyz, K):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    K = np.ascontiguousarray(K, np.float32)
+    uv = np.zeros((xyz.shape[0], 2), np.float32)
+    lib().po_points3Dto2D(_p(xyz), xyz.shape[0], _p(K), _p(uv))
+    return uv
+
+
+def umeyama_f32(src, dst):
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.ascontiguousarray(dst, np.float32)
+    T = np.zeros(16, np.float32)
+    ok = lib().po_umeyama_f32(_p(src), _p(dst), src.shape[0], _p(T))
+    return T.reshape(4, 4).T.copy(), bool(ok)  # returned as a normal (row, col) matrix
+
+
+def jacobi_svd3(A, dtype=np.float32):
+    A = np.ascontiguousarray(A, dtype)
+    U = np.zeros((3, 3), dtype)
+    S = np.zeros(3, dtype)
+    V = np.zeros((3, 3), dtype)
+    fn = lib().po_jacobi_svd3_f32 if dtype == np.float32 else lib().po_jacobi_svd3_f64
+    fn(_p(A), _p(U), _p(S), _p(V))
+    return U, S, V
+
+
+def inverse4_f32(T):
+    Tc = np.ascontiguousarray(np.asarray(T, np.float32).T)  # column-major storage
+    R = np.zeros(16, np.float32)
+    lib().po_inverse4_f32(_p(Tc), _p(R))
+    return R.reshape(4, 4).T.copy()
+
+
+def ransac_iterations(r, p=0.98, n=3):
+    return lib().po_ransac_iterations(r, p, n)
+
+
+def usac_stopping(inl, tot, s=3):
+    return lib().po_usac_stopping(inl, tot, s)
+
+
+def sample_triplet(cfg, h, M):
+    idx = (C.c_int * 3)()
+    lib().po_sample_triplet(C.byref(cfg), C.c_uint64(cfg.seed), int(h), int(M), idx)
+    return list(idx)
+
+
+def is_inlier(mode, T, K, prev_pt, cur_pt, thrE, thrR):
+    Tc = np.ascontiguousarray(np.asarray(T, np.float32).T)
+    Ti = np.zeros(16, np.float32)
+    lib().po_inverse4_f32(_p(Tc), _p(Ti))
+    K = np.ascontiguousarray(K, np.float32)
+    pp = np.ascontiguousarray(prev_pt, np.float32)
+    cp = np.ascontiguousarray(cur_pt, np.float32)
+    return lib().po_is_inlier(int(mode), _p(Tc), _p(Ti), _p(K), _p(pp), _p(cp), float(thrE), float(thrR))
+
+
+def ransac_rigid3d(params, cfg, K, prev, cur, matches, want_counts=False):
+    prev = np.ascontiguousarray(prev, np.float32)
+    cur = np.ascontiguousarray(cur, np.float32)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    K = None if K is None else np.ascontiguousarray(K, np.float32)
+    m = matches.shape[0]
+    pose = np.zeros(16, np.float32)
+    inl = np.zeros(max(m, 1), DMATCH_DTYPE)
+    ninl = C.c_int(0)
+    mask = np.zeros(max(m, 1), np.uint8)
+    stats = np.zeros(1, STATS_DTYPE)
+    counts = np.zeros(max(cfg.numHypotheses, 1), np.int32) if want_counts else None
+    rc = lib().po_ransac_rigid3d(C.byref(params), C.byref(cfg), _p(K), _p(prev), prev.shape[0], _p(cur),
+                                 cur.shape[0], _p(matches), m, _p(pose), _p(inl), C.byref(ninl), _p(mask),
+                                 _p(stats), _p(counts))
+    assert rc == 0
+    res = dict(pose=pose.reshape(4, 4).T.copy(), inliers=inl[: ninl.value].copy(), mask=mask[:m].copy(),
+               stats=stats[0].copy())
+    if want_counts:
+        res["counts"] = counts[: cfg.numHypotheses]
+    return res
+
+
+def hypothesis_counts(params, cfg, K, prev, cur, matches):
+    prev = np.ascontiguousarray(prev, np.float32)
+    cur = np.ascontiguousarray(cur, np.float32)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    K = None if K is None else np.ascontiguousarray(K, np.float32)
+    counts = np.zeros(max(cfg.numHypotheses, 1), np.int32)
+    M = C.c_int(0)
+    lib().po_hypothesis_counts(C.byref(params), C.byref(cfg), _p(K), _p(prev), prev.shape[0], _p(cur),
+                               cur.shape[0], _p(matches), matches.shape[0], _p(counts), C.byref(M))
+    return counts[: cfg.numHypotheses], M.value
+
+
+def point_inlier_ratio(inliers, allm):
+    inliers = np.ascontiguousarray(inliers, DMATCH_DTYPE)
+    allm = np.ascontiguousarray(allm, DMATCH_DTYPE)
+    return lib().po_point_inlier_ratio(_p(inliers), inliers.shape[0], _p(allm), allm.shape[0])
+
+
+def kabsch_f64(A, B):
+    """A, B: (n,3) arrays. Returns the 4x4 transform mapping A onto B."""
+    A = np.asfortranarray(A, np.float64)
+    B = np.asfortranarray(B, np.float64)
+    n = A.shape[0]
+    T = np.zeros(16, np.float64)
+    lib().po_kabsch_f64(_p(A), _p(B), n, max(n, 1), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def vo_pairs(params, cfg, K, desc, pts, nkpts, pairs, threads=1):
+    """Host-memory batch: desc (F,cap,32) u8, pts (F,cap,3) f32, nkpts (F,) i32, pairs (P,2) i32."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    pts = np.ascontiguousarray(pts, np.float32)
+    nkpts = np.ascontiguousarray(nkpts, np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    K = np.ascontiguousarray(K, np.float32)
+    F, cap = desc.shape[0], desc.shape[1]
+    P = pairs.shape[0]
+    fs = PsFrameSet(_p(desc).value, _p(pts).value, _p(nkpts).value, F, cap)
+    out = dict(matches=np.zeros((P, cap), DMATCH_DTYPE), numMatches=np.zeros(P, np.int32),
+               inlierMask=np.zeros((P, cap), np.uint8), pose=np.zeros((P, 16), np.float32),
+               stats=np.zeros(P, STATS_DTYPE))
+    res = PsPairResults(_p(out["matches"]).value, _p(out["numMatches"]).value, _p(out["inlierMask"]).value,
+                        _p(out["pose"]).value, _p(out["stats"]).value)
+    rc = lib().po_vo_pairs(C.byref(params), C.byref(cfg), _p(K), C.byref(fs), _p(pairs), P, C.byref(res),
+                           int(threads))
+    assert rc == 0
+    return out

@@ -1,0 +1,749 @@
+/* putslam_oracle.c -- CPU restatement of PUTSLAM's Matcher -> RANSAC/USAC -> Kabsch path.
+ *
+ * TEST INFRASTRUCTURE ONLY (checker + timed CPU baseline); see putslam_oracle.h.
+ * PARITY UNPINNED: restates OpenCV 3.x / Eigen 3.3 published algorithms, neither library is
+ * available to compile the reference here; checked against analytic KATs and float64 numpy.
+ *
+ * Citations are file:line under the reference tree (LRMPUT/PUTSLAM).
+ * Build: gcc -O3 -march=native -ffp-contract=off -fno-fast-math (no FMA contraction: the
+ * reference is an x86-64 SSE2 scalar build, CMakeLists.txt:23,147).
+ */
+#include "putslam_oracle.h"
+
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * A1  cv::BFMatcher(NORM_HAMMING, crossCheck = true).match(query = prev, train = cur)
+ *     call site: src/Matcher/matcherOpenCV.cpp:198-206 (matcher built at :100-105)
+ * OpenCV 3.x semantics (BFMatcher::knnMatchImpl + cv::batchDistance with crosscheck, K = 1):
+ *   1. for every train row t: nn(t) = argmin_q ham(t,q), q ascending, strict '<'
+ *   2. dist[q] = INT_MAX, idx[q] = -1; for t ascending: q = nn(t); if d(t) < dist[q]: take it
+ *   3. emit DMatch(q, idx[q], 0, (float)dist[q]) for q ascending with idx[q] >= 0
+ * ------------------------------------------------------------------------------------------ */
+int po_hamming256(const uint8_t *a, const uint8_t *b)
+{
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+int po_match_hamming256(const uint8_t *query, int nq, size_t qstep, const uint8_t *train, int nt,
+                        size_t tstep, PsDMatch *out, int *nout)
+{
+    *nout = 0;
+    if (nq <= 0 || nt <= 0) return 0;
+    int *dist = (int *)malloc(sizeof(int) * (size_t)nq);
+    int *idx = (int *)malloc(sizeof(int) * (size_t)nq);
+    if (!dist || !idx) {
+        free(dist);
+        free(idx);
+        return -1;
+    }
+    for (int q = 0; q < nq; ++q) {
+        dist[q] = INT_MAX;
+        idx[q] = -1;
+    }
+    for (int t = 0; t < nt; ++t) {
+        const uint8_t *tr = train + (size_t)t * tstep;
+        int best = INT_MAX, bq = -1;
+        for (int q = 0; q < nq; ++q) {
+            int d = po_hamming256(tr, query + (size_t)q * qstep);
+            if (d < best) {
+                best = d;
+                bq = q;
+            }
+        }
+        if (bq >= 0 && best < dist[bq]) {
+            dist[bq] = best;
+            idx[bq] = t;
+        }
+    }
+    int n = 0;
+    for (int q = 0; q < nq; ++q)
+        if (idx[q] >= 0) {
+            out[n].queryIdx = q;
+            out[n].trainIdx = idx[q];
+            out[n].imgIdx = 0;
+            out[n].distance = (float)dist[q];
+            ++n;
+        }
+    *nout = n;
+    free(dist);
+    free(idx);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A3  RGBD helpers, src/RGBD/RGBD.cpp
+ * ------------------------------------------------------------------------------------------ */
+int po_round_size(double x, int size) /* RGBD.cpp:10-16, including the size (not size-1) clamp */
+{
+    if (x < 0)
+        x = 0;
+    else if (x > size - 1)
+        x = size;
+    return (int)round(x);
+}
+
+void po_keypoints2Dto3D(const float *xy, int n, const uint16_t *depth, int rows, int cols,
+                        size_t depthStep, const float *K, double depthImageScale, float *out)
+{
+    for (int i = 0; i < n; ++i) { /* RGBD.cpp:47-65 */
+        float fx = xy[2 * i], fy = xy[2 * i + 1];
+        int uR = po_round_size(fx, cols);
+        int vR = po_round_size(fy, rows);
+        /* cv::Mat::at(v,u) is plain pointer arithmetic: u == cols walks into the next row.
+         * Reads past the last row are undefined in the reference; they yield depth 0 here. */
+        size_t off = (size_t)vR * depthStep + (size_t)uR * 2;
+        uint16_t dv = 0;
+        if (off + 2 <= (size_t)rows * depthStep) memcpy(&dv, (const uint8_t *)depth + off, 2);
+        float Z = (float)(((double)dv) / depthImageScale);
+        float u = (fx - K[2]) / K[0];
+        float v = (fy - K[5]) / K[4];
+        out[3 * i] = u * Z;
+        out[3 * i + 1] = v * Z;
+        out[3 * i + 2] = Z;
+    }
+}
+
+static void project_pt(const float *p, const float *K, float *u, float *v) /* RGBD.cpp:92-98 */
+{
+    *u = p[0] * K[0] / p[2] + K[2];
+    *v = p[1] * K[4] / p[2] + K[5];
+}
+
+void po_points3Dto2D(const float *xyz, int n, const float *K, float *uv)
+{
+    for (int i = 0; i < n; ++i) project_pt(xyz + 3 * i, K, &uv[2 * i], &uv[2 * i + 1]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 3x3 Jacobi SVD, float and double instances
+ * ------------------------------------------------------------------------------------------ */
+#define REAL float
+#define REAL_MIN FLT_MIN
+#define REAL_EPS FLT_EPSILON
+#define REAL_SQRT sqrtf
+#define REAL_ABS fabsf
+#define FN(n) n##_f32
+#include "po_svd.inc"
+#undef REAL
+#undef REAL_MIN
+#undef REAL_EPS
+#undef REAL_SQRT
+#undef REAL_ABS
+#undef FN
+
+#define REAL double
+#define REAL_MIN DBL_MIN
+#define REAL_EPS DBL_EPSILON
+#define REAL_SQRT sqrt
+#define REAL_ABS fabs
+#define FN(n) n##_f64
+#include "po_svd.inc"
+#undef REAL
+#undef REAL_MIN
+#undef REAL_EPS
+#undef REAL_SQRT
+#undef REAL_ABS
+#undef FN
+
+void po_jacobi_svd3_f32(const float *A, float *U, float *S, float *V) { jacobi_svd3_f32(A, U, S, V); }
+void po_jacobi_svd3_f64(const double *A, double *U, double *S, double *V) { jacobi_svd3_f64(A, U, S, V); }
+
+/* ------------------------------------------------------------------------------------------
+ * A7  RANSAC::computeTransformationModel (RANSAC.cpp:207-244) = Eigen::umeyama(src = current,
+ *     dst = previous, with_scaling = false) on dynamic-size float matrices, then isnan(T(0,0)).
+ * Eigen 3.3 Umeyama: mean = rowwise sum * (1/n); demean; sigma = (1/n) * dst_dem * src_dem^T;
+ * JacobiSVD(sigma, FullU|FullV); S = diag(1,1,-1) iff det(U)*det(V) < 0; R = U*S*V^T (dynamic
+ * 3x3 lazy products: sequential inner sums); t = dst_mean; t -= R*src_mean (gemv, column by column).
+ *
+ * Summation order over the k points (the one place where it is a free choice, because Eigen's
+ * own order for k >= ~14 is its blocked GEMM): 64 strided partial sums, partial[i % 64] taken
+ * in ascending i, then a binary tree with strides 1,2,4,...,32.  For k = 3 this IS Eigen's
+ * sequential ((a+b)+c).  The device kernel uses the identical order (one wavefront).
+ * ------------------------------------------------------------------------------------------ */
+static float canon_reduce64(float *p)
+{
+    for (int o = 1; o < 64; o <<= 1)
+        for (int l = 0; l < 64; l += 2 * o) p[l] = p[l] + p[l + o];
+    return p[0];
+}
+
+static float det3_f32(const float *M) /* row-major; only its sign is used */
+{
+    return (M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6])) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+static void set_identity4(float *T)
+{
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+}
+
+int po_umeyama_f32(const float *src, const float *dst, int k, float *T)
+{
+    float part[64];
+    float sm[3], dm[3];
+    const float one_over_n = 1.0f / (float)k;
+    for (int c = 0; c < 3; ++c) {
+        for (int l = 0; l < 64; ++l) part[l] = 0.0f;
+        for (int i = 0; i < k; ++i) part[i & 63] = part[i & 63] + src[3 * i + c];
+        sm[c] = canon_reduce64(part) * one_over_n;
+        for (int l = 0; l < 64; ++l) part[l] = 0.0f;
+        for (int i = 0; i < k; ++i) part[i & 63] = part[i & 63] + dst[3 * i + c];
+        dm[c] = canon_reduce64(part) * one_over_n;
+    }
+    float sigma[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            for (int l = 0; l < 64; ++l) part[l] = 0.0f;
+            for (int i = 0; i < k; ++i) {
+                float dd = dst[3 * i + r] - dm[r];
+                float ss = src[3 * i + c] - sm[c];
+                part[i & 63] = part[i & 63] + dd * ss;
+            }
+            sigma[3 * r + c] = one_over_n * canon_reduce64(part);
+        }
+    float U[9], S[3], V[9];
+    jacobi_svd3_f32(sigma, U, S, V);
+    float s2 = (det3_f32(U) * det3_f32(V) < 0.0f) ? -1.0f : 1.0f;
+    float R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[3 * i + j] = (U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1]) + (U[3 * i + 2] * s2) * V[3 * j + 2];
+    float t[3];
+    for (int i = 0; i < 3; ++i)
+        t[i] = ((dm[i] - R[3 * i] * sm[0]) - R[3 * i + 1] * sm[1]) - R[3 * i + 2] * sm[2];
+    if (isnan(R[0])) { /* RANSAC.cpp:239-242 */
+        set_identity4(T);
+        return 0;
+    }
+    /* column-major 4x4 */
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
+        T[12 + i] = t[i];
+        T[4 * i + 3] = 0.0f;
+    }
+    T[15] = 1.0f;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Eigen Matrix4f::inverse(), generic cofactor path (RANSAC.cpp:337-338,386-387).
+ * ------------------------------------------------------------------------------------------ */
+#define M4(m, r, c) ((m)[4 * (c) + (r)])
+static float det3_helper(const float *m, int i1, int i2, int i3, int j1, int j2, int j3)
+{
+    return M4(m, i1, j1) * (M4(m, i2, j2) * M4(m, i3, j3) - M4(m, i2, j3) * M4(m, i3, j2));
+}
+static float cofactor4(const float *m, int i, int j)
+{
+    int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4;
+    int j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+    return (det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3)) +
+           det3_helper(m, i3, i1, i2, j1, j2, j3);
+}
+void po_inverse4_f32(const float *T, float *R)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float c = cofactor4(T, i, j);
+            M4(R, j, i) = ((i + j) & 1) ? -c : c;
+        }
+    float p0 = M4(T, 0, 0) * M4(R, 0, 0), p1 = M4(T, 1, 0) * M4(R, 0, 1);
+    float p2 = M4(T, 2, 0) * M4(R, 0, 2), p3 = M4(T, 3, 0) * M4(R, 0, 3);
+    float det = (p0 + p1) + (p2 + p3);
+    for (int i = 0; i < 16; ++i) R[i] = R[i] / det;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A8  inlier metrics, RANSAC.cpp:251-281 (Euclid / adaptive), :325-375 (reprojection),
+ *     :377-436 (both).  Fixed-size Eigen 3.3 products: a 3-term sum is a0 + (a1 + a2).
+ * ------------------------------------------------------------------------------------------ */
+static void xform(const float *T, const float *p, float *o) /* R*p + t, T column-major 4x4 */
+{
+    for (int i = 0; i < 3; ++i)
+        o[i] = (M4(T, i, 0) * p[0] + (M4(T, i, 1) * p[1] + M4(T, i, 2) * p[2])) + M4(T, i, 3);
+}
+static float norm3(const float *a, const float *b)
+{
+    float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    return sqrtf(d0 * d0 + (d1 * d1 + d2 * d2));
+}
+static double cvnorm2(float ax, float ay, float bx, float by) /* cv::norm(Point2f a - b) */
+{
+    float dx = ax - bx, dy = ay - by;
+    return sqrt((double)dx * dx + (double)dy * dy);
+}
+
+int po_is_inlier(int mode, const float *T, const float *Tinv, const float *K, const float *pp,
+                 const float *cp, double thrE, double thrR)
+{
+    float estOld[3];
+    xform(T, cp, estOld);
+    if (mode == PS_EUCLIDEAN_ERROR || mode == PS_ADAPTIVE_ERROR) {
+        double thr = thrE;
+        if (mode == PS_ADAPTIVE_ERROR) thr *= pp[2];
+        return norm3(estOld, pp) < thr;
+    }
+    if (mode == PS_REPROJECTION_ERROR || mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+        float estNew[3];
+        xform(Tinv, pp, estNew);
+        float pnu, pnv, rnu, rnv, pou, pov, rou, rov;
+        project_pt(estNew, K, &pnu, &pnv);
+        project_pt(cp, K, &rnu, &rnv);
+        project_pt(estOld, K, &pou, &pov);
+        project_pt(pp, K, &rou, &rov);
+        double e0 = cvnorm2(pnu, pnv, rnu, rnv);
+        double e1 = cvnorm2(pou, pov, rou, rov);
+        if (mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+            double e3 = norm3(estOld, pp);
+            return e3 < thrE && e0 < thrR && e1 < thrR;
+        }
+        return e0 < thrR && e1 < thrR;
+    }
+    return 0; /* Mahalanobis (dead, RANSAC.cpp:301-303) and unknown modes (RANSAC.cpp:134-135) score 0 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6  iteration schedule
+ * ------------------------------------------------------------------------------------------ */
+int po_ransac_iterations(double inlierRatio, double successProbability, int numberOfPairs)
+{
+    double v = log(1 - successProbability) / log(1 - pow(inlierRatio, numberOfPairs)); /* RANSAC.cpp:459-460 */
+    if (!(v < 2147483647.0)) return INT_MAX; /* int(v) is UB there; also catches NaN / +inf */
+    if (v < 0) return 0;
+    return (int)v;
+}
+
+#define USAC_CONF 0.99
+#define USAC_MAX_HYP 850000u
+unsigned po_usac_stopping(unsigned numInliers, unsigned totPoints, unsigned sampleSize)
+{
+    double n_inliers = 1.0, n_pts = 1.0; /* USAC.h:944-971 */
+    for (unsigned i = 0; i < sampleSize; ++i) {
+        n_inliers *= numInliers - i;
+        n_pts *= totPoints - i;
+    }
+    double prob_good_model = n_inliers / n_pts;
+    if (prob_good_model < DBL_EPSILON) return USAC_MAX_HYP;
+    if (1 - prob_good_model < DBL_EPSILON) return 1;
+    double nusample_s = log(1 - USAC_CONF) / log(1 - prob_good_model);
+    return (unsigned)ceil(nusample_s);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5  sample stream.  The reference draws rand() % M after srand(time(0)) (RANSAC.cpp:13,191;
+ * USAC.h:562-579) and redraws on a repeat; the build makes the stream an explicit input.
+ * ------------------------------------------------------------------------------------------ */
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+uint32_t po_draw31(uint64_t seed, uint32_t h, uint32_t j)
+{
+    return (uint32_t)(mix64(seed ^ mix64(((uint64_t)h << 8) | (uint64_t)j)) >> 33);
+}
+void po_sample_triplet(const PsRansacConfig *cfg, uint64_t seed, int h, int M, int idx[3])
+{
+    if (cfg->sampleIdx) {
+        for (int j = 0; j < 3; ++j) {
+            int v = (int)(cfg->sampleIdx[3 * (size_t)h + j] % (uint32_t)M);
+            for (;;) {
+                int rep = 0;
+                for (int i = 0; i < j; ++i) rep |= (idx[i] == v);
+                if (!rep) break;
+                v = (v + 1) % M;
+            }
+            idx[j] = v;
+        }
+        return;
+    }
+    int count = 0;
+    for (uint32_t j = 0; count < 3 && j < 256; ++j) {
+        int v = (int)(po_draw31(seed, (uint32_t)h, j) % (uint32_t)M);
+        int rep = 0;
+        for (int i = 0; i < count; ++i) rep |= (idx[i] == v);
+        if (!rep) idx[count++] = v;
+    }
+    for (int v = 0; count < 3; ++v) { /* unreachable for M >= 3 in practice: fill deterministically */
+        int rep = 0;
+        for (int i = 0; i < count; ++i) rep |= (idx[i] == v);
+        if (!rep) idx[count++] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4 / A9 / A11  estimateTransformation
+ * ------------------------------------------------------------------------------------------ */
+static int depth_ok(const float *p) /* RANSAC.cpp:65-74, USAC_wrapper.cpp:41-60 */
+{
+    if (isnan(p[0]) || isnan(p[1]) || isnan(p[2])) return 0;
+    if (p[2] < 0.1 || p[2] > 6) return 0; /* float promoted to double against 0.1 / 6 */
+    return 1;
+}
+
+typedef struct {
+    int n;
+    int *src; /* index into the caller's match list */
+} MatchList;
+
+static int fit_sample(const float *prev, const float *cur, const PsDMatch *matches, const int *valid,
+                      const int idx[3], float *T)
+{
+    float s[9], d[9];
+    for (int j = 0; j < 3; ++j) {
+        const PsDMatch *mm = &matches[valid[idx[j]]];
+        memcpy(&d[3 * j], &prev[3 * (size_t)mm->queryIdx], 12);
+        memcpy(&s[3 * j], &cur[3 * (size_t)mm->trainIdx], 12);
+    }
+    return po_umeyama_f32(s, d, 3, T);
+}
+
+static int score_all(int mode, const float *T, const float *K, const float *prev, const float *cur,
+                     const PsDMatch *matches, const int *valid, int M, double thrE, double thrR,
+                     uint8_t *flags)
+{
+    float Tinv[16];
+    int need_inv = (mode == PS_REPROJECTION_ERROR || mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
+    if (need_inv) po_inverse4_f32(T, Tinv);
+    int cnt = 0;
+    for (int i = 0; i < M; ++i) {
+        const PsDMatch *mm = &matches[valid[i]];
+        int in = po_is_inlier(mode, T, need_inv ? Tinv : NULL, K, &prev[3 * (size_t)mm->queryIdx],
+                              &cur[3 * (size_t)mm->trainIdx], thrE, thrR);
+        if (flags) flags[i] = (uint8_t)in;
+        cnt += in;
+    }
+    return cnt;
+}
+
+static const float K_ZERO[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+int po_hypothesis_counts(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                         const float *prev, int nprev, const float *cur, int ncur,
+                         const PsDMatch *matches, int m, int32_t *counts, int *Mvalid)
+{
+    (void)nprev;
+    (void)ncur;
+    if (!K) K = K_ZERO;
+    int *valid = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    int M = 0;
+    for (int i = 0; i < m; ++i)
+        if (depth_ok(&prev[3 * (size_t)matches[i].queryIdx]) && depth_ok(&cur[3 * (size_t)matches[i].trainIdx]))
+            valid[M++] = i;
+    *Mvalid = M;
+    for (int h = 0; h < cfg->numHypotheses; ++h) {
+        counts[h] = 0;
+        if (M < 3) continue;
+        int idx[3];
+        float T[16];
+        po_sample_triplet(cfg, cfg->seed, h, M, idx);
+        if (!fit_sample(prev, cur, matches, valid, idx, T)) continue;
+        counts[h] = score_all(params->errorVersion, T, K, prev, cur, matches, valid, M,
+                              params->inlierThresholdEuclidean, params->inlierThresholdReprojection, NULL);
+    }
+    free(valid);
+    return 0;
+}
+
+double po_point_inlier_ratio(const PsDMatch *inl, int ninl, const PsDMatch *all, int nall)
+{
+    /* RANSAC.h:56-66: |unique trainIdx of inliers| / |unique trainIdx of all matches| */
+    int maxIdx = -1;
+    for (int i = 0; i < nall; ++i)
+        if (all[i].trainIdx > maxIdx) maxIdx = all[i].trainIdx;
+    for (int i = 0; i < ninl; ++i)
+        if (inl[i].trainIdx > maxIdx) maxIdx = inl[i].trainIdx;
+    uint8_t *seen = (uint8_t *)calloc((size_t)maxIdx + 2, 1);
+    int ua = 0, ui = 0;
+    for (int i = 0; i < nall; ++i)
+        if (all[i].trainIdx >= 0 && !(seen[all[i].trainIdx] & 1)) {
+            seen[all[i].trainIdx] |= 1;
+            ++ua;
+        }
+    for (int i = 0; i < ninl; ++i)
+        if (inl[i].trainIdx >= 0 && !(seen[inl[i].trainIdx] & 2)) {
+            seen[inl[i].trainIdx] |= 2;
+            ++ui;
+        }
+    free(seen);
+    return (double)ui / (double)ua;
+}
+
+int po_ransac_rigid3d(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                      const float *prev, int nprev, const float *cur, int ncur,
+                      const PsDMatch *matches, int m, float *pose, PsDMatch *inliers, int *ninl,
+                      uint8_t *mask, PsRansacStats *stats, int32_t *hypCounts)
+{
+    (void)nprev;
+    (void)ncur;
+    if (!K) K = K_ZERO;
+    const int H = cfg->numHypotheses;
+    const int mode = params->errorVersion;
+    const double thrE = params->inlierThresholdEuclidean, thrR = params->inlierThresholdReprojection;
+    PsRansacStats st;
+    memset(&st, 0, sizeof st);
+    st.numMatchesIn = m;
+    st.bestHypothesis = -1;
+    st.pointInlierRatio = NAN;
+    set_identity4(pose);
+    *ninl = 0;
+    if (mask && m > 0) memset(mask, 0, (size_t)m);
+    if (hypCounts)
+        for (int h = 0; h < H; ++h) hypCounts[h] = -1;
+
+    int *valid = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    uint8_t *flags = (uint8_t *)malloc((size_t)(m > 0 ? m : 1));
+    uint8_t *bestFlags = (uint8_t *)calloc((size_t)(m > 0 ? m : 1), 1);
+    int M = 0;
+    for (int i = 0; i < m; ++i)
+        if (depth_ok(&prev[3 * (size_t)matches[i].queryIdx]) && depth_ok(&cur[3 * (size_t)matches[i].trainIdx]))
+            valid[M++] = i;
+    st.numMatchesValid = M;
+
+    const int usac = (cfg->estimator == PS_EST_USAC);
+    const int minMatches = usac ? 8 : params->minimalNumberOfMatches; /* USAC_wrapper.cpp:120-122 / RANSAC.cpp:77-80 */
+    /* M < 3: the reference's sampler would never return */
+    const int run = !(M < minMatches || M < 3);
+
+    float bestT[16];
+    set_identity4(bestT);
+    int bestCount = 0;
+    float bestRatioF = 0.0f;
+    double bestRatio = 0.0;
+    int iterationsRun = 0;
+
+    if (!run) {
+        /* too few matches: identity, inliers cleared (RANSAC.cpp:77-80) */
+    } else if (!usac) {
+        /* RANSAC.cpp:87-150.  iterationCount starts at computeRANSACIteration(0.20) (ctor, :30). */
+        int iterationCount = (cfg->estimator == PS_EST_FIXED) ? H : po_ransac_iterations(0.20, 0.98, 3);
+        for (int i = 0; i < iterationCount && i < H; ++i) {
+            ++iterationsRun;
+            int idx[3];
+            float T[16];
+            po_sample_triplet(cfg, cfg->seed, i, M, idx);
+            if (!fit_sample(prev, cur, matches, valid, idx, T)) {
+                if (hypCounts) hypCounts[i] = 0;
+                continue; /* :107 model not computed -> iteration skipped */
+            }
+            int cnt = score_all(mode, T, K, prev, cur, matches, valid, M, thrE, thrR, flags);
+            if (hypCounts) hypCounts[i] = cnt;
+            float ratio = (float)cnt / (float)M; /* :280 */
+            if ((double)ratio > bestRatio) {     /* :443 strict > */
+                memcpy(bestT, T, sizeof bestT);
+                bestRatio = (double)ratio;
+                bestRatioF = ratio;
+                bestCount = cnt;
+                st.bestHypothesis = i;
+                memcpy(bestFlags, flags, (size_t)M);
+                if (cfg->estimator != PS_EST_FIXED) {
+                    int a = po_ransac_iterations(params->minimalInlierRatioThreshold, 0.98, 3);
+                    int b = po_ransac_iterations(bestRatio, 0.98, 3);
+                    iterationCount = a < b ? a : b; /* :450-453 */
+                }
+            }
+        }
+        /* :152-158 refit on the best inliers, then the (always Euclidean / adaptive) re-selection */
+        int kk = 0;
+        for (int i = 0; i < M; ++i) kk += bestFlags[i];
+        float *s = (float *)malloc(sizeof(float) * 3 * (size_t)(kk > 0 ? kk : 1));
+        float *d = (float *)malloc(sizeof(float) * 3 * (size_t)(kk > 0 ? kk : 1));
+        int j = 0;
+        for (int i = 0; i < M; ++i)
+            if (bestFlags[i]) {
+                const PsDMatch *mm = &matches[valid[i]];
+                memcpy(&d[3 * j], &prev[3 * (size_t)mm->queryIdx], 12);
+                memcpy(&s[3 * j], &cur[3 * (size_t)mm->trainIdx], 12);
+                ++j;
+            }
+        float refT[16];
+        po_umeyama_f32(s, d, kk, refT); /* NaN (e.g. kk == 0) -> identity, return value ignored (:153) */
+        free(s);
+        free(d);
+        int refMode = (mode == PS_ADAPTIVE_ERROR) ? PS_ADAPTIVE_ERROR : PS_EUCLIDEAN_ERROR; /* :268-271 */
+        int nfinal = 0;
+        for (int i = 0; i < M; ++i) {
+            if (!bestFlags[i]) continue;
+            const PsDMatch *mm = &matches[valid[i]];
+            if (po_is_inlier(refMode, refT, NULL, K, &prev[3 * (size_t)mm->queryIdx],
+                             &cur[3 * (size_t)mm->trainIdx], thrE, thrR)) {
+                inliers[nfinal++] = *mm;
+                if (mask) mask[valid[i]] = 1;
+            }
+        }
+        memcpy(pose, refT, sizeof refT);
+        *ninl = nfinal;
+        st.accepted = 1;
+        if (bestRatio < params->minimalInlierRatioThreshold) { /* :161-164 */
+            set_identity4(pose);
+            *ninl = 0;
+            if (mask) memset(mask, 0, (size_t)m);
+            st.accepted = 0;
+        }
+    } else {
+        /* USAC<T>::solve, USAC.h:326,409-414,498-509 with SAMP_UNIFORM / VERIF_STANDARD / LO_NONE */
+        unsigned adaptive = USAC_MAX_HYP;
+        unsigned hyp = 0;
+        while (hyp < adaptive && hyp < USAC_MAX_HYP && (int)hyp < H) {
+            int i = (int)hyp;
+            ++hyp;
+            ++iterationsRun;
+            int idx[3];
+            float T[16];
+            po_sample_triplet(cfg, cfg->seed, i, M, idx);
+            if (!fit_sample(prev, cur, matches, valid, idx, T)) {
+                if (hypCounts) hypCounts[i] = 0;
+                continue;
+            }
+            int cnt = score_all(mode, T, K, prev, cur, matches, valid, M, thrE, thrR, flags);
+            if (hypCounts) hypCounts[i] = cnt;
+            if (cnt > bestCount) {
+                bestCount = cnt;
+                memcpy(bestT, T, sizeof bestT);
+                memcpy(bestFlags, flags, (size_t)M);
+                st.bestHypothesis = i;
+                bestRatioF = (float)cnt / (float)M;
+                adaptive = po_usac_stopping((unsigned)bestCount, (unsigned)M, 3);
+            }
+        }
+        int nfinal = 0;
+        for (int i = 0; i < M; ++i)
+            if (bestFlags[i]) {
+                inliers[nfinal++] = matches[valid[i]];
+                if (mask) mask[valid[i]] = 1;
+            }
+        *ninl = nfinal;
+        memcpy(pose, bestT, sizeof bestT);
+        st.accepted = 1;
+        if ((double)bestRatioF < params->minimalInlierRatioThreshold) { /* USAC_wrapper.cpp:139-141: inliers kept */
+            set_identity4(pose);
+            st.accepted = 0;
+        }
+    }
+    st.bestInlierCount = bestCount;
+    st.bestInlierRatio = bestRatioF;
+    st.iterationsRun = iterationsRun;
+
+    st.numInliers = *ninl;
+    if (m > 0) st.pointInlierRatio = po_point_inlier_ratio(inliers, *ninl, matches, m);
+    if (stats) *stats = st;
+    free(valid);
+    free(flags);
+    free(bestFlags);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A10  KabschEst::computeTransformation, src/TransformEst/kabschEst.cpp:24-68 (double)
+ * ------------------------------------------------------------------------------------------ */
+static double det3_lu_f64(const double *Ain) /* Eigen dynamic-size determinant = PartialPivLU */
+{
+    double a[9];
+    memcpy(a, Ain, sizeof a);
+    double det = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        int piv = k;
+        double big = fabs(a[3 * k + k]);
+        for (int r = k + 1; r < 3; ++r)
+            if (fabs(a[3 * r + k]) > big) {
+                big = fabs(a[3 * r + k]);
+                piv = r;
+            }
+        if (big == 0.0) return 0.0;
+        if (piv != k) {
+            for (int c = 0; c < 3; ++c) {
+                double t = a[3 * k + c];
+                a[3 * k + c] = a[3 * piv + c];
+                a[3 * piv + c] = t;
+            }
+            det = -det;
+        }
+        det *= a[3 * k + k];
+        for (int r = k + 1; r < 3; ++r) {
+            double f = a[3 * r + k] / a[3 * k + k];
+            for (int c = k + 1; c < 3; ++c) a[3 * r + c] -= f * a[3 * k + c];
+        }
+    }
+    return det;
+}
+
+void po_kabsch_f64(const double *A, const double *B, int n, int ld, double *T)
+{
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (n == 0) return; /* :28 */
+    double cA[3], cB[3];
+    for (int c = 0; c < 3; ++c) { /* :31-34 col(i).mean() = sequential sum / n */
+        double sa = 0, sb = 0;
+        for (int i = 0; i < n; ++i) {
+            sa += A[(size_t)c * ld + i];
+            sb += B[(size_t)c * ld + i];
+        }
+        cA[c] = sa / (double)n;
+        cB[c] = sb / (double)n;
+    }
+    double Am[9]; /* :44 A = setAnew^T * setBnew */
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int i = 0; i < n; ++i) s += (A[(size_t)r * ld + i] - cA[r]) * (B[(size_t)c * ld + i] - cB[c]);
+            Am[3 * r + c] = s;
+        }
+    double V[9], S[3], W[9]; /* :47-49  V = svd.matrixU(), W = svd.matrixV() */
+    jacobi_svd3_f64(Am, V, S, W);
+    double det = det3_lu_f64(Am);
+    double dsg = (det != 0) ? det : 1; /* :53 */
+    double d = (double)((dsg > 0) - (dsg < 0));
+    double R[9]; /* :56 U = W * diag(1,1,d) * V^T */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[3 * i + j] = (W[3 * i] * V[3 * j] + W[3 * i + 1] * V[3 * j + 1]) + (W[3 * i + 2] * d) * V[3 * j + 2];
+    for (int i = 0; i < 3; ++i) { /* :59-62 T = U*(-cA) + cB */
+        double ti = (R[3 * i] * (-cA[0]) + (R[3 * i + 1] * (-cA[1]) + R[3 * i + 2] * (-cA[2]))) + cB[i];
+        for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
+        T[12 + i] = ti;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A2  Matcher::match data flow over a batch of pairs (matcher.cpp:470-515), host memory.
+ * ------------------------------------------------------------------------------------------ */
+int po_vo_pairs(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                const PsFrameSet *fs, const int32_t *pairs, int P, const PsPairResults *out, int threads)
+{
+    int rc = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int p = 0; p < P; ++p) {
+        int fa = pairs[2 * p], fb = pairs[2 * p + 1];
+        size_t cap = (size_t)fs->maxKpts;
+        const uint8_t *qd = fs->desc + (size_t)fa * cap * 32;
+        const uint8_t *td = fs->desc + (size_t)fb * cap * 32;
+        const float *pp = fs->pts + (size_t)fa * cap * 3;
+        const float *cp = fs->pts + (size_t)fb * cap * 3;
+        PsDMatch *mm = out->matches + (size_t)p * cap;
+        int nm = 0;
+        if (po_match_hamming256(qd, fs->nkpts[fa], 32, td, fs->nkpts[fb], 32, mm, &nm)) rc = -1;
+        out->numMatches[p] = nm;
+        PsRansacConfig c = *cfg;
+        c.seed = cfg->seed + (uint64_t)p;
+        PsDMatch *inl = (PsDMatch *)malloc(sizeof(PsDMatch) * (cap ? cap : 1));
+        int ninl = 0;
+        po_ransac_rigid3d(params, &c, K, pp, fs->nkpts[fa], cp, fs->nkpts[fb], mm, nm,
+                          out->pose + (size_t)p * 16, inl, &ninl, out->inlierMask + (size_t)p * cap,
+                          &out->stats[p], NULL);
+        free(inl);
+    }
+    return rc;
+}

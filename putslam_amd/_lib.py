@@ -1,0 +1,77 @@
+"""Loader of the HIP C-ABI library (putslam_amd/libputslam_hip.so).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing the import fails loudly and tells the caller how to build it.
+"""
+import ctypes as C
+import os
+
+from ._abi import PsDMatch, PsFrameSet, PsPairResults, PsRansacConfig, PsRansacParams, PsRansacStats
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libputslam_hip.so")
+
+# every symbol include/putslam_hip.h declares
+EXPORTED = [
+    "ps_context_create", "ps_context_destroy", "ps_context_set_stream", "ps_context_synchronize",
+    "ps_last_error", "ps_abi_version", "ps_device_arch",
+    "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
+    "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device",
+    "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_context_enable_timing",
+    "ps_debug_ransac_counts", "ps_debug_limits",
+    "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
+    "ps_abi_sizeof_frameset", "ps_abi_sizeof_results",
+]
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.ps_context_create.argtypes = [i32, C.POINTER(vp)]
+    L.ps_context_destroy.argtypes = [vp]
+    L.ps_context_destroy.restype = None
+    L.ps_context_set_stream.argtypes = [vp, vp]
+    L.ps_context_synchronize.argtypes = [vp]
+    L.ps_last_error.argtypes = [vp]
+    L.ps_last_error.restype = C.c_char_p
+    L.ps_device_arch.argtypes = [vp]
+    L.ps_device_arch.restype = C.c_char_p
+    L.ps_match_hamming256.argtypes = [vp, vp, i32, sz, vp, i32, sz, vp, C.POINTER(i32)]
+    L.ps_ransac_rigid3d.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, i32, vp, i32,
+                                    vp, i32, vp, vp, C.POINTER(i32), vp, vp]
+    L.ps_debug_ransac_counts.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, i32, vp,
+                                         i32, vp, i32, vp, C.POINTER(i32)]
+    L.ps_debug_limits.argtypes = [vp, i32, C.c_double, i32, i32, vp]
+    L.ps_umeyama_f32.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    L.ps_kabsch_f64.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.ps_keypoints2Dto3D.argtypes = [vp, vp, i32, vp, i32, i32, sz, vp, C.c_double, vp]
+    L.ps_points3Dto2D.argtypes = [vp, vp, i32, vp, vp]
+    L.ps_vo_pairs_device.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp,
+                                     C.POINTER(PsFrameSet), vp, i32, C.POINTER(PsPairResults)]
+    L.ps_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
+    L.ps_algorithmic_bytes.restype = C.c_uint64
+    L.ps_kernel_names.restype = C.POINTER(C.c_char)
+    L.ps_last_kernel_times_ms.argtypes = [vp, vp]
+    L.ps_context_enable_timing.argtypes = [vp, i32]
+    for n in ("dmatch", "params", "config", "stats", "frameset", "results"):
+        getattr(L, "ps_abi_sizeof_" + n).restype = sz
+    _lib = L
+    return L
+
+
+def struct_sizes():
+    return dict(dmatch=C.sizeof(PsDMatch), params=C.sizeof(PsRansacParams), config=C.sizeof(PsRansacConfig),
+                stats=C.sizeof(PsRansacStats), frameset=C.sizeof(PsFrameSet), results=C.sizeof(PsPairResults))

@@ -1,0 +1,206 @@
+"""Thin Python access to the C ABI (include/putslam_hip.h) for tests, the bench and Python callers.
+
+Every function here ends in a HIP kernel launch inside libputslam_hip.so; nothing is computed
+in Python/numpy and nothing falls back to the CPU.  The C++ drop-in classes that mirror the
+reference's Matcher / RANSAC / TransformEst surface live in putslam_amd/csrc/dropin/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._abi import (DMATCH_DTYPE, STATS_DTYPE, PS_OK, PsFrameSet, PsPairResults, PsRansacConfig,  # noqa: F401
+                   PsRansacParams, default_ransac_params, make_config)
+
+
+class PsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"putslam_hip error {code}: {msg}")
+        self.code = code
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One HIP stream + scratch arena (PsContext).  Not shared between threads."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.ps_context_create(int(device), C.byref(h))
+        if rc != PS_OK:
+            raise PsError(rc, "ps_context_create failed (no usable HIP device? there is no CPU fallback)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ps_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != PS_OK:
+            raise PsError(rc, self._L.ps_last_error(self._h).decode())
+
+    @property
+    def arch(self):
+        return self._L.ps_device_arch(self._h).decode()
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.ps_context_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self._L.ps_context_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        self._chk(self._L.ps_context_enable_timing(self._h, 1 if on else 0))
+
+    def last_kernel_times_ms(self):
+        ms = np.zeros(8, np.float32)
+        n = self._L.ps_last_kernel_times_ms(self._h, _p(ms))
+        if n < 0:
+            self._chk(n)
+        names = kernel_names()
+        return {names[i] if i < len(names) else f"k{i}": float(ms[i]) for i in range(n)}
+
+    # ---- A1 ----
+    def match_hamming256(self, query, train):
+        """MatcherOpenCV::performMatching (matcherOpenCV.cpp:198-206): query=prev rows, train=cur rows (uint8, 32 cols)."""
+        assert query.dtype == np.uint8 and train.dtype == np.uint8
+        nq, nt = query.shape[0], train.shape[0]
+        out = np.zeros(max(nq, 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        qs = query.strides[0] if nq else 32
+        ts = train.strides[0] if nt else 32
+        self._chk(self._L.ps_match_hamming256(self._h, _p(query), nq, qs, _p(train), nt, ts, _p(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    # ---- A4..A9, A11 ----
+    def ransac_rigid3d(self, params, cfg, K, prev, cur, matches):
+        """RANSAC::estimateTransformation (RANSAC.cpp:50-174) / RANSAC_USAC (USAC_wrapper.cpp:104-151)."""
+        prev = np.ascontiguousarray(prev, np.float32)
+        cur = np.ascontiguousarray(cur, np.float32)
+        matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        K = None if K is None else np.ascontiguousarray(K, np.float32)
+        m = matches.shape[0]
+        pose = np.zeros(16, np.float32)
+        inl = np.zeros(max(m, 1), DMATCH_DTYPE)
+        ninl = C.c_int(0)
+        mask = np.zeros(max(m, 1), np.uint8)
+        stats = np.zeros(1, STATS_DTYPE)
+        self._chk(self._L.ps_ransac_rigid3d(self._h, C.byref(params), C.byref(cfg), _p(K), _p(prev), prev.shape[0],
+                                            _p(cur), cur.shape[0], _p(matches), m, _p(pose), _p(inl), C.byref(ninl),
+                                            _p(mask), _p(stats)))
+        return dict(pose=pose.reshape(4, 4).T.copy(), inliers=inl[: ninl.value].copy(), mask=mask[:m].copy(),
+                    stats=stats[0].copy())
+
+    def debug_ransac_counts(self, params, cfg, K, prev, cur, matches):
+        prev = np.ascontiguousarray(prev, np.float32)
+        cur = np.ascontiguousarray(cur, np.float32)
+        matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        K = None if K is None else np.ascontiguousarray(K, np.float32)
+        counts = np.zeros(max(cfg.numHypotheses, 1), np.int32)
+        n = C.c_int(0)
+        self._chk(self._L.ps_debug_ransac_counts(self._h, C.byref(params), C.byref(cfg), _p(K), _p(prev),
+                                                 prev.shape[0], _p(cur), cur.shape[0], _p(matches),
+                                                 matches.shape[0], _p(counts), C.byref(n)))
+        return counts[: n.value].copy()
+
+    def debug_limits(self, estimator, min_ratio, H, M):
+        out = np.zeros(M, np.int32)
+        self._chk(self._L.ps_debug_limits(self._h, int(estimator), float(min_ratio), int(H), int(M), _p(out)))
+        return out
+
+    # ---- A7 ----
+    def umeyama_f32(self, src, dst):
+        """src, dst: (nsets, k, 3) or (k, 3). Returns (T (nsets,4,4) row/col matrices, valid (nsets,))."""
+        src = np.ascontiguousarray(src, np.float32)
+        dst = np.ascontiguousarray(dst, np.float32)
+        single = src.ndim == 2
+        if single:
+            src, dst = src[None], dst[None]
+        nsets, k = src.shape[0], src.shape[1]
+        T = np.zeros((nsets, 16), np.float32)
+        valid = np.zeros(nsets, np.int32)
+        self._chk(self._L.ps_umeyama_f32(self._h, _p(src), _p(dst), k, nsets, _p(T), _p(valid)))
+        T = T.reshape(nsets, 4, 4).transpose(0, 2, 1).copy()
+        return (T[0], bool(valid[0])) if single else (T, valid.astype(bool))
+
+    # ---- A10 ----
+    def kabsch_f64(self, A, B):
+        """KabschEst::computeTransformation (kabschEst.cpp:24-68). A, B (n,3). Returns 4x4 mapping A onto B."""
+        A = np.asfortranarray(A, np.float64)
+        B = np.asfortranarray(B, np.float64)
+        n = A.shape[0]
+        T = np.zeros(16, np.float64)
+        self._chk(self._L.ps_kabsch_f64(self._h, _p(A), _p(B), n, max(n, 1), _p(T)))
+        return T.reshape(4, 4).T.copy()
+
+    # ---- A3 ----
+    def keypoints2Dto3D(self, xy, depth, K, scale):
+        xy = np.ascontiguousarray(xy, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        assert depth.dtype == np.uint16 and depth.ndim == 2
+        out = np.zeros((xy.shape[0], 3), np.float32)
+        self._chk(self._L.ps_keypoints2Dto3D(self._h, _p(xy), xy.shape[0], _p(depth), depth.shape[0], depth.shape[1],
+                                             depth.strides[0], _p(K), float(scale), _p(out)))
+        return out
+
+    def points3Dto2D(self, xyz, K):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        uv = np.zeros((xyz.shape[0], 2), np.float32)
+        self._chk(self._L.ps_points3Dto2D(self._h, _p(xyz), xyz.shape[0], _p(K), _p(uv)))
+        return uv
+
+    # ---- A2 / A12: device-resident batch ----
+    def vo_pairs_device(self, params, cfg, K, frames: "DeviceFrames", pairs_dev_ptr, P, out: "DeviceResults"):
+        K = np.ascontiguousarray(K, np.float32)
+        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts)
+        res = PsPairResults(out.matches_ptr, out.num_matches_ptr, out.mask_ptr, out.pose_ptr, out.stats_ptr)
+        self._chk(self._L.ps_vo_pairs_device(self._h, C.byref(params), C.byref(cfg), _p(K), C.byref(fs),
+                                             C.c_void_p(pairs_dev_ptr), int(P), C.byref(res)))
+
+
+class DeviceFrames:
+    """Raw device pointers of a frame set (PsFrameSet)."""
+
+    def __init__(self, desc_ptr, pts_ptr, nkpts_ptr, num_frames, max_kpts):
+        self.desc_ptr, self.pts_ptr, self.nkpts_ptr = desc_ptr, pts_ptr, nkpts_ptr
+        self.num_frames, self.max_kpts = int(num_frames), int(max_kpts)
+
+
+class DeviceResults:
+    """Raw device pointers of per-pair outputs (PsPairResults)."""
+
+    def __init__(self, matches_ptr, num_matches_ptr, mask_ptr, pose_ptr, stats_ptr):
+        self.matches_ptr, self.num_matches_ptr, self.mask_ptr = matches_ptr, num_matches_ptr, mask_ptr
+        self.pose_ptr, self.stats_ptr = pose_ptr, stats_ptr
+
+
+def kernel_names():
+    L = _lib.load()
+    raw = L.ps_kernel_names()
+    names, cur, i = [], b"", 0
+    while True:
+        ch = raw[i]
+        i += 1
+        if ch == b"\x00":
+            if not cur:
+                break
+            names.append(cur.decode())
+            cur = b""
+        else:
+            cur += ch
+    return names
+
+
+def algorithmic_bytes(nkpts, matches_in, matches_valid, H):
+    return int(_lib.load().ps_algorithmic_bytes(int(nkpts), int(matches_in), int(matches_valid), int(H)))

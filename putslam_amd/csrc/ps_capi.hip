@@ -1,0 +1,851 @@
+// ps_capi.hip -- C ABI of the MI355X-native PUTSLAM front end (include/putslam_hip.h).
+//
+// Host side: one PsContext = one HIP stream + one grow-only scratch arena (the reference's
+// Matcher/RANSAC objects are per-thread instances with no shared state, PUTSLAM.cpp:566,570).
+// There is no CPU fallback anywhere in this file: every entry point launches the HIP kernels
+// of ps_kernels.h or fails with a negative PsStatus.
+#include "ps_kernels.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace psdev;
+
+namespace {
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+constexpr int kMaxTimed = 8;
+
+} // namespace
+
+struct PsContext {
+    int device = 0;
+    hipStream_t own = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char arch[64] = {0};
+    // scratch arena (device)
+    Buf keys, recA, recB, recC, recD, counts, mvalid, idxList, raw;
+    Buf tabR, tabU;
+    // staging for the host-pointer entry points (device)
+    Buf sDesc, sPts, sNk, sPairs, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
+    // cached stop tables
+    int tabEstimator = -1, tabH = -1, tabRN = 0, tabUN = 0, tabIter0 = 0;
+    double tabMinRatio = -1.0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[2 * kMaxTimed] = {};
+    int nTimed = 0;
+};
+
+namespace {
+
+int fail(PsContext *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define PS_HIP(call)                                                  \
+    do {                                                              \
+        hipError_t e_ = (call);                                       \
+        if (e_ != hipSuccess) return fail(ctx, PS_ERR_HIP, #call, e_); \
+    } while (0)
+
+int ensure(PsContext *ctx, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return PS_OK;
+    size_t want = bytes + bytes / 4 + 256;
+    if (b.p) {
+        // The old block may still be referenced by work queued on the stream.
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, PS_ERR_HIP, "hipStreamSynchronize", e);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return fail(ctx, PS_ERR_ALLOC, "hipMalloc", e);
+    b.cap = want;
+    return PS_OK;
+}
+#define PS_ENSURE(buf, bytes)                        \
+    do {                                             \
+        int rc_ = ensure(ctx, (buf), (bytes));       \
+        if (rc_ != PS_OK) return rc_;                \
+    } while (0)
+
+void release(Buf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// RANSAC::computeRANSACIteration (reference src/TransformEst/RANSAC.cpp:457-461) evaluated with the
+// host's libm exactly as the reference evaluates it; the int conversion (UB there for huge
+// quotients) saturates.
+int ransac_iterations_host(double inlierRatio, double successProbability = 0.98, int numberOfPairs = 3)
+{
+    double v = std::log(1 - successProbability) / std::log(1 - std::pow(inlierRatio, numberOfPairs));
+    if (!(v < 2147483647.0)) return INT_MAX;
+    if (v < 0) return 0;
+    return (int)v;
+}
+
+// USAC<T>::updateStandardStopping (reference include/putslam/USAC/USAC.h:944-971) as a function of the
+// good-model probability, with confThreshold 0.99 and maxHypotheses 850000 (USAC_wrapper.cpp:66,70).
+constexpr unsigned kUsacMaxHyp = 850000u;
+unsigned usac_stopping_host(double prob_good_model)
+{
+    if (prob_good_model < DBL_EPSILON) return kUsacMaxHyp;
+    if (1 - prob_good_model < DBL_EPSILON) return 1;
+    double n = std::log(1 - 0.99) / std::log(1 - prob_good_model);
+    return (unsigned)std::ceil(n);
+}
+
+// Threshold tables: the device never evaluates log/pow, it binary-searches these host-built
+// (hence libm-identical) step positions.
+void build_ransac_table(double minRatio, int H, std::vector<float> &tab, int &iter0)
+{
+    int itersMin = ransac_iterations_host(minRatio);
+    int kcap = itersMin < H ? itersMin : H;
+    if (kcap < 0) kcap = 0;
+    tab.resize((size_t)kcap);
+    uint32_t one;
+    float onef = 1.0f;
+    memcpy(&one, &onef, 4);
+    uint32_t hi = one; // iterations(1.0) = 0 <= k for every k
+    for (int k = 0; k < kcap; ++k) {
+        // smallest float r in (0,1] with iterations(r) <= k.  The table is non-increasing in k, so the
+        // previous entry (iterations <= k-1 <= k) is a valid upper end of the bracket.
+        uint32_t lo = 0; // bits of +0.0f: iterations(0) saturates, > k
+        while (hi - lo > 1) {
+            uint32_t mid = lo + (hi - lo) / 2;
+            float mf;
+            memcpy(&mf, &mid, 4);
+            if (ransac_iterations_host((double)mf) <= k) hi = mid; else lo = mid;
+        }
+        memcpy(&tab[(size_t)k], &hi, 4);
+    }
+    int i0 = ransac_iterations_host(0.20); // RANSAC ctor, RANSAC.cpp:30
+    iter0 = i0 < H ? i0 : H;
+}
+
+void build_usac_table(int H, std::vector<double> &tab)
+{
+    int n = H < (int)kUsacMaxHyp ? H : (int)kUsacMaxHyp;
+    tab.resize((size_t)(n > 0 ? n : 0));
+    uint64_t oneb;
+    double oned = 1.0;
+    memcpy(&oneb, &oned, 8);
+    uint64_t hiPrev = oneb;
+    for (int k = 0; k < n; ++k) {
+        unsigned target = (unsigned)k + 1u; // smallest p with stopping(p) <= k+1
+        uint64_t lo = 0, hi = hiPrev;       // stopping(0.0) = maxHyp > target (target < maxHyp here... see below)
+        if (target >= kUsacMaxHyp) {
+            tab[(size_t)k] = 0.0;
+            continue;
+        }
+        while (hi - lo > 1) {
+            uint64_t mid = lo + (hi - lo) / 2;
+            double md;
+            memcpy(&md, &mid, 8);
+            if (usac_stopping_host(md) <= target) hi = mid; else lo = mid;
+        }
+        memcpy(&tab[(size_t)k], &hi, 8);
+        hiPrev = hi;
+    }
+}
+
+double sq_bound_f64(double thr)
+{
+    // smallest double x >= 0 with sqrt(x) >= thr  (cv::norm(Point2f) < thr  <=>  dx^2+dy^2 < x)
+    if (!(thr > 0.0)) return 0.0;
+    if (thr > 1.3407807929942596e154) return INFINITY;
+    double x = thr * thr;
+    const double tiny = 4.9406564584124654e-324;
+    if (!(x > 0.0)) x = tiny;
+    while (x > tiny && std::sqrt(std::nextafter(x, 0.0)) >= thr) x = std::nextafter(x, 0.0);
+    while (std::sqrt(x) < thr) x = std::nextafter(x, INFINITY);
+    return x;
+}
+
+int prepare_tables(PsContext *ctx, int estimator, double minRatio, int H, SelectArgs &sa)
+{
+    sa.ransacTab = nullptr;
+    sa.ransacTabN = 0;
+    sa.usacTab = nullptr;
+    sa.usacTabN = 0;
+    if (estimator == PS_EST_FIXED) {
+        sa.iter0 = H;
+        return PS_OK;
+    }
+    if (!(ctx->tabEstimator == estimator && ctx->tabH == H && ctx->tabMinRatio == minRatio)) {
+        if (estimator == PS_EST_RANSAC) {
+            std::vector<float> tab;
+            int iter0 = 0;
+            build_ransac_table(minRatio, H, tab, iter0);
+            PS_ENSURE(ctx->tabR, tab.size() * sizeof(float) + 4);
+            if (!tab.empty()) {
+                PS_HIP(hipMemcpyAsync(ctx->tabR.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice,
+                                      ctx->stream));
+                PS_HIP(hipStreamSynchronize(ctx->stream)); // tab goes out of scope
+            }
+            ctx->tabRN = (int)tab.size();
+            ctx->tabIter0 = iter0;
+        } else {
+            std::vector<double> tab;
+            build_usac_table(H, tab);
+            PS_ENSURE(ctx->tabU, tab.size() * sizeof(double) + 8);
+            if (!tab.empty()) {
+                PS_HIP(hipMemcpyAsync(ctx->tabU.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice,
+                                      ctx->stream));
+                PS_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            ctx->tabUN = (int)tab.size();
+            ctx->tabIter0 = H < (int)kUsacMaxHyp ? H : (int)kUsacMaxHyp;
+        }
+        ctx->tabEstimator = estimator;
+        ctx->tabH = H;
+        ctx->tabMinRatio = minRatio;
+    }
+    sa.iter0 = ctx->tabIter0;
+    if (estimator == PS_EST_RANSAC) {
+        sa.ransacTab = (const float *)ctx->tabR.p;
+        sa.ransacTabN = ctx->tabRN;
+    } else {
+        sa.usacTab = (const double *)ctx->tabU.p;
+        sa.usacTabN = ctx->tabUN;
+    }
+    return PS_OK;
+}
+
+int effective_mode(int errorVersion)
+{
+    switch (errorVersion) {
+    case PS_EUCLIDEAN_ERROR:
+    case PS_REPROJECTION_ERROR:
+    case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
+    case PS_ADAPTIVE_ERROR:
+        return errorVersion;
+    default:
+        // MAHALANOBIS is dead in the reference (RANSAC.cpp:301-303) and unknown values print
+        // "incorrect error version" and score 0 (RANSAC.cpp:134-135): both score 0 here.
+        return PS_MAHALANOBIS_ERROR;
+    }
+}
+
+struct Plan {
+    int mode = 0;
+    int H = 0;        // hypotheses scored
+    int minRun = 3;
+    ScoreConsts sc{};
+    PrepArgs pa{};
+    SelectArgs sa{};
+    ModelArgs ma{};
+};
+
+int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
+              int trainRange, Plan &pl)
+{
+    if (!prm || !cfg) return fail(ctx, PS_ERR_BAD_ARG, "null params/config");
+    if (prm->usedPairs != 3) return fail(ctx, PS_ERR_UNSUPPORTED, "usedPairs must be 3");
+    if (cfg->numHypotheses < 1 || cfg->numHypotheses > PS_MAX_HYPOTHESES)
+        return fail(ctx, PS_ERR_BAD_ARG, "numHypotheses out of range");
+    if (cfg->estimator < PS_EST_RANSAC || cfg->estimator > PS_EST_FIXED)
+        return fail(ctx, PS_ERR_BAD_ARG, "unknown estimator");
+    pl.mode = effective_mode(prm->errorVersion);
+    float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (K) memcpy(k, K, sizeof k);
+    pl.sc.fx = k[0]; pl.sc.fy = k[4]; pl.sc.cx = k[2]; pl.sc.cy = k[5];
+    pl.sc.boundR = sq_bound_f64(prm->inlierThresholdReprojection);
+    pl.pa.fx = k[0]; pl.pa.fy = k[4]; pl.pa.cx = k[2]; pl.pa.cy = k[5];
+    pl.pa.thrE = prm->inlierThresholdEuclidean;
+    pl.pa.mode = pl.mode;
+    pl.pa.cap = cap;
+    pl.sa.estimator = cfg->estimator;
+    pl.sa.mode = pl.mode;
+    pl.sa.cap = cap;
+    pl.sa.minMatches = (cfg->estimator == PS_EST_USAC) ? 8 : prm->minimalNumberOfMatches;
+    pl.sa.minRatio = prm->minimalInlierRatioThreshold;
+    pl.sa.trainRange = trainRange;
+    pl.minRun = pl.sa.minMatches > 3 ? pl.sa.minMatches : 3;
+    // hypotheses that can ever be consumed by the sequential schedule
+    int H = cfg->numHypotheses;
+    if (cfg->estimator == PS_EST_RANSAC) {
+        int a = ransac_iterations_host(0.20), b = ransac_iterations_host(prm->minimalInlierRatioThreshold);
+        int most = a > b ? a : b;
+        if (most < H) H = most;
+        if (H < 1) H = 1;
+    } else if (cfg->estimator == PS_EST_USAC) {
+        if (H > (int)kUsacMaxHyp) H = (int)kUsacMaxHyp;
+    }
+    pl.H = H;
+    pl.sa.H = H;
+    int rc = prepare_tables(ctx, cfg->estimator, prm->minimalInlierRatioThreshold, H, pl.sa);
+    if (rc != PS_OK) return rc;
+    if (pl.sa.iter0 > H) pl.sa.iter0 = H;
+    pl.ma.seed = cfg->seed;
+    pl.ma.raw = nullptr;
+    return PS_OK;
+}
+
+void tick(PsContext *ctx, int slot, bool stop)
+{
+    if (!ctx->timing || slot >= kMaxTimed) return;
+    (void)hipEventRecord(ctx->ev[2 * slot + (stop ? 1 : 0)], ctx->stream);
+    if (stop && slot + 1 > ctx->nTimed) ctx->nTimed = slot + 1;
+}
+
+int pick_split(long long blocksWithout, int maxSplit, int minChunkOf, int total)
+{
+    // Few pairs and many CUs: split the inner range so that ~8 workgroups per CU are in flight.
+    const long long want = 2048;
+    if (blocksWithout >= want) return 1;
+    long long s = (want + blocksWithout - 1) / (blocksWithout > 0 ? blocksWithout : 1);
+    if (s > maxSplit) s = maxSplit;
+    while (s > 1 && total / s < minChunkOf) --s;
+    return (int)(s < 1 ? 1 : s);
+}
+
+template <int MODE>
+void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit)
+{
+    hipLaunchKernelGGL(ps_ransac_score<MODE>, grid, dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p,
+                       (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p, (const int32_t *)ctx->mvalid.p,
+                       pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
+}
+
+// Kernels 3 + 4 over records already in the arena.
+int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMatch *dMatches,
+                     const int32_t *dNumMatches, int matchStride, float *dPose, uint8_t *dMask, PsRansacStats *dStats,
+                     int slot0)
+{
+    const int H = pl.H;
+    PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
+    PS_ENSURE(ctx->idxList, (size_t)P * cap * sizeof(int32_t));
+    const int hb = (H + kBlock - 1) / kBlock;
+    int msplit = pick_split((long long)P * hb, 32, 64, cap);
+    if (msplit > 1) PS_HIP(hipMemsetAsync(ctx->counts.p, 0, (size_t)P * H * sizeof(int32_t), ctx->stream));
+    dim3 grid((unsigned)hb, (unsigned)msplit, (unsigned)P);
+    tick(ctx, slot0, false);
+    switch (pl.mode) {
+    case PS_EUCLIDEAN_ERROR: launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit); break;
+    case PS_REPROJECTION_ERROR: launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit); break;
+    case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
+        launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
+        break;
+    case PS_ADAPTIVE_ERROR: launch_score<PS_ADAPTIVE_ERROR>(ctx, grid, pl, cap, msplit); break;
+    default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
+    }
+    tick(ctx, slot0, true);
+    PS_HIP(hipGetLastError());
+    size_t lds = 2 * (size_t)((pl.sa.trainRange + 31) / 32) * sizeof(uint32_t);
+    tick(ctx, slot0 + 1, false);
+    hipLaunchKernelGGL(ps_select_refit, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream,
+                       (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
+                       (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
+                       dMatches, dNumMatches, matchStride, pl.ma, pl.sc, pl.sa, (int32_t *)ctx->idxList.p, dPose,
+                       dMask, dStats);
+    tick(ctx, slot0 + 1, true);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+int ensure_records(PsContext *ctx, size_t n)
+{
+    PS_ENSURE(ctx->recA, n * 16);
+    PS_ENSURE(ctx->recB, n * 16);
+    PS_ENSURE(ctx->recC, n * 16);
+    PS_ENSURE(ctx->recD, n * 16);
+    return PS_OK;
+}
+
+// Kernels 1 + 2 for P pairs of a device-resident frame set.
+int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs, int P, bool withRecords,
+                    const PrepArgs &pa, PsDMatch *dMatches, int32_t *dNumMatches, int slot0)
+{
+    const int cap = fs.maxKpts;
+    PS_ENSURE(ctx->keys, (size_t)P * cap * sizeof(uint32_t));
+    PS_ENSURE(ctx->mvalid, (size_t)P * sizeof(int32_t));
+    if (withRecords) {
+        int rc = ensure_records(ctx, (size_t)P * cap);
+        if (rc != PS_OK) return rc;
+    }
+    constexpr int TPL = 2;
+    const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
+    int qsplit = pick_split((long long)P * tiles, 16, 64, cap);
+    if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+    tick(ctx, slot0, false);
+    hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit), (unsigned)P), dim3(kBlock), 0, ctx->stream,
+                       (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, qsplit, (uint32_t *)ctx->keys.p);
+    tick(ctx, slot0, true);
+    PS_HIP(hipGetLastError());
+    size_t lds = (size_t)cap * sizeof(uint32_t);
+    tick(ctx, slot0 + 1, false);
+    if (withRecords)
+        hipLaunchKernelGGL(ps_crosscheck_prep<true>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
+                           fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
+                           (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
+                           (int32_t *)ctx->mvalid.p);
+    else
+        hipLaunchKernelGGL(ps_crosscheck_prep<false>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
+                           fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
+                           (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr,
+                           (int32_t *)ctx->mvalid.p);
+    tick(ctx, slot0 + 1, true);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+void identity16(float *T)
+{
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+}
+
+int bind(PsContext *ctx)
+{
+    if (!ctx) return PS_ERR_BAD_ARG;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, PS_ERR_HIP, "hipSetDevice", e);
+    ctx->err.clear();
+    return PS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ps_abi_version(void) { return PS_ABI_VERSION; }
+
+size_t ps_abi_sizeof_dmatch(void) { return sizeof(PsDMatch); }
+size_t ps_abi_sizeof_params(void) { return sizeof(PsRansacParams); }
+size_t ps_abi_sizeof_config(void) { return sizeof(PsRansacConfig); }
+size_t ps_abi_sizeof_stats(void) { return sizeof(PsRansacStats); }
+size_t ps_abi_sizeof_frameset(void) { return sizeof(PsFrameSet); }
+size_t ps_abi_sizeof_results(void) { return sizeof(PsPairResults); }
+
+int ps_context_create(int device, PsContext **out)
+{
+    if (!out) return PS_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return PS_ERR_NO_DEVICE; // no CPU fallback: fail loudly
+    if (device < 0 || device >= n) return PS_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return PS_ERR_HIP;
+    PsContext *ctx = new PsContext();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        strncpy(ctx->arch, prop.gcnArchName, sizeof(ctx->arch) - 1);
+    }
+    if (hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PS_ERR_HIP;
+    }
+    ctx->stream = ctx->own;
+    for (int i = 0; i < 2 * kMaxTimed; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
+            delete ctx;
+            return PS_ERR_HIP;
+        }
+    // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
+    *out = ctx;
+    return PS_OK;
+}
+
+void ps_context_destroy(PsContext *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->counts, &ctx->mvalid,
+                  &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sPts, &ctx->sNk,
+                  &ctx->sPairs, &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
+                  &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
+    for (Buf *b : all) release(*b);
+    for (int i = 0; i < 2 * kMaxTimed; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own) (void)hipStreamDestroy(ctx->own);
+    delete ctx;
+}
+
+int ps_context_set_stream(PsContext *ctx, void *s)
+{
+    if (!ctx) return PS_ERR_BAD_ARG;
+    ctx->stream = s ? (hipStream_t)s : ctx->own;
+    return PS_OK;
+}
+
+int ps_context_synchronize(PsContext *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+const char *ps_last_error(const PsContext *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *ps_device_arch(const PsContext *ctx) { return ctx ? ctx->arch : ""; }
+
+int ps_context_enable_timing(PsContext *ctx, int enable)
+{
+    if (!ctx) return PS_ERR_BAD_ARG;
+    ctx->timing = enable != 0;
+    ctx->nTimed = 0;
+    return PS_OK;
+}
+
+int ps_last_kernel_times_ms(PsContext *ctx, float *ms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->nTimed; ++i) {
+        float t = 0.f;
+        PS_HIP(hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+        ms[i] = t;
+    }
+    return ctx->nTimed;
+}
+
+const char *ps_kernel_names(void)
+{
+    return "ps_hamming_nn\0ps_crosscheck_prep\0ps_ransac_score\0ps_select_refit\0";
+}
+
+uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int H)
+{
+    // descriptors read + matches written + 3-D points read + match index
+    // pairs read by RANSAC + sample triplets + inlier counts + final mask + pose.
+    return 2ull * nkpts * 32 + 16ull * matchesIn + 2ull * nkpts * 12 + 8ull * matchesValid + 12ull * H + 4ull * H +
+           (uint64_t)matchesValid + 64ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+int ps_match_hamming256(PsContext *ctx, const uint8_t *query, int nq, size_t qstep, const uint8_t *train, int nt,
+                        size_t tstep, PsDMatch *out, int *nout)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (nout) *nout = 0;
+    if (!out || !nout || nq < 0 || nt < 0 || (nq > 0 && !query) || (nt > 0 && !train))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_match_hamming256: bad argument");
+    if ((nq > 0 && qstep < PS_DESC_BYTES) || (nt > 0 && tstep < PS_DESC_BYTES))
+        return fail(ctx, PS_ERR_UNSUPPORTED, "descriptor rows must be 32 bytes (ORB/LDB); float descriptors are out of scope");
+    if (nq > PS_MAX_KPTS || nt > PS_MAX_KPTS) return fail(ctx, PS_ERR_UNSUPPORTED, "more than PS_MAX_KPTS rows");
+    if (nq == 0 || nt == 0) return PS_OK; // BFMatcher on an empty side: no matches
+    int cap = nq > nt ? nq : nt;
+    PS_ENSURE(ctx->sDesc, (size_t)2 * cap * 32);
+    PS_ENSURE(ctx->sNk, 2 * sizeof(int32_t) + 2 * sizeof(int32_t));
+    PS_ENSURE(ctx->sMatches, (size_t)cap * sizeof(PsDMatch));
+    PS_ENSURE(ctx->sNumM, sizeof(int32_t));
+    uint8_t *dDesc = (uint8_t *)ctx->sDesc.p;
+    PS_HIP(hipMemcpy2DAsync(dDesc, 32, query, qstep, 32, (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpy2DAsync(dDesc + (size_t)cap * 32, 32, train, tstep, 32, (size_t)nt, hipMemcpyHostToDevice,
+                            ctx->stream));
+    int32_t hostMeta[4] = {nq, nt, 0, 1}; // nkpts[2], pair (0,1)
+    PS_HIP(hipMemcpyAsync(ctx->sNk.p, hostMeta, sizeof hostMeta, hipMemcpyHostToDevice, ctx->stream));
+    PsFrameSet fs;
+    fs.desc = dDesc;
+    fs.pts = nullptr;
+    fs.nkpts = (const int32_t *)ctx->sNk.p;
+    fs.numFrames = 2;
+    fs.maxKpts = cap;
+    PrepArgs pa{};
+    pa.cap = cap;
+    rc = run_match_stage(ctx, fs, (const int32_t *)ctx->sNk.p + 2, 1, false, pa, (PsDMatch *)ctx->sMatches.p,
+                         (int32_t *)ctx->sNumM.p, 0);
+    if (rc) return rc;
+    int32_t n = 0;
+    PS_HIP(hipMemcpyAsync(&n, ctx->sNumM.p, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        PS_HIP(hipMemcpyAsync(out, ctx->sMatches.p, (size_t)n * sizeof(PsDMatch), hipMemcpyDeviceToHost, ctx->stream));
+        PS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *nout = n;
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                             const float *prev, int nprev, const float *cur, int ncur, const PsDMatch *matches, int m,
+                             float *pose, PsDMatch *inliers, int *ninl, uint8_t *mask, PsRansacStats *stats,
+                             int32_t *countsOut)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    PsRansacStats st;
+    memset(&st, 0, sizeof st);
+    st.bestHypothesis = -1;
+    st.numMatchesIn = m > 0 ? m : 0;
+    st.pointInlierRatio = NAN;
+    if (pose) identity16(pose);
+    if (ninl) *ninl = 0;
+    if (stats) *stats = st;
+    if (!pose || !ninl || m < 0 || nprev < 0 || ncur < 0 || (m > 0 && (!matches || !prev || !cur || !inliers)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_ransac_rigid3d: bad argument");
+    if (mask && m > 0) memset(mask, 0, (size_t)m);
+    if (m > (1 << 22)) return fail(ctx, PS_ERR_UNSUPPORTED, "too many matches");
+    for (int i = 0; i < m; ++i)
+        if (matches[i].queryIdx < 0 || matches[i].queryIdx >= nprev || matches[i].trainIdx < 0 ||
+            matches[i].trainIdx >= ncur)
+            return fail(ctx, PS_ERR_BAD_ARG, "match index out of range");
+    const int cap = m > 0 ? m : 1;
+    const int trainRange = ncur <= 65536 ? ncur : 0;
+    Plan pl;
+    rc = make_plan(ctx, params, cfg, K, cap, trainRange, pl);
+    if (rc) return rc;
+    if (cfg->sampleIdx) {
+        PS_ENSURE(ctx->raw, (size_t)pl.H * 3 * sizeof(uint32_t));
+        PS_HIP(hipMemcpyAsync(ctx->raw.p, cfg->sampleIdx, (size_t)pl.H * 3 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+        pl.ma.raw = (const uint32_t *)ctx->raw.p;
+    }
+    PS_ENSURE(ctx->sMisc0, (size_t)(nprev > 0 ? nprev : 1) * 12);
+    PS_ENSURE(ctx->sMisc1, (size_t)(ncur > 0 ? ncur : 1) * 12);
+    PS_ENSURE(ctx->sMatches, (size_t)cap * sizeof(PsDMatch));
+    PS_ENSURE(ctx->sNumM, sizeof(int32_t));
+    PS_ENSURE(ctx->sMask, (size_t)cap);
+    PS_ENSURE(ctx->sPose, 16 * sizeof(float));
+    PS_ENSURE(ctx->sStats, sizeof(PsRansacStats));
+    PS_ENSURE(ctx->mvalid, sizeof(int32_t));
+    rc = ensure_records(ctx, (size_t)cap);
+    if (rc) return rc;
+    if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (ncur > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, cur, (size_t)ncur * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (m > 0)
+        PS_HIP(hipMemcpyAsync(ctx->sMatches.p, matches, (size_t)m * sizeof(PsDMatch), hipMemcpyHostToDevice,
+                              ctx->stream));
+    int32_t mm = m;
+    PS_HIP(hipMemcpyAsync(ctx->sNumM.p, &mm, sizeof mm, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ps_prep_from_matches, dim3(1), dim3(kBlock), 0, ctx->stream, (const float *)ctx->sMisc0.p,
+                       (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa,
+                       (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
+                       (int32_t *)ctx->mvalid.p);
+    PS_HIP(hipGetLastError());
+    rc = run_ransac_stage(ctx, pl, 1, cap, (const PsDMatch *)ctx->sMatches.p, (const int32_t *)ctx->sNumM.p, cap,
+                          (float *)ctx->sPose.p, (uint8_t *)ctx->sMask.p, (PsRansacStats *)ctx->sStats.p, 2);
+    if (rc) return rc;
+    std::vector<uint8_t> hmask((size_t)cap);
+    PS_HIP(hipMemcpyAsync(pose, ctx->sPose.p, 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(&st, ctx->sStats.p, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    if (m > 0) PS_HIP(hipMemcpyAsync(hmask.data(), ctx->sMask.p, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    if (countsOut) {
+        int32_t mv = 0;
+        PS_HIP(hipMemcpyAsync(&mv, ctx->mvalid.p, sizeof mv, hipMemcpyDeviceToHost, ctx->stream));
+        PS_HIP(hipStreamSynchronize(ctx->stream));
+        if (mv >= pl.minRun)
+            PS_HIP(hipMemcpyAsync(countsOut, ctx->counts.p, (size_t)pl.H * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        else
+            memset(countsOut, 0, (size_t)pl.H * sizeof(int32_t));
+    }
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (int i = 0; i < m; ++i)
+        if (hmask[(size_t)i]) inliers[n++] = matches[i];
+    *ninl = n;
+    if (mask && m > 0) memcpy(mask, hmask.data(), (size_t)m);
+    if (trainRange == 0 && m > 0) {
+        // train indices beyond the device bitmap: RANSAC::pointInlierRatio (RANSAC.h:56-66) on the host lists
+        std::vector<uint8_t> seen((size_t)ncur, 0);
+        int ua = 0, ui = 0;
+        for (int i = 0; i < m; ++i) {
+            uint8_t &s = seen[(size_t)matches[i].trainIdx];
+            if (!(s & 1)) { s |= 1; ++ua; }
+            if (hmask[(size_t)i] && !(s & 2)) { s |= 2; ++ui; }
+        }
+        st.pointInlierRatio = (double)ui / (double)ua;
+    }
+    if (stats) *stats = st;
+    return PS_OK;
+}
+
+int ps_ransac_rigid3d(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                      const float *prev, int nprev, const float *cur, int ncur, const PsDMatch *matches, int m,
+                      float *pose, PsDMatch *inliers, int *ninl, uint8_t *mask, PsRansacStats *stats)
+{
+    return ransac_host_entry(ctx, params, cfg, K, prev, nprev, cur, ncur, matches, m, pose, inliers, ninl, mask, stats,
+                             nullptr);
+}
+
+// Diagnostic twin of ps_ransac_rigid3d that also returns the per-hypothesis inlier counts the
+// scoring kernel produced (length = hypotheses actually scored, returned through *numScored).
+int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                           const float *prev, int nprev, const float *cur, int ncur, const PsDMatch *matches, int m,
+                           int32_t *counts, int *numScored)
+{
+    if (!cfg || !counts || !numScored) return PS_ERR_BAD_ARG;
+    std::vector<PsDMatch> inl((size_t)(m > 0 ? m : 1));
+    float pose[16];
+    int ninl = 0;
+    PsRansacStats st;
+    // the number of scored hypotheses follows the same rule as make_plan
+    int H = cfg->numHypotheses;
+    if (cfg->estimator == PS_EST_RANSAC && params) {
+        int a = ransac_iterations_host(0.20), b = ransac_iterations_host(params->minimalInlierRatioThreshold);
+        int most = a > b ? a : b;
+        if (most < H) H = most;
+        if (H < 1) H = 1;
+    } else if (cfg->estimator == PS_EST_USAC && H > (int)kUsacMaxHyp)
+        H = (int)kUsacMaxHyp;
+    *numScored = H;
+    return ransac_host_entry(ctx, params, cfg, K, prev, nprev, cur, ncur, matches, m, pose, inl.data(), &ninl, nullptr,
+                             &st, counts);
+}
+
+// Diagnostic: device-side trip limits for every inlier count 1..M (see ps_limits_table).
+int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M, int32_t *out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (M < 1 || !out) return PS_ERR_BAD_ARG;
+    SelectArgs sa{};
+    sa.estimator = estimator;
+    sa.H = H;
+    rc = prepare_tables(ctx, estimator, minRatio, H, sa);
+    if (rc) return rc;
+    PS_ENSURE(ctx->sMisc2, (size_t)M * sizeof(int32_t));
+    hipLaunchKernelGGL(ps_limits_table, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, sa, M,
+                       (int32_t *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(out, ctx->sMisc2.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int ps_umeyama_f32(PsContext *ctx, const float *src, const float *dst, int k, int nsets, float *T, int32_t *valid)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (k < 0 || nsets < 0 || !T || !valid || (k > 0 && nsets > 0 && (!src || !dst)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_umeyama_f32: bad argument");
+    if (nsets == 0) return PS_OK;
+    size_t bytes = (size_t)nsets * (k > 0 ? k : 1) * 12;
+    PS_ENSURE(ctx->sMisc0, bytes);
+    PS_ENSURE(ctx->sMisc1, bytes);
+    PS_ENSURE(ctx->sPose, (size_t)nsets * 16 * sizeof(float));
+    PS_ENSURE(ctx->sMisc2, (size_t)nsets * sizeof(int32_t));
+    if (k > 0) {
+        PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, src, (size_t)nsets * k * 12, hipMemcpyHostToDevice, ctx->stream));
+        PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, dst, (size_t)nsets * k * 12, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(ps_umeyama_sets, dim3((unsigned)nsets), dim3(64), 0, ctx->stream, (const float *)ctx->sMisc0.p,
+                       (const float *)ctx->sMisc1.p, k, nsets, (float *)ctx->sPose.p, (int32_t *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(T, ctx->sPose.p, (size_t)nsets * 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(valid, ctx->sMisc2.p, (size_t)nsets * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+int ps_kabsch_f64(PsContext *ctx, const double *A, const double *B, int n, int ld, double *T)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (T)
+        for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (!T || n < 0 || (n > 0 && (!A || !B || ld < n))) return fail(ctx, PS_ERR_BAD_ARG, "ps_kabsch_f64: bad argument");
+    if (n == 0) return PS_OK; // kabschEst.cpp:28
+    size_t bytes = (size_t)3 * ld * sizeof(double);
+    PS_ENSURE(ctx->sMisc0, bytes);
+    PS_ENSURE(ctx->sMisc1, bytes);
+    PS_ENSURE(ctx->sMisc2, 16 * sizeof(double));
+    PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, A, bytes - (size_t)(ld - n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, B, bytes - (size_t)(ld - n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ps_kabsch_f64_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->sMisc0.p,
+                       (const double *)ctx->sMisc1.p, n, ld, (double *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(T, ctx->sMisc2.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+int ps_keypoints2Dto3D(PsContext *ctx, const float *xy, int n, const uint16_t *depth, int rows, int cols,
+                       size_t depthStep, const float *K, double depthImageScale, float *out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n < 0 || rows <= 0 || cols <= 0 || !depth || !K || depthStep < (size_t)cols * 2 || (n > 0 && (!xy || !out)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_keypoints2Dto3D: bad argument");
+    if (n == 0) return PS_OK;
+    PS_ENSURE(ctx->sMisc0, (size_t)n * 8);
+    PS_ENSURE(ctx->sMisc1, (size_t)rows * depthStep);
+    PS_ENSURE(ctx->sMisc2, (size_t)n * 12);
+    PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, depth, (size_t)rows * depthStep, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ps_backproject, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const float *)ctx->sMisc0.p, n, (const uint8_t *)ctx->sMisc1.p, rows, cols, depthStep, K[0],
+                       K[4], K[2], K[5], depthImageScale, (float *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(out, ctx->sMisc2.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, float *uv)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n < 0 || !K || (n > 0 && (!xyz || !uv))) return fail(ctx, PS_ERR_BAD_ARG, "ps_points3Dto2D: bad argument");
+    if (n == 0) return PS_OK;
+    PS_ENSURE(ctx->sMisc0, (size_t)n * 12);
+    PS_ENSURE(ctx->sMisc2, (size_t)n * 8);
+    PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ps_project_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const float *)ctx->sMisc0.p, n, K[0], K[4], K[2], K[5], (float *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(uv, ctx->sMisc2.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                       const PsFrameSet *frames, const int32_t *pairs, int P, const PsPairResults *out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!frames || !out || P < 0 || (P > 0 && !pairs)) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_pairs_device: bad argument");
+    if (P == 0) return PS_OK;
+    if (!frames->desc || !frames->pts || !frames->nkpts || frames->maxKpts < 1 || frames->maxKpts > PS_MAX_KPTS)
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_pairs_device: bad frame set");
+    if (!out->matches || !out->numMatches || !out->inlierMask || !out->pose || !out->stats)
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_pairs_device: null output");
+    if (cfg && cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are per call, not per batch");
+    const int cap = frames->maxKpts;
+    Plan pl;
+    rc = make_plan(ctx, params, cfg, K, cap, cap, pl);
+    if (rc) return rc;
+    ctx->nTimed = 0;
+    rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
+    if (rc) return rc;
+    return run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask,
+                            out->stats, 2);
+}
+
+} // extern "C"

@@ -1,0 +1,900 @@
+// ps_kernels.h -- HIP kernels of the PUTSLAM front-end hot path for gfx950 (wave64, 256 CUs).
+//
+// Data layout in HBM (one "frame set" + one "pair batch", see include/putslam_hip.h):
+//   desc   [F][cap][32 B]      binary descriptors (ORB / LDB, 256 bit)
+//   pts    [F][cap][3] f32     back-projected 3-D points (Eigen::Vector3f storage)
+//   keys   [P][cap]    u32     per train row: (hamming << 16) | nearest query   (scratch)
+//   recA/B/C/D [P][cap] 16 B   per depth-valid match: prev xyz + squared Euclid bound |
+//                              cur xyz | projections of prev and cur | indices    (scratch)
+//   counts [P][H]      i32     inlier count of every hypothesis                   (scratch)
+// Nothing of size N*N or H*M ever touches HBM: distances live in VGPRs, models in VGPRs.
+//
+// Kernel 1  ps_hamming_nn      train -> nearest query (the N x N popcount sweep)
+// Kernel 2  ps_crosscheck_prep OpenCV cross-check, ordered compaction, depth filter, records
+// Kernel 3  ps_ransac_score    one lane = one 3-point hypothesis: Umeyama fit + score all M matches
+// Kernel 4  ps_select_refit    replay of the sequential best-model rule, refit, final inliers
+#pragma once
+
+#include "ps_device_math.h"
+
+#include "../../include/putslam_hip.h"
+
+namespace psdev {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+// v_bcnt_u32_b32: popcount(x) + acc in one VALU op (the compiler emits bcnt + add otherwise).
+PS_D uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+PS_D uint32_t ham_key(const uint4 &a, const uint4 &b, const uint4 &x, const uint4 &y, uint32_t q)
+{
+    uint32_t d = bcnt_acc(a.x ^ x.x, 0u);
+    d = bcnt_acc(a.y ^ x.y, d);
+    d = bcnt_acc(a.z ^ x.z, d);
+    d = bcnt_acc(a.w ^ x.w, d);
+    d = bcnt_acc(b.x ^ y.x, d);
+    d = bcnt_acc(b.y ^ y.y, d);
+    d = bcnt_acc(b.z ^ y.z, d);
+    d = bcnt_acc(b.w ^ y.w, d);
+    return (d << 16) | q; // lexicographic (distance, query): min == strict '<' scan in ascending q
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1.  cv::batchDistance(train, query, K=1) inside BFMatcher's cross-check
+// (reference call site src/Matcher/matcherOpenCV.cpp:203): for each train row the nearest
+// query row, ties to the lowest query index.
+// One lane owns TPL train descriptors in VGPRs (8 dwords each).  The query rows are
+// wave-uniform, so they are fetched with scalar loads (s_load_dwordx8) into SGPRs and feed
+// v_xor/v_bcnt directly: no LDS traffic, no bank conflicts, 18 VALU ops per pair.
+// grid = (tiles * qsplit, P).  qsplit > 1 splits the query range across workgroups (few pairs,
+// many CUs) and merges with atomicMin on the packed key.
+// ------------------------------------------------------------------------------------------
+template <int TPL>
+__global__ __launch_bounds__(kBlock) void ps_hamming_nn(const uint4 *__restrict__ desc,
+                                                        const int32_t *__restrict__ nkpts,
+                                                        const int32_t *__restrict__ pairs, int cap, int qsplit,
+                                                        uint32_t *__restrict__ keys)
+{
+    const int p = blockIdx.y;
+    const int fq = pairs[2 * p], ft = pairs[2 * p + 1]; // query = previous frame, train = current
+    const int nq = nkpts[fq], nt = nkpts[ft];
+    const int tile = blockIdx.x / qsplit, qs = blockIdx.x - tile * qsplit;
+    const int t0 = tile * (kBlock * TPL);
+    if (t0 >= nt) return;
+    const int q0 = (int)(((long long)nq * qs) / qsplit), q1 = (int)(((long long)nq * (qs + 1)) / qsplit);
+
+    const uint4 *__restrict__ tdesc = desc + (size_t)ft * cap * 2;
+    const uint4 *__restrict__ qdesc = desc + (size_t)fq * cap * 2;
+
+    uint4 a[TPL], b[TPL];
+    uint32_t best[TPL];
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) {
+        int t = t0 + i * kBlock + threadIdx.x;
+        int tc = t < nt ? t : nt - 1;
+        a[i] = tdesc[2 * tc];
+        b[i] = tdesc[2 * tc + 1];
+        best[i] = kNoKey;
+    }
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {
+        uint4 x0 = qdesc[2 * q], y0 = qdesc[2 * q + 1];
+        uint4 x1 = qdesc[2 * q + 2], y1 = qdesc[2 * q + 3];
+        uint4 x2 = qdesc[2 * q + 4], y2 = qdesc[2 * q + 5];
+        uint4 x3 = qdesc[2 * q + 6], y3 = qdesc[2 * q + 7];
+#pragma unroll
+        for (int i = 0; i < TPL; ++i) {
+            best[i] = min(best[i], ham_key(a[i], b[i], x0, y0, (uint32_t)q));
+            best[i] = min(best[i], ham_key(a[i], b[i], x1, y1, (uint32_t)q + 1));
+            best[i] = min(best[i], ham_key(a[i], b[i], x2, y2, (uint32_t)q + 2));
+            best[i] = min(best[i], ham_key(a[i], b[i], x3, y3, (uint32_t)q + 3));
+        }
+    }
+    for (; q < q1; ++q) {
+        uint4 x0 = qdesc[2 * q], y0 = qdesc[2 * q + 1];
+#pragma unroll
+        for (int i = 0; i < TPL; ++i) best[i] = min(best[i], ham_key(a[i], b[i], x0, y0, (uint32_t)q));
+    }
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) {
+        int t = t0 + i * kBlock + threadIdx.x;
+        if (t < nt) {
+            if (qsplit == 1)
+                keys[(size_t)p * cap + t] = best[i];
+            else
+                atomicMin(&keys[(size_t)p * cap + t], best[i]);
+        }
+    }
+}
+
+// ---- workgroup-wide ordered compaction helper (4 waves) ----
+// Returns the exclusive prefix of `flag` over the 256 threads; `total` = number of set flags.
+PS_D int block_scan_flag(bool flag, int &total, int *wsum)
+{
+    unsigned long long bal = __ballot(flag);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) {
+        int s = wsum[i];
+        if (i < w) off += s;
+        total += s;
+    }
+    __syncthreads();
+    return off + pre;
+}
+
+struct PrepArgs {
+    float fx, fy, cx, cy;   // camera matrix entries (cv::Mat CV_32FC1, RGBD.cpp:93-96)
+    double thrE;            // inlierThresholdEuclidean
+    int mode;               // RANSAC::ERROR_VERSION
+    int cap;
+};
+
+// Builds the four 16-byte records of one depth-valid match.
+PS_D void write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t, float px, float py, float pz,
+                        float cx_, float cy_, float cz_, float4 *recA, float4 *recB, float4 *recC, int4 *recD)
+{
+    // Euclid rule of RANSAC.cpp:268-272: thr = inlierThresholdEuclidean (* prev.z in ADAPTIVE mode),
+    // turned into its exact squared-domain bound.
+    double thr = a.thrE;
+    if (a.mode == PS_ADAPTIVE_ERROR) thr *= (double)pz;
+    float bound = sq_bound_f32(thr);
+    float ou, ov, nu, nv;
+    project(px, py, pz, a.fx, a.fy, a.cx, a.cy, ou, ov);    // realOld  (RANSAC.cpp:357-358)
+    project(cx_, cy_, cz_, a.fx, a.fy, a.cx, a.cy, nu, nv); // realNew  (RANSAC.cpp:352-353)
+    recA[slot] = make_float4(px, py, pz, bound);
+    recB[slot] = make_float4(cx_, cy_, cz_, 0.0f);
+    recC[slot] = make_float4(ou, ov, nu, nv);
+    recD[slot] = make_int4(srcIdx, q, t, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2.  Cross-check + ordered compaction (BFMatcher with crossCheck=true) followed by the
+// depth filter of RANSAC::estimateTransformation (RANSAC.cpp:65-74) and record building.
+// One workgroup per pair; best[q] lives in LDS (cap x 4 B).
+// ------------------------------------------------------------------------------------------
+template <bool WITH_RECORDS>
+__global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__restrict__ pts,
+                                                             const int32_t *__restrict__ nkpts,
+                                                             const int32_t *__restrict__ pairs,
+                                                             const uint32_t *__restrict__ keys, PrepArgs a,
+                                                             PsDMatch *__restrict__ matches,
+                                                             int32_t *__restrict__ numMatches,
+                                                             float4 *__restrict__ recA, float4 *__restrict__ recB,
+                                                             float4 *__restrict__ recC, int4 *__restrict__ recD,
+                                                             int32_t *__restrict__ mvalid)
+{
+    extern __shared__ __align__(16) uint32_t s_best[];
+    __shared__ int s_wsum[kBlock / 64];
+    const int p = blockIdx.x;
+    const int cap = a.cap;
+    const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
+    const int nq = nkpts[fq], nt = nkpts[ft];
+    for (int q = threadIdx.x; q < nq; q += kBlock) s_best[q] = kNoKey;
+    __syncthreads();
+    // step 2 of the cross-check: query q keeps the closest train row among those that chose it,
+    // ties to the lowest train index (strict '<' while scanning t ascending).
+    for (int t = threadIdx.x; t < nt; t += kBlock) {
+        uint32_t key = keys[(size_t)p * cap + t];
+        if (key != kNoKey) {
+            uint32_t q = key & 0xFFFFu, d = key >> 16;
+            atomicMin(&s_best[q], (d << 16) | (uint32_t)t);
+        }
+    }
+    __syncthreads();
+    const float *pp = pts + (size_t)fq * cap * 3;
+    const float *cp = pts + (size_t)ft * cap * 3;
+    int base = 0, vbase = 0;
+    for (int q0 = 0; q0 < nq; q0 += kBlock) {
+        const int q = q0 + threadIdx.x;
+        uint32_t key = (q < nq) ? s_best[q] : kNoKey;
+        const bool has = key != kNoKey;
+        int total;
+        int pos = block_scan_flag(has, total, s_wsum);
+        const int t = (int)(key & 0xFFFFu);
+        if (has) {
+            PsDMatch m;
+            m.queryIdx = q;
+            m.trainIdx = t;
+            m.imgIdx = 0;
+            m.distance = (float)(key >> 16);
+            matches[(size_t)p * cap + base + pos] = m;
+        }
+        if (WITH_RECORDS) {
+            float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
+            bool ok = false;
+            if (has) {
+                px = pp[3 * q]; py = pp[3 * q + 1]; pz = pp[3 * q + 2];
+                cx_ = cp[3 * t]; cy_ = cp[3 * t + 1]; cz_ = cp[3 * t + 2];
+                ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
+            }
+            int vtotal;
+            int vpos = block_scan_flag(ok, vtotal, s_wsum);
+            if (ok)
+                write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_, recA,
+                              recB, recC, recD);
+            vbase += vtotal;
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) {
+        numMatches[p] = base;
+        if (WITH_RECORDS) mvalid[p] = vbase;
+    }
+}
+
+// Depth filter + records for a caller-supplied match list (stand-alone RANSAC entry point).
+__global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__restrict__ prev,
+                                                               const float *__restrict__ cur,
+                                                               const PsDMatch *__restrict__ matches, int m, PrepArgs a,
+                                                               float4 *__restrict__ recA, float4 *__restrict__ recB,
+                                                               float4 *__restrict__ recC, int4 *__restrict__ recD,
+                                                               int32_t *__restrict__ mvalid)
+{
+    __shared__ int s_wsum[kBlock / 64];
+    int vbase = 0;
+    for (int i0 = 0; i0 < m; i0 += kBlock) {
+        const int i = i0 + threadIdx.x;
+        float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
+        int q = 0, t = 0;
+        bool ok = false;
+        if (i < m) {
+            q = matches[i].queryIdx;
+            t = matches[i].trainIdx;
+            px = prev[3 * q]; py = prev[3 * q + 1]; pz = prev[3 * q + 2];
+            cx_ = cur[3 * t]; cy_ = cur[3 * t + 1]; cz_ = cur[3 * t + 2];
+            ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
+        }
+        int vtotal;
+        int vpos = block_scan_flag(ok, vtotal, s_wsum);
+        if (ok) write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD);
+        vbase += vtotal;
+    }
+    if (threadIdx.x == 0) mvalid[0] = vbase;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hypothesis model: sample -> gather 3 correspondences -> float Umeyama (+ general inverse when a
+// reprojection mode needs it).  Used identically by kernel 3 (all hypotheses) and kernel 4 (the
+// selected one), so both see the same bits.
+// ------------------------------------------------------------------------------------------
+struct ModelArgs {
+    uint64_t seed;
+    const uint32_t *raw; // optional explicit draws, H x 3 (device)
+};
+
+PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ recB, size_t rbase, uint32_t M,
+                    const ModelArgs &ma, uint64_t pairSeed, uint32_t h, Rigid &mdl)
+{
+    uint32_t idx[3];
+    sample_triplet(pairSeed, ma.raw, h, M, idx);
+    float src[3][3], dst[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float4 A = recA[rbase + idx[j]]; // previous frame = dst
+        float4 B = recB[rbase + idx[j]]; // current frame  = src   (umeyama(cur, prev), RANSAC.cpp:225-226)
+        dst[j][0] = A.x; dst[j][1] = A.y; dst[j][2] = A.z;
+        src[j][0] = B.x; src[j][1] = B.y; src[j][2] = B.z;
+    }
+    return umeyama3(src, dst, mdl);
+}
+
+struct ScoreConsts {
+    float fx, fy, cx, cy;
+    double boundR; // squared-domain bound of inlierThresholdReprojection (double, cv::norm)
+};
+
+template <int MODE>
+PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, const float4 &A, const float4 &B,
+                      const float4 &C)
+{
+    float ex, ey, ez;
+    xform(mdl, B.x, B.y, B.z, ex, ey, ez); // estimatedOldPosition = R * features[train] + t
+    bool in = true;
+    if (MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+        float d0 = ex - A.x, d1 = ey - A.y, d2 = ez - A.z;
+        float s = d0 * d0 + (d1 * d1 + d2 * d2);
+        in = s < A.w;
+    }
+    if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+        float nx, ny, nz;
+        xform(inv, A.x, A.y, A.z, nx, ny, nz); // estimatedNewPosition = Rinv * prev[query] + tinv
+        float pnu, pnv, pou, pov;
+        project(nx, ny, nz, k.fx, k.fy, k.cx, k.cy, pnu, pnv);
+        project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pou, pov);
+        float dxn = pnu - C.z, dyn = pnv - C.w; // predictedNew - realNew
+        float dxo = pou - C.x, dyo = pov - C.y; // predictedOld - realOld
+        double e0 = (double)dxn * (double)dxn + (double)dyn * (double)dyn;
+        double e1 = (double)dxo * (double)dxo + (double)dyo * (double)dyo;
+        in = in && (e0 < k.boundR) && (e1 < k.boundR);
+    }
+    return in;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3.  RANSAC loop body of RANSAC.cpp:93-135 for ALL hypotheses at once.
+// lane = hypothesis (model in VGPRs); the match records are wave-uniform and arrive through
+// scalar loads.  grid = (ceil(H/256), msplit, P); msplit > 1 splits the match range and merges
+// the integer counts with atomicAdd.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restrict__ recA,
+                                                          const float4 *__restrict__ recB,
+                                                          const float4 *__restrict__ recC,
+                                                          const int32_t *__restrict__ mvalid, ModelArgs ma,
+                                                          ScoreConsts k, int H, int cap, int minRun, int msplit,
+                                                          int32_t *__restrict__ counts)
+{
+    const int p = blockIdx.z;
+    const int M = mvalid[p];
+    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
+    const int h = blockIdx.x * kBlock + threadIdx.x;
+    const size_t rbase = (size_t)p * cap;
+    const int m0 = (int)(((long long)M * blockIdx.y) / msplit);
+    const int m1 = (int)(((long long)M * (blockIdx.y + 1)) / msplit);
+
+    Rigid mdl, inv;
+    bool valid = false;
+    if (h < H) {
+        valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, ma.seed + (uint64_t)p, (uint32_t)h, mdl);
+        if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR)
+            inverse_rigid_general(mdl, inv);
+    }
+    int cnt = 0;
+    if (MODE == PS_MAHALANOBIS_ERROR) valid = false; // dead metric in the reference: scores 0
+    const float4 *__restrict__ pa = recA + rbase;
+    const float4 *__restrict__ pb = recB + rbase;
+    const float4 *__restrict__ pc = recC + rbase;
+    for (int m = m0; m < m1; ++m) {
+        float4 A = pa[m], B = pb[m], C = make_float4(0, 0, 0, 0);
+        if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) C = pc[m];
+        cnt += inlier_test<MODE>(mdl, inv, k, A, B, C) ? 1 : 0;
+    }
+    if (h < H) {
+        if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
+        if (msplit == 1)
+            counts[(size_t)p * H + h] = cnt;
+        else if (cnt)
+            atomicAdd(&counts[(size_t)p * H + h], cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-level N-point Umeyama (refit, RANSAC.cpp:153): the canonical summation order is
+// 64 strided partials (lane l takes elements l, l+64, ...) and a stride-1,2,4,..,32 tree.
+// getter(j, src[3], dst[3]) yields the j-th correspondence.  All 64 lanes return the model.
+// ------------------------------------------------------------------------------------------
+PS_D float wave_tree_sum(float v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+template <typename Getter> PS_D bool wave_umeyama(int k, Getter get, Rigid &mdl)
+{
+    const int lane = threadIdx.x & 63;
+    const float one_over_n = 1.0f / (float)k;
+    float ss[3] = {0.0f, 0.0f, 0.0f}, ds[3] = {0.0f, 0.0f, 0.0f};
+    for (int j = lane; j < k; j += 64) {
+        float s[3], d[3];
+        get(j, s, d);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ss[c] = ss[c] + s[c];
+            ds[c] = ds[c] + d[c];
+        }
+    }
+    float sm[3], dm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sm[c] = wave_tree_sum(ss[c]) * one_over_n;
+        dm[c] = wave_tree_sum(ds[c]) * one_over_n;
+    }
+    float acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = 0.0f;
+    for (int j = lane; j < k; j += 64) {
+        float s[3], d[3];
+        get(j, s, d);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[r][c] = acc[r][c] + (d[r] - dm[r]) * (s[c] - sm[c]);
+    }
+    float sigma[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sigma[r][c] = one_over_n * wave_tree_sum(acc[r][c]);
+    bool ok = umeyama_finish(sigma, sm, dm, mdl);
+    if (!ok) set_identity(mdl);
+    return ok;
+}
+
+struct SelectArgs {
+    int estimator;       // PsEstimator
+    int mode;            // RANSAC::ERROR_VERSION
+    int H, cap;
+    int minMatches;      // minimalNumberOfMatches (RANSAC) or 8 (USAC_wrapper.cpp:120)
+    int iter0;           // initial trip limit: min(computeRANSACIteration(0.20), H) or min(850000, H)
+    double minRatio;     // minimalInlierRatioThreshold
+    const float *ransacTab;  // non-increasing; ransacTab[k] = smallest ratio r with iterations(r) <= k
+    int ransacTabN;
+    const double *usacTab;   // non-increasing; usacTab[k] = smallest p with stopping(p) <= k+1
+    int usacTabN;
+    int trainRange;      // train indices are < trainRange (size of the uniqueness bitmaps, 0 = skip)
+};
+
+// min(Kcap, computeRANSACIteration(r)) through the host-built threshold table (RANSAC.cpp:450-461).
+PS_D int ransac_limit(const SelectArgs &a, float r)
+{
+    int lo = 0, hi = a.ransacTabN; // first k with r >= tab[k]
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (r < a.ransacTab[mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// min(H, updateStandardStopping(inliers, M, 3)) through the host-built table (USAC.h:944-971).
+PS_D int usac_limit(const SelectArgs &a, unsigned c, unsigned M)
+{
+    double n_in = 1.0, n_pts = 1.0;
+#pragma unroll
+    for (unsigned i = 0; i < 3; ++i) {
+        n_in *= (double)(unsigned)(c - i);
+        n_pts *= (double)(unsigned)(M - i);
+    }
+    double pgood = n_in / n_pts;
+    int lo = 0, hi = a.usacTabN;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (pgood < a.usacTab[mid]) lo = mid + 1; else hi = mid;
+    }
+    int stop = lo + 1;
+    return stop < a.H ? stop : a.H;
+}
+
+PS_D void store_pose(float *pose, const Rigid &m)
+{
+    // column-major 4x4 (Eigen::Matrix4f storage)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pose[4 * c + r] = m.R[r][c];
+        pose[4 * c + 3] = 0.0f;
+    }
+    pose[12] = m.t[0]; pose[13] = m.t[1]; pose[14] = m.t[2]; pose[15] = 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4.  One workgroup per pair:
+//  (1) replay of the sequential selection over counts[0..H): strict '>' first-best with the
+//      adaptive trip limit (RANSAC.cpp:87,438-455 / USAC.h:326,409-414,498-509) or plain arg-max;
+//  (2) inliers of the selected hypothesis, in match order;
+//  (3) Umeyama refit on them and the Euclidean re-selection (RANSAC.cpp:152-158);
+//  (4) ratio gate (RANSAC.cpp:161-164 / USAC_wrapper.cpp:139-141), pointInlierRatio (RANSAC.h:56-66).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restrict__ recA,
+                                                          const float4 *__restrict__ recB,
+                                                          const float4 *__restrict__ recC,
+                                                          const int4 *__restrict__ recD,
+                                                          const int32_t *__restrict__ mvalid,
+                                                          const int32_t *__restrict__ counts,
+                                                          const PsDMatch *__restrict__ matches,
+                                                          const int32_t *__restrict__ numMatches, int matchStride,
+                                                          ModelArgs ma, ScoreConsts k, SelectArgs a,
+                                                          int32_t *__restrict__ idxList, float *__restrict__ poseOut,
+                                                          uint8_t *__restrict__ maskOut,
+                                                          PsRansacStats *__restrict__ statsOut)
+{
+    extern __shared__ __align__(16) uint32_t s_bits[]; // two bitmaps over train indices: 2 * ceil(trainRange/32) words
+    __shared__ int s_wsum[kBlock / 64];
+    __shared__ unsigned long long s_red[kBlock / 64];
+    __shared__ int s_sel[4];
+    __shared__ Rigid s_model;
+    __shared__ int s_uniq[2];
+
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int M = mvalid[p];
+    const int nIn = numMatches[p];
+    const size_t rbase = (size_t)p * a.cap;
+    const int32_t *cnts = counts + (size_t)p * a.H;
+    uint8_t *mask = maskOut + (size_t)p * matchStride;
+    int32_t *list = idxList + rbase;
+
+    for (int i = tid; i < nIn; i += kBlock) mask[i] = 0;
+
+    const bool run = !(M < a.minMatches || M < 3);
+    int bestIdx = -1, bestCount = 0, trips = 0;
+
+    if (run) {
+        if (a.estimator == PS_EST_FIXED) {
+            unsigned long long key = 0ull;
+            for (int i = tid; i < a.H; i += kBlock) {
+                unsigned long long kk = ((unsigned long long)(unsigned)cnts[i] << 32) | (0xFFFFFFFFu - (unsigned)i);
+                key = kk > key ? kk : key;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long other = __shfl_down(key, o, 64);
+                key = other > key ? other : key;
+            }
+            if (lane == 0) s_red[wv] = key;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long b = s_red[0];
+                for (int i = 1; i < kBlock / 64; ++i) b = s_red[i] > b ? s_red[i] : b;
+                int c = (int)(b >> 32);
+                s_sel[0] = c > 0 ? (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFu)) : -1;
+                s_sel[1] = c;
+                s_sel[2] = a.H;
+            }
+            __syncthreads();
+        } else {
+            // Sequential replay.  State changes only at "records" (count > best so far), so the
+            // workgroup repeatedly finds the first index in [pos, limit) that beats the best.
+            int pos = 0, limit = a.iter0, best = 0, bIdx = -1;
+            for (;;) {
+                unsigned found = 0xFFFFFFFFu;
+                for (int i = pos + tid; i < limit; i += kBlock)
+                    if (cnts[i] > best) {
+                        found = (unsigned)i;
+                        break;
+                    }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    unsigned other = __shfl_down(found, o, 64);
+                    found = other < found ? other : found;
+                }
+                if (lane == 0) s_red[wv] = found;
+                __syncthreads();
+                unsigned f = (unsigned)s_red[0];
+                for (int i = 1; i < kBlock / 64; ++i) f = (unsigned)s_red[i] < f ? (unsigned)s_red[i] : f;
+                __syncthreads();
+                if (f == 0xFFFFFFFFu) break;
+                bIdx = (int)f;
+                best = cnts[bIdx];
+                pos = bIdx + 1;
+                if (a.estimator == PS_EST_USAC)
+                    limit = usac_limit(a, (unsigned)best, (unsigned)M);
+                else
+                    limit = ransac_limit(a, (float)best / (float)M); // ratio as RANSAC.cpp:280
+            }
+            if (tid == 0) {
+                s_sel[0] = bIdx;
+                s_sel[1] = best;
+                s_sel[2] = (bIdx + 1 > limit) ? bIdx + 1 : limit;
+            }
+            __syncthreads();
+        }
+        bestIdx = s_sel[0];
+        bestCount = s_sel[1];
+        trips = s_sel[2];
+    }
+
+    // ---- (2) inliers of the selected hypothesis ----
+    Rigid mdl, inv;
+    set_identity(mdl);
+    set_identity(inv);
+    int kin = 0;
+    if (run && bestIdx >= 0) {
+        gen_model(recA, recB, rbase, (uint32_t)M, ma, ma.seed + (uint64_t)p, (uint32_t)bestIdx, mdl);
+        const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
+        if (needInv) inverse_rigid_general(mdl, inv);
+        for (int i0 = 0; i0 < M; i0 += kBlock) {
+            const int i = i0 + tid;
+            bool in = false;
+            if (i < M) {
+                float4 A = recA[rbase + i], B = recB[rbase + i], C = recC[rbase + i];
+                switch (a.mode) {
+                case PS_EUCLIDEAN_ERROR: in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, C); break;
+                case PS_ADAPTIVE_ERROR: in = inlier_test<PS_ADAPTIVE_ERROR>(mdl, inv, k, A, B, C); break;
+                case PS_REPROJECTION_ERROR: in = inlier_test<PS_REPROJECTION_ERROR>(mdl, inv, k, A, B, C); break;
+                case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
+                    in = inlier_test<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(mdl, inv, k, A, B, C);
+                    break;
+                default: in = false; break;
+                }
+            }
+            int total;
+            int pos = block_scan_flag(in, total, s_wsum);
+            if (in) list[kin + pos] = i;
+            kin += total;
+        }
+        __syncthreads(); // list visible to the whole workgroup (global memory, same CU)
+    }
+
+    const float ratioF = run ? (float)bestCount / (float)M : 0.0f;
+    const double ratioD = (double)ratioF;
+    bool accepted = run && !(ratioD < a.minRatio);
+    int nfinal = 0;
+
+    if (run && a.estimator != PS_EST_USAC) {
+        // ---- (3) refit on the best inliers (wave 0), re-selection with the Euclid/adaptive rule ----
+        if (wv == 0) {
+            Rigid ref;
+            wave_umeyama(kin,
+                         [&](int j, float (&s)[3], float (&d)[3]) {
+                             int i = list[j];
+                             float4 A = recA[rbase + i], B = recB[rbase + i];
+                             d[0] = A.x; d[1] = A.y; d[2] = A.z;
+                             s[0] = B.x; s[1] = B.y; s[2] = B.z;
+                         },
+                         ref);
+            if (lane == 0) s_model = ref;
+        }
+        __syncthreads();
+        mdl = s_model;
+        for (int j0 = 0; j0 < kin; j0 += kBlock) {
+            const int j = j0 + tid;
+            bool in = false;
+            int i = 0;
+            if (j < kin) {
+                i = list[j];
+                float4 A = recA[rbase + i], B = recB[rbase + i];
+                in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, A); // s < A.w : plain or adaptive bound
+            }
+            int total;
+            block_scan_flag(in, total, s_wsum);
+            if (in && accepted) mask[recD[rbase + i].x] = 1;
+            nfinal += total;
+        }
+        if (!accepted) nfinal = 0; // identity + inliers cleared (RANSAC.cpp:161-164)
+    } else if (run) {
+        // USAC: no refit (USAC_wrapper.cpp:204-222 commented out); the loop's inliers are returned even
+        // when the ratio gate replaces the pose by identity (USAC_wrapper.cpp:139-141).
+        for (int j = tid; j < kin; j += kBlock) mask[recD[rbase + list[j]].x] = 1;
+        nfinal = kin;
+    }
+    __syncthreads();
+
+    // ---- (4) pointInlierRatio: unique trainIdx among final inliers / among all input matches ----
+    const int words = (a.trainRange + 31) >> 5;
+    for (int i = tid; i < 2 * words; i += kBlock) s_bits[i] = 0u;
+    if (tid == 0) s_uniq[0] = s_uniq[1] = 0;
+    __syncthreads();
+    const PsDMatch *mm = matches + (size_t)p * matchStride;
+    int ua = 0, ui = 0;
+    for (int i = tid; i < nIn; i += kBlock) {
+        int t = mm[i].trainIdx;
+        if (t >= 0 && t < a.trainRange) {
+            uint32_t bit = 1u << (t & 31);
+            uint32_t old = atomicOr(&s_bits[t >> 5], bit);
+            ua += (old & bit) ? 0 : 1;
+            if (mask[i]) {
+                old = atomicOr(&s_bits[words + (t >> 5)], bit);
+                ui += (old & bit) ? 0 : 1;
+            }
+        }
+    }
+    atomicAdd(&s_uniq[0], ua);
+    atomicAdd(&s_uniq[1], ui);
+    __syncthreads();
+
+    if (tid == 0) {
+        Rigid out = mdl;
+        if (!accepted) set_identity(out);
+        store_pose(poseOut + (size_t)p * 16, out);
+        PsRansacStats st;
+        st.numMatchesIn = nIn;
+        st.numMatchesValid = M;
+        st.bestHypothesis = bestIdx;
+        st.bestInlierCount = bestCount;
+        st.iterationsRun = trips;
+        st.numInliers = nfinal;
+        st.accepted = accepted ? 1 : 0;
+        st.bestInlierRatio = ratioF;
+        st.pointInlierRatio = (double)s_uniq[1] / (double)s_uniq[0];
+        statsOut[p] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone fits
+// ------------------------------------------------------------------------------------------
+// ps_umeyama_f32: one wavefront per point set.
+__global__ __launch_bounds__(64) void ps_umeyama_sets(const float *__restrict__ src, const float *__restrict__ dst,
+                                                      int k, int nsets, float *__restrict__ T,
+                                                      int32_t *__restrict__ valid)
+{
+    const int s = blockIdx.x;
+    if (s >= nsets) return;
+    const float *sp = src + (size_t)s * k * 3;
+    const float *dp = dst + (size_t)s * k * 3;
+    Rigid m;
+    bool ok = wave_umeyama(k,
+                           [&](int j, float (&sv)[3], float (&dv)[3]) {
+                               sv[0] = sp[3 * j]; sv[1] = sp[3 * j + 1]; sv[2] = sp[3 * j + 2];
+                               dv[0] = dp[3 * j]; dv[1] = dp[3 * j + 1]; dv[2] = dp[3 * j + 2];
+                           },
+                           m);
+    if ((threadIdx.x & 63) == 0) {
+        store_pose(T + (size_t)s * 16, m);
+        valid[s] = ok ? 1 : 0;
+    }
+}
+
+PS_D double wave_tree_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+PS_D double det3_lu(const double (&Ain)[3][3])
+{
+    // Eigen's dynamic-size determinant goes through PartialPivLU (kabschEst.cpp:53).
+    double m[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[i][j] = Ain[i][j];
+    double det = 1.0;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        int piv = kx;
+        double big = fabs(m[kx][kx]);
+#pragma unroll
+        for (int r = kx + 1; r < 3; ++r)
+            if (fabs(m[r][kx]) > big) {
+                big = fabs(m[r][kx]);
+                piv = r;
+            }
+        if (big == 0.0) return 0.0;
+#pragma unroll
+        for (int r = kx + 1; r < 3; ++r)
+            if (r == piv) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double t = m[kx][c];
+                    m[kx][c] = m[r][c];
+                    m[r][c] = t;
+                }
+                det = -det;
+            }
+        det *= m[kx][kx];
+#pragma unroll
+        for (int r = kx + 1; r < 3; ++r) {
+            double f = m[r][kx] / m[kx][kx];
+#pragma unroll
+            for (int c = kx + 1; c < 3; ++c) m[r][c] -= f * m[kx][c];
+        }
+    }
+    return det;
+}
+
+// KabschEst::computeTransformation (reference src/TransformEst/kabschEst.cpp:24-68), double precision.
+// A, B: n x 3 column-major with leading dimension ld.  One wavefront.
+__global__ __launch_bounds__(64) void ps_kabsch_f64_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                           int n, int ld, double *__restrict__ T)
+{
+    const int lane = threadIdx.x & 63;
+    double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+    for (int i = lane; i < n; i += 64) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sa[c] += A[(size_t)c * ld + i];
+            sb[c] += B[(size_t)c * ld + i];
+        }
+    }
+    double cA[3], cB[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cA[c] = wave_tree_sum_f64(sa[c]) / (double)n;
+        cB[c] = wave_tree_sum_f64(sb[c]) / (double)n;
+    }
+    double acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        double a[3], b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = A[(size_t)c * ld + i] - cA[c];
+            b[c] = B[(size_t)c * ld + i] - cB[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[r][c] += a[r] * b[c];
+    }
+    double Am[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Am[r][c] = wave_tree_sum_f64(acc[r][c]);
+    double V[3][3], W[3][3], S[3];
+    jacobi_svd3<double>(Am, V, S, W); // V = svd.matrixU(), W = svd.matrixV()  (kabschEst.cpp:48-49)
+    double det = det3_lu(Am);
+    double dsg = (det != 0.0) ? det : 1.0;
+    double d = (double)((dsg > 0.0) - (dsg < 0.0));
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = (W[i][0] * V[j][0] + W[i][1] * V[j][1]) + (W[i][2] * d) * V[j][2];
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double ti = (R[i][0] * (-cA[0]) + (R[i][1] * (-cA[1]) + R[i][2] * (-cA[2]))) + cB[i];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) T[4 * j + i] = R[i][j];
+                T[12 + i] = ti;
+            }
+        }
+    }
+}
+
+// RGBD::keypoints2Dto3D / point2Dto3D / roundSize (reference src/RGBD/RGBD.cpp:10-16,30-65).
+PS_D int round_size(double x, int size)
+{
+    if (x < 0)
+        x = 0;
+    else if (x > size - 1)
+        x = size; // sic: the reference clamps to size, not size-1
+    return (int)round(x);
+}
+__global__ __launch_bounds__(kBlock) void ps_backproject(const float *__restrict__ xy, int n,
+                                                         const uint8_t *__restrict__ depth, int rows, int cols,
+                                                         size_t step, float fx, float fy, float cx, float cy,
+                                                         double scale, float *__restrict__ out)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float x = xy[2 * i], y = xy[2 * i + 1];
+    int uR = round_size((double)x, cols), vR = round_size((double)y, rows);
+    size_t off = (size_t)vR * step + (size_t)uR * 2;
+    unsigned dv = 0;
+    // cv::Mat::at is plain pointer arithmetic: u == cols reads the first pixel of the next row;
+    // past the last row the reference reads out of bounds, here that is depth 0 (= missing).
+    if (off + 2 <= (size_t)rows * step) dv = (unsigned)depth[off] | ((unsigned)depth[off + 1] << 8);
+    float Z = (float)(((double)dv) / scale);
+    float u = (x - cx) / fx;
+    float v = (y - cy) / fy;
+    out[3 * i] = u * Z;
+    out[3 * i + 1] = v * Z;
+    out[3 * i + 2] = Z;
+}
+
+__global__ __launch_bounds__(kBlock) void ps_project_kernel(const float *__restrict__ xyz, int n, float fx, float fy,
+                                                            float cx, float cy, float *__restrict__ uv)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float u, v;
+    project(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], fx, fy, cx, cy, u, v);
+    uv[2 * i] = u;
+    uv[2 * i + 1] = v;
+}
+
+// Diagnostic: tabulates the device-side trip limits so tests can compare them with the direct
+// libm evaluation (RANSAC.cpp:457-461, USAC.h:944-971) for every (count, M).
+__global__ void ps_limits_table(SelectArgs a, int M, int32_t *__restrict__ out)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (c > M) return;
+    out[c - 1] = (a.estimator == PS_EST_USAC) ? usac_limit(a, (unsigned)c, (unsigned)M)
+                                              : ransac_limit(a, (float)c / (float)M);
+}
+
+} // namespace psdev

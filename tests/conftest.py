@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+    oracle_py.build()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """HIP context on device 0.  GPU tests fail (not skip) when the library or the device is missing."""
+    from putslam_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,311 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bar: bit-exact for match indices/distances, per-hypothesis inlier counts, the selected
+hypothesis, inlier masks and loop statistics; pose within 1e-5 of the oracle (it is in fact
+bit-identical because the device repeats the oracle's operation order, asserted separately).
+"""
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import (ADAPTIVE_ERROR, DMATCH_DTYPE, EST_FIXED, EST_RANSAC, EST_USAC, EUCLIDEAN_AND_REPROJECTION_ERROR,
+                              EUCLIDEAN_ERROR, MAHALANOBIS_ERROR, REPROJECTION_ERROR, TUM_FR1_K, default_ransac_params,
+                              make_config)
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5  # north_star: "pose within 1e-5"
+
+
+def _stats_equal(a, b):
+    for f in ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
+              "accepted"):
+        assert int(a[f]) == int(b[f]), (f, a, b)
+    assert np.float32(a["bestInlierRatio"]).tobytes() == np.float32(b["bestInlierRatio"]).tobytes()
+    pa, pb = float(a["pointInlierRatio"]), float(b["pointInlierRatio"])
+    assert (np.isnan(pa) and np.isnan(pb)) or pa == pb
+
+
+# ---------------------------------------------------------------- A1 matcher
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 500, 2000])
+def test_match_bit_exact(ctx, oracle, n):
+    a, b = synth.make_pair(n, config=2, index=n)
+    g = ctx.match_hamming256(a["desc"], b["desc"])
+    c = oracle.match_hamming256(a["desc"], b["desc"])
+    assert g.tobytes() == c.tobytes()
+
+
+@pytest.mark.parametrize("nq,nt", [(300, 1000), (1000, 300), (1, 700), (700, 1), (513, 511)])
+def test_match_ragged(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    t[:k] = q[rng.permutation(nq)[:k]] ^ np.packbits(rng.random((k, 256)) < 0.05, axis=1)
+    assert ctx.match_hamming256(q, t).tobytes() == oracle.match_hamming256(q, t).tobytes()
+
+
+def test_match_empty_and_pitch(ctx, oracle):
+    q = np.zeros((0, 32), np.uint8)
+    t = np.random.default_rng(0).integers(0, 256, (10, 32), dtype=np.uint8)
+    assert len(ctx.match_hamming256(q, t)) == 0
+    assert len(ctx.match_hamming256(t, q)) == 0
+    # cv::Mat with step > 32: padding bytes must be ignored
+    big = np.random.default_rng(1).integers(0, 256, (200, 48), dtype=np.uint8)
+    qv, tv = big[:100, :32], big[100:, :32]
+    assert not qv.flags["C_CONTIGUOUS"]
+    g = ctx.match_hamming256(qv, tv)
+    c = oracle.match_hamming256(np.ascontiguousarray(qv), np.ascontiguousarray(tv))
+    assert g.tobytes() == c.tobytes()
+
+
+def test_match_ties_and_duplicates(ctx, oracle):
+    # identical rows everywhere: every tie must resolve to the lowest index in both passes
+    q = np.tile(np.arange(32, dtype=np.uint8), (50, 1))
+    t = np.tile(np.arange(32, dtype=np.uint8), (70, 1))
+    g = ctx.match_hamming256(q, t)
+    c = oracle.match_hamming256(q, t)
+    assert g.tobytes() == c.tobytes()
+    assert len(g) == 1 and g[0]["queryIdx"] == 0 and g[0]["trainIdx"] == 0 and g[0]["distance"] == 0.0
+    # all-0 vs all-1: distance 256
+    g = ctx.match_hamming256(np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8))
+    assert g[0]["distance"] == 256.0
+
+
+# ---------------------------------------------------------------- A7 Umeyama
+@pytest.mark.parametrize("k", [3, 4, 5, 17, 63, 64, 65, 128, 500, 1500])
+def test_umeyama_bits(ctx, oracle, k):
+    rng = np.random.default_rng(k)
+    nsets = 20
+    src = (rng.uniform(-2, 2, (nsets, k, 3)) + [0, 0, 3]).astype(np.float32)
+    dst = np.empty_like(src)
+    for s in range(nsets):
+        R, t = synth.random_motion(rng, 30.0, 0.5)
+        dst[s] = (src[s] @ R.T + t + rng.normal(0, 0.004, (k, 3))).astype(np.float32)
+    T, valid = ctx.umeyama_f32(src, dst)
+    for s in range(nsets):
+        To, ok = oracle.umeyama_f32(src[s], dst[s])
+        assert ok == bool(valid[s])
+        assert T[s].tobytes() == To.tobytes(), (k, s, np.abs(T[s] - To).max())
+
+
+def test_umeyama_degenerate(ctx, oracle):
+    cases = []
+    p = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    cases.append((p, p.copy()))                                   # identity
+    cases.append((p, p + np.float32([0.1, 0.2, -0.3])))           # translation
+    cases.append((p, (p @ np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1]], np.float32))))  # 90 deg about z
+    cases.append((p, p * np.float32([1, -1, -1])))                # 180 deg about x
+    col = np.array([[0, 0, 1], [1, 1, 2], [2, 2, 3]], np.float32)
+    cases.append((col, col + np.float32(0.5)))                    # collinear
+    same = np.ones((3, 3), np.float32)
+    cases.append((same, same * 2))                                # coincident
+    nanp = p.copy()
+    nanp[1, 1] = np.nan
+    cases.append((nanp, p))                                       # NaN -> invalid -> identity
+    mirror = p * np.float32([1, 1, -1])
+    cases.append((p, mirror))                                     # reflection wanted by naive U V^T
+    for src, dst in cases:
+        Tg, vg = ctx.umeyama_f32(src, dst)
+        To, vo = oracle.umeyama_f32(src, dst)
+        assert vg == vo
+        assert Tg.tobytes() == To.tobytes()
+        if vo:
+            assert abs(np.linalg.det(Tg[:3, :3].astype(np.float64)) - 1.0) < 1e-5
+
+
+# ---------------------------------------------------------------- A4-A9, A11
+def _pair(n, idx):
+    a, b = synth.make_pair(n, config=2, index=idx)
+    return a, b
+
+
+@pytest.mark.parametrize("mode", [EUCLIDEAN_ERROR, REPROJECTION_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR, ADAPTIVE_ERROR,
+                                  MAHALANOBIS_ERROR])
+@pytest.mark.parametrize("est,H", [(EST_RANSAC, 487), (EST_USAC, 600), (EST_FIXED, 1024)])
+@pytest.mark.parametrize("n", [64, 500, 2000])
+def test_ransac_parity(ctx, oracle, mode, est, H, n):
+    a, b = _pair(n, 1000 + n)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    for seed in (1, 2):
+        cfg, _ = make_config(est, H, seed=seed)
+        g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+        c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+        _stats_equal(g["stats"], c["stats"])
+        assert np.array_equal(g["mask"], c["mask"])
+        assert g["inliers"].tobytes() == c["inliers"].tobytes()
+        assert np.abs(g["pose"] - c["pose"]).max() <= POSE_TOL
+        assert g["pose"].tobytes() == c["pose"].tobytes()  # same operation order => same bits
+
+
+@pytest.mark.parametrize("mode", [EUCLIDEAN_ERROR, REPROJECTION_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR, ADAPTIVE_ERROR])
+def test_hypothesis_counts_bit_exact(ctx, oracle, mode):
+    a, b = _pair(700, 77)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(EST_FIXED, 2048, seed=5)
+    g = ctx.debug_ransac_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    c, M = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    assert M > 100 and len(g) == 2048
+    assert np.array_equal(g, c)
+
+
+def test_hard_data_low_inliers(ctx, oracle):
+    # 25 % true correspondences, heavy noise: exercises the adaptive schedule with many records
+    for idx in range(6):
+        a, b = synth.make_pair(800, config=2, index=500 + idx, inlier_frac=0.25, noise=0.02)
+        m = oracle.match_hamming256(a["desc"], b["desc"])
+        for mode in (EUCLIDEAN_ERROR, REPROJECTION_ERROR):
+            for lc in (False, True):
+                prm = default_ransac_params(mode, lc=lc)
+                for est, H in ((EST_RANSAC, 1157), (EST_USAC, 3000)):
+                    cfg, _ = make_config(est, H, seed=idx)
+                    g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+                    c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+                    _stats_equal(g["stats"], c["stats"])
+                    assert np.array_equal(g["mask"], c["mask"])
+                    assert g["pose"].tobytes() == c["pose"].tobytes()
+
+
+def test_ransac_edge_cases(ctx, oracle):
+    a, b = _pair(300, 9)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=3)
+    K = TUM_FR1_K
+    # (a) no matches at all
+    g = ctx.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], np.zeros(0, DMATCH_DTYPE))
+    c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], np.zeros(0, DMATCH_DTYPE))
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["pose"], np.eye(4, dtype=np.float32))
+    # (b) fewer than minimalNumberOfMatches
+    g = ctx.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], m[:10])
+    c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], m[:10])
+    _stats_equal(g["stats"], c["stats"])
+    assert len(g["inliers"]) == 0 and np.array_equal(g["pose"], np.eye(4, dtype=np.float32))
+    # (c) all depths invalid -> filtered to zero
+    bad = np.zeros_like(b["pts"])
+    g = ctx.ransac_rigid3d(prm, cfg, K, a["pts"], bad, m)
+    c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], bad, m)
+    _stats_equal(g["stats"], c["stats"])
+    # (d) pure outliers: ratio gate rejects, identity + cleared inliers
+    rng = np.random.default_rng(4)
+    junk = (rng.uniform(-1, 1, b["pts"].shape) + [0, 0, 3]).astype(np.float32)
+    g = ctx.ransac_rigid3d(prm, cfg, K, a["pts"], junk, m)
+    c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], junk, m)
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+    # (e) NaN points and depth filter edges z = 0.1, 6.0 kept; 0.0999, 6.0001 dropped
+    p2, c2 = a["pts"].copy(), b["pts"].copy()
+    p2[m["queryIdx"][0]] = np.nan
+    c2[m["trainIdx"][1], 2] = 0.1
+    c2[m["trainIdx"][2], 2] = 6.0
+    c2[m["trainIdx"][3], 2] = 0.0999
+    c2[m["trainIdx"][4], 2] = 6.0001
+    g = ctx.ransac_rigid3d(prm, cfg, K, p2, c2, m)
+    c = oracle.ransac_rigid3d(prm, cfg, K, p2, c2, m)
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+    # (f) duplicate train indices in the match list -> pointInlierRatio counts unique indices
+    dup = m.copy()
+    dup["trainIdx"][: len(dup) // 2] = dup["trainIdx"][0]
+    g = ctx.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], dup)
+    c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], dup)
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["mask"], c["mask"])
+
+
+def test_explicit_sample_stream(ctx, oracle):
+    a, b = _pair(400, 21)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 2 ** 32, (487, 3), dtype=np.uint64).astype(np.uint32)
+    raw[5] = [7, 7, 7]          # repeats must be moved to the next free index
+    raw[6] = [0, 1, 0]
+    cfg, keep = make_config(EST_RANSAC, 487, seed=0, sample_idx=raw)
+    g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+    gc = ctx.debug_ransac_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    cc, _ = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    assert np.array_equal(gc, cc[: len(gc)])
+
+
+def test_threshold_edge_exact(ctx, oracle):
+    # residual exactly at float(0.04): inlier iff (double)norm < 0.04; craft points on the edge
+    n = 40
+    prev = np.zeros((n, 3), np.float32)
+    prev[:, 2] = 1.0
+    prev[:, 0] = np.linspace(-1, 1, n, dtype=np.float32)
+    prev[:, 1] = np.linspace(1, -1, n, dtype=np.float32) ** 2
+    cur = prev.copy()
+    thr = np.float32(0.04)
+    edge = [np.nextafter(thr, np.float32(0)), thr, np.nextafter(thr, np.float32(1))]
+    for i, e in enumerate(edge * 4):
+        cur[20 + i, 0] = prev[20 + i, 0] + e
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    prm.minimalNumberOfMatches = 5
+    raw = np.tile(np.uint32([0, 5, 10]), (8, 1))
+    cfg, keep = make_config(EST_FIXED, 8, seed=0, sample_idx=raw)
+    g = ctx.ransac_rigid3d(prm, cfg, None, prev, cur, m)
+    c = oracle.ransac_rigid3d(prm, cfg, None, prev, cur, m)
+    _stats_equal(g["stats"], c["stats"])
+    assert np.array_equal(g["mask"], c["mask"])
+    assert g["pose"].tobytes() == c["pose"].tobytes()
+
+
+# ---------------------------------------------------------------- A6 / A11 schedules
+@pytest.mark.parametrize("min_ratio", [0.2, 0.15, 0.1])
+def test_ransac_limit_table(ctx, oracle, min_ratio):
+    H = 4096
+    a = oracle.ransac_iterations(min_ratio)
+    for M in (3, 15, 133, 1200, 1283, 2000, 4999):
+        dev = ctx.debug_limits(EST_RANSAC, min_ratio, H, M)
+        ref = np.array([min(H, a, oracle.ransac_iterations(float(np.float32(c) / np.float32(M))))
+                        for c in range(1, M + 1)], np.int32)
+        assert np.array_equal(dev, ref), (M, np.nonzero(dev != ref)[0][:5])
+
+
+def test_usac_limit_table(ctx, oracle):
+    H = 5000
+    for M in (8, 133, 200, 1200, 3000):
+        dev = ctx.debug_limits(EST_USAC, 0.2, H, M)
+        ref = np.array([min(H, oracle.usac_stopping(c, M, 3)) for c in range(1, M + 1)], np.int32)
+        assert np.array_equal(dev, ref), (M, np.nonzero(dev != ref)[0][:5])
+
+
+# ---------------------------------------------------------------- A10 Kabsch (double)
+@pytest.mark.parametrize("n", [3, 100, 500, 4097])
+def test_kabsch_f64(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    A = rng.uniform(-1.5, 1.5, (n, 3))
+    R, _ = synth.random_motion(rng, 40.0, 0.0)
+    B = A @ R.T + np.array([0.1, 0.2, -0.3]) + rng.normal(0, 1, (n, 3)) * [0.01, 0.02, 0.03]
+    Tg = ctx.kabsch_f64(A, B)
+    To = oracle.kabsch_f64(A, B)
+    assert np.abs(Tg - To).max() < 1e-12  # summation tree differs from the oracle's sequential sums
+    assert abs(np.linalg.det(Tg[:3, :3]) - 1) < 1e-12
+    assert np.array_equal(ctx.kabsch_f64(np.zeros((0, 3)), np.zeros((0, 3))), np.eye(4))
+
+
+# ---------------------------------------------------------------- A3 geometry helpers
+def test_backprojection_bits(ctx, oracle):
+    rng = np.random.default_rng(3)
+    depth = rng.integers(0, 30000, (480, 640)).astype(np.uint16)
+    xy = np.stack([rng.uniform(-5, 645, 3000), rng.uniform(-5, 485, 3000)], 1).astype(np.float32)
+    xy[:8] = [[318.6, 255.3], [0, 0], [639, 479], [639.4, 10], [639.6, 10], [10, 479.6], [640, 480], [-1, -1]]
+    g = ctx.keypoints2Dto3D(xy, depth, TUM_FR1_K, 5000.0)
+    c = oracle.keypoints2Dto3D(xy, depth, TUM_FR1_K, 5000.0)
+    assert g.tobytes() == c.tobytes()
+    d1 = np.full((480, 640), 5000, np.uint16)
+    g = ctx.keypoints2Dto3D(np.float32([[318.6, 255.3]]), d1, TUM_FR1_K, 5000.0)
+    assert np.array_equal(g, np.float32([[0, 0, 1]]))
+    uvg = ctx.points3Dto2D(c, TUM_FR1_K)
+    uvc = oracle.points3Dto2D(c, TUM_FR1_K)
+    assert uvg.tobytes() == uvc.tobytes()
