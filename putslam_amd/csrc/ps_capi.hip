@@ -41,6 +41,7 @@ struct PsContext {
     // cached stop tables
     int tabEstimator = -1, tabH = -1, tabRN = 0, tabUN = 0, tabIter0 = 0;
     double tabMinRatio = -1.0;
+    float tabTiny = 0.0f;
     // timing
     bool timing = false;
     hipEvent_t ev[2 * kMaxTimed] = {};
@@ -121,8 +122,24 @@ unsigned usac_stopping_host(double prob_good_model)
 
 // Threshold tables: the device never evaluates log/pow, it binary-searches these host-built
 // (hence libm-identical) step positions.
-void build_ransac_table(double minRatio, int H, std::vector<float> &tab, int &iter0)
+void build_ransac_table(double minRatio, int H, std::vector<float> &tab, int &iter0, float &tiny)
 {
+    // For r below ~6e-6, 1 - r^3 rounds to 1, log(1) = +0 and the quotient is -inf: the reference's
+    // int(-inf) is UB (INT_MIN on x86: the loop ends); ransac_iterations_host returns 0 there.  The
+    // step positions below are searched above that range, and the range itself is passed to the
+    // device as `tiny` (limit 0), so device and host agree for every float ratio.
+    uint32_t tlo = 0, thi;
+    {
+        float probe = 1e-4f; // iterations(1e-4) saturates at INT_MAX
+        memcpy(&thi, &probe, 4);
+        while (thi - tlo > 1) {
+            uint32_t mid = tlo + (thi - tlo) / 2;
+            float mf;
+            memcpy(&mf, &mid, 4);
+            if (ransac_iterations_host((double)mf) == 0) tlo = mid; else thi = mid;
+        }
+        memcpy(&tiny, &tlo, 4); // largest float whose quotient is -inf
+    }
     int itersMin = ransac_iterations_host(minRatio);
     int kcap = itersMin < H ? itersMin : H;
     if (kcap < 0) kcap = 0;
@@ -134,7 +151,7 @@ void build_ransac_table(double minRatio, int H, std::vector<float> &tab, int &it
     for (int k = 0; k < kcap; ++k) {
         // smallest float r in (0,1] with iterations(r) <= k.  The table is non-increasing in k, so the
         // previous entry (iterations <= k-1 <= k) is a valid upper end of the bracket.
-        uint32_t lo = 0; // bits of +0.0f: iterations(0) saturates, > k
+        uint32_t lo = thi; // just above the -inf range: iterations saturate at INT_MAX > k
         while (hi - lo > 1) {
             uint32_t mid = lo + (hi - lo) / 2;
             float mf;
@@ -200,7 +217,7 @@ int prepare_tables(PsContext *ctx, int estimator, double minRatio, int H, Select
         if (estimator == PS_EST_RANSAC) {
             std::vector<float> tab;
             int iter0 = 0;
-            build_ransac_table(minRatio, H, tab, iter0);
+            build_ransac_table(minRatio, H, tab, iter0, ctx->tabTiny);
             PS_ENSURE(ctx->tabR, tab.size() * sizeof(float) + 4);
             if (!tab.empty()) {
                 PS_HIP(hipMemcpyAsync(ctx->tabR.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice,
@@ -229,6 +246,7 @@ int prepare_tables(PsContext *ctx, int estimator, double minRatio, int H, Select
     if (estimator == PS_EST_RANSAC) {
         sa.ransacTab = (const float *)ctx->tabR.p;
         sa.ransacTabN = ctx->tabRN;
+        sa.ransacTiny = ctx->tabTiny;
     } else {
         sa.usacTab = (const double *)ctx->tabU.p;
         sa.usacTabN = ctx->tabUN;

@@ -434,6 +434,7 @@ struct SelectArgs {
     double minRatio;     // minimalInlierRatioThreshold
     const float *ransacTab;  // non-increasing; ransacTab[k] = smallest ratio r with iterations(r) <= k
     int ransacTabN;
+    float ransacTiny;        // ratios <= this make the reference's quotient -inf (limit 0)
     const double *usacTab;   // non-increasing; usacTab[k] = smallest p with stopping(p) <= k+1
     int usacTabN;
     int trainRange;      // train indices are < trainRange (size of the uniqueness bitmaps, 0 = skip)
@@ -442,6 +443,7 @@ struct SelectArgs {
 // min(Kcap, computeRANSACIteration(r)) through the host-built threshold table (RANSAC.cpp:450-461).
 PS_D int ransac_limit(const SelectArgs &a, float r)
 {
+    if (r <= a.ransacTiny) return 0;
     int lo = 0, hi = a.ransacTabN; // first k with r >= tab[k]
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
