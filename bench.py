@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/s through match + RANSAC + Kabsch/Umeyama on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (ps_vo_pairs_device: Hamming match -> cross-check ->
+depth filter -> H Umeyama hypotheses scored on all matches -> selection -> refit -> final
+inliers) over one batch of synthetic frame pairs that is already resident in HBM.
+
+Workload (BASELINE.json configs[2], the 2000-keypoint throughput case of the metric; configs[3]
+= the same per GPU at N > 1): one TUM-fr1-style synthetic sequence of 500 frames = 499 frame
+pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypotheses per pair
+(fixed, adaptive stop disabled), reprojection error (errorVersion 1, north_star), shipped
+thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
+72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
+
+Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one non-FMA op per lane-cycle)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=500, help="frames per sequence (pairs = frames - 1)")
+    ap.add_argument("--kpts", type=int, default=2000)
+    ap.add_argument("--hyp", type=int, default=4096)
+    ap.add_argument("--error-version", type=int, default=1, help="RANSAC::ERROR_VERSION (0 Euclid, 1 reprojection)")
+    ap.add_argument("--estimator", default="fixed", choices=["fixed", "ransac", "usac"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from putslam_amd import api, synth
+    from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config)
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+
+    est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
+    ctx = api.Context(local_rank)
+    prm = default_ransac_params(args.error_version)
+    cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + rank)
+
+    # -- synthetic sequence of this rank (config 3; config 4 = one such sequence per GPU) --
+    seq = synth.make_sequence(args.frames, args.kpts, config=3, index=rank)
+    P = len(seq["pairs"])
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
+    rec = torch.zeros((P, 18), dtype=torch.float32, device=dev)      # pose16 + inliers + matches (72 B / pair)
+    gathered = [torch.zeros_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)                 # inputs already in HBM
+        if world > 1:
+            # the only exchange of the path: per-pair results to rank 0 (RCCL gather over xGMI)
+            rec[:, :16] = pb.pose
+            st = pb.stats.view(torch.int32).view(P, -1)
+            rec[:, 16] = st[:, 5].to(torch.float32)
+            rec[:, 17] = st[:, 0].to(torch.float32)
+            dist.gather(rec, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.enable_timing(True)                                            # HIP events on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    totals = ctx.kernel_time_totals()
+    ctx.enable_timing(False)
+    res = pb.download()
+
+    if rank == 0:
+        stats = res["stats"]
+        pairs_total = P * world * args.steps
+        value = pairs_total / elapsed
+        m_in = float(stats["numMatchesIn"].mean())
+        m_valid = float(stats["numMatchesValid"].mean())
+        Hs = args.hyp
+        bytes_per_pair = float(np.mean([api.algorithmic_bytes(args.kpts, int(s["numMatchesIn"]),
+                                                              int(s["numMatchesValid"]), Hs) for s in stats]))
+        kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # average launch duration, ms
+        dom = max(kern, key=kern.get)
+        dom_ms = kern[dom]
+        achieved = bytes_per_pair * P / (dom_ms * 1e-3) / 1e9
+        # non-FMA VALU work of the two sweeps: 18 ops per descriptor pair; per (hypothesis, match)
+        # 29 ops (Euclid) or ~150 (reprojection incl. 4 IEEE divides).
+        ops_match = 18.0 * args.kpts * args.kpts
+        ops_score = (29.0 if args.error_version in (0, 4) else 150.0) * Hs * m_valid
+        valu = {
+            "ps_hamming_nn": ops_match * P / (kern.get("ps_hamming_nn", float("nan")) * 1e-3) / 1e12,
+            "ps_ransac_score": ops_score * P / (kern.get("ps_ransac_score", float("nan")) * 1e-3) / 1e12,
+        }
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf))
+                key = f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}"
+                traffic = t.get(key, {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
+            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[2]: TUM fr1/desk-style synthetic sequence, "
+                             f"{args.frames} frames = {P} frame pairs per step per GPU, {args.kpts} kpts/frame, "
+                             "256-bit descriptors, Hamming BF + cross-check -> depth filter -> "
+                             f"H={args.hyp} 3-pt Umeyama hypotheses ({args.estimator}) scored with errorVersion "
+                             f"{args.error_version} -> refit; inputs resident in HBM" +
+                             ("; configs[3]: one sequence per GPU, RCCL gather of 72 B/pair to rank 0" if world > 1
+                              else "")),
+                "pairs_per_step": P * world, "kpts": args.kpts, "hypotheses": args.hyp,
+                "errorVersion": args.error_version, "estimator": args.estimator,
+                "mean_matches": m_in, "mean_valid_matches": m_valid,
+                "mean_inliers": float(stats["numInliers"].mean()),
+                "accepted_pairs": int(stats["accepted"].sum()),
+            },
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": P,
+                         "avg_launch_ms": dom_ms,
+                         "note": "path is VALU-bound, not HBM-bound (DESIGN.md): see valu_tops"},
+            "kernel_ms": kern,
+            "valu_tops": {"achieved": valu, "peak": VALU_PEAK_TOPS,
+                          "frac": {k: v / VALU_PEAK_TOPS for k, v in valu.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline(args, seq, prm, cfg, est))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, seq, prm, cfg, est):
+    """The oracle (CPU restatement of the reference algorithm) timed on this host's cores, on a bounded
+    sample of the same workload.  It is the checker being timed as a baseline, never the product."""
+    from oracle import oracle_py as po
+    from putslam_amd._abi import EST_RANSAC, TUM_FR1_K, make_config
+    cores = os.cpu_count() or 1
+    pairs = seq["pairs"]
+
+    def run(cfg_, n, threads):
+        t0 = time.perf_counter()
+        po.vo_pairs(prm, cfg_, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], pairs[:n], threads=threads)
+        return time.perf_counter() - t0
+
+    n0 = min(len(pairs), max(cores, 2))
+    t = run(cfg, n0, cores)                                   # calibration (also warms the pages)
+    n = int(min(len(pairs), max(n0, n0 * args.cpu_seconds / max(t, 1e-3))))
+    t = run(cfg, n, cores)
+    out = {"cpu_baseline": {"value": n / t, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                            "sample": f"first {n} of {len(pairs)} pairs of the same sequence, same H/errorVersion/"
+                                      f"estimator as the GPU run, OpenMP over pairs, {t:.1f} s"}}
+    # what the reference itself would do: sequential adaptive schedule, <= 487 iterations (RANSAC.cpp:30,450-453)
+    cfg_ref, _ = make_config(EST_RANSAC, 487, seed=cfg.seed)
+    n2 = min(len(pairs), max(n, 4 * cores))
+    t2 = run(cfg_ref, n2, cores)
+    t1 = run(cfg_ref, min(n2, 16), 1)
+    out["cpu_reference_schedule"] = {
+        "value": n2 / t2, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+        "single_thread_value": min(n2, 16) / t1,
+        "sample": f"{n2} pairs, adaptive RANSAC schedule of the reference (<=487 iterations), all cores; "
+                  f"single_thread_value on {min(n2, 16)} pairs"}
+    return out
+
+
+if __name__ == "__main__":
+    main()

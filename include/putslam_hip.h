@@ -197,10 +197,14 @@ uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int nu
  * double-NUL terminated (used by the bench to pick rows out of rocprofv3 output). */
 const char *ps_kernel_names(void);
 
-/* Time the kernels of the most recent ps_vo_pairs_device call (HIP events recorded on the
- * context's stream around every launch).  ms must hold 8 floats; returns the kernel count. */
-int ps_last_kernel_times_ms(PsContext *ctx, float *ms);
+/* Kernel timing: when enabled, every ps_vo_pairs_device call brackets each of its kernel
+ * launches with HIP events recorded on the context's stream (the stream the kernels run on).
+ * Enabling (again) resets the record; the last 128 calls are kept.
+ * ps_last_kernel_times_ms: the most recent call (ms holds 8 floats; returns the kernel count).
+ * ps_kernel_time_totals: sums and launch counts over all kept calls (arrays of 8). */
 int ps_context_enable_timing(PsContext *ctx, int enable);
+int ps_last_kernel_times_ms(PsContext *ctx, float *ms);
+int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches);
 
 /* ---- diagnostics (used by the parity tests; no reference counterpart) -------------------- */
 /* ps_ransac_rigid3d's scoring stage only: counts[h] = inlier count kernel 3 produced for

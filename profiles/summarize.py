@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turns one gpurun_out/prof_<tag>/ directory (written by profiles/run_profiles.sh on the GPU box) into
+the tracked summary under profiles/<tag>/ and refreshes profiles/pmc_traffic.json, which bench.py reads
+for roofline.traffic (HBM bytes per launch of each kernel from the rocprofv3 PMC passes).
+
+usage: python profiles/summarize.py <tag> [workload-key]
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    key = sys.argv[2] if len(sys.argv) > 2 else "500x2000xH4096xE1xfixed"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    for log in ("bench_trace.log",):
+        for line in open(os.path.join(src, log)):
+            if line.startswith("{"):
+                with open(os.path.join(dst, "bench_under_rocprof.json"), "w") as f:
+                    f.write(line)
+    kern = {}
+    for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        path = os.path.join(src, name, "bench_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            k = r["Kernel_Name"]
+            if "psdev::" not in k or r["Counter_Name"] != ctr:
+                continue
+            agg[k.split("psdev::")[1].split("<")[0].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            kern.setdefault(k, {})[ctr + "_KB_per_launch"] = sum(v) / len(v)
+            kern[k]["launches"] = len(v)
+    summary = {
+        "command": "profiles/run_profiles.sh " + tag + "  (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE: "
+                   "three separate passes of the same bench.py command)",
+        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch. The reads of these kernels are scalar loads "
+                "(s_load_dwordx4/x8 through the scalar cache) and 16-byte vector loads; the gfx950 x2 correction "
+                "of MI355X_MICROARCH.md is stated for wide coalesced streams only and is NOT applied "
+                "(uncalibrated for this access pattern).",
+        "kernels": kern}
+    with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    allt[key] = {k: int((v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024)
+                 for k, v in kern.items()}
+    allt[key]["_source"] = f"profiles/{tag}/pmc_summary.json"
+    with open(tf, "w") as f:
+        json.dump(allt, f, indent=1)
+    print(json.dumps(summary["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,8 @@ EXPORTED = [
     "ps_last_error", "ps_abi_version", "ps_device_arch",
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device",
-    "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_context_enable_timing",
+    "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
+    "ps_context_enable_timing",
     "ps_debug_ransac_counts", "ps_debug_limits",
     "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
     "ps_abi_sizeof_frameset", "ps_abi_sizeof_results",
@@ -38,6 +39,15 @@ def load():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Loading it first lets
+    # the dynamic linker satisfy our DT_NEEDED libamdhip64.so.7 with the copy torch uses, so torch tensors,
+    # torch streams and our kernels share one runtime (two runtimes in one process cannot both see the GPU).
+    # Consumers that do not use torch (the C++ drop-in) link /opt/rocm's runtime as usual.
+    if os.environ.get("PUTSLAM_HIP_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: stand-alone use
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     L.ps_context_create.argtypes = [i32, C.POINTER(vp)]
@@ -65,6 +75,7 @@ def load():
     L.ps_algorithmic_bytes.restype = C.c_uint64
     L.ps_kernel_names.restype = C.POINTER(C.c_char)
     L.ps_last_kernel_times_ms.argtypes = [vp, vp]
+    L.ps_kernel_time_totals.argtypes = [vp, vp, vp]
     L.ps_context_enable_timing.argtypes = [vp, i32]
     for n in ("dmatch", "params", "config", "stats", "frameset", "results"):
         getattr(L, "ps_abi_sizeof_" + n).restype = sz

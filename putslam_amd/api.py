@@ -70,6 +70,16 @@ class Context:
         names = kernel_names()
         return {names[i] if i < len(names) else f"k{i}": float(ms[i]) for i in range(n)}
 
+    def kernel_time_totals(self):
+        """{kernel name: (sum of launch durations in ms, launches)} over the calls since enable_timing()."""
+        sums = np.zeros(8, np.float64)
+        cnt = np.zeros(8, np.int32)
+        n = self._L.ps_kernel_time_totals(self._h, _p(sums), _p(cnt))
+        if n < 0:
+            self._chk(n)
+        names = kernel_names()
+        return {names[i]: (float(sums[i]), int(cnt[i])) for i in range(n)}
+
     # ---- A1 ----
     def match_hamming256(self, query, train):
         """MatcherOpenCV::performMatching (matcherOpenCV.cpp:198-206): query=prev rows, train=cur rows (uint8, 32 cols)."""

@@ -23,7 +23,8 @@ struct Buf {
     size_t cap = 0;
 };
 
-constexpr int kMaxTimed = 8;
+constexpr int kMaxTimed = 8;   // kernels timed per call
+constexpr int kTimingRing = 128; // calls kept (HIP events on the launch stream around every kernel)
 
 } // namespace
 
@@ -44,8 +45,10 @@ struct PsContext {
     float tabTiny = 0.0f;
     // timing
     bool timing = false;
-    hipEvent_t ev[2 * kMaxTimed] = {};
-    int nTimed = 0;
+    std::vector<hipEvent_t> ev; // [kTimingRing][kMaxTimed][2], created when timing is first enabled
+    long long timedCalls = 0;   // calls recorded since timing was (re)enabled
+    int curCall = 0;            // ring slot of the call being recorded
+    int nTimed = 0;             // kernels per call
 };
 
 namespace {
@@ -326,8 +329,8 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
 
 void tick(PsContext *ctx, int slot, bool stop)
 {
-    if (!ctx->timing || slot >= kMaxTimed) return;
-    (void)hipEventRecord(ctx->ev[2 * slot + (stop ? 1 : 0)], ctx->stream);
+    if (!ctx->timing || slot >= kMaxTimed || ctx->ev.empty()) return;
+    (void)hipEventRecord(ctx->ev[((size_t)ctx->curCall * kMaxTimed + slot) * 2 + (stop ? 1 : 0)], ctx->stream);
     if (stop && slot + 1 > ctx->nTimed) ctx->nTimed = slot + 1;
 }
 
@@ -437,6 +440,14 @@ void identity16(float *T)
     for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
 }
 
+// The host-pointer entry points are not part of the timed record.
+struct TimingOff {
+    PsContext *c;
+    bool saved;
+    explicit TimingOff(PsContext *ctx) : c(ctx), saved(ctx->timing) { c->timing = false; }
+    ~TimingOff() { c->timing = saved; }
+};
+
 int bind(PsContext *ctx)
 {
     if (!ctx) return PS_ERR_BAD_ARG;
@@ -479,11 +490,6 @@ int ps_context_create(int device, PsContext **out)
         return PS_ERR_HIP;
     }
     ctx->stream = ctx->own;
-    for (int i = 0; i < 2 * kMaxTimed; ++i)
-        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
-            delete ctx;
-            return PS_ERR_HIP;
-        }
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
@@ -503,8 +509,8 @@ void ps_context_destroy(PsContext *ctx)
                   &ctx->sPairs, &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
     for (Buf *b : all) release(*b);
-    for (int i = 0; i < 2 * kMaxTimed; ++i)
-        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (hipEvent_t e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
 }
@@ -529,8 +535,15 @@ const char *ps_device_arch(const PsContext *ctx) { return ctx ? ctx->arch : ""; 
 
 int ps_context_enable_timing(PsContext *ctx, int enable)
 {
-    if (!ctx) return PS_ERR_BAD_ARG;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (enable && ctx->ev.empty()) {
+        ctx->ev.assign((size_t)kTimingRing * kMaxTimed * 2, nullptr);
+        for (hipEvent_t &e : ctx->ev) PS_HIP(hipEventCreate(&e));
+    }
     ctx->timing = enable != 0;
+    ctx->timedCalls = 0;
+    ctx->curCall = 0;
     ctx->nTimed = 0;
     return PS_OK;
 }
@@ -539,12 +552,36 @@ int ps_last_kernel_times_ms(PsContext *ctx, float *ms)
 {
     int rc = bind(ctx);
     if (rc) return rc;
+    if (!ctx->timing || ctx->timedCalls == 0) return 0;
     PS_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ctx->nTimed; ++i) {
         float t = 0.f;
-        PS_HIP(hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+        size_t b = ((size_t)ctx->curCall * kMaxTimed + i) * 2;
+        PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
         ms[i] = t;
     }
+    return ctx->nTimed;
+}
+
+int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < kMaxTimed; ++i) {
+        sum_ms[i] = 0.0;
+        launches[i] = 0;
+    }
+    if (!ctx->timing || ctx->timedCalls == 0) return 0;
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    long long n = ctx->timedCalls < kTimingRing ? ctx->timedCalls : kTimingRing;
+    for (long long c = 0; c < n; ++c)
+        for (int i = 0; i < ctx->nTimed; ++i) {
+            float t = 0.f;
+            size_t b = ((size_t)c * kMaxTimed + i) * 2;
+            PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
+            sum_ms[i] += t;
+            launches[i] += 1;
+        }
     return ctx->nTimed;
 }
 
@@ -567,6 +604,7 @@ int ps_match_hamming256(PsContext *ctx, const uint8_t *query, int nq, size_t qst
 {
     int rc = bind(ctx);
     if (rc) return rc;
+    TimingOff toff(ctx);
     if (nout) *nout = 0;
     if (!out || !nout || nq < 0 || nt < 0 || (nq > 0 && !query) || (nt > 0 && !train))
         return fail(ctx, PS_ERR_BAD_ARG, "ps_match_hamming256: bad argument");
@@ -615,6 +653,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
 {
     int rc = bind(ctx);
     if (rc) return rc;
+    TimingOff toff(ctx);
     PsRansacStats st;
     memset(&st, 0, sizeof st);
     st.bestHypothesis = -1;
@@ -859,7 +898,10 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     Plan pl;
     rc = make_plan(ctx, params, cfg, K, cap, cap, pl);
     if (rc) return rc;
-    ctx->nTimed = 0;
+    if (ctx->timing) {
+        ctx->curCall = (int)(ctx->timedCalls % kTimingRing);
+        ctx->timedCalls++;
+    }
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     return run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask,

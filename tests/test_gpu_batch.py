@@ -1,0 +1,102 @@
+"""Device-resident batched path (ps_vo_pairs_device) vs the oracle's Matcher::match data flow."""
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, EUCLIDEAN_ERROR, REPROJECTION_ERROR, TUM_FR1_K,
+                              default_ransac_params, make_config)
+
+pytestmark = pytest.mark.gpu
+
+STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
+               "accepted", "bestInlierRatio", "pointInlierRatio")
+
+
+def _compare(g, c, P):
+    assert np.array_equal(g["numMatches"], c["numMatches"])
+    for p in range(P):
+        n = int(c["numMatches"][p])
+        assert g["matches"][p, :n].tobytes() == c["matches"][p, :n].tobytes(), p
+        assert np.array_equal(g["inlierMask"][p, :n], c["inlierMask"][p, :n]), p
+        for f in STAT_FIELDS:
+            a, b = g["stats"][p][f], c["stats"][p][f]
+            assert a == b or (np.isnan(a) and np.isnan(b)), (p, f, a, b)
+    assert np.abs(g["pose"] - c["pose"]).max() <= 1e-5
+    assert g["pose"].tobytes() == c["pose"].tobytes()
+
+
+@pytest.mark.parametrize("mode,est,H", [(EUCLIDEAN_ERROR, EST_RANSAC, 487), (REPROJECTION_ERROR, EST_RANSAC, 487),
+                                        (REPROJECTION_ERROR, EST_FIXED, 1024), (EUCLIDEAN_ERROR, EST_USAC, 800)])
+def test_sequence_batch(ctx, oracle, mode, est, H):
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(9, 600, config=3, index=mode * 10 + est)
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(est, H, seed=1234)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=4)
+    _compare(g, c, len(seq["pairs"]))
+    # poses must also be close to the generator's ground truth (sanity of the whole path)
+    for p in range(len(seq["pairs"])):
+        if g["stats"][p]["accepted"]:
+            T = g["pose"][p].reshape(4, 4).T
+            assert np.abs(T - seq["gt"][p]).max() < (3e-2 if est == EST_USAC else 5e-3)  # USAC: minimal-sample pose, no refit
+
+
+def test_ragged_frames_and_arbitrary_pairs(ctx, oracle):
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(6, 512, config=3, index=77)
+    nk = np.array([512, 300, 511, 1, 0, 450], np.int32)  # ragged, a single-keypoint and an empty frame
+    pairs = np.array([[0, 1], [1, 2], [2, 0], [3, 2], [4, 5], [5, 4], [0, 0], [5, 3]], np.int32)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=5)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], nk)
+    pb = PairBatchDevice(pairs, fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], nk, pairs, threads=2)
+    _compare(g, c, len(pairs))
+
+
+def test_full_size_properties(ctx, oracle):
+    """BASELINE config sizes (2000 kpts, H = 4096): oracle on a sample of pairs + size-independent properties."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(33, 2000, config=3, index=1)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=42)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    P = len(seq["pairs"])
+    # idempotence: a second run over the same inputs is bit-identical
+    pb2 = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb2)
+    g2 = pb2.download()
+    assert g["pose"].tobytes() == g2["pose"].tobytes() and np.array_equal(g["inlierMask"], g2["inlierMask"])
+    for p in range(P):
+        n = int(g["numMatches"][p])
+        m = g["matches"][p, :n]
+        assert np.all(np.diff(m["queryIdx"]) > 0)                 # ascending queryIdx, unique
+        assert len(np.unique(m["trainIdx"])) == n                 # each train row chose exactly one query
+        assert np.all((m["distance"] >= 0) & (m["distance"] <= 256))
+        st = g["stats"][p]
+        assert st["numMatchesIn"] == n and st["numInliers"] == int(g["inlierMask"][p, :n].sum())
+        assert st["numInliers"] <= st["bestInlierCount"] <= st["numMatchesValid"] <= n
+        T = g["pose"][p].reshape(4, 4).T.astype(np.float64)
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-5 and np.abs(T[:3, :3] @ T[:3, :3].T - np.eye(3)).max() < 1e-5
+        assert np.abs(T - seq["gt"][p]).max() < 5e-3
+    sample = [0, 7, 31]
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][sample], threads=3)
+    gs = {k: v[sample] for k, v in g.items()}
+    # hypothesis streams are seeded with seed + pair index: re-run the sampled pairs at their own index
+    for j, p in enumerate(sample):
+        cfgp, _ = make_config(EST_FIXED, 4096, seed=42 + p)
+        n = int(g["numMatches"][p])
+        cc = oracle.ransac_rigid3d(prm, cfgp, TUM_FR1_K, seq["desc"] is None or seq["pts"][p], seq["pts"][p + 1],
+                                   g["matches"][p, :n])
+        assert c["matches"][j, :n].tobytes() == g["matches"][p, :n].tobytes()
+        assert np.array_equal(cc["mask"], g["inlierMask"][p, :n])
+        assert cc["pose"].T.astype(np.float32).tobytes() == g["pose"][p].tobytes()
