@@ -82,18 +82,17 @@ def main():
     P = len(seq["pairs"])
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
-    rec = torch.zeros((P, 18), dtype=torch.float32, device=dev)      # pose16 + inliers + matches (72 B / pair)
-    gathered = [torch.zeros_like(rec) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from putslam_amd import sharding
+    gathered = ([torch.zeros((P, sharding.RECORD_FLOATS), dtype=torch.float32, device=dev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
 
     def step():
         run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)                 # inputs already in HBM
         if world > 1:
-            # the only exchange of the path: per-pair results to rank 0 (RCCL gather over xGMI)
-            rec[:, :16] = pb.pose
-            st = pb.stats.view(torch.int32).view(P, -1)
-            rec[:, 16] = st[:, 5].to(torch.float32)
-            rec[:, 17] = st[:, 0].to(torch.float32)
-            dist.gather(rec, gathered, dst=0)
+            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI
+            st = pb.stats.view(torch.int32).view(P, -1)              # PsRansacStats: [5] numInliers, [0] numMatchesIn
+            rec = sharding.pack_records(pb.pose, st[:, 5], st[:, 0])
+            sharding.gather_records(rec, dst=0, out=gathered)
 
     def fence():
         if world > 1:

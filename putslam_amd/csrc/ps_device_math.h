@@ -72,11 +72,13 @@ template <typename T> PS_HD void make_jacobi(T x, T y, T z, T &c, T &s)
 template <typename T> PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3])
 {
     T W[3][3];
-    T scale = T(0);
+    // cwiseAbs().maxCoeff(): the visitor starts from (0,0) and walks column by column keeping
+    // `value > current`, so a NaN at (0,0) makes the scale (and then the whole work matrix) NaN.
+    T scale = ps_abs(A[0][0]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int i = 0; i < 3; ++i) {
             T a = ps_abs(A[i][j]);
             if (a > scale) scale = a;
         }

@@ -1,0 +1,68 @@
+"""C-ABI library: loads here (no GPU), exports every symbol include/putslam_hip.h declares, PODs have the
+sizes the Python/foreign bindings assume, and a missing device fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "putslam_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ps_[a-zA-Z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from putslam_amd import _lib
+    L = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/putslam_hip.h but not exported by libputslam_hip.so"
+    for n in _lib.EXPORTED:
+        assert n in names, f"{n} bound in Python but not declared in the header"
+
+
+def test_struct_layout_matches_library():
+    from putslam_amd import _lib
+    L = _lib.load()
+    for name, size in _lib.struct_sizes().items():
+        assert getattr(L, "ps_abi_sizeof_" + name)() == size, name
+    assert L.ps_abi_version() == 1
+
+
+def test_kernel_names_and_bytes_formula():
+    from putslam_amd import api
+    assert api.kernel_names() == ["ps_hamming_nn", "ps_crosscheck_prep", "ps_ransac_score", "ps_select_refit"]
+    # SURVEY.md section 8(d) reference points
+    assert api.algorithmic_bytes(2000, 1200, 1200, 4096) == 271600
+    assert api.algorithmic_bytes(2000, 1200, 1200, 487) == 213856
+    assert api.algorithmic_bytes(5000, 3000, 3000, 100000) == 2115064
+
+
+def test_no_device_fails_loudly():
+    import torch
+    from putslam_amd import api
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.PsError) as e:
+        api.Context(0)
+    assert e.value.code == -2  # PS_ERR_NO_DEVICE: the product never falls back to a CPU path
+
+
+def test_product_never_touches_oracle():
+    """The oracle is test infrastructure: nothing under putslam_amd/ or include/ may reference it."""
+    for base in ("putslam_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "oracle_py" not in txt and "putslam_oracle" not in txt and "po_" + "match" not in txt, \
+                        os.path.join(dp, f)
+    so = os.path.join(ROOT, "putslam_amd", "libputslam_hip.so")
+    syms = os.popen(f"nm -D --undefined-only {so}").read()
+    assert "po_" not in syms

@@ -1,0 +1,308 @@
+"""Known-answer tests that pin the CPU oracle.  The reference has no tests and
+cannot be compiled here (OpenCV/Eigen absent), so the oracle is pinned by analytic answers, by the
+tables of section 8a (A6, A11) and by independent float64 numpy computations."""
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import (ADAPTIVE_ERROR, DMATCH_DTYPE, EST_FIXED, EST_RANSAC, EST_USAC,
+                              EUCLIDEAN_AND_REPROJECTION_ERROR, EUCLIDEAN_ERROR, REPROJECTION_ERROR, TUM_FR1_K,
+                              default_ransac_params, make_config)
+
+
+def dm(rows):
+    a = np.zeros(len(rows), DMATCH_DTYPE)
+    for i, (q, t, d) in enumerate(rows):
+        a[i] = (q, t, 0, d)
+    return a
+
+
+# ------------------------------------------------------------------ Hamming + cross-check (A1)
+def test_hamming_known_answers(oracle):
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert oracle.hamming256(z, o) == 256 and oracle.hamming256(z, z) == 0
+    for bit in (0, 7, 8, 63, 64, 255):
+        v = z.copy()
+        v[bit // 8] = 1 << (bit % 8)
+        assert oracle.hamming256(z, v) == 1
+    v = z.copy()
+    v[31] = 0xF0
+    assert oracle.hamming256(z, v) == 4
+
+
+def _bits(n):
+    v = np.zeros(32, np.uint8)
+    for i in range(n):
+        v[i // 8] |= 1 << (i % 8)
+    return v
+
+
+def test_crosscheck_semantics(oracle):
+    # (i) mutual pair
+    q = np.stack([_bits(0), _bits(100)])
+    t = np.stack([_bits(101), _bits(1)])
+    assert oracle.match_hamming256(q, t).tolist() == dm([(0, 1, 1), (1, 0, 1)]).tolist()
+    # (ii) OpenCV rule, not strict mutual NN: q0's own nearest train (t0, d=1) chose q1 (d=0);
+    # q0 still gets t1, the best train AMONG THOSE THAT CHOSE q0.
+    q = np.stack([_bits(10), _bits(11)])
+    t = np.stack([_bits(11), _bits(6)])
+    got = oracle.match_hamming256(q, t)
+    assert got.tolist() == dm([(0, 1, 4), (1, 0, 0)]).tolist()
+    # (iii) exact ties resolve to the lowest index in both passes
+    q = np.stack([_bits(5), _bits(5), _bits(5)])
+    t = np.stack([_bits(5), _bits(5)])
+    assert oracle.match_hamming256(q, t).tolist() == dm([(0, 0, 0)]).tolist()
+    # (iv) a query nobody chose is omitted; output ascends in queryIdx
+    q = np.stack([_bits(200), _bits(0), _bits(50)])
+    t = np.stack([_bits(49), _bits(1)])
+    assert oracle.match_hamming256(q, t).tolist() == dm([(1, 1, 1), (2, 0, 1)]).tolist()
+    # padding beyond 32 bytes per row (cv::Mat step) is ignored
+    big = np.random.default_rng(0).integers(0, 256, (40, 64), dtype=np.uint8)
+    a = oracle.match_hamming256(big[:20, :32], big[20:, :32])
+    b = oracle.match_hamming256(np.ascontiguousarray(big[:20, :32]), np.ascontiguousarray(big[20:, :32]))
+    assert a.tobytes() == b.tobytes()
+
+
+def test_matcher_vs_numpy_bruteforce(oracle):
+    rng = np.random.default_rng(5)
+    for nq, nt in ((200, 260), (333, 100)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        k = min(nq, nt) // 2
+        t[:k] = q[rng.permutation(nq)[:k]] ^ np.packbits(rng.random((k, 256)) < 0.06, axis=1)
+        D = np.unpackbits(t[:, None, :] ^ q[None, :, :], axis=2).sum(2)
+        nn, d = D.argmin(1), D.min(1)
+        best = {}
+        for ti in range(nt):
+            if nn[ti] not in best or d[ti] < best[nn[ti]][0]:
+                best[nn[ti]] = (d[ti], ti)
+        ref = dm([(qi, best[qi][1], best[qi][0]) for qi in sorted(best)])
+        assert oracle.match_hamming256(q, t).tolist() == ref.tolist()
+
+
+# ------------------------------------------------------------------ schedules (A6, A11)
+def test_ransac_iteration_table(oracle):
+    table = {0.15: 1157, 0.2: 487, 0.25: 248, 0.3: 142, 0.4: 59, 0.5: 29, 0.6: 16, 0.7: 9, 0.8: 5, 0.9: 2}
+    for r, it in table.items():
+        assert oracle.ransac_iterations(r) == it
+    assert oracle.ransac_iterations(1.0) == 0
+    assert oracle.ransac_iterations(1e-4) == 2 ** 31 - 1  # int(v) is UB in the reference: saturated
+
+
+def test_usac_stopping_table(oracle):
+    assert oracle.usac_stopping(100, 200) == 36
+    assert oracle.usac_stopping(600, 1200) == 35
+    assert oracle.usac_stopping(240, 1200) == 580
+    assert oracle.usac_stopping(0, 100) == 850000 and oracle.usac_stopping(2, 100) == 850000
+    assert oracle.usac_stopping(100, 100) == 1
+
+
+def test_point_inlier_ratio(oracle):
+    allm = dm([(0, 5, 1), (1, 5, 2), (2, 6, 3), (3, 7, 4)])
+    inl = dm([(0, 5, 1), (1, 5, 2)])
+    assert oracle.point_inlier_ratio(inl, allm) == 1.0 / 3.0
+    assert oracle.point_inlier_ratio(allm[:0], allm) == 0.0
+
+
+# ------------------------------------------------------------------ geometry helpers (A3)
+def test_round_size_and_backprojection(oracle):
+    assert oracle.round_size(-3.0, 640) == 0
+    assert oracle.round_size(638.6, 640) == 639
+    assert oracle.round_size(639.2, 640) == 640  # sic: clamps to size, not size-1 (RGBD.cpp:13-14)
+    assert oracle.round_size(2.5, 640) == 3      # round half away from zero
+    depth = np.full((480, 640), 5000, np.uint16)
+    p = oracle.keypoints2Dto3D(np.float32([[318.6, 255.3]]), depth, TUM_FR1_K, 5000.0)
+    assert np.array_equal(p, np.float32([[0, 0, 1]]))
+    depth[100, 200] = 12345
+    p = oracle.keypoints2Dto3D(np.float32([[200.4, 99.6]]), depth, TUM_FR1_K, 5000.0)
+    Z = np.float32(12345 / 5000.0)
+    assert p[0, 2] == Z
+    assert p[0, 0] == (np.float32(200.4) - np.float32(318.6)) / np.float32(517.3) * Z
+    uv = oracle.points3Dto2D(np.float32([[0.5, -0.25, 2.0]]), TUM_FR1_K)
+    assert uv[0, 0] == np.float32(0.5) * np.float32(517.3) / np.float32(2.0) + np.float32(318.6)
+    assert uv[0, 1] == np.float32(-0.25) * np.float32(516.5) / np.float32(2.0) + np.float32(255.3)
+
+
+# ------------------------------------------------------------------ SVD / Umeyama / inverse (A7)
+def test_jacobi_svd_vs_numpy(oracle):
+    rng = np.random.default_rng(2)
+    for dt, tol in ((np.float32, 2e-6), (np.float64, 1e-14)):
+        for i in range(300):
+            A = rng.standard_normal((3, 3)).astype(dt)
+            if i % 7 == 0:
+                A[2] = A[0] + A[1]  # rank 2
+            U, S, V = oracle.jacobi_svd3(A, dt)
+            assert np.all(np.diff(S) <= 0) and np.all(S >= 0)
+            assert np.abs(U @ np.diag(S) @ V.T - A).max() < tol * 10 * max(1, np.abs(A).max())
+            assert np.abs(U @ U.T - np.eye(3)).max() < tol * 10 and np.abs(V @ V.T - np.eye(3)).max() < tol * 10
+            assert np.allclose(S, np.linalg.svd(A.astype(np.float64), compute_uv=False), atol=tol * 10)
+    U, S, V = oracle.jacobi_svd3(np.zeros((3, 3)), np.float32)
+    assert np.array_equal(S, np.zeros(3)) and np.array_equal(U, np.eye(3)) and np.array_equal(V, np.eye(3))
+
+
+def _umeyama64(src, dst):
+    src, dst = src.astype(np.float64), dst.astype(np.float64)
+    sm, dmn = src.mean(0), dst.mean(0)
+    U, s, Vt = np.linalg.svd((dst - dmn).T @ (src - sm) / len(src))
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, dmn - R @ sm
+    return T
+
+
+def test_umeyama_analytic(oracle):
+    p = np.float32([[0, 0, 1], [1, 0, 1], [0, 1, 1], [0.3, 0.2, 2.0]])
+    T, ok = oracle.umeyama_f32(p, p)
+    assert ok and np.abs(T - np.eye(4)).max() < 1e-6
+    T, ok = oracle.umeyama_f32(p, p + np.float32([0.1, 0.2, -0.3]))
+    assert ok and np.abs(T[:3, :3] - np.eye(3)).max() < 1e-6 and np.abs(T[:3, 3] - [0.1, 0.2, -0.3]).max() < 1e-6
+    Rz = np.float32([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    T, ok = oracle.umeyama_f32(p, p @ Rz.T)
+    assert ok and np.abs(T[:3, :3] - Rz).max() < 1e-6 and np.abs(T[:3, 3]).max() < 1e-6
+    Rx = np.diag(np.float32([1, -1, -1]))
+    T, ok = oracle.umeyama_f32(p, p @ Rx.T)
+    assert ok and np.abs(T[:3, :3] - Rx).max() < 1e-6
+    # 3-point minimal sample (rank-2 covariance) whose naive U V^T is a reflection: must come out with det +1
+    tri = np.float32([[0, 0, 1], [1, 0, 1], [0, 1, 1]])
+    T, ok = oracle.umeyama_f32(tri, tri * np.float32([1, 1, -1]))
+    assert ok and abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-5
+    # NaN reaching the covariance: Eigen 3.3's JacobiSVD scales by maxCoeff (NaN when sigma(0,0) is NaN), the
+    # work matrix becomes NaN, no rotation is applied, U = V = I: the ROTATION is identity and only the
+    # translation is NaN, so isnan(T(0,0)) (RANSAC.cpp:239) does not fire.  (The depth filter removes NaN points
+    # before any fit, RANSAC.cpp:65-74; the empty refit below is the case that matters.)
+    bad = tri.copy()
+    bad[0, 0] = np.nan
+    T, ok = oracle.umeyama_f32(bad, tri)
+    assert ok and np.array_equal(T[:3, :3], np.eye(3, dtype=np.float32)) and np.isnan(T[0, 3])
+    # NaN only in y: sigma(0,0) is finite, the x/z block is rotated normally, R(0,0) may be finite -> parity only
+    # zero points (refit on an empty inlier set, RANSAC.cpp:153): means are 0 * (1/0) = NaN -> R = I, t = NaN;
+    # estimateTransformation then replaces the pose by identity through the ratio gate (RANSAC.cpp:161-164)
+    T, ok = oracle.umeyama_f32(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert ok and np.array_equal(T[:3, :3], np.eye(3, dtype=np.float32)) and np.all(np.isnan(T[:3, 3]))
+    # coincident points: covariance 0, Eigen's scale guard gives U = V = I -> a valid identity rotation
+    same = np.ones((3, 3), np.float32)
+    T, ok = oracle.umeyama_f32(same, same * 2)
+    assert ok and np.array_equal(T[:3, :3], np.eye(3, dtype=np.float32))
+
+
+@pytest.mark.parametrize("k", [3, 8, 64, 65, 500, 1500])
+def test_umeyama_vs_float64(oracle, k):
+    rng = np.random.default_rng(k)
+    worst = 0.0
+    for _ in range(40):
+        src = (rng.uniform(-2, 2, (k, 3)) + [0, 0, 3]).astype(np.float32)
+        R, t = synth.random_motion(rng, 25.0, 0.5)
+        dst = (src @ R.T + t + rng.normal(0, 0.004, (k, 3))).astype(np.float32)
+        T, ok = oracle.umeyama_f32(src, dst)
+        assert ok
+        worst = max(worst, np.abs(T - _umeyama64(src, dst)).max())
+        assert abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-5
+    # north_star tolerance 1e-5 for the N-point refit; a 3-point minimal sample is allowed float conditioning
+    assert worst < (1e-5 if k >= 8 else 2e-4), worst
+
+
+def test_inverse4_vs_numpy(oracle):
+    rng = np.random.default_rng(9)
+    for _ in range(100):
+        R, t = synth.random_motion(rng, 60.0, 1.0)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t
+        Ti = oracle.inverse4_f32(T)
+        assert np.abs(Ti - np.linalg.inv(T.astype(np.float64))).max() < 2e-6
+        assert np.array_equal(Ti[3], np.float32([0, 0, 0, 1]))
+
+
+# ------------------------------------------------------------------ inlier metrics (A8)
+def test_inlier_thresholds_exact(oracle):
+    I4 = np.eye(4, dtype=np.float32)
+    p = np.float32([0.25, -0.5, 2.0])
+    thr = np.float32(0.04)
+    below, above = np.nextafter(thr, np.float32(0)), np.nextafter(thr, np.float32(1))
+    for d, want in ((below, 1), (thr, 0 if float(thr) >= 0.04 else 1), (above, 0)):
+        c = p + np.float32([d, 0, 0])
+        # residual is exactly |d| (float subtraction of nearby values is exact here)
+        res = np.float32(c[0] - p[0])
+        want = 1 if float(abs(res)) < 0.04 else 0
+        assert oracle.is_inlier(EUCLIDEAN_ERROR, I4, TUM_FR1_K, p, c, 0.04, 2.0) == want
+    # float(0.04) = 0.03999999910593033 < 0.04 (double): a residual of exactly float(0.04) IS an inlier
+    assert float(thr) < 0.04
+    # adaptive mode scales the threshold by prev.z (RANSAC.cpp:270-271)
+    c = p + np.float32([0.07, 0, 0])
+    assert oracle.is_inlier(EUCLIDEAN_ERROR, I4, TUM_FR1_K, p, c, 0.04, 2.0) == 0
+    assert oracle.is_inlier(ADAPTIVE_ERROR, I4, TUM_FR1_K, p, c, 0.04, 2.0) == 1
+    # reprojection: 1 px of horizontal error at z = 2 is dx = z / fx
+    dx = np.float32(2.0 / 517.3)
+    assert oracle.is_inlier(REPROJECTION_ERROR, I4, TUM_FR1_K, p, p + np.float32([1.5 * dx, 0, 0]), 0.04, 2.0) == 1
+    assert oracle.is_inlier(REPROJECTION_ERROR, I4, TUM_FR1_K, p, p + np.float32([2.5 * dx, 0, 0]), 0.04, 2.0) == 0
+    # both: Euclid fails although reprojection passes (motion along the ray)
+    far = p * np.float32(1.05)
+    assert oracle.is_inlier(REPROJECTION_ERROR, I4, TUM_FR1_K, p, far, 0.04, 2.0) == 1
+    assert oracle.is_inlier(EUCLIDEAN_AND_REPROJECTION_ERROR, I4, TUM_FR1_K, p, far, 0.04, 2.0) == 0
+    # z <= 0 / NaN project to inf/NaN: every comparison false -> outlier
+    assert oracle.is_inlier(REPROJECTION_ERROR, I4, TUM_FR1_K, p, np.float32([0, 0, 0]), 0.04, 2.0) == 0
+
+
+# ------------------------------------------------------------------ sampler (A5)
+def test_sample_stream(oracle):
+    cfg, _ = make_config(EST_RANSAC, 64, seed=77)
+    for M in (3, 4, 15, 1200):
+        for h in range(64):
+            idx = oracle.sample_triplet(cfg, h, M)
+            assert len(set(idx)) == 3 and all(0 <= i < M for i in idx)
+    assert oracle.sample_triplet(cfg, 5, 1200) == oracle.sample_triplet(cfg, 5, 1200)
+    raw = np.uint32([[7, 7, 7], [0, 1, 0], [1199, 1199, 0], [5, 6, 7]])
+    cfg, keep = make_config(EST_RANSAC, 4, seed=0, sample_idx=raw)
+    assert oracle.sample_triplet(cfg, 0, 1200) == [7, 8, 9]
+    assert oracle.sample_triplet(cfg, 1, 1200) == [0, 1, 2]
+    assert oracle.sample_triplet(cfg, 2, 1200) == [1199, 0, 1]
+    assert oracle.sample_triplet(cfg, 3, 1200) == [5, 6, 7]
+
+
+# ------------------------------------------------------------------ estimateTransformation (A4, A9, A11)
+def test_estimate_semantics(oracle):
+    a, b = synth.make_pair(400, config=2, index=3)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=1)
+    r = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m, want_counts=True)
+    st = r["stats"]
+    assert st["accepted"] == 1 and st["numInliers"] == r["mask"].sum() == len(r["inliers"])
+    assert np.abs(r["pose"] - b["T_prev_from_cur"]).max() < 5e-3      # maps current into previous frame
+    # sequential replay from the per-hypothesis counts reproduces bestHypothesis / iterationsRun
+    counts = r["counts"]
+    M = int(st["numMatchesValid"])
+    best, bi, limit, i = 0.0, -1, 487, 0
+    while i < limit and i < 487:
+        c = counts[i]
+        assert c >= 0
+        ratio = np.float32(c) / np.float32(M)
+        if float(ratio) > best:
+            best, bi = float(ratio), i
+            limit = min(oracle.ransac_iterations(0.2), oracle.ransac_iterations(best))
+        i += 1
+    assert bi == st["bestHypothesis"] and i == st["iterationsRun"]
+    assert np.all(counts[i:] == -1)                                     # never evaluated by the sequential loop
+    # USAC: no refit, inliers of the best sample, best-count rule + standard stopping
+    cfg, _ = make_config(EST_USAC, 2000, seed=1)
+    u = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m, want_counts=True)
+    assert u["stats"]["numInliers"] == u["stats"]["bestInlierCount"]
+    assert u["stats"]["iterationsRun"] >= oracle.usac_stopping(int(u["stats"]["bestInlierCount"]), M) or \
+        u["stats"]["iterationsRun"] == u["stats"]["bestHypothesis"] + 1
+    # fixed H: the arg-max with first-best tie-break
+    cfg, _ = make_config(EST_FIXED, 300, seed=1)
+    f = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m, want_counts=True)
+    assert f["stats"]["bestHypothesis"] == int(np.argmax(f["counts"])) and f["stats"]["iterationsRun"] == 300
+    # too few matches -> identity, inliers cleared (RANSAC.cpp:77-80)
+    z = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m[:14])
+    assert z["stats"]["accepted"] == 0 and len(z["inliers"]) == 0 and np.array_equal(z["pose"], np.eye(4))
+    # depth filter edges (RANSAC.cpp:65-74): 0.1 and 6.0 kept, 0.0999 / 6.0001 / NaN dropped
+    p2, c2 = a["pts"].copy(), b["pts"].copy()
+    for k, zv in enumerate((0.1, 6.0, 0.0999, 6.0001, np.nan)):
+        c2[m["trainIdx"][k], 2] = zv
+        p2[m["queryIdx"][k], 2] = 1.0
+    w = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, p2, c2, m[:40])
+    base = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, p2, b["pts"], m[5:40])
+    assert w["stats"]["numMatchesValid"] == base["stats"]["numMatchesValid"] + 2
