@@ -1,0 +1,418 @@
+// putslam_dropin.cpp -- reference-shaped C++ classes over the C ABI (see putslam_dropin.h).
+// Host code only: marshals std::vector / cv::Mat / Eigen storage into plain pointers and calls
+// libputslam_hip.so.  One PsContext (HIP stream + scratch arena) per calling thread, because the
+// reference constructs a fresh RANSAC object per call (matcher.cpp:493) and runs a second Matcher on
+// the loop-closure thread (featuresMap.cpp:650-652): contexts are never shared between threads.
+#include "putslam_dropin.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <sstream>
+#include <iomanip>
+
+#include "putslam_hip.h"
+
+static_assert(sizeof(cv::DMatch) == sizeof(PsDMatch), "cv::DMatch layout");
+static_assert(sizeof(Eigen::Vector3f) == 12, "Eigen::Vector3f storage");
+
+namespace {
+
+struct ThreadContext {
+    PsContext *ctx = nullptr;
+    int status = PS_OK;
+    ThreadContext()
+    {
+        int dev = 0;
+        if (const char *e = std::getenv("PUTSLAM_HIP_DEVICE")) dev = std::atoi(e);
+        status = ps_context_create(dev, &ctx);
+        if (status != PS_OK)
+            std::cerr << "putslam_hip: no usable HIP device (status " << status << "); the GPU path has no CPU fallback"
+                      << std::endl;
+    }
+    ~ThreadContext() { ps_context_destroy(ctx); }
+};
+
+PsContext *threadContext(int *status)
+{
+    static thread_local ThreadContext tc;
+    if (status) *status = tc.status;
+    return tc.ctx;
+}
+
+void cameraToK(const cv::Mat &cameraMatrix, float K[9], bool &have)
+{
+    have = !cameraMatrix.empty() && cameraMatrix.rows >= 3 && cameraMatrix.cols >= 3;
+    for (int i = 0; i < 9; ++i) K[i] = 0.0f;
+    if (have)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) K[3 * r + c] = cameraMatrix.at<float>(r, c);
+}
+
+PsRansacParams toPs(const RANSAC::parameters &p)
+{
+    PsRansacParams q;
+    q.verbose = p.verbose;
+    q.errorVersion = p.errorVersion;
+    q.errorVersionVO = p.errorVersionVO;
+    q.errorVersionMap = p.errorVersionMap;
+    q.inlierThresholdEuclidean = p.inlierThresholdEuclidean;
+    q.inlierThresholdReprojection = p.inlierThresholdReprojection;
+    q.inlierThresholdMahalanobis = p.inlierThresholdMahalanobis;
+    q.minimalInlierRatioThreshold = p.minimalInlierRatioThreshold;
+    q.minimalNumberOfMatches = p.minimalNumberOfMatches;
+    q.usedPairs = p.usedPairs;
+    q.iterationCount = p.iterationCount;
+    return q;
+}
+
+Eigen::Matrix4f runEstimator(int estimator, int H, uint64_t seed, const PsRansacParams &prm, const cv::Mat &cameraMatrix,
+                             const std::vector<Eigen::Vector3f> &prev, const std::vector<Eigen::Vector3f> &cur,
+                             const std::vector<cv::DMatch> &matches, std::vector<cv::DMatch> &inliers, bool clearOnFail,
+                             int &status)
+{
+    Eigen::Matrix4f pose = Eigen::Matrix4f::Identity();
+    PsContext *ctx = threadContext(&status);
+    if (!ctx) {
+        if (clearOnFail) inliers.clear();
+        return pose;
+    }
+    float K[9];
+    bool haveK;
+    cameraToK(cameraMatrix, K, haveK);
+    PsRansacConfig cfg;
+    cfg.estimator = estimator;
+    cfg.numHypotheses = H;
+    cfg.seed = seed;
+    cfg.sampleIdx = nullptr;
+    std::vector<cv::DMatch> out(matches.size() ? matches.size() : 1);
+    int n = 0;
+    PsRansacStats st;
+    status = ps_ransac_rigid3d(ctx, &prm, &cfg, haveK ? K : nullptr, reinterpret_cast<const float *>(prev.data()),
+                               (int)prev.size(), reinterpret_cast<const float *>(cur.data()), (int)cur.size(),
+                               reinterpret_cast<const PsDMatch *>(matches.data()), (int)matches.size(), pose.data(),
+                               reinterpret_cast<PsDMatch *>(out.data()), &n, nullptr, &st);
+    if (status != PS_OK) {
+        std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+        pose = Eigen::Matrix4f::Identity();
+        if (clearOnFail) inliers.clear();
+        return pose;
+    }
+    if (estimator == PS_EST_USAC && st.numMatchesValid < 8) return pose; // USAC_wrapper.cpp:120-122: inliers untouched
+    out.resize((size_t)n);
+    inliers.swap(out);
+    if (prm.verbose > 0) {
+        std::cout << "RANSAC: matches.size() = " << st.numMatchesValid << std::endl;
+        std::cout << "RANSAC best model : inlierRatio = " << st.bestInlierRatio * 100.0 << "%" << std::endl;
+    }
+    return pose;
+}
+
+int ransacIterations(double inlierRatio, double successProbability = 0.98, int numberOfPairs = 3)
+{
+    // RANSAC::computeRANSACIteration, RANSAC.cpp:457-461 (saturating instead of UB)
+    double v = std::log(1 - successProbability) / std::log(1 - std::pow(inlierRatio, numberOfPairs));
+    if (!(v < 2147483647.0)) return 2147483647;
+    return v < 0 ? 0 : (int)v;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+RANSAC::RANSAC(RANSAC::parameters _RANSACParameters, cv::Mat _cameraMatrix)
+{
+    seed_ = (uint64_t)std::time(nullptr); // the reference: srand(time(0)), RANSAC.cpp:13
+    cameraMatrix = _cameraMatrix;
+    RANSACParams = _RANSACParameters;
+    RANSACParams.iterationCount = ransacIterations(0.20); // RANSAC.cpp:30
+    if (RANSACParams.verbose > 0) {
+        std::cout << "RANSACParams.verbose --> " << RANSACParams.verbose << std::endl;
+        std::cout << "RANSACParams.usedPairs --> " << RANSACParams.usedPairs << std::endl;
+        std::cout << "RANSACParams.errorVersion --> " << RANSACParams.errorVersion << std::endl;
+        std::cout << "RANSACParams.inlierThresholdEuclidean --> " << RANSACParams.inlierThresholdEuclidean << std::endl;
+        std::cout << "RANSACParams.inlierThresholdReprojection --> " << RANSACParams.inlierThresholdReprojection << std::endl;
+        std::cout << "RANSACParams.minimalInlierRatioThreshold --> " << RANSACParams.minimalInlierRatioThreshold << std::endl;
+    }
+}
+
+Eigen::Matrix4f RANSAC::estimateTransformation(std::vector<Eigen::Vector3f> prevFeatures, std::vector<Eigen::Vector3f> features,
+                                               std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &bestInlierMatches)
+{
+    if (RANSACParams.verbose > 0) std::cout << "RANSAC: original matches.size() = " << matches.size() << std::endl;
+    // enough samples for the longest schedule the reference can run: max(iters(0.2), iters(minRatio))
+    int a = ransacIterations(0.20), b = ransacIterations(RANSACParams.minimalInlierRatioThreshold);
+    int H = a > b ? a : b;
+    if (H < 1) H = 1;
+    if (H > PS_MAX_HYPOTHESES) H = PS_MAX_HYPOTHESES;
+    PsRansacParams prm = toPs(RANSACParams);
+    return runEstimator(PS_EST_RANSAC, H, seed_, prm, cameraMatrix, prevFeatures, features, matches, bestInlierMatches, true,
+                        lastStatus_);
+}
+
+// ---------------------------------------------------------------------------------------------
+RANSAC_USAC::RANSAC_USAC(PUTSLAMEstimator::parameters p, cv::Mat _cameraMatrix)
+{
+    seed_ = (uint64_t)std::time(nullptr); // USAC_wrapper.cpp:16
+    cameraMatrix = _cameraMatrix;
+    params_ = p;
+}
+RANSAC_USAC::~RANSAC_USAC() {}
+
+Eigen::Matrix4f RANSAC_USAC::estimateTransformation(std::vector<Eigen::Vector3f> prevFeatures, std::vector<Eigen::Vector3f> features,
+                                                    std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &bestInlierMatches)
+{
+    PsRansacParams prm;
+    std::memset(&prm, 0, sizeof prm);
+    prm.verbose = params_.verbose;
+    prm.errorVersion = params_.errorVersion;
+    prm.errorVersionVO = params_.errorVersionVO;
+    prm.errorVersionMap = params_.errorVersionMap;
+    prm.inlierThresholdEuclidean = params_.inlierThresholdEuclidean;
+    prm.inlierThresholdReprojection = params_.inlierThresholdReprojection;
+    prm.inlierThresholdMahalanobis = params_.inlierThresholdMahalanobis;
+    prm.minimalInlierRatioThreshold = params_.minimalInlierRatioThreshold;
+    prm.minimalNumberOfMatches = 8; // USAC_wrapper.cpp:120
+    prm.usedPairs = params_.usedPairs;
+    return runEstimator(PS_EST_USAC, maxHyp_, seed_, prm, cameraMatrix, prevFeatures, features, matches, bestInlierMatches, false,
+                        lastStatus_);
+}
+
+// ---------------------------------------------------------------------------------------------
+int RGBD::roundSize(double x, int size)
+{
+    if (x < 0)
+        x = 0;
+    else if (x > size - 1)
+        x = size;
+    return (int)std::round(x);
+}
+
+std::vector<Eigen::Vector3f> RGBD::keypoints2Dto3D(std::vector<cv::Point2f> f2d, cv::Mat depthImage, cv::Mat cameraMatrix,
+                                                   double depthImageScale, int startingID)
+{
+    size_t n = f2d.size() > (size_t)startingID ? f2d.size() - (size_t)startingID : 0;
+    std::vector<Eigen::Vector3f> out(n);
+    if (n == 0) return out;
+    int status;
+    PsContext *ctx = threadContext(&status);
+    float K[9];
+    bool haveK;
+    cameraToK(cameraMatrix, K, haveK);
+    if (!ctx) return out;
+    status = ps_keypoints2Dto3D(ctx, reinterpret_cast<const float *>(f2d.data() + startingID), (int)n,
+                                reinterpret_cast<const uint16_t *>(depthImage.data), depthImage.rows, depthImage.cols,
+                                (size_t)depthImage.step, K, depthImageScale, reinterpret_cast<float *>(out.data()));
+    if (status != PS_OK) std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+    return out;
+}
+
+std::vector<cv::Point2f> RGBD::points3Dto2D(std::vector<Eigen::Vector3f> f3d, cv::Mat cameraMatrix)
+{
+    std::vector<cv::Point2f> out(f3d.size());
+    if (f3d.empty()) return out;
+    int status;
+    PsContext *ctx = threadContext(&status);
+    float K[9];
+    bool haveK;
+    cameraToK(cameraMatrix, K, haveK);
+    if (!ctx) return out;
+    status = ps_points3Dto2D(ctx, reinterpret_cast<const float *>(f3d.data()), (int)f3d.size(), K,
+                             reinterpret_cast<float *>(out.data()));
+    if (status != PS_OK) std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+    return out;
+}
+
+namespace putslam {
+
+// ---------------------------------------------------------------------------------------------
+KabschEst::Ptr kabsch; // "A single instance of Kabsch Estimator", kabschEst.cpp:8
+
+KabschEst::KabschEst(void) : name("Kabsch Estimator") {}
+const std::string &KabschEst::getName() const { return name; }
+
+Mat34 &KabschEst::computeTransformation(const Eigen::MatrixXd &setA, const Eigen::MatrixXd &setB)
+{
+    transformation.setIdentity();
+    if (setA.rows() == 0) return transformation; // kabschEst.cpp:28
+    int status;
+    PsContext *ctx = threadContext(&status);
+    if (!ctx) return transformation;
+    double T[16];
+    status = ps_kabsch_f64(ctx, setA.data(), setB.data(), (int)setA.rows(), (int)setA.rows(), T);
+    if (status != PS_OK) {
+        std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+        return transformation;
+    }
+#if PUTSLAM_HAVE_CV_EIGEN
+    std::memcpy(transformation.matrix().data(), T, sizeof T);
+#else
+    std::memcpy(transformation.data(), T, sizeof T);
+#endif
+    return transformation;
+}
+
+TransformEst *createKabschEstimator(void)
+{
+    kabsch.reset(new KabschEst());
+    return kabsch.get();
+}
+
+// ---------------------------------------------------------------------------------------------
+Matcher::MatcherParameters::MatcherParameters()
+{
+    // shipped defaults, resources/putslammatcherOpenCVParameters.xml:29-37
+    RANSACParams.verbose = 0;
+    RANSACParams.errorVersion = 0;
+    RANSACParams.errorVersionVO = 0;
+    RANSACParams.errorVersionMap = 0;
+    RANSACParams.inlierThresholdEuclidean = 0.04;
+    RANSACParams.inlierThresholdReprojection = 2.0;
+    RANSACParams.inlierThresholdMahalanobis = 0.0002;
+    RANSACParams.minimalInlierRatioThreshold = 0.2;
+    RANSACParams.minimalNumberOfMatches = 15;
+    RANSACParams.usedPairs = 3;
+    RANSACParams.iterationCount = 0;
+    // resources/datasetConfig/freiburg1_desk.xml:5-6 (also hard-coded at RGBD.cpp:22-23)
+    cameraMatrixMat = cv::Mat(3, 3, CV_32FC1);
+    const float K[9] = {517.3f, 0.0f, 318.6f, 0.0f, 516.5f, 255.3f, 0.0f, 0.0f, 1.0f};
+    for (int i = 0; i < 9; ++i) cameraMatrixMat.at<float>(i / 3, i % 3) = K[i];
+}
+
+void Matcher::detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
+{
+    prevDescriptors = descriptors;
+    prevFeatures3D.swap(features3D);
+    frameCounter = 0;
+}
+
+double Matcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
+                      std::vector<cv::DMatch> &inlierMatches)
+{
+    std::vector<cv::DMatch> matches = performMatching(prevDescriptors, descriptors); // matcher.cpp:470
+    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // :491-492
+    RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
+    if (seeded_) ransac.setSampleSeed(seed_ + (uint64_t)frameCounter);
+    estimatedTransformation = ransac.estimateTransformation(prevFeatures3D, features3D, matches, inlierMatches);
+    features3D.swap(prevFeatures3D); // :506-513 save computed values for the next iteration
+    prevDescriptors = descriptors;
+    ++frameCounter;
+    return RANSAC::pointInlierRatio(inlierMatches, matches); // :515
+}
+
+double Matcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
+                                        std::vector<Eigen::Vector3f> pts1, Eigen::Matrix4f &estimatedTransformation,
+                                        std::vector<cv::DMatch> &inlierMatches)
+{
+    if (pts0.size() < 10 || pts1.size() < 10) return 0; // matcher.cpp:830-834
+    std::vector<cv::DMatch> matches = performMatching(desc0, desc1); // :835
+    if (matches.size() <= 0) return -1.0;                            // :838-839
+    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionMap; // :843-844
+    RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
+    if (seeded_) ransac.setSampleSeed(seed_ + 0x9E3779B97F4A7C15ull + (uint64_t)frameCounter);
+    estimatedTransformation = ransac.estimateTransformation(pts0, pts1, matches, inlierMatches);
+    return RANSAC::pointInlierRatio(inlierMatches, matches);
+}
+
+void VOTrajectory::addIncrement(Eigen::Matrix4f inc)
+{
+    // PUTSLAM.cpp:735-740
+    double translationVO = std::sqrt(std::pow(inc(0, 3), 2) + std::pow(inc(1, 3), 2) + std::pow(inc(2, 3), 2));
+    if (translationVO > 0.1) inc = Eigen::Matrix4f::Identity();
+    Eigen::Matrix4f r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float p0 = VOPoseEstimate(i, 0) * inc(0, j), p1 = VOPoseEstimate(i, 1) * inc(1, j);
+            float p2 = VOPoseEstimate(i, 2) * inc(2, j), p3 = VOPoseEstimate(i, 3) * inc(3, j);
+            r(i, j) = (p0 + p1) + (p2 + p3);
+        }
+    VOPoseEstimate = r;
+}
+
+std::string VOTrajectory::freiburgLine(const Eigen::Matrix4f &T, double timestamp)
+{
+    // saveTrajectoryFreiburgFormat, PUTSLAM.cpp:1006-1016; Eigen::Quaternion<float>(Matrix3f)
+    float m[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = T(i, j);
+    float q[4]; // x y z w
+    float t = (m[0][0] + m[1][1]) + m[2][2];
+    if (t > 0.0f) {
+        t = std::sqrt(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[2][1] - m[1][2]) * t;
+        q[1] = (m[0][2] - m[2][0]) * t;
+        q[2] = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(((m[i][i] - m[j][j]) - m[k][k]) + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (m[k][j] - m[j][k]) * t;
+        q[j] = (m[j][i] + m[i][j]) * t;
+        q[k] = (m[k][i] + m[i][k]) * t;
+    }
+    std::ostringstream ossTimestamp;
+    ossTimestamp << std::setfill('0') << std::setprecision(17) << timestamp;
+    std::ostringstream o;
+    o << ossTimestamp.str() << " " << T(0, 3) << " " << T(1, 3) << " " << T(2, 3) << " " << q[0] << " " << q[1] << " " << q[2]
+      << " " << q[3];
+    return o.str();
+}
+
+// "A single instance of OpenCV matcher", matcherOpenCV.cpp:20
+MatcherOpenCV::Ptr matcherClass, loopClosingMatcherClass;
+
+Matcher *createMatcherOpenCV(void)
+{
+    matcherClass.reset(new MatcherOpenCV());
+    return matcherClass.get();
+}
+Matcher *createMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile)
+{
+    matcherClass.reset(new MatcherOpenCV(_parametersFile, _grabberParametersFile));
+    return matcherClass.get();
+}
+Matcher *createloopClosingMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile)
+{
+    loopClosingMatcherClass.reset(new MatcherOpenCV(_parametersFile, _grabberParametersFile));
+    return loopClosingMatcherClass.get();
+}
+
+} // namespace putslam
+
+// ---------------------------------------------------------------------------------------------
+MatcherOpenCV::MatcherOpenCV(void) : putslam::Matcher("OpenCV Matcher") {}
+// XML parsing (tinyXML, matcher.h:188-357) is outside the path: parameters are plain members to set.
+MatcherOpenCV::MatcherOpenCV(const std::string, const std::string) : putslam::Matcher("OpenCVMatcher") {}
+MatcherOpenCV::~MatcherOpenCV(void) {}
+const std::string &MatcherOpenCV::getName() const { return name; }
+
+std::vector<cv::DMatch> MatcherOpenCV::performMatching(cv::Mat prevDescriptors, cv::Mat descriptors)
+{
+    std::vector<cv::DMatch> matches;
+    if (prevDescriptors.empty() || descriptors.empty()) return matches;
+    if (prevDescriptors.cols != PS_DESC_BYTES || descriptors.cols != PS_DESC_BYTES) {
+        // float descriptors (SURF/SIFT, NORM_L2: matcherOpenCV.cpp:100-102) are outside the path
+        std::cerr << "putslam_hip: performMatching supports 32-byte binary descriptors (ORB/LDB) only" << std::endl;
+        return matches;
+    }
+    int status;
+    PsContext *ctx = threadContext(&status);
+    if (!ctx) return matches;
+    matches.resize((size_t)prevDescriptors.rows);
+    int n = 0;
+    status = ps_match_hamming256(ctx, prevDescriptors.data, prevDescriptors.rows, (size_t)prevDescriptors.step, descriptors.data,
+                                 descriptors.rows, (size_t)descriptors.step, reinterpret_cast<PsDMatch *>(matches.data()), &n);
+    if (status != PS_OK) {
+        std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+        n = 0;
+    }
+    matches.resize((size_t)n);
+    return matches;
+}

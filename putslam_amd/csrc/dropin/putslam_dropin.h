@@ -1,0 +1,208 @@
+// putslam_dropin.h -- the reference's C++ surface for the hot path, implemented over the C ABI
+// (include/putslam_hip.h).  Class names, namespaces, signatures, ownership and error behaviour follow
+// the reference so that PUTSLAM's callers compile unchanged against this header:
+//
+//   ::RANSAC                       include/putslam/TransformEst/RANSAC.h:20-66, src/TransformEst/RANSAC.cpp
+//   ::RANSAC_USAC                  include/putslam/USAC/USAC_wrapper.h:16-65, src/USAC/USAC_wrapper.cpp
+//   putslam::TransformEst          include/putslam/TransformEst/transformEst.h:16-26
+//   putslam::KabschEst + factory   include/putslam/TransformEst/kabschEst.h, src/TransformEst/kabschEst.cpp
+//   putslam::Matcher (hot-path part) include/putslam/Matcher/matcher.h:24,100-151,405-422
+//   MatcherOpenCV factories        include/putslam/Matcher/matcherOpenCV.h:17-22, src/Matcher/matcherOpenCV.cpp:20-47
+//   RGBD helpers                   include/putslam/RGBD/RGBD.h:38-51, src/RGBD/RGBD.cpp:10-16,30-65,92-98
+//
+// Everything computes on the GPU through libputslam_hip.so; there is no host fallback.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "putslam_compat_types.h"
+
+// ---------------------------------------------------------------------------------------------
+class RANSAC {
+  public:
+    enum ERROR_VERSION { EUCLIDEAN_ERROR, REPROJECTION_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR, MAHALANOBIS_ERROR, ADAPTIVE_ERROR };
+    struct parameters {
+        int verbose;
+        int errorVersion, errorVersionVO, errorVersionMap;
+        double inlierThresholdEuclidean, inlierThresholdReprojection, inlierThresholdMahalanobis;
+        double minimalInlierRatioThreshold;
+        int minimalNumberOfMatches;
+        int usedPairs;
+        int iterationCount;
+    };
+
+    RANSAC(RANSAC::parameters RANSACParameters, cv::Mat cameraMatrix = cv::Mat());
+
+    // prevFeatures / features: 3-D points of the previous / current frame; matches: queryIdx into
+    // prevFeatures, trainIdx into features.  Returns the pose mapping current-frame points into the
+    // previous frame; identity + cleared inliers on failure (no exceptions, no error codes).
+    Eigen::Matrix4f estimateTransformation(std::vector<Eigen::Vector3f> prevFeatures, std::vector<Eigen::Vector3f> features,
+                                           std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &inlierMatches);
+
+    static double pointInlierRatio(std::vector<cv::DMatch> &inlierMatches, std::vector<cv::DMatch> &allMatches)
+    {
+        std::set<int> inlier, all;
+        for (auto &m : allMatches) all.insert(m.trainIdx);
+        for (auto &in : inlierMatches) inlier.insert(in.trainIdx);
+        return double(inlier.size()) / double(all.size());
+    }
+
+    // --- additions with no reference counterpart (the reference seeds rand() from time(0), RANSAC.cpp:13) ---
+    void setSampleSeed(uint64_t seed) { seed_ = seed; }
+    uint64_t sampleSeed() const { return seed_; }
+    int lastStatus() const { return lastStatus_; }   // PsStatus of the last call (0 = ok)
+
+  private:
+    cv::Mat cameraMatrix;
+    parameters RANSACParams;
+    uint64_t seed_;
+    int lastStatus_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+class PUTSLAMEstimator { // only the parameter block of the reference class is part of the surface
+  public:
+    struct parameters {
+        int verbose;
+        int errorVersion, errorVersionVO, errorVersionMap;
+        double inlierThresholdEuclidean, inlierThresholdReprojection, inlierThresholdMahalanobis;
+        double minimalInlierRatioThreshold;
+        int usedPairs;
+        int iterationCount;
+    };
+};
+
+class RANSAC_USAC {
+  public:
+    RANSAC_USAC(PUTSLAMEstimator::parameters RANSACParameters, cv::Mat cameraMatrix = cv::Mat());
+    ~RANSAC_USAC();
+    Eigen::Matrix4f estimateTransformation(std::vector<Eigen::Vector3f> prevFeatures, std::vector<Eigen::Vector3f> features,
+                                           std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &bestInlierMatches);
+    void setSampleSeed(uint64_t seed) { seed_ = seed; }
+    void setMaxHypotheses(int h) { maxHyp_ = h; } // samples made available to the USAC loop (default 4096)
+    int lastStatus() const { return lastStatus_; }
+
+  private:
+    cv::Mat cameraMatrix;
+    PUTSLAMEstimator::parameters params_;
+    uint64_t seed_;
+    int maxHyp_ = 4096;
+    int lastStatus_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+class RGBD {
+  public:
+    static int roundSize(double x, int size);
+    static std::vector<Eigen::Vector3f> keypoints2Dto3D(std::vector<cv::Point2f> undistortedFeatures2D, cv::Mat depthImage,
+                                                        cv::Mat cameraMatrix, double depthImageScale = 5000, int startingID = 0);
+    static std::vector<cv::Point2f> points3Dto2D(std::vector<Eigen::Vector3f> features3D, cv::Mat cameraMatrix);
+};
+
+namespace putslam {
+
+// ---------------------------------------------------------------------------------------------
+class TransformEst {
+  public:
+    virtual const std::string &getName() const = 0;
+    // setA, setB: N x 3; returns a reference to the member `transformation` (maps A onto B)
+    virtual Mat34 &computeTransformation(const Eigen::MatrixXd &setA, const Eigen::MatrixXd &setB) = 0;
+    virtual ~TransformEst() {}
+
+  protected:
+    Mat34 transformation;
+};
+
+class KabschEst : public TransformEst {
+  public:
+    typedef std::unique_ptr<KabschEst> Ptr;
+    KabschEst(void);
+    const std::string &getName() const;
+    Mat34 &computeTransformation(const Eigen::MatrixXd &setA, const Eigen::MatrixXd &setB);
+    virtual ~KabschEst() {}
+
+  private:
+    const std::string name;
+};
+
+// library-owned singleton, raw pointer returned, a second call replaces the instance (kabschEst.cpp:8,70-73)
+TransformEst *createKabschEstimator(void);
+
+// ---------------------------------------------------------------------------------------------
+// Hot-path part of the Matcher plugin.  Detection / description / tracking are image-domain OpenCV
+// stages outside the path: their pure virtuals are not part of this class; the
+// frame enters at the point where Matcher::match has descriptors and 3-D points (matcher.cpp:467-480).
+class Matcher {
+  public:
+    struct MatcherParameters {
+        int verbose = 0;
+        RANSAC::parameters RANSACParams;
+        cv::Mat cameraMatrixMat; // 3x3 CV_32FC1
+        MatcherParameters();
+    };
+
+    Matcher(const std::string _name) : name(_name), frameCounter(0) {}
+    virtual ~Matcher() {}
+    virtual const std::string &getName() const = 0;
+    virtual std::vector<cv::DMatch> performMatching(cv::Mat prevDescriptors, cv::Mat descriptors) = 0;
+
+    // First frame: stores descriptors + 3-D points as the "previous" state (detectInitFeatures, matcher.cpp:17-64).
+    void detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D);
+    // matcher.cpp:470-515 from the described frame on: performMatching(prev, cur) -> RANSAC with errorVersionVO
+    // -> swap cur -> prev; returns RANSAC::pointInlierRatio(inliers, matches).
+    double match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
+                 std::vector<cv::DMatch> &inlierMatches);
+    double runVO(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
+                 std::vector<cv::DMatch> &inlierMatches)
+    {
+        return match(descriptors, features3D, estimatedTransformation, inlierMatches);
+    }
+    // Loop-closure matching of two feature sets (matchFeatureLoopClosure, matcher.cpp:802-861): BF match +
+    // RANSAC with errorVersionMap; returns -1 when there are no matches, 0 when either set has < 10 features.
+    double matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
+                                   std::vector<Eigen::Vector3f> pts1, Eigen::Matrix4f &estimatedTransformation,
+                                   std::vector<cv::DMatch> &inlierMatches);
+    int getNumberOfFeatures() const { return (int)prevFeatures3D.size(); }
+    void setSampleSeed(uint64_t s) { seed_ = s; seeded_ = true; }
+
+    MatcherParameters matcherParameters;
+
+  protected:
+    const std::string name;
+    cv::Mat prevDescriptors;
+    std::vector<Eigen::Vector3f> prevFeatures3D;
+    int frameCounter;
+    uint64_t seed_ = 0;
+    bool seeded_ = false;
+};
+
+Matcher *createMatcherOpenCV(void);
+Matcher *createMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
+Matcher *createloopClosingMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
+
+// ---------------------------------------------------------------------------------------------
+// VO driver (PUTSLAM::startProcessing, src/PUTSLAM/PUTSLAM.cpp:733-740,1006-1016): pose composition with
+// the 0.1 m gate and the TUM trajectory line format.
+struct VOTrajectory {
+    Eigen::Matrix4f VOPoseEstimate = Eigen::Matrix4f::Identity();
+    void addIncrement(Eigen::Matrix4f poseIncrement);
+    static std::string freiburgLine(const Eigen::Matrix4f &pose, double timestamp);
+};
+
+} // namespace putslam
+
+// The reference declares its concrete matcher in the global namespace (matcherOpenCV.h:26-30).
+class MatcherOpenCV : public putslam::Matcher {
+  public:
+    typedef std::unique_ptr<MatcherOpenCV> Ptr;
+    MatcherOpenCV(void);
+    MatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
+    ~MatcherOpenCV(void);
+    virtual const std::string &getName() const;
+    // cv::BFMatcher(NORM_HAMMING, crossCheck = true).match(prevDescriptors, descriptors) on the GPU
+    virtual std::vector<cv::DMatch> performMatching(cv::Mat prevDescriptors, cv::Mat descriptors);
+};

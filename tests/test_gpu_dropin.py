@@ -1,0 +1,51 @@
+"""C++ drop-in classes (reference Matcher / RANSAC / RANSAC_USAC / TransformEst surface over the C ABI):
+the oracle writes a case file, tests/cpp/test_dropin replays it through the classes on the GPU."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import EST_RANSAC, EUCLIDEAN_ERROR, REPROJECTION_ERROR, TUM_FR1_K, default_ransac_params, make_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_dropin")
+
+
+@pytest.mark.parametrize("mode", [EUCLIDEAN_ERROR, REPROJECTION_ERROR])
+def test_cpp_dropin(oracle, tmp_path, mode):
+    if not os.path.exists(EXE):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_dropin()
+    n, seed = 600, 0x1234_5678_9ABC
+    a, b = synth.make_pair(n, config=2, index=40 + mode)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=seed)
+    r = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    rng = np.random.default_rng(1)
+    A = rng.uniform(-1.5, 1.5, (500, 3))
+    B = A + [0.1, 0.2, -0.3] + rng.normal(0, 1, (500, 3)) * [0.01, 0.02, 0.03]
+    T = oracle.kabsch_f64(A, B)
+    path = tmp_path / "case.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i", n, len(m), 487, mode, seed & 0xFFFFFFFF, seed >> 32, int(r["stats"]["numInliers"]), 0))
+        f.write(a["desc"].tobytes())
+        f.write(b["desc"].tobytes())
+        f.write(a["pts"].tobytes())
+        f.write(b["pts"].tobytes())
+        f.write(m.tobytes())
+        f.write(np.ascontiguousarray(r["pose"].T).tobytes())   # column-major
+        f.write(r["mask"].tobytes())
+        f.write(struct.pack("<i", 500))
+        f.write(np.asfortranarray(A).tobytes(order="F"))
+        f.write(np.asfortranarray(B).tobytes(order="F"))
+        f.write(np.ascontiguousarray(T.T).tobytes())
+    p = subprocess.run([EXE, str(path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all checks passed" in p.stdout
