@@ -217,6 +217,9 @@ int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const P
  * min(H, iterations(minRatio), iterations(float(c)/float(M))) for PS_EST_RANSAC (RANSAC.cpp:450-461),
  * min(H, updateStandardStopping(c, M, 3)) for PS_EST_USAC (USAC.h:944-971). */
 int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M, int32_t *out);
+/* Runs blocks*256*perThread random (a0, a1, b) triples through the scoring kernel's shared-reciprocal
+ * division and through the '/' operator; *mismatches must come back 0 (bitwise comparison). */
+int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, uint64_t *mismatches, uint64_t *tested);
 /* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
 size_t ps_abi_sizeof_dmatch(void);
 size_t ps_abi_sizeof_params(void);

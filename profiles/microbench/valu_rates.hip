@@ -70,6 +70,46 @@ constexpr int CHAINS = 8;  // independent dependency chains per lane
         out[blockIdx.x * 256 + threadIdx.x] = __float_as_uint(r);                          \
     }
 
+#define KERNEL_F32_3(NAME, ASM)                                                            \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed)              \
+    {                                                                                      \
+        float v[CHAINS];                                                                   \
+        for (int i = 0; i < CHAINS; ++i) v[i] = 1.0f + 1e-3f * (float)(threadIdx.x + i + (seed & 3)); \
+        float s = 1.0000001f, t = 0.9999999f + (float)(seed & 1);                          \
+        for (int it = 0; it < ITERS; ++it) {                                               \
+            _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) asm volatile(ASM : "+v"(v[i]) : "v"(s), "v"(t)); \
+        }                                                                                  \
+        float r = 0;                                                                       \
+        for (int i = 0; i < CHAINS; ++i) r += v[i];                                        \
+        out[blockIdx.x * 256 + threadIdx.x] = __float_as_uint(r);                          \
+    }
+#define KERNEL_F32_S(NAME, ASM)                                                            \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed)              \
+    {                                                                                      \
+        float v[CHAINS];                                                                   \
+        for (int i = 0; i < CHAINS; ++i) v[i] = 1.0f + 1e-3f * (float)(threadIdx.x + i + (seed & 3)); \
+        float s = 1.0000001f + (float)(seed & 1);                                          \
+        for (int it = 0; it < ITERS; ++it) {                                               \
+            _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) asm volatile(ASM : "+v"(v[i]) : "s"(s)); \
+        }                                                                                  \
+        float r = 0;                                                                       \
+        for (int i = 0; i < CHAINS; ++i) r += v[i];                                        \
+        out[blockIdx.x * 256 + threadIdx.x] = __float_as_uint(r);                          \
+    }
+KERNEL_F32_3(k_fma3_f32, "v_fma_f32 %0, %0, %1, %2")
+KERNEL_F32_3(k_fmac_f32, "v_fmac_f32 %0, %1, %2")
+KERNEL_F32_3(k_min3_f32, "v_min3_f32 %0, %0, %1, %2")
+KERNEL_F32_S(k_mul_f32_s, "v_mul_f32 %0, %1, %0")
+KERNEL_F32_S(k_fma_f32_s, "v_fma_f32 %0, %0, %1, %0")
+KERNEL_F32(k_max_f32, "v_max_f32 %0, %0, %1")
+KERNEL_F32(k_cmp_only, "v_cmp_lt_f32 vcc, %0, %1")
+KERNEL_U32(k_add_u32, "v_add_u32 %0, %0, %1")
+KERNEL_U32(k_and_b32, "v_and_b32 %0, %0, %1")
+KERNEL_U32(k_max_u32, "v_max_u32 %0, %0, %1")
+KERNEL_U32(k_min_i32, "v_min_i32 %0, %0, %1")
+KERNEL_U32(k_lshlrev, "v_lshlrev_b32 %0, 1, %0")
+KERNEL_U32(k_xor_s, "v_xor_b32 %0, s4, %0")
+KERNEL_U32(k_mov, "v_mov_b32 %0, %1")
 KERNEL_U32(k_xor, "v_xor_b32 %0, %0, %1")
 KERNEL_U32(k_bcnt, "v_bcnt_u32_b32 %0, %1, %0")
 KERNEL_U32(k_min_u32, "v_min_u32 %0, %0, %1")
@@ -119,6 +159,11 @@ int main()
     const int blocks = cus * wavesPerSimd;            // 256 threads = 4 waves = one per SIMD
     CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     Entry es[] = {
+        {"v_fma_f32 (3 regs)", k_fma3_f32, 1}, {"v_fmac_f32", k_fmac_f32, 1}, {"v_min3_f32", k_min3_f32, 1},
+        {"v_mul_f32 (sgpr)", k_mul_f32_s, 1}, {"v_fma_f32 (sgpr)", k_fma_f32_s, 1}, {"v_max_f32", k_max_f32, 1},
+        {"v_cmp_lt_f32", k_cmp_only, 1}, {"v_add_u32", k_add_u32, 1}, {"v_and_b32", k_and_b32, 1},
+        {"v_max_u32", k_max_u32, 1}, {"v_min_i32", k_min_i32, 1}, {"v_lshlrev_b32", k_lshlrev, 1},
+        {"v_xor_b32 (sgpr)", k_xor_s, 1}, {"v_mov_b32", k_mov, 1},
         {"v_xor_b32", k_xor, 1}, {"v_bcnt_u32_b32", k_bcnt, 1}, {"v_min_u32", k_min_u32, 1}, {"v_lshl_or_b32", k_lshl_or, 1},
         {"v_mul_f32", k_mul_f32, 1}, {"v_add_f32", k_add_f32, 1}, {"v_fma_f32", k_fma_f32, 1}, {"v_rcp_f32", k_rcp_f32, 1},
         {"v_sqrt_f32", k_sqrt_f32, 1}, {"v_div_scale_f32", k_div_scale, 1}, {"v_div_fmas_f32", k_div_fmas, 1},

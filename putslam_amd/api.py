@@ -128,6 +128,11 @@ class Context:
         self._chk(self._L.ps_debug_limits(self._h, int(estimator), float(min_ratio), int(H), int(M), _p(out)))
         return out
 
+    def debug_fastdiv(self, seed=1, blocks=2048, per_thread=2048):
+        bad, n = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.ps_debug_fastdiv(self._h, int(seed), int(blocks), int(per_thread), C.byref(bad), C.byref(n)))
+        return bad.value, n.value
+
     # ---- A7 ----
     def umeyama_f32(self, src, dst):
         """src, dst: (nsets, k, 3) or (k, 3). Returns (T (nsets,4,4) row/col matrices, valid (nsets,))."""

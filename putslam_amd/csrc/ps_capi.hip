@@ -364,7 +364,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     const int hb = (H + kBlock - 1) / kBlock;
     int msplit = pick_split((long long)P * hb, 32, 64, cap);
     if (msplit > 1) PS_HIP(hipMemsetAsync(ctx->counts.p, 0, (size_t)P * H * sizeof(int32_t), ctx->stream));
-    dim3 grid((unsigned)hb, (unsigned)msplit, (unsigned)P);
+    dim3 grid((unsigned)hb * (unsigned)msplit * (unsigned)P);
     tick(ctx, slot0, false);
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR: launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit); break;
@@ -414,8 +414,8 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     int qsplit = pick_split((long long)P * tiles, 16, 64, cap);
     if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
     tick(ctx, slot0, false);
-    hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit), (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                       (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, qsplit, (uint32_t *)ctx->keys.p);
+    hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
+                       (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, tiles, qsplit, (uint32_t *)ctx->keys.p);
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     size_t lds = (size_t)cap * sizeof(uint32_t);
@@ -772,6 +772,25 @@ int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const P
     *numScored = H;
     return ransac_host_entry(ctx, params, cfg, K, prev, nprev, cur, ncur, matches, m, pose, inl.data(), &ninl, nullptr,
                              &st, counts);
+}
+
+// Diagnostic: bitwise comparison of the shared-reciprocal division with the '/' operator on random inputs.
+int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, uint64_t *mismatches, uint64_t *tested)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!mismatches || !tested || blocks < 1 || perThread < 1) return PS_ERR_BAD_ARG;
+    PS_ENSURE(ctx->sMisc2, 16);
+    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(ps_fastdiv_check, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, seed, perThread,
+                       (unsigned long long *)ctx->sMisc2.p, (unsigned long long *)ctx->sMisc2.p + 1);
+    PS_HIP(hipGetLastError());
+    uint64_t h[2] = {0, 0};
+    PS_HIP(hipMemcpyAsync(h, ctx->sMisc2.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches = h[0];
+    *tested = h[1];
+    return PS_OK;
 }
 
 // Diagnostic: device-side trip limits for every inlier count 1..M (see ps_limits_table).

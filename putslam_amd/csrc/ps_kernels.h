@@ -24,6 +24,18 @@ namespace psdev {
 constexpr int kBlock = 256;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
+// XCD-aware work-group order.  Work-groups are dealt round-robin over the 8 XCDs (each with its own
+// 4 MiB L2), so linear ids L and L+8 share an L2.  This bijection gives every XCD a CONTIGUOUS range of
+// logical ids, so the work-groups that sweep the same frame pair (same query rows / same match records)
+// run on one XCD and re-read them from its L2 instead of each XCD fetching its own copy.  Speed only:
+// nothing depends on where a work-group actually lands.
+PS_D unsigned xcd_remap(unsigned L, unsigned total)
+{
+    const unsigned xcd = L & 7u, idx = L >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
+
 // v_bcnt_u32_b32: popcount(x) + acc in one VALU op (the compiler emits bcnt + add otherwise).
 PS_D uint32_t bcnt_acc(uint32_t x, uint32_t acc)
 {
@@ -52,19 +64,22 @@ PS_D uint32_t ham_key(const uint4 &a, const uint4 &b, const uint4 &x, const uint
 // One lane owns TPL train descriptors in VGPRs (8 dwords each).  The query rows are
 // wave-uniform, so they are fetched with scalar loads (s_load_dwordx8) into SGPRs and feed
 // v_xor/v_bcnt directly: no LDS traffic, no bank conflicts, 18 VALU ops per pair.
-// grid = (tiles * qsplit, P).  qsplit > 1 splits the query range across workgroups (few pairs,
+// grid = tiles * qsplit * P work-groups in XCD-aware order.  qsplit > 1 splits the query range across workgroups (few pairs,
 // many CUs) and merges with atomicMin on the packed key.
 // ------------------------------------------------------------------------------------------
 template <int TPL>
 __global__ __launch_bounds__(kBlock) void ps_hamming_nn(const uint4 *__restrict__ desc,
                                                         const int32_t *__restrict__ nkpts,
-                                                        const int32_t *__restrict__ pairs, int cap, int qsplit,
-                                                        uint32_t *__restrict__ keys)
+                                                        const int32_t *__restrict__ pairs, int cap, int tiles,
+                                                        int qsplit, uint32_t *__restrict__ keys)
 {
-    const int p = blockIdx.y;
+    const unsigned perPair = (unsigned)(tiles * qsplit);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = (int)(L / perPair);
+    const int inner = (int)(L - (unsigned)p * perPair);
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1]; // query = previous frame, train = current
     const int nq = nkpts[fq], nt = nkpts[ft];
-    const int tile = blockIdx.x / qsplit, qs = blockIdx.x - tile * qsplit;
+    const int tile = inner / qsplit, qs = inner - tile * qsplit;
     const int t0 = tile * (kBlock * TPL);
     if (t0 >= nt) return;
     const int q0 = (int)(((long long)nq * qs) / qsplit), q1 = (int)(((long long)nq * (qs + 1)) / qsplit);
@@ -295,7 +310,57 @@ struct ScoreConsts {
     double boundR; // squared-domain bound of inlierThresholdReprojection (double, cv::norm)
 };
 
-template <int MODE>
+// ---- IEEE division without the range fix-ups, two numerators sharing one reciprocal -------------
+// hipcc expands a correctly rounded float a/b into
+//   div_scale(b), div_scale(a), rcp, fma, fma, mul, fma, fma, fma, div_fmas, div_fixup        (11 VALU ops)
+// The two div_scale ops rescale operands only when an exponent is extreme (|b| or |a| outside roughly
+// 2^+-96, a quotient that would be subnormal, a subnormal denominator); div_fmas is a plain fma when no
+// scaling happened and div_fixup returns its first operand unless an operand is 0 / inf / NaN or the
+// quotient leaves the normal range.  Inside the window checked by div_window_ok() none of that can
+// trigger, so the sequence below IS the compiler's sequence with the no-op instructions removed and
+// returns the same bits.  x*fx/z and y*fy/z share z, hence one rcp + refinement for both quotients:
+// 13 VALU ops instead of 22.  Outside the window the caller uses the ordinary '/' operator.
+constexpr float kDivLo = 9.094947017729282e-13f; // 2^-40
+constexpr float kDivHi = 1.099511627776e12f;     // 2^+40
+
+PS_D void div2_shared(float a0, float a1, float b, float &q0, float &q1)
+{
+    float r0 = __builtin_amdgcn_rcpf(b);
+    float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    float r1 = __builtin_fmaf(e0, r0, r0);
+    float m0 = a0 * r1;
+    float m1 = a1 * r1;
+    float f0 = __builtin_fmaf(-b, m0, a0);
+    float f1 = __builtin_fmaf(-b, m1, a1);
+    float g0 = __builtin_fmaf(f0, r1, m0);
+    float g1 = __builtin_fmaf(f1, r1, m1);
+    float h0 = __builtin_fmaf(-b, g0, a0);
+    float h1 = __builtin_fmaf(-b, g1, a1);
+    q0 = __builtin_fmaf(h0, r1, g0);
+    q1 = __builtin_fmaf(h1, r1, g1);
+}
+
+PS_D float min3_abs(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+PS_D float max3_abs(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// true when every magnitude of both (numerator, numerator, denominator) triples lies in [2^-40, 2^40]
+// (a NaN operand is ignored by min3/max3; it then yields NaN on either division path: same outcome)
+PS_D bool div_window_ok(float a0, float a1, float b, float c0, float c1, float d)
+{
+    return min3_abs(a0, a1, b) >= kDivLo && min3_abs(c0, c1, d) >= kDivLo && max3_abs(a0, a1, b) <= kDivHi &&
+           max3_abs(c0, c1, d) <= kDivHi;
+}
+
+template <int MODE, bool FASTDIV = false>
 PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, const float4 &A, const float4 &B,
                       const float4 &C)
 {
@@ -311,8 +376,24 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
         float nx, ny, nz;
         xform(inv, A.x, A.y, A.z, nx, ny, nz); // estimatedNewPosition = Rinv * prev[query] + tinv
         float pnu, pnv, pou, pov;
-        project(nx, ny, nz, k.fx, k.fy, k.cx, k.cy, pnu, pnv);
-        project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pou, pov);
+        if (FASTDIV) {
+            // RGBD::point3Dto2D with the two quotients of each point sharing the reciprocal of z; the whole
+            // wavefront takes this branch only when every lane is inside the division window
+            const float a0 = nx * k.fx, a1 = ny * k.fy, c0 = ex * k.fx, c1 = ey * k.fy;
+            if (__all(div_window_ok(a0, a1, nz, c0, c1, ez))) {
+                float q0, q1, q2, q3;
+                div2_shared(a0, a1, nz, q0, q1);
+                div2_shared(c0, c1, ez, q2, q3);
+                pnu = q0 + k.cx; pnv = q1 + k.cy;
+                pou = q2 + k.cx; pov = q3 + k.cy;
+            } else {
+                pnu = a0 / nz + k.cx; pnv = a1 / nz + k.cy;
+                pou = c0 / ez + k.cx; pov = c1 / ez + k.cy;
+            }
+        } else {
+            project(nx, ny, nz, k.fx, k.fy, k.cx, k.cy, pnu, pnv);
+            project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pou, pov);
+        }
         float dxn = pnu - C.z, dyn = pnv - C.w; // predictedNew - realNew
         float dxo = pou - C.x, dyo = pov - C.y; // predictedOld - realOld
         double e0 = (double)dxn * (double)dxn + (double)dyn * (double)dyn;
@@ -325,8 +406,8 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
 // ------------------------------------------------------------------------------------------
 // Kernel 3.  RANSAC loop body of RANSAC.cpp:93-135 for ALL hypotheses at once.
 // lane = hypothesis (model in VGPRs); the match records are wave-uniform and arrive through
-// scalar loads.  grid = (ceil(H/256), msplit, P); msplit > 1 splits the match range and merges
-// the integer counts with atomicAdd.
+// scalar loads.  grid = ceil(H/256) * msplit * P work-groups in XCD-aware order; msplit > 1 splits the
+// match range and merges the integer counts with atomicAdd.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restrict__ recA,
@@ -336,13 +417,16 @@ __global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restri
                                                           ScoreConsts k, int H, int cap, int minRun, int msplit,
                                                           int32_t *__restrict__ counts)
 {
-    const int p = blockIdx.z;
+    const unsigned hb = (unsigned)((H + kBlock - 1) / kBlock);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
+    const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int h = blockIdx.x * kBlock + threadIdx.x;
+    const int h = (int)bx * kBlock + threadIdx.x;
     const size_t rbase = (size_t)p * cap;
-    const int m0 = (int)(((long long)M * blockIdx.y) / msplit);
-    const int m1 = (int)(((long long)M * (blockIdx.y + 1)) / msplit);
+    const int m0 = (int)(((long long)M * by) / msplit);
+    const int m1 = (int)(((long long)M * (by + 1)) / msplit);
 
     Rigid mdl, inv;
     bool valid = false;
@@ -356,10 +440,11 @@ __global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restri
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
+#pragma unroll 4
     for (int m = m0; m < m1; ++m) {
         float4 A = pa[m], B = pb[m], C = make_float4(0, 0, 0, 0);
         if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) C = pc[m];
-        cnt += inlier_test<MODE>(mdl, inv, k, A, B, C) ? 1 : 0;
+        cnt += inlier_test<MODE, true>(mdl, inv, k, A, B, C) ? 1 : 0;
     }
     if (h < H) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
@@ -887,6 +972,42 @@ __global__ __launch_bounds__(kBlock) void ps_project_kernel(const float *__restr
     project(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], fx, fy, cx, cy, u, v);
     uv[2 * i] = u;
     uv[2 * i + 1] = v;
+}
+
+// Diagnostic: counts inputs inside the division window for which div2_shared differs from the '/' operator.
+__global__ __launch_bounds__(kBlock) void ps_fastdiv_check(uint64_t seed, int perThread, unsigned long long *mismatch,
+                                                           unsigned long long *tested)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long bad = 0, n = 0;
+    for (int i = 0; i < perThread; ++i) {
+        uint64_t r0 = mix64(seed ^ mix64(tid * 0x10001ull + (uint64_t)i));
+        uint64_t r1 = mix64(r0);
+        // random sign, exponent in [2^-40, 2^40), random mantissa
+        auto mk = [](uint32_t bits) {
+            uint32_t sign = bits & 0x80000000u;
+            uint32_t ex = 87u + ((bits >> 23) & 0xFFu) % 80u;
+            uint32_t v = sign | (ex << 23) | (bits & 0x007FFFFFu);
+            float f;
+            memcpy(&f, &v, 4);
+            return f;
+        };
+        float a0 = mk((uint32_t)r0), a1 = mk((uint32_t)(r0 >> 32)), b = mk((uint32_t)r1);
+        if (i & 1) { // the regime of the kernel: metres times focal length over depth
+            a0 = a0 * 0.0f + (float)((int)((r0 >> 8) & 0xFFFF) - 32768) * 0.37f;
+            b = 0.1f + (float)((r1 >> 8) & 0xFFFF) * 1e-4f;
+        }
+        if (!div_window_ok(a0, a1, b, a0, a1, b)) continue;
+        float q0, q1;
+        div2_shared(a0, a1, b, q0, q1);
+        float e0 = a0 / b, e1 = a1 / b;
+        uint32_t x0, y0, x1, y1;
+        memcpy(&x0, &q0, 4); memcpy(&y0, &e0, 4); memcpy(&x1, &q1, 4); memcpy(&y1, &e1, 4);
+        bad += (x0 != y0) + (x1 != y1);
+        n += 2;
+    }
+    atomicAdd(mismatch, bad);
+    atomicAdd(tested, n);
 }
 
 // Diagnostic: tabulates the device-side trip limits so tests can compare them with the direct

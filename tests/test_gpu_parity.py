@@ -309,3 +309,11 @@ def test_backprojection_bits(ctx, oracle):
     uvg = ctx.points3Dto2D(c, TUM_FR1_K)
     uvc = oracle.points3Dto2D(c, TUM_FR1_K)
     assert uvg.tobytes() == uvc.tobytes()
+
+
+# ---------------------------------------------------------------- scoring kernel's division fast path
+def test_shared_reciprocal_division_is_ieee(ctx):
+    """The reprojection sweep divides with one rcp + refinement shared by x*fx/z and y*fy/z inside a checked
+    exponent window; it must return the bits of the '/' operator (~2e9 random quotients, both regimes)."""
+    bad, n = ctx.debug_fastdiv(seed=20261003, blocks=2048, per_thread=2048)
+    assert n > 1_500_000_000 and bad == 0, (bad, n)
