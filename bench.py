@@ -42,9 +42,17 @@ def parse():
     ap.add_argument("--hyp", type=int, default=4096)
     ap.add_argument("--error-version", type=int, default=1, help="RANSAC::ERROR_VERSION (0 Euclid, 1 reprojection)")
     ap.add_argument("--estimator", default="fixed", choices=["fixed", "ransac", "usac"])
+    ap.add_argument("--preset", default=None, choices=["demoMatching", "sequence", "stress"],
+                    help="BASELINE configs: demoMatching = configs[1] (one pair per step), sequence = configs[2] "
+                         "(default), stress = configs[4] (5000 kpts, H = 100000, 8 pairs per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.preset == "demoMatching":
+        a.frames = 2
+    elif a.preset == "stress":
+        a.frames, a.kpts, a.hyp = 9, 5000, 100000
+    return a
 
 
 def main():
@@ -183,12 +191,24 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Threads this process may really use: CPU affinity capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, seq, prm, cfg, est):
     """The oracle (CPU restatement of the reference algorithm) timed on this host's cores, on a bounded
     sample of the same workload.  It is the checker being timed as a baseline, never the product."""
     from oracle import oracle_py as po
     from putslam_amd._abi import EST_RANSAC, TUM_FR1_K, make_config
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     pairs = seq["pairs"]
 
     def run(cfg_, n, threads):

@@ -100,3 +100,34 @@ def test_full_size_properties(ctx, oracle):
         assert c["matches"][j, :n].tobytes() == g["matches"][p, :n].tobytes()
         assert np.array_equal(cc["mask"], g["inlierMask"][p, :n])
         assert cc["pose"].T.astype(np.float32).tobytes() == g["pose"][p].tobytes()
+
+
+def test_stress_config_sizes(ctx, oracle):
+    """BASELINE configs[4]: 5000 keypoints, 256-bit descriptors, 100 000 hypotheses (adaptive stop disabled)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(3, 5000, config=5, index=0)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    # Euclidean mode: the oracle scores all 100 000 hypotheses in a few seconds -> full bit-exact comparison
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 100000, seed=9)
+    pb = PairBatchDevice(seq["pairs"][:1], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][:1], threads=1)
+    _compare(g, c, 1)
+    # reprojection mode: size-independent properties + the selected hypothesis re-scored by the oracle
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    for p in range(2):
+        st = g["stats"][p]
+        n = int(g["numMatches"][p])
+        assert st["iterationsRun"] == 100000 and 0 <= st["bestHypothesis"] < 100000
+        assert st["numInliers"] == int(g["inlierMask"][p, :n].sum()) and st["accepted"] == 1
+        T = g["pose"][p].reshape(4, 4).T.astype(np.float64)
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-5 and np.abs(T - seq["gt"][p]).max() < 5e-3
+        # the winner's count must be what the oracle counts for that very sample (explicit one-sample stream)
+        cfgp, _ = make_config(EST_FIXED, int(st["bestHypothesis"]) + 1, seed=9 + p)
+        cnt, M = oracle.hypothesis_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], g["matches"][p, :n])
+        assert M == st["numMatchesValid"] and cnt[-1] == st["bestInlierCount"] and cnt.max() == cnt[-1]
