@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -296,6 +297,18 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
     if (K) memcpy(k, K, sizeof k);
     pl.sc.fx = k[0]; pl.sc.fy = k[4]; pl.sc.cx = k[2]; pl.sc.cy = k[5];
     pl.sc.boundR = sq_bound_f64(prm->inlierThresholdReprojection);
+    // float pre-filter band (see inlier_test): only when boundR is comfortably inside the float range
+    pl.sc.bLo = -1.0f;      // never "surely inside"
+    pl.sc.bHi = INFINITY;   // never "surely outside"
+    if (pl.sc.boundR >= 1e-20 && pl.sc.boundR <= 1e30) {
+        const double w = 4.76837158203125e-07; // 2^-21
+        double lo = pl.sc.boundR * (1.0 - w), hi = pl.sc.boundR * (1.0 + w);
+        float flo = (float)lo, fhi = (float)hi;
+        if ((double)flo > lo) flo = std::nextafterf(flo, 0.0f);
+        if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+        pl.sc.bLo = flo;
+        pl.sc.bHi = fhi;
+    }
     pl.pa.fx = k[0]; pl.pa.fy = k[4]; pl.pa.cx = k[2]; pl.pa.cy = k[5];
     pl.pa.thrE = prm->inlierThresholdEuclidean;
     pl.pa.mode = pl.mode;

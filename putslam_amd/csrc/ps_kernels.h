@@ -308,6 +308,7 @@ PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ 
 struct ScoreConsts {
     float fx, fy, cx, cy;
     double boundR; // squared-domain bound of inlierThresholdReprojection (double, cv::norm)
+    float bLo, bHi; // float pre-filter band around boundR: f < bLo => surely < boundR, f > bHi => surely >= boundR
 };
 
 // ---- IEEE division without the range fix-ups, two numerators sharing one reciprocal -------------
@@ -396,6 +397,25 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
         }
         float dxn = pnu - C.z, dyn = pnv - C.w; // predictedNew - realNew
         float dxo = pou - C.x, dyo = pov - C.y; // predictedOld - realOld
+        if (FASTDIV) {
+            // cv::norm(Point2f) squares in double.  The float sums f0, f1 are within 2^-22 of the exact values,
+            // so outside the band [bLo, bHi] (half-width 2^-21 around boundR) the float comparison already
+            // decides; the larger of the two (as unsigned bit patterns: sums of squares are >= +0 and any
+            // NaN sorts above +inf) settles both tests at once.  Inside the band, or on NaN, the wave falls
+            // back to the double evaluation below.
+            float f0 = dxn * dxn + dyn * dyn, f1 = dxo * dxo + dyo * dyo;
+            uint32_t u0, u1;
+            memcpy(&u0, &f0, 4);
+            memcpy(&u1, &f1, 4);
+            uint32_t um = u0 > u1 ? u0 : u1;
+            float fm;
+            memcpy(&fm, &um, 4);
+            const bool sureIn = fm < k.bLo, sureOut = fm > k.bHi;
+            if (__all(sureIn || sureOut)) return in && sureIn;
+            // keep the double evaluation on the cold side of the branch (the compiler would otherwise
+            // speculate its eight f64 instructions above it)
+            asm volatile("" : "+v"(dxn), "+v"(dyn), "+v"(dxo), "+v"(dyo));
+        }
         double e0 = (double)dxn * (double)dxn + (double)dyn * (double)dyn;
         double e1 = (double)dxo * (double)dxo + (double)dyo * (double)dyo;
         in = in && (e0 < k.boundR) && (e1 < k.boundR);
