@@ -163,6 +163,22 @@ int ps_keypoints2Dto3D(PsContext *ctx, const float *xy, int n,
 /* ---- A3: RGBD::point3Dto2D, src/RGBD/RGBD.cpp:92-98 (n points). */
 int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, float *uv);
 
+/* ---- N2: guided map matching, core of Matcher::matchXYZ, src/Matcher/matcher.cpp:606-746.
+ * For every map feature j: candidates i among the current frame's keypoints with
+ * |mapPos[j] - curPos[i]| < sphereRadius and |curLevel[i] - mapLevel[j]| <= 1 (:699-711); their value is
+ * cv::norm(mapDesc[j] - curDesc[i], NORM_HAMMING) on CV_8U rows = popcount of the per-byte SATURATING
+ * difference (:719-721); every candidate with acceptRatio * value <= best value is emitted (:734-746) as
+ * DMatch(queryIdx = j, trainIdx = i, imgIdx = -1, distance = value), ordered by (j, i).
+ * mapPos: (float) casts of MapFeature::position (:701-702); levels from ps_predicted_level.
+ * Returns PS_ERR_BAD_ARG with *nout = required capacity if cap is too small.  Host pointers. */
+int ps_match_xyz(PsContext *ctx, const float *mapPos, const uint8_t *mapDesc, size_t mapDescStep,
+                 const int32_t *mapLevel, int nmap, const float *curPos, const uint8_t *curDesc,
+                 size_t curDescStep, const int32_t *curLevel, int ncur, double sphereRadius,
+                 double acceptRatio, PsDMatch *out, int cap, int *nout);
+/* Predicted ORB pyramid level, matcher.cpp:639-652 (keypoints) and :681-692 (map features):
+ * clamp(ceil(log(1.2^octave * detDist / curDist) / log 1.2), 0, 7).  Pure host arithmetic (libm). */
+int ps_predicted_level(int octave, double detDist, double curDist);
+
 /* ---- A2 + A12: the data flow of Matcher::match (src/Matcher/matcher.cpp:470-515) for a
  * whole batch of independent frame pairs, everything resident in HBM.  All pointers in
  * PsFrameSet / PsPairResults are DEVICE pointers; nothing is copied to or from the host. */

@@ -235,3 +235,35 @@ def vo_pairs(params, cfg, K, desc, pts, nkpts, pairs, threads=1):
                            int(threads))
     assert rc == 0
     return out
+
+
+def predicted_level(octave, det_dist, cur_dist):
+    lib().po_predicted_level.restype = C.c_int
+    lib().po_predicted_level.argtypes = [C.c_int, C.c_double, C.c_double]
+    return lib().po_predicted_level(int(octave), float(det_dist), float(cur_dist))
+
+
+def satdiff_hamming256(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().po_satdiff_hamming256(_p(a), _p(b))
+
+
+def match_xyz(map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, radius, ratio):
+    map_pos = np.ascontiguousarray(map_pos, np.float32)
+    cur_pos = np.ascontiguousarray(cur_pos, np.float32)
+    map_desc = np.ascontiguousarray(map_desc, np.uint8)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    map_level = np.ascontiguousarray(map_level, np.int32)
+    cur_level = np.ascontiguousarray(cur_level, np.int32)
+    nmap, ncur = map_pos.shape[0], cur_pos.shape[0]
+    cap = max(1, nmap * 8)
+    while True:
+        out = np.zeros(cap, DMATCH_DTYPE)
+        n = C.c_int(0)
+        lib().po_match_xyz(_p(map_pos), _p(map_desc), C.c_size_t(32), _p(map_level), nmap, _p(cur_pos), _p(cur_desc),
+                           C.c_size_t(32), _p(cur_level), ncur, C.c_double(radius), C.c_double(ratio), _p(out), cap,
+                           C.byref(n))
+        if n.value <= cap:
+            return out[: n.value].copy()
+        cap = n.value

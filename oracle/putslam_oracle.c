@@ -717,6 +717,76 @@ void po_kabsch_f64(const double *A, const double *B, int n, int ld, double *T)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * N2  guided map matching, Matcher::matchXYZ (src/Matcher/matcher.cpp:606-746)
+ * ------------------------------------------------------------------------------------------ */
+int po_predicted_level(int octave, double detDist, double curDist)
+{
+    const double scaleFactor = 1.2; /* matcher.h:26-28 */
+    const int nLevels = 8;
+    const double logScaleFactor = log(scaleFactor);
+    double detLevelScaleFactor = pow(scaleFactor, octave);
+    double curLevelScaleFactor = detLevelScaleFactor * detDist / curDist;
+    int curLevel = (int)ceil(log(curLevelScaleFactor) / logScaleFactor); /* :648,690 */
+    if (curLevel < 0) curLevel = 0;
+    if (curLevel > nLevels - 1) curLevel = nLevels - 1;
+    return curLevel;
+}
+
+int po_satdiff_hamming256(const uint8_t *a, const uint8_t *b)
+{
+    int v = 0;
+    for (int k = 0; k < 32; ++k) {
+        int d = (int)a[k] - (int)b[k];
+        if (d < 0) d = 0; /* cv::Mat subtraction of CV_8U saturates */
+        v += __builtin_popcount((unsigned)d);
+    }
+    return v;
+}
+
+int po_match_xyz(const float *mapPos, const uint8_t *mapDesc, size_t mapStep, const int32_t *mapLevel, int nmap,
+                 const float *curPos, const uint8_t *curDesc, size_t curStep, const int32_t *curLevel, int ncur,
+                 double sphereRadius, double acceptRatio, PsDMatch *out, int cap, int *nout)
+{
+    int n = 0;
+    int *cand = (int *)malloc(sizeof(int) * (size_t)(ncur > 0 ? ncur : 1));
+    for (int j = 0; j < nmap; ++j) {
+        const float *tmp = &mapPos[3 * (size_t)j];
+        const int curLevelJ = mapLevel[j];
+        int nc = 0;
+        for (int i = 0; i < ncur; ++i) { /* :699-711 */
+            float nrm = norm3(tmp, &curPos[3 * (size_t)i]);
+            int scaleCheck = (curLevel[i] - 1 <= curLevelJ) && (curLevelJ <= curLevel[i] + 1);
+            int posCheck = nrm < sphereRadius;
+            if (posCheck && scaleCheck) cand[nc++] = i;
+        }
+        int bestId = -1;
+        float bestVal = 99999;
+        for (int c = 0; c < nc; ++c) { /* :714-727 */
+            float value = (float)po_satdiff_hamming256(mapDesc + (size_t)j * mapStep, curDesc + (size_t)cand[c] * curStep);
+            if (value < bestVal || bestId == -1) {
+                bestVal = value;
+                bestId = cand[c];
+            }
+        }
+        for (int c = 0; c < nc; ++c) { /* :734-746 */
+            float value = (float)po_satdiff_hamming256(mapDesc + (size_t)j * mapStep, curDesc + (size_t)cand[c] * curStep);
+            if (acceptRatio * value <= bestVal) {
+                if (n < cap) {
+                    out[n].queryIdx = j;
+                    out[n].trainIdx = cand[c];
+                    out[n].imgIdx = -1; /* default-constructed cv::DMatch */
+                    out[n].distance = value;
+                }
+                ++n;
+            }
+        }
+    }
+    free(cand);
+    *nout = n;
+    return n <= cap ? 0 : 1;
+}
+
+/* ------------------------------------------------------------------------------------------
  * A2  Matcher::match data flow over a batch of pairs (matcher.cpp:470-515), host memory.
  * ------------------------------------------------------------------------------------------ */
 int po_vo_pairs(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,

@@ -88,6 +88,16 @@ double po_point_inlier_ratio(const PsDMatch *inliers, int ninl, const PsDMatch *
 /* KabschEst::computeTransformation (kabschEst.cpp:24-68). A,B n x 3 column-major (ld), T 4x4 column-major. */
 void po_kabsch_f64(const double *A, const double *B, int n, int ld, double *T);
 
+/* N2: guided map matching core of Matcher::matchXYZ, src/Matcher/matcher.cpp:606-746.
+ * Predicted pyramid level (matcher.cpp:639-652 for keypoints, :681-692 for map features). */
+int po_predicted_level(int octave, double detDist, double curDist);
+/* value = (float)cv::norm(a - b, NORM_HAMMING) on CV_8U rows (matcher.cpp:719-721): the subtraction
+ * SATURATES per byte, so this is popcount(max(a_k - b_k, 0)) summed over 32 bytes, not XOR Hamming. */
+int po_satdiff_hamming256(const uint8_t *a, const uint8_t *b);
+int po_match_xyz(const float *mapPos, const uint8_t *mapDesc, size_t mapStep, const int32_t *mapLevel, int nmap,
+                 const float *curPos, const uint8_t *curDesc, size_t curStep, const int32_t *curLevel, int ncur,
+                 double sphereRadius, double acceptRatio, PsDMatch *out, int cap, int *nout);
+
 /* Matcher::match data flow (matcher.cpp:470-515) over P independent pairs of a frame set
  * held in HOST memory (same layout as PsFrameSet/PsPairResults but host pointers);
  * threads > 1 runs pairs in parallel with OpenMP (the reference itself is single-threaded). */

@@ -175,6 +175,33 @@ class Context:
         self._chk(self._L.ps_points3Dto2D(self._h, _p(xyz), xyz.shape[0], _p(K), _p(uv)))
         return uv
 
+    # ---- N2 ----
+    def match_xyz(self, map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, radius=0.12, ratio=0.55):
+        """Guided map matching core of Matcher::matchXYZ (matcher.cpp:694-746)."""
+        map_pos = np.ascontiguousarray(map_pos, np.float32)
+        cur_pos = np.ascontiguousarray(cur_pos, np.float32)
+        map_desc = np.ascontiguousarray(map_desc, np.uint8)
+        cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+        map_level = np.ascontiguousarray(map_level, np.int32)
+        cur_level = np.ascontiguousarray(cur_level, np.int32)
+        nmap, ncur = map_pos.shape[0], cur_pos.shape[0]
+        cap = max(1, 4 * nmap)
+        while True:
+            out = np.zeros(cap, DMATCH_DTYPE)
+            n = C.c_int(0)
+            rc = self._L.ps_match_xyz(self._h, _p(map_pos), _p(map_desc), 32, _p(map_level), nmap, _p(cur_pos),
+                                      _p(cur_desc), 32, _p(cur_level), ncur, float(radius), float(ratio), _p(out), cap,
+                                      C.byref(n))
+            if rc == PS_OK:
+                return out[: n.value].copy()
+            if n.value > cap:
+                cap = n.value
+                continue
+            self._chk(rc)
+
+    def predicted_level(self, octave, det_dist, cur_dist):
+        return self._L.ps_predicted_level(int(octave), float(det_dist), float(cur_dist))
+
     # ---- A2 / A12: device-resident batch ----
     def vo_pairs_device(self, params, cfg, K, frames: "DeviceFrames", pairs_dev_ptr, P, out: "DeviceResults"):
         K = np.ascontiguousarray(K, np.float32)

@@ -5,6 +5,7 @@
 // the loop-closure thread (featuresMap.cpp:650-652): contexts are never shared between threads.
 #include "putslam_dropin.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -312,6 +313,62 @@ double Matcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector
     RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
     if (seeded_) ransac.setSampleSeed(seed_ + 0x9E3779B97F4A7C15ull + (uint64_t)frameCounter);
     estimatedTransformation = ransac.estimateTransformation(pts0, pts1, matches, inlierMatches);
+    return RANSAC::pointInlierRatio(inlierMatches, matches);
+}
+
+double Matcher::matchXYZ(const std::vector<MapFeatureXYZ> &mapFeatures, cv::Mat currentPoseDescriptors,
+                         std::vector<Eigen::Vector3f> &currentPoseFeatures3D, const std::vector<int> &currentPoseOctaves,
+                         const std::vector<double> &currentPoseDetDists, Eigen::Matrix4f &estimatedTransformation,
+                         std::vector<cv::DMatch> &inlierMatches, int computationNumber)
+{
+    double matchingXYZSphereRadius = matcherParameters.OpenCVParams.matchingXYZSphereRadius; // matcher.cpp:616-622
+    double matchingXYZacceptRatioOfBestMatch = matcherParameters.OpenCVParams.matchingXYZacceptRatioOfBestMatch;
+    if (computationNumber > 1) {
+        matchingXYZSphereRadius += 0.02 * (computationNumber - 1);
+        matchingXYZacceptRatioOfBestMatch = std::max(0.1, matchingXYZacceptRatioOfBestMatch - 0.05 * (computationNumber - 1));
+    }
+    const size_t nmap = mapFeatures.size(), ncur = currentPoseFeatures3D.size();
+    std::vector<int32_t> curLevels(ncur), mapLevels(nmap);
+    for (size_t i = 0; i < ncur; ++i) { // :639-652; curDist = Eigen float norm()
+        const Eigen::Vector3f &p = currentPoseFeatures3D[i];
+        float nrm = std::sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
+        curLevels[i] = ps_predicted_level(currentPoseOctaves[i], currentPoseDetDists[i], (double)nrm);
+    }
+    std::vector<Eigen::Vector3f> mapFeaturePositions3D(nmap);
+    std::vector<unsigned char> mapDesc(nmap * 32);
+    for (size_t j = 0; j < nmap; ++j) { // :681-692,701-702
+        const MapFeatureXYZ &f = mapFeatures[j];
+        double curDist = std::sqrt(f.position[0] * f.position[0] + f.position[1] * f.position[1] + f.position[2] * f.position[2]);
+        mapLevels[j] = ps_predicted_level(f.octave, f.detDist, curDist);
+        mapFeaturePositions3D[j] = Eigen::Vector3f((float)f.position[0], (float)f.position[1], (float)f.position[2]);
+        if (!f.descriptor.empty()) std::memcpy(&mapDesc[j * 32], f.descriptor.data, 32);
+    }
+    std::vector<cv::DMatch> matches;
+    int status;
+    PsContext *ctx = threadContext(&status);
+    if (!ctx || nmap == 0 || ncur == 0) return -1.0;
+    int cap = (int)(4 * nmap + 16), n = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        matches.resize((size_t)cap);
+        status = ps_match_xyz(ctx, reinterpret_cast<const float *>(mapFeaturePositions3D.data()), mapDesc.data(), 32,
+                              mapLevels.data(), (int)nmap, reinterpret_cast<const float *>(currentPoseFeatures3D.data()),
+                              currentPoseDescriptors.data, (size_t)currentPoseDescriptors.step, curLevels.data(), (int)ncur,
+                              matchingXYZSphereRadius, matchingXYZacceptRatioOfBestMatch,
+                              reinterpret_cast<PsDMatch *>(matches.data()), cap, &n);
+        if (status == PS_OK || n <= cap) break;
+        cap = n;
+    }
+    if (status != PS_OK) {
+        std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+        return -1.0;
+    }
+    matches.resize((size_t)n);
+    if (matcherParameters.verbose > 0) std::cout << "MatchesXYZ - we found : " << matches.size() << std::endl;
+    if (matches.size() <= 0) return -1.0; // :755-756
+    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionMap; // :760-761
+    RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
+    if (seeded_) ransac.setSampleSeed(seed_ + 0x51ED270B0B5ull + (uint64_t)frameCounter);
+    estimatedTransformation = ransac.estimateTransformation(mapFeaturePositions3D, currentPoseFeatures3D, matches, inlierMatches);
     return RANSAC::pointInlierRatio(inlierMatches, matches);
 }
 

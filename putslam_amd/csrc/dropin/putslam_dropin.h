@@ -142,8 +142,24 @@ class Matcher {
         int verbose = 0;
         RANSAC::parameters RANSACParams;
         cv::Mat cameraMatrixMat; // 3x3 CV_32FC1
+        struct {
+            double matchingXYZSphereRadius = 0.12;            // putslammatcherOpenCVParameters.xml:71
+            double matchingXYZacceptRatioOfBestMatch = 0.55;  // :72
+        } OpenCVParams;
         MatcherParameters();
     };
+
+    // What Matcher::matchXYZ reads of a MapFeature (putslam_defs.h:120-216): position, the descriptor of the
+    // chosen view with its octave and detection distance (ExtendedDescriptor), and the feature id.
+    struct MapFeatureXYZ {
+        unsigned int id = 0;
+        double position[3] = {0, 0, 0};
+        cv::Mat descriptor; // 1 x 32 CV_8U
+        int octave = 0;
+        double detDist = 1.0;
+    };
+    static constexpr double scaleFactor = 1.2; // matcher.h:26-27
+    static constexpr int nLevels = 8;
 
     Matcher(const std::string _name) : name(_name), frameCounter(0) {}
     virtual ~Matcher() {}
@@ -166,6 +182,12 @@ class Matcher {
     double matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
                                    std::vector<Eigen::Vector3f> pts1, Eigen::Matrix4f &estimatedTransformation,
                                    std::vector<cv::DMatch> &inlierMatches);
+    // Guided matching of map features against the current pose's keypoints + RANSAC with errorVersionMap
+    // (matchXYZ, matcher.cpp:606-798): returns RANSAC::pointInlierRatio, or -1 when nothing matched.
+    double matchXYZ(const std::vector<MapFeatureXYZ> &mapFeatures, cv::Mat currentPoseDescriptors,
+                    std::vector<Eigen::Vector3f> &currentPoseFeatures3D, const std::vector<int> &currentPoseOctaves,
+                    const std::vector<double> &currentPoseDetDists, Eigen::Matrix4f &estimatedTransformation,
+                    std::vector<cv::DMatch> &inlierMatches, int computationNumber = 1);
     int getNumberOfFeatures() const { return (int)prevFeatures3D.size(); }
     void setSampleSeed(uint64_t s) { seed_ = s; seeded_ = true; }
 

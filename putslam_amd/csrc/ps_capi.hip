@@ -827,6 +827,79 @@ int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M
 }
 
 // ---------------------------------------------------------------------------------------------
+int ps_predicted_level(int octave, double detDist, double curDist)
+{
+    // Matcher::matchXYZ, matcher.cpp:639-652,681-692 with scaleFactor 1.2 / nLevels 8 (matcher.h:26-28); host libm
+    // exactly as the reference evaluates it.
+    const double scaleFactor = 1.2;
+    const int nLevels = 8;
+    const double logScaleFactor = std::log(scaleFactor);
+    double detLevelScaleFactor = std::pow(scaleFactor, octave);
+    double curLevelScaleFactor = detLevelScaleFactor * detDist / curDist;
+    int curLevel = (int)std::ceil(std::log(curLevelScaleFactor) / logScaleFactor);
+    if (curLevel < 0) curLevel = 0;
+    if (curLevel > nLevels - 1) curLevel = nLevels - 1;
+    return curLevel;
+}
+
+int ps_match_xyz(PsContext *ctx, const float *mapPos, const uint8_t *mapDesc, size_t mapDescStep, const int32_t *mapLevel,
+                 int nmap, const float *curPos, const uint8_t *curDesc, size_t curDescStep, const int32_t *curLevel, int ncur,
+                 double sphereRadius, double acceptRatio, PsDMatch *out, int cap, int *nout)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    TimingOff toff(ctx);
+    if (nout) *nout = 0;
+    if (!nout || nmap < 0 || ncur < 0 || cap < 0 || (cap > 0 && !out) ||
+        (nmap > 0 && (!mapPos || !mapDesc || !mapLevel)) || (ncur > 0 && (!curPos || !curDesc || !curLevel)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_match_xyz: bad argument");
+    if ((nmap > 0 && mapDescStep < PS_DESC_BYTES) || (ncur > 0 && curDescStep < PS_DESC_BYTES))
+        return fail(ctx, PS_ERR_UNSUPPORTED, "descriptor rows must be 32 bytes (ORB/LDB)");
+    if (nmap == 0 || ncur == 0) return PS_OK;
+    PS_ENSURE(ctx->sMisc0, (size_t)nmap * 12);
+    PS_ENSURE(ctx->sMisc1, (size_t)ncur * 12);
+    PS_ENSURE(ctx->sDesc, (size_t)(nmap + ncur) * 32);
+    PS_ENSURE(ctx->sNk, (size_t)(nmap + ncur) * sizeof(int32_t));
+    PS_ENSURE(ctx->sMisc2, (size_t)(2 * nmap + 2) * sizeof(int32_t));
+    PS_ENSURE(ctx->sMatches, (size_t)(cap > 0 ? cap : 1) * sizeof(PsDMatch));
+    uint8_t *dDesc = (uint8_t *)ctx->sDesc.p;
+    int32_t *dLvl = (int32_t *)ctx->sNk.p;
+    int32_t *dCnt = (int32_t *)ctx->sMisc2.p, *dOff = dCnt + nmap;
+    PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, mapPos, (size_t)nmap * 12, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, curPos, (size_t)ncur * 12, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpy2DAsync(dDesc, 32, mapDesc, mapDescStep, 32, (size_t)nmap, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpy2DAsync(dDesc + (size_t)nmap * 32, 32, curDesc, curDescStep, 32, (size_t)ncur, hipMemcpyHostToDevice,
+                            ctx->stream));
+    PS_HIP(hipMemcpyAsync(dLvl, mapLevel, (size_t)nmap * 4, hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpyAsync(dLvl + nmap, curLevel, (size_t)ncur * 4, hipMemcpyHostToDevice, ctx->stream));
+    const float bound = sq_bound_f32(sphereRadius); // (float)norm < (double)radius  <=>  squared sum < bound
+    const unsigned blocks = (unsigned)((nmap + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL(ps_match_xyz_kernel<false>, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       (const float *)ctx->sMisc0.p, (const uint4 *)dDesc, dLvl, nmap, (const float *)ctx->sMisc1.p,
+                       (const uint4 *)(dDesc + (size_t)nmap * 32), dLvl + nmap, ncur, bound, acceptRatio, dCnt,
+                       (const int32_t *)nullptr, (PsDMatch *)nullptr, 0);
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ps_exclusive_scan, dim3(1), dim3(kBlock), 0, ctx->stream, dCnt, nmap, dOff);
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ps_match_xyz_kernel<true>, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       (const float *)ctx->sMisc0.p, (const uint4 *)dDesc, dLvl, nmap, (const float *)ctx->sMisc1.p,
+                       (const uint4 *)(dDesc + (size_t)nmap * 32), dLvl + nmap, ncur, bound, acceptRatio, dCnt,
+                       (const int32_t *)dOff, (PsDMatch *)ctx->sMatches.p, cap);
+    PS_HIP(hipGetLastError());
+    int32_t total = 0;
+    PS_HIP(hipMemcpyAsync(&total, dOff + nmap, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    *nout = total;
+    int ncopy = total < cap ? total : cap;
+    if (ncopy > 0) {
+        PS_HIP(hipMemcpyAsync(out, ctx->sMatches.p, (size_t)ncopy * sizeof(PsDMatch), hipMemcpyDeviceToHost, ctx->stream));
+        PS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (total > cap) return fail(ctx, PS_ERR_BAD_ARG, "ps_match_xyz: output capacity too small (*nout = needed)");
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 int ps_umeyama_f32(PsContext *ctx, const float *src, const float *dst, int k, int nsets, float *T, int32_t *valid)
 {
     int rc = bind(ctx);

@@ -379,17 +379,17 @@ PS_HD void sample_triplet(uint64_t seed, const uint32_t *raw, uint32_t h, uint32
 PS_HD float next_up_pos(float x)
 {
     uint32_t b;
-    memcpy(&b, &x, 4);
+    __builtin_memcpy(&b, &x, 4);
     ++b;
-    memcpy(&x, &b, 4);
+    __builtin_memcpy(&x, &b, 4);
     return x;
 }
 PS_HD float next_down_pos(float x)
 {
     uint32_t b;
-    memcpy(&b, &x, 4);
+    __builtin_memcpy(&b, &x, 4);
     --b;
-    memcpy(&x, &b, 4);
+    __builtin_memcpy(&x, &b, 4);
     return x;
 }
 PS_HD float sq_bound_f32(double thr)

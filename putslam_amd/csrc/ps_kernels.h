@@ -812,6 +812,143 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// N2: guided map matching, core of Matcher::matchXYZ (reference src/Matcher/matcher.cpp:694-746).
+// One wavefront per map feature j; lanes sweep the current frame's keypoints 64 at a time.
+//   candidate i : |mapPos[j] - curPos[i]| < sphereRadius (float norm against a double radius, exact
+//                 squared-domain bound) and |predictedLevel[i] - level[j]| <= 1          (:699-711)
+//   value(i)    : popcount of the per-byte SATURATING difference mapDesc[j] - curDesc[i]
+//                 (cv::Mat subtraction of CV_8U + NORM_HAMMING, :719-721 -- not XOR Hamming)
+//   best        : smallest value, first index on ties                                      (:714-727)
+//   accepted    : acceptRatio * value <= best (double)                                     (:734-746)
+// WRITE = false counts the accepted candidates per map feature, WRITE = true emits them at the
+// offsets of the exclusive scan, so the output is ordered by (j, i) like the reference's push_back loop.
+// ------------------------------------------------------------------------------------------
+PS_D uint32_t satdiff_popc256(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1)
+{
+    const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    uint32_t v = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int d = (int)((aw[w] >> (8 * k)) & 0xFFu) - (int)((bw[w] >> (8 * k)) & 0xFFu);
+            d = d < 0 ? 0 : d;
+            v += (uint32_t)__popc((unsigned)d);
+        }
+    return v;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void ps_match_xyz_kernel(const float *__restrict__ mapPos,
+                                                              const uint4 *__restrict__ mapDesc,
+                                                              const int32_t *__restrict__ mapLevel, int nmap,
+                                                              const float *__restrict__ curPos,
+                                                              const uint4 *__restrict__ curDesc,
+                                                              const int32_t *__restrict__ curLevel, int ncur,
+                                                              float radiusBound, double acceptRatio,
+                                                              int32_t *__restrict__ counts,
+                                                              const int32_t *__restrict__ offsets,
+                                                              PsDMatch *__restrict__ out, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (j >= nmap) return;
+    const float mx = mapPos[3 * j], my = mapPos[3 * j + 1], mz = mapPos[3 * j + 2];
+    const int lj = mapLevel[j];
+    const uint4 a0 = mapDesc[2 * j], a1 = mapDesc[2 * j + 1];
+
+    // sweep 1: best value among the candidates (packed (value, index) minimum = first index on ties)
+    unsigned long long best = ~0ull;
+    for (int i0 = 0; i0 < ncur; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < ncur) {
+            float d0 = mx - curPos[3 * i], d1 = my - curPos[3 * i + 1], d2 = mz - curPos[3 * i + 2];
+            float s = d0 * d0 + (d1 * d1 + d2 * d2);
+            int li = curLevel[i];
+            if (s < radiusBound && li - 1 <= lj && lj <= li + 1) {
+                uint32_t v = satdiff_popc256(a0, a1, curDesc[2 * i], curDesc[2 * i + 1]);
+                unsigned long long key = ((unsigned long long)v << 32) | (unsigned)i;
+                best = key < best ? key : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_down(best, o, 64);
+        best = other < best ? other : best;
+    }
+    best = __shfl(best, 0, 64);
+    if (best == ~0ull) { // no candidate: nothing is emitted for this map feature
+        if (!WRITE && lane == 0) counts[j] = 0;
+        return;
+    }
+    const float bestVal = (float)(uint32_t)(best >> 32);
+
+    // sweep 2: every candidate within the accept ratio of the best, ascending i
+    int n = 0;
+    const int base = WRITE ? offsets[j] : 0;
+    for (int i0 = 0; i0 < ncur; i0 += 64) {
+        const int i = i0 + lane;
+        bool acc = false;
+        float value = 0.f;
+        if (i < ncur) {
+            float d0 = mx - curPos[3 * i], d1 = my - curPos[3 * i + 1], d2 = mz - curPos[3 * i + 2];
+            float s = d0 * d0 + (d1 * d1 + d2 * d2);
+            int li = curLevel[i];
+            if (s < radiusBound && li - 1 <= lj && lj <= li + 1) {
+                value = (float)satdiff_popc256(a0, a1, curDesc[2 * i], curDesc[2 * i + 1]);
+                acc = acceptRatio * (double)value <= (double)bestVal;
+            }
+        }
+        unsigned long long bal = __ballot(acc);
+        if (WRITE && acc) {
+            int pos = base + n + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                PsDMatch m;
+                m.queryIdx = j;
+                m.trainIdx = i;
+                m.imgIdx = -1; // default-constructed cv::DMatch (matcher.cpp:741)
+                m.distance = value;
+                out[pos] = m;
+            }
+        }
+        n += __popcll(bal);
+    }
+    if (!WRITE && lane == 0) counts[j] = n;
+}
+
+// exclusive scan of counts[0..n) by one work-group; total written to offsets[n]
+__global__ __launch_bounds__(kBlock) void ps_exclusive_scan(const int32_t *__restrict__ counts, int n,
+                                                            int32_t *__restrict__ offsets)
+{
+    __shared__ int s_w[kBlock / 64];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+        const int i = i0 + threadIdx.x;
+        int v = i < n ? counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (i < n) offsets[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = s_carry;
+}
+
+// ------------------------------------------------------------------------------------------
 // Stand-alone fits
 // ------------------------------------------------------------------------------------------
 // ps_umeyama_f32: one wavefront per point set.

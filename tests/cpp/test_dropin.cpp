@@ -117,6 +117,39 @@ int main(int argc, char **argv)
     std::vector<Eigen::Vector3f> tiny(5);
     CHECK(lc->matchFeatureLoopClosure(A, tiny, B, cur, Tlc, inlLc) == 0.0); // < 10 features
 
+    // ---- guided map matching (matchXYZ, matcher.cpp:606-798): previous frame's features as the "map" ----
+    {
+        std::vector<putslam::Matcher::MapFeatureXYZ> mapF;
+        std::vector<Eigen::Vector3f> curF;
+        std::vector<int> oct;
+        std::vector<double> det;
+        std::vector<uint8_t> curD;
+        for (int i = 0; i < N; ++i) {
+            if (!(prev[(size_t)i].z() > 0.1f)) continue;
+            putslam::Matcher::MapFeatureXYZ f;
+            f.id = (unsigned)i;
+            for (int c = 0; c < 3; ++c) f.position[c] = prev[(size_t)i][c];
+            f.descriptor = cv::Mat(1, 32, CV_8U, da.data() + (size_t)i * 32);
+            f.octave = i % 4;
+            f.detDist = std::sqrt(f.position[0] * f.position[0] + f.position[1] * f.position[1] + f.position[2] * f.position[2]);
+            mapF.push_back(f);
+            // the same physical point observed again 1 cm away, at the same scale
+            curF.push_back(Eigen::Vector3f(prev[(size_t)i].x() + 0.01f, prev[(size_t)i].y(), prev[(size_t)i].z()));
+            oct.push_back(i % 4);
+            det.push_back(f.detDist);
+            curD.insert(curD.end(), da.begin() + (size_t)i * 32, da.begin() + (size_t)(i + 1) * 32);
+        }
+        cv::Mat curDesc((int)curF.size(), 32, CV_8U, curD.data());
+        Eigen::Matrix4f Tx;
+        std::vector<cv::DMatch> inlx;
+        matcher->matcherParameters.RANSACParams.errorVersionMap = 0;
+        double rx = matcher->matchXYZ(mapF, curDesc, curF, oct, det, Tx, inlx, 1);
+        CHECK(rx > 0.9 && inlx.size() > mapF.size() / 2);
+        CHECK(std::fabs(Tx(0, 3) + 0.01f) < 1e-4f && std::fabs(Tx(1, 3)) < 1e-4f && std::fabs(Tx(0, 0) - 1.0f) < 1e-5f);
+        std::vector<putslam::Matcher::MapFeatureXYZ> none;
+        CHECK(matcher->matchXYZ(none, curDesc, curF, oct, det, Tx, inlx, 1) == -1.0);
+    }
+
     // ---- USAC wrapper: same signature, no refit, best-count rule ----
     PUTSLAMEstimator::parameters up;
     up.verbose = 0;

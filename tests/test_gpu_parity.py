@@ -317,3 +317,33 @@ def test_shared_reciprocal_division_is_ieee(ctx):
     exponent window; it must return the bits of the '/' operator (~2e9 random quotients, both regimes)."""
     bad, n = ctx.debug_fastdiv(seed=20261003, blocks=2048, per_thread=2048)
     assert n > 1_500_000_000 and bad == 0, (bad, n)
+
+
+# ---------------------------------------------------------------- N2 guided map matching (matchXYZ core)
+@pytest.mark.parametrize("nmap,ncur", [(1, 1), (300, 1000), (1500, 2000), (65, 63)])
+def test_match_xyz_parity(ctx, oracle, nmap, ncur):
+    rng = np.random.default_rng(nmap * 31 + ncur)
+    cur_pos = (rng.uniform(-1.5, 1.5, (ncur, 3)) + [0, 0, 2.5]).astype(np.float32)
+    cur_desc = rng.integers(0, 256, (ncur, 32), dtype=np.uint8)
+    cur_oct = rng.integers(0, 8, ncur)
+    src = rng.integers(0, ncur, nmap)
+    # map features sit near observed keypoints (guided matching), some far away, descriptors lightly corrupted
+    map_pos = (cur_pos[src] + rng.normal(0, 0.05, (nmap, 3))).astype(np.float32)
+    map_desc = cur_desc[src] ^ np.packbits(rng.random((nmap, 256)) < 0.05, axis=1)
+    cur_level = np.array([oracle.predicted_level(o, np.linalg.norm(p) * rng.uniform(0.8, 1.25), np.linalg.norm(p))
+                          for o, p in zip(cur_oct, cur_pos)], np.int32)
+    map_level = np.clip(cur_level[src] + rng.integers(-2, 3, nmap), 0, 7).astype(np.int32)
+    for radius, ratio in ((0.12, 0.55), (0.16, 0.45), (0.5, 0.1)):
+        g = ctx.match_xyz(map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, radius, ratio)
+        c = oracle.match_xyz(map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, radius, ratio)
+        assert g.tobytes() == c.tobytes(), (radius, ratio, len(g), len(c))
+    assert ctx.predicted_level(2, 2.0, 1.0) == oracle.predicted_level(2, 2.0, 1.0) == 6
+    # matches feed RANSAC with errorVersionMap exactly like the cross-check matches do (matcher.cpp:757-768)
+    if nmap >= 300:
+        m = oracle.match_xyz(map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, 0.12, 0.55)
+        prm = default_ransac_params(EUCLIDEAN_ERROR)
+        cfg, _ = make_config(EST_RANSAC, 487, seed=4)
+        rg = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, map_pos, cur_pos, m)
+        rc = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, map_pos, cur_pos, m)
+        _stats_equal(rg["stats"], rc["stats"])
+        assert np.array_equal(rg["mask"], rc["mask"]) and rg["pose"].tobytes() == rc["pose"].tobytes()

@@ -306,3 +306,29 @@ def test_estimate_semantics(oracle):
     w = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, p2, c2, m[:40])
     base = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, p2, b["pts"], m[5:40])
     assert w["stats"]["numMatchesValid"] == base["stats"]["numMatchesValid"] + 2
+
+
+# ------------------------------------------------------------------ N2 guided map matching (matchXYZ)
+def test_match_xyz_semantics(oracle):
+    # the descriptor distance is popcount of the per-byte SATURATING difference, not XOR Hamming (matcher.cpp:719-721)
+    lo, hi = np.full(32, 0x0F, np.uint8), np.full(32, 0xF0, np.uint8)
+    assert oracle.satdiff_hamming256(lo, hi) == 0 and oracle.satdiff_hamming256(hi, lo) == 128
+    assert oracle.hamming256(lo, hi) == 256
+    # predicted level: clamp(ceil(log(1.2^octave * detDist / curDist) / log 1.2), 0, 7)
+    assert oracle.predicted_level(0, 1.0, 1.0) == 0 and oracle.predicted_level(2, 2.0, 1.0) == 6
+    assert oracle.predicted_level(7, 5.0, 1.0) == 7 and oracle.predicted_level(0, 1.0, 3.0) == 0
+    # one map feature, four keypoints: outside the sphere / wrong level / best / within the accept ratio
+    map_pos = np.float32([[0, 0, 1]])
+    cur_pos = np.float32([[0.2, 0, 1], [0.01, 0, 1], [0.02, 0, 1], [0.03, 0, 1], [0.05, 0, 1]])
+    md = np.full((1, 32), 0xFF, np.uint8)
+    cd = np.full((5, 32), 0xFF, np.uint8)
+    cd[2, :2] = 0x00          # value 16
+    cd[3, :3] = 0x00          # value 24
+    cd[4, :8] = 0x00          # value 64
+    cd[1, :1] = 0x00          # value 8 but two pyramid levels away
+    m = oracle.match_xyz(map_pos, md, [3], cur_pos, cd, [3, 5, 3, 4, 2], 0.12, 0.55)
+    # best = keypoint 2 (16); 0.55*24 = 13.2 <= 16 accepted; 0.55*64 = 35.2 > 16 rejected
+    assert [(int(x["queryIdx"]), int(x["trainIdx"]), int(x["imgIdx"]), float(x["distance"])) for x in m] == \
+        [(0, 2, -1, 16.0), (0, 3, -1, 24.0)]
+    # no candidate -> no match
+    assert len(oracle.match_xyz(map_pos, md, [3], cur_pos[:1], cd[:1], [3], 0.12, 0.55)) == 0
