@@ -347,3 +347,33 @@ def test_match_xyz_parity(ctx, oracle, nmap, ncur):
         rc = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, map_pos, cur_pos, m)
         _stats_equal(rg["stats"], rc["stats"])
         assert np.array_equal(rg["mask"], rc["mask"]) and rg["pose"].tobytes() == rc["pose"].tobytes()
+
+
+def test_reprojection_outside_division_window(ctx, oracle):
+    """Inputs that push the projection quotients outside the fast-division window (zero camera matrix, huge and
+    tiny coordinates, points on the camera plane): the scoring kernel must fall back to the '/' operator and stay
+    bit-identical to the oracle."""
+    a, b = _pair(300, 61)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 512, seed=11)
+    cases = [(None, a["pts"], b["pts"]),                                    # K = 0: every numerator is 0
+             (TUM_FR1_K * np.float32(1e12), a["pts"], b["pts"]),            # numerators ~1e15 > 2^40
+             (TUM_FR1_K * np.float32(1e-14), a["pts"], b["pts"])]           # numerators ~1e-12 < 2^-40
+    for K, pa, pb in cases:
+        for mode in (REPROJECTION_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR):
+            prm.errorVersion = mode
+            g = ctx.debug_ransac_counts(prm, cfg, K, pa, pb, m)
+            c, _ = oracle.hypothesis_counts(prm, cfg, K, pa, pb, m)
+            assert np.array_equal(g, c)
+            rg = ctx.ransac_rigid3d(prm, cfg, K, pa, pb, m)
+            rc = oracle.ransac_rigid3d(prm, cfg, K, pa, pb, m)
+            _stats_equal(rg["stats"], rc["stats"])
+            assert np.array_equal(rg["mask"], rc["mask"]) and rg["pose"].tobytes() == rc["pose"].tobytes()
+    # a hypothesis that maps points onto z ~ 0 (division by ~0 -> inf / NaN pixels -> outliers on both sides)
+    flat_prev, flat_cur = a["pts"].copy(), b["pts"].copy()
+    flat_cur[:, 2] = np.where(flat_cur[:, 2] > 0, 0.1000001, 0)           # valid depth, all on one plane
+    prm.errorVersion = REPROJECTION_ERROR
+    g = ctx.debug_ransac_counts(prm, cfg, TUM_FR1_K, flat_prev, flat_cur, m)
+    c, _ = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, flat_prev, flat_cur, m)
+    assert np.array_equal(g, c)
