@@ -160,6 +160,12 @@ int ps_keypoints2Dto3D(PsContext *ctx, const float *xy, int n,
                        const uint16_t *depth, int rows, int cols, size_t depthStep,
                        const float *K, double depthImageScale, float *out);
 
+/* ---- N4: RGBD::removeImageDistortion, src/RGBD/RGBD.cpp:254-314 = cv::undistortPoints(pts, K, dist) with
+ * R = P = I (5 fixed-point iterations of the Brown model, double) followed by u = x_n*fx + cx in float.
+ * xy, out: n x 2 floats (cv::Point2f); dist5 = (k1, k2, p1, p2, k3) (datasetConfig rgbDistortion). */
+int ps_remove_image_distortion(PsContext *ctx, const float *xy, int n, const float *K, const double *dist5,
+                               float *out);
+
 /* ---- A3: RGBD::point3Dto2D, src/RGBD/RGBD.cpp:92-98 (n points). */
 int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, float *uv);
 

@@ -267,3 +267,12 @@ def match_xyz(map_pos, map_desc, map_level, cur_pos, cur_desc, cur_level, radius
         if n.value <= cap:
             return out[: n.value].copy()
         cap = n.value
+
+
+def remove_image_distortion(xy, K, dist5):
+    xy = np.ascontiguousarray(xy, np.float32)
+    K = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist5, np.float64)
+    out = np.zeros_like(xy)
+    lib().po_remove_image_distortion(_p(xy), xy.shape[0], _p(K), _p(d), _p(out))
+    return out

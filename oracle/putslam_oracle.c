@@ -787,6 +787,33 @@ int po_match_xyz(const float *mapPos, const uint8_t *mapDesc, size_t mapStep, co
 }
 
 /* ------------------------------------------------------------------------------------------
+ * N4  RGBD::removeImageDistortion, src/RGBD/RGBD.cpp:254-314
+ * ------------------------------------------------------------------------------------------ */
+void po_remove_image_distortion(const float *xy, int n, const float *K, const double *dist5, float *out)
+{
+    double k[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; ++i) k[i] = dist5[i];
+    const double fx = (double)K[0], fy = (double)K[4], cx = (double)K[2], cy = (double)K[5];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; ++i) {
+        double x = (double)xy[2 * i], y = (double)xy[2 * i + 1];
+        double x0 = x = (x - cx) * ifx;
+        double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; ++j) {
+            double r2 = x * x + y * y;
+            double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        float xn = (float)x, yn = (float)y;             /* dst is CV_32FC2 */
+        out[2 * i] = xn * K[0] + K[2];                  /* RGBD.cpp:276-282 */
+        out[2 * i + 1] = yn * K[4] + K[5];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * A2  Matcher::match data flow over a batch of pairs (matcher.cpp:470-515), host memory.
  * ------------------------------------------------------------------------------------------ */
 int po_vo_pairs(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,

@@ -98,6 +98,11 @@ int po_match_xyz(const float *mapPos, const uint8_t *mapDesc, size_t mapStep, co
                  const float *curPos, const uint8_t *curDesc, size_t curStep, const int32_t *curLevel, int ncur,
                  double sphereRadius, double acceptRatio, PsDMatch *out, int cap, int *nout);
 
+/* N4: RGBD::removeImageDistortion (src/RGBD/RGBD.cpp:254-314) = cv::undistortPoints(pts, K, dist)
+ * (5 fixed-point iterations of the Brown model in double, OpenCV 3.x cvUndistortPoints with R = P = I)
+ * followed by u = x_n * fx + cx in float.  dist = (k1, k2, p1, p2, k3). */
+void po_remove_image_distortion(const float *xy, int n, const float *K, const double *dist5, float *out);
+
 /* Matcher::match data flow (matcher.cpp:470-515) over P independent pairs of a frame set
  * held in HOST memory (same layout as PsFrameSet/PsPairResults but host pointers);
  * threads > 1 runs pairs in parallel with OpenMP (the reference itself is single-threaded). */

@@ -168,6 +168,15 @@ class Context:
                                              depth.strides[0], _p(K), float(scale), _p(out)))
         return out
 
+    def remove_image_distortion(self, xy, K, dist5):
+        """RGBD::removeImageDistortion (RGBD.cpp:254-314)."""
+        xy = np.ascontiguousarray(xy, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        d = np.ascontiguousarray(dist5, np.float64)
+        out = np.zeros_like(xy)
+        self._chk(self._L.ps_remove_image_distortion(self._h, _p(xy), xy.shape[0], _p(K), _p(d), _p(out)))
+        return out
+
     def points3Dto2D(self, xyz, K):
         xyz = np.ascontiguousarray(xyz, np.float32)
         K = np.ascontiguousarray(K, np.float32)

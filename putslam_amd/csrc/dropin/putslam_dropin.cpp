@@ -209,6 +209,25 @@ std::vector<Eigen::Vector3f> RGBD::keypoints2Dto3D(std::vector<cv::Point2f> f2d,
     return out;
 }
 
+std::vector<cv::Point2f> RGBD::removeImageDistortion(std::vector<cv::Point2f> &features, cv::Mat cameraMatrix, cv::Mat distCoeffs)
+{
+    if (features.size() == 0) return std::vector<cv::Point2f>(); // RGBD.cpp:258-259
+    std::vector<cv::Point2f> out(features.size());
+    int status;
+    PsContext *ctx = threadContext(&status);
+    float K[9];
+    bool haveK;
+    cameraToK(cameraMatrix, K, haveK);
+    double d[5] = {0, 0, 0, 0, 0};
+    const int nd = distCoeffs.empty() ? 0 : distCoeffs.rows * distCoeffs.cols;
+    for (int i = 0; i < 5 && i < nd; ++i) d[i] = (double)distCoeffs.at<float>(distCoeffs.rows == 1 ? 0 : i, distCoeffs.rows == 1 ? i : 0);
+    if (!ctx) return out;
+    status = ps_remove_image_distortion(ctx, reinterpret_cast<const float *>(features.data()), (int)features.size(), K, d,
+                                        reinterpret_cast<float *>(out.data()));
+    if (status != PS_OK) std::cerr << "putslam_hip: " << ps_last_error(ctx) << std::endl;
+    return out;
+}
+
 std::vector<cv::Point2f> RGBD::points3Dto2D(std::vector<Eigen::Vector3f> f3d, cv::Mat cameraMatrix)
 {
     std::vector<cv::Point2f> out(f3d.size());

@@ -101,6 +101,9 @@ class RGBD {
     static std::vector<Eigen::Vector3f> keypoints2Dto3D(std::vector<cv::Point2f> undistortedFeatures2D, cv::Mat depthImage,
                                                         cv::Mat cameraMatrix, double depthImageScale = 5000, int startingID = 0);
     static std::vector<cv::Point2f> points3Dto2D(std::vector<Eigen::Vector3f> features3D, cv::Mat cameraMatrix);
+    // distCoeffs: 1x5 (or 5x1) CV_32F/CV_64F-like access through at<float>: (k1, k2, p1, p2, k3)
+    static std::vector<cv::Point2f> removeImageDistortion(std::vector<cv::Point2f> &features, cv::Mat cameraMatrix,
+                                                          cv::Mat distCoeffs);
 };
 
 namespace putslam {

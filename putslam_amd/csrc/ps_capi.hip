@@ -969,6 +969,27 @@ int ps_keypoints2Dto3D(PsContext *ctx, const float *xy, int n, const uint16_t *d
     return PS_OK;
 }
 
+int ps_remove_image_distortion(PsContext *ctx, const float *xy, int n, const float *K, const double *dist5, float *out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n < 0 || !K || !dist5 || (n > 0 && (!xy || !out)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_remove_image_distortion: bad argument");
+    if (n == 0) return PS_OK;
+    PS_ENSURE(ctx->sMisc0, (size_t)n * 8);
+    PS_ENSURE(ctx->sMisc2, (size_t)n * 8);
+    PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    DistArgs a;
+    for (int i = 0; i < 5; ++i) a.k[i] = dist5[i];
+    a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5];
+    hipLaunchKernelGGL(ps_undistort_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const float *)ctx->sMisc0.p, n, a, (float *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipMemcpyAsync(out, ctx->sMisc2.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    return PS_OK;
+}
+
 int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, float *uv)
 {
     int rc = bind(ctx);

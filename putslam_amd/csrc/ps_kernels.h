@@ -1120,6 +1120,38 @@ __global__ __launch_bounds__(kBlock) void ps_backproject(const float *__restrict
     out[3 * i + 2] = Z;
 }
 
+// RGBD::removeImageDistortion (reference src/RGBD/RGBD.cpp:254-314): cv::undistortPoints with R = P = I
+// (OpenCV 3.x cvUndistortPoints: 5 fixed-point iterations of the Brown model, double precision) and
+// u = x_n * fx + cx in float.
+struct DistArgs {
+    double k[5]; // k1 k2 p1 p2 k3
+    float fx, fy, cx, cy;
+};
+__global__ __launch_bounds__(kBlock) void ps_undistort_kernel(const float *__restrict__ xy, int n, DistArgs a,
+                                                              float *__restrict__ out)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double fx = (double)a.fx, fy = (double)a.fy, cx = (double)a.cx, cy = (double)a.cy;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
+    const double z = 0.0; // k[5..11] of OpenCV's 12-coefficient form: absent in the reference's configs
+    double x = (double)xy[2 * i], y = (double)xy[2 * i + 1];
+    double x0 = x = (x - cx) * ifx;
+    double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; ++j) {
+        double r2 = x * x + y * y;
+        double icdist = (1 + ((z * r2 + z) * r2 + z) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + z * r2 + z * r2 * r2;
+        double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + z * r2 + z * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    float xn = (float)x, yn = (float)y;
+    out[2 * i] = xn * a.fx + a.cx;
+    out[2 * i + 1] = yn * a.fy + a.cy;
+}
+
 __global__ __launch_bounds__(kBlock) void ps_project_kernel(const float *__restrict__ xyz, int n, float fx, float fy,
                                                             float cx, float cy, float *__restrict__ uv)
 {

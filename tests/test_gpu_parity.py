@@ -377,3 +377,12 @@ def test_reprojection_outside_division_window(ctx, oracle):
     g = ctx.debug_ransac_counts(prm, cfg, TUM_FR1_K, flat_prev, flat_cur, m)
     c, _ = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, flat_prev, flat_cur, m)
     assert np.array_equal(g, c)
+
+
+def test_remove_image_distortion_bits(ctx, oracle):
+    rng = np.random.default_rng(2)
+    xy = np.stack([rng.uniform(-20, 660, 4000), rng.uniform(-20, 500, 4000)], 1).astype(np.float32)
+    for dist in ([0, 0, 0, 0, 0], [-0.0410, 0.3286, 0.0087, 0.0051, -0.5643], [0.2, -0.1, 0.001, -0.002, 0.05]):
+        g = ctx.remove_image_distortion(xy, TUM_FR1_K, dist)
+        c = oracle.remove_image_distortion(xy, TUM_FR1_K, dist)
+        assert g.tobytes() == c.tobytes()

@@ -332,3 +332,28 @@ def test_match_xyz_semantics(oracle):
         [(0, 2, -1, 16.0), (0, 3, -1, 24.0)]
     # no candidate -> no match
     assert len(oracle.match_xyz(map_pos, md, [3], cur_pos[:1], cd[:1], [3], 0.12, 0.55)) == 0
+
+
+# ------------------------------------------------------------------ N4 undistortion
+TUM_FR1_DIST = [-0.0410, 0.3286, 0.0087, 0.0051, -0.5643]  # resources/datasetConfig/freiburg1_desk.xml:7
+
+
+def test_remove_image_distortion(oracle):
+    rng = np.random.default_rng(1)
+    xy = np.stack([rng.uniform(0, 640, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+    # no distortion: back to the input up to the float round trip through normalised coordinates
+    u0 = oracle.remove_image_distortion(xy, TUM_FR1_K, [0, 0, 0, 0, 0])
+    assert np.abs(u0 - xy).max() < 1e-3
+    # with the fr1 coefficients: distorting the result again (forward Brown model, float64) must return the input
+    und = oracle.remove_image_distortion(xy, TUM_FR1_K, TUM_FR1_DIST).astype(np.float64)
+    fx, fy, cx, cy = 517.3, 516.5, 318.6, 255.3
+    k1, k2, p1, p2, k3 = TUM_FR1_DIST
+    x, y = (und[:, 0] - cx) / fx, (und[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    back = np.stack([xd * fx + cx, yd * fy + cy], 1)
+    err = np.abs(back - xy).max(axis=1)
+    assert np.median(err) < 2e-3 and err.max() < 0.2   # 5 fixed-point iterations: the corners keep a residual
+    assert np.abs(und - xy).max() > 0.5         # the coefficients do move points near the border
