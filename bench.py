@@ -138,14 +138,32 @@ def main():
         dom = max(kern, key=kern.get)
         dom_ms = kern[dom]
         achieved = bytes_per_pair * P / (dom_ms * 1e-3) / 1e9
-        # non-FMA VALU work of the two sweeps: 18 ops per descriptor pair; per (hypothesis, match)
-        # 29 ops (Euclid) or ~150 (reprojection incl. 4 IEEE divides).
-        ops_match = 18.0 * args.kpts * args.kpts
-        ops_score = (29.0 if args.error_version in (0, 4) else 150.0) * Hs * m_valid
-        valu = {
-            "ps_hamming_nn": ops_match * P / (kern.get("ps_hamming_nn", float("nan")) * 1e-3) / 1e12,
-            "ps_ransac_score": ops_score * P / (kern.get("ps_ransac_score", float("nan")) * 1e-3) / 1e12,
-        }
+        # VALU issue model of the two sweeps: static instruction mix of the hot loops (profiles/isa_mix.json,
+        # from profiles/isa_mix.py) priced with the per-instruction issue costs measured on this GPU model
+        # (profiles/microbench/valu_rates_mi355x.txt).  frac = modelled issue time / measured kernel time.
+        valu_issue = None
+        try:
+            mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+            simd_hz = 256 * 4 * 2.4e9
+            waves_match = P * (args.kpts / 64.0)                      # one lane per train row
+            units_match = waves_match * args.kpts                     # descriptor pairs per wave
+            waves_score = P * (Hs / 64.0)
+            units_score = waves_score * m_valid
+            km, ks = mix["ps_hamming_nn"], mix["ps_ransac_score<%d>" % (args.error_version if args.error_version in (0, 1, 2, 4) else 0)]
+            t_match = units_match * km["model_cycles_per_unit"] / simd_hz * 1e3
+            t_score = units_score * ks["model_cycles_per_unit"] / simd_hz * 1e3
+            valu_issue = {
+                "ps_hamming_nn": {"valu_per_pair": km["valu_per_unit"], "model_ms": t_match,
+                                  "frac": t_match / kern.get("ps_hamming_nn", float("nan"))},
+                "ps_ransac_score": {"valu_per_eval": ks["valu_per_unit"], "model_ms": t_score,
+                                    "frac": t_score / kern.get("ps_ransac_score", float("nan"))},
+                "peak_lane_ops_per_s": VALU_PEAK_TOPS * 1e12,
+                "achieved_lane_ops_per_s": {
+                    "ps_hamming_nn": units_match * km["valu_per_unit"] * 64 / (kern.get("ps_hamming_nn", float("nan")) * 1e-3),
+                    "ps_ransac_score": units_score * ks["valu_per_unit"] * 64 / (kern.get("ps_ransac_score", float("nan")) * 1e-3)},
+            }
+        except Exception:
+            valu_issue = None
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
@@ -178,10 +196,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": P,
                          "avg_launch_ms": dom_ms,
-                         "note": "path is VALU-bound, not HBM-bound (DESIGN.md): see valu_tops"},
+                         "note": "path is VALU-issue-bound, not HBM-bound (DESIGN.md section 4): see valu_issue"},
             "kernel_ms": kern,
-            "valu_tops": {"achieved": valu, "peak": VALU_PEAK_TOPS,
-                          "frac": {k: v / VALU_PEAK_TOPS for k, v in valu.items()}},
+            "valu_issue": valu_issue,
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))

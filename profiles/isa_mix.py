@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Static VALU instruction mix of the two sweep loops + their modelled issue time.
+
+Compiles ps_capi.hip to gfx950 assembly, finds the hot loop of ps_hamming_nn<2> and of every
+ps_ransac_score<MODE>, counts VALU instructions per unit of work (descriptor pair / (hypothesis, match)
+evaluation per wave) and prices them with the per-instruction issue costs measured on the MI355X box by
+profiles/microbench/valu_rates (cycles per wave64 instruction per SIMD, normalised to 2.4 GHz).
+Writes profiles/isa_mix.json, which bench.py uses for its `valu_issue` block.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from collections import Counter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RATES = os.path.join(ROOT, "profiles", "microbench", "valu_rates_mi355x.txt")
+
+
+def load_costs():
+    cost = {}
+    for line in open(RATES):
+        parts = line.split()
+        if len(parts) >= 4 and parts[0].startswith("v_"):
+            try:
+                cost[" ".join(parts[:-3])] = float(parts[-1])
+            except ValueError:
+                pass
+    return cost
+
+
+def price(mn, cost):
+    table = [("v_pk_", cost.get("v_pk_mul_f32", 4.4)), ("v_fma_f32", cost.get("v_fma_f32 (3 regs)", 3.0)),
+             ("v_fmac_f32", cost.get("v_fmac_f32", 2.8)), ("v_mul_f32", cost.get("v_mul_f32", 2.6)),
+             ("v_add_f32", cost.get("v_add_f32", 2.6)), ("v_sub_f32", cost.get("v_add_f32", 2.6)),
+             ("v_rcp_f32", cost.get("v_rcp_f32", 8.3)), ("v_sqrt_f32", cost.get("v_sqrt_f32", 8.3)),
+             ("v_xor_b32", cost.get("v_xor_b32", 2.4)), ("v_and_b32", cost.get("v_and_b32", 2.4)),
+             ("v_add_u32", cost.get("v_add_u32", 2.4)), ("v_addc", cost.get("v_add_u32", 2.4)),
+             ("v_mov_b32", cost.get("v_mov_b32", 2.3)), ("v_bcnt", cost.get("v_bcnt_u32_b32", 4.4)),
+             ("v_min_u32", cost.get("v_min_u32", 4.2)), ("v_lshl_or", cost.get("v_lshl_or_b32", 4.45))]
+    for pre, c in table:
+        if mn.startswith(pre):
+            return c
+    return 4.2  # compares, min3/max3, f64, cvt, div_*, cndmask, ...: the half-rate class
+
+
+def hot_loop(body, key):
+    """The innermost loop block with the most occurrences of `key`."""
+    blocks = re.split(r"\n(\.LBB\d+_\d+):", body)
+    best = None
+    for i in range(1, len(blocks), 2):
+        n = blocks[i + 1].count(key)
+        if best is None or n > best[0]:
+            best = (n, blocks[i + 1])
+    return best[1]
+
+
+def valu_of(txt):
+    ins = [l.split()[0] for l in txt.split("\n") if l.strip().startswith("v_")]
+    return Counter(ins)
+
+
+def main():
+    cost = load_costs()
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+                               "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
+                              stderr=subprocess.DEVNULL)
+        s = open(asm).read()
+    out = {"cost_source": "profiles/microbench/valu_rates_mi355x.txt (cycles per wave64 instruction per SIMD @ 2.4 GHz)"}
+    # Hamming sweep: the 4-query unrolled loop evaluates 4 queries x TPL(2) train rows per lane
+    a = s.index("\n_ZN5psdev13ps_hamming_nnILi2EE")
+    body = s[a:s.index(".Lfunc_end", a)]
+    c = valu_of(hot_loop(body, "v_bcnt"))
+    pairs = c["v_bcnt_u32_b32"] / 8.0
+    out["ps_hamming_nn"] = {"unit": "descriptor pair per wave", "valu_per_unit": sum(c.values()) / pairs,
+                            "model_cycles_per_unit": sum(price(k, cost) * v for k, v in c.items()) / pairs,
+                            "mix": dict(c)}
+    for mode in (0, 1, 2, 4):
+        a = s.index("\n_ZN5psdev15ps_ransac_scoreILi%dEE" % mode)
+        body = s[a:s.index(".Lfunc_end", a)]
+        # basic blocks: explicit labels and the fall-through blocks the assembler comments as "; %bb.N:"
+        blocks = re.split(r"\n(\.LBB\d+_\d+:|; %bb\.\d+:)", body)
+        names = [blocks[i] for i in range(1, len(blocks), 2)]
+        texts = [blocks[i + 1] for i in range(1, len(blocks), 2)]
+        heads = [i for i, t in enumerate(texts) if "s_load_dwordx4" in t and "v_pk_mul_f32" in t]
+        head = heads[-1]
+        # the loop latch is the labelled block right before the head (it holds the count update and the back edge target)
+        latch = head - 1
+        latch_label = names[latch].rstrip(":")
+        back = [i for i, t in enumerate(texts) if i >= head and re.search(r"s_c?branch\w* " + re.escape(latch_label) + r"\b", t)]
+        tot = Counter()
+        cold = Counter()
+        if not back:  # single-block (unrolled) loop of the Euclidean modes: the head block is the whole body
+            latch, back = head, [head]
+        end = max(back)
+        for i in range(latch, end + 1):
+            t = texts[i]
+            if "v_div_scale_f32" in t or "v_cvt_f64_f32" in t:
+                cold += valu_of(t)   # '/' fallback and double fallback: taken only outside the window / inside the band
+                continue
+            tot += valu_of(t)
+        per = 1.0
+        if mode in (0, 4):
+            per = max(1, texts[head].count("s_load_dwordx4") // 2)  # unrolled: 2 record loads per match
+        out["ps_ransac_score<%d>" % mode] = {"unit": "(hypothesis, match) evaluation per wave",
+                                             "valu_per_unit": sum(tot.values()) / per,
+                                             "model_cycles_per_unit": sum(price(k, cost) * v for k, v in tot.items()) / per,
+                                             "mix": dict(tot), "cold_fallback_valu": sum(cold.values()) / per}
+    with open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        if isinstance(v, dict):
+            print(k, round(v["valu_per_unit"], 1), "VALU,", round(v["model_cycles_per_unit"], 1), "cycles per", v["unit"])
+
+
+if __name__ == "__main__":
+    main()

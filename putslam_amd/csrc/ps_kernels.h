@@ -341,6 +341,10 @@ PS_D void div2_shared(float a0, float a1, float b, float &q0, float &q1)
     q1 = __builtin_fmaf(h1, r1, g1);
 }
 
+// wave-uniform "every active lane satisfies p": compares the ballot with the exec mask directly, so the
+// predicate never has to be materialised in a VGPR (hipcc's __all() costs a v_cndmask + v_cmp_ne)
+PS_D bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+
 PS_D float min3_abs(float a, float b, float c)
 {
     float r;
@@ -381,7 +385,7 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
             // RGBD::point3Dto2D with the two quotients of each point sharing the reciprocal of z; the whole
             // wavefront takes this branch only when every lane is inside the division window
             const float a0 = nx * k.fx, a1 = ny * k.fy, c0 = ex * k.fx, c1 = ey * k.fy;
-            if (__all(div_window_ok(a0, a1, nz, c0, c1, ez))) {
+            if (wave_all(div_window_ok(a0, a1, nz, c0, c1, ez))) {
                 float q0, q1, q2, q3;
                 div2_shared(a0, a1, nz, q0, q1);
                 div2_shared(c0, c1, ez, q2, q3);
@@ -411,7 +415,7 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
             float fm;
             memcpy(&fm, &um, 4);
             const bool sureIn = fm < k.bLo, sureOut = fm > k.bHi;
-            if (__all(sureIn || sureOut)) return in && sureIn;
+            if (wave_all(sureIn || sureOut)) return in && sureIn;
             // keep the double evaluation on the cold side of the branch (the compiler would otherwise
             // speculate its eight f64 instructions above it)
             asm volatile("" : "+v"(dxn), "+v"(dyn), "+v"(dxo), "+v"(dyo));
