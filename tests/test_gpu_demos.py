@@ -1,0 +1,56 @@
+"""Harness semantics of the reference's demos + the pose accuracy claim."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_demo_kabsch(ctx):
+    from demos import demo_kabsch
+    T, err, sigma = demo_kabsch.main(["--points", "500"])
+    assert np.all(err < 3 * sigma) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+
+
+def test_demo_matching_trajectory(ctx, tmp_path):
+    from demos import demo_matching
+    out = tmp_path / "VO_trajectory.res"
+    traj, gt, ate = demo_matching.main(["--frames", "40", "--kpts", "1000", "--out", str(out)])
+    lines = open(out).read().strip().split("\n")
+    assert len(lines) == 40 and all(len(l.split()) == 8 for l in lines)
+    assert lines[0].split()[1:] == ["0", "0", "0", "0", "0", "0", "1"]
+    assert ate < 0.02                                       # 39 increments of <= 5 cm each, 4 mm point noise
+
+
+def test_demo_usac(ctx):
+    from demos import demo_usac
+    out, gt = demo_usac.main([])
+    for name in ("RANSAC", "USAC"):
+        assert out[name]["stats"]["accepted"] == 1
+        assert np.abs(out[name]["pose"] - gt).max() < (5e-3 if name == "RANSAC" else 3e-2)
+
+
+def test_noise_free_pose_within_1e5(ctx):
+    """north_star: pose within 1e-5.  Exact correspondences under a known rigid motion: the refit pose must
+    agree with the ground truth to 1e-5 (float32 Umeyama over ~1000 points), for every error mode."""
+    from putslam_amd import synth
+    from putslam_amd._abi import DMATCH_DTYPE, EST_RANSAC, TUM_FR1_K, default_ransac_params, make_config
+    rng = np.random.default_rng(7)
+    n = 1200
+    cur = (rng.uniform(-1.0, 1.0, (n, 3)) * [1.2, 0.9, 1.0] + [0, 0, 2.5]).astype(np.float32)
+    R, t = synth.random_motion(rng, 2.0, 0.05)
+    prev = (cur.astype(np.float64) @ R.T + t).astype(np.float32)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    for mode in (0, 1, 2, 4):
+        cfg, _ = make_config(EST_RANSAC, 487, seed=mode)
+        r = ctx.ransac_rigid3d(default_ransac_params(mode), cfg, TUM_FR1_K, prev, cur, m)
+        assert r["stats"]["numInliers"] == n
+        assert np.abs(r["pose"] - T).max() < 1e-5, (mode, np.abs(r["pose"] - T).max())
