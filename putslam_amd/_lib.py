@@ -31,10 +31,26 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+def _try_build():
+    """The .so is a build artefact (git-ignored): if it is absent but hipcc is here, compile it in-tree."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(_HERE, "csrc", "ps_capi.hip")
+    if not (os.path.exists(hipcc) and os.path.exists(src)):
+        return
+    import subprocess
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared", src, "-o", LIB_PATH]
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        pass
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH):
+        _try_build()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

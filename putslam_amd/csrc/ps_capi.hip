@@ -39,7 +39,7 @@ struct PsContext {
     Buf keys, recA, recB, recC, recD, counts, mvalid, idxList, raw;
     Buf tabR, tabU;
     // staging for the host-pointer entry points (device)
-    Buf sDesc, sPts, sNk, sPairs, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
+    Buf sDesc, sNk, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
     // cached stop tables
     int tabEstimator = -1, tabH = -1, tabRN = 0, tabUN = 0, tabIter0 = 0;
     double tabMinRatio = -1.0;
@@ -390,12 +390,14 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     }
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
-    size_t lds = 2 * (size_t)((pl.sa.trainRange + 31) / 32) * sizeof(uint32_t);
+    SelectArgs sa = pl.sa;
+    sa.stageCap = cap < 1536 ? cap : 1536; // 36 KiB of LDS for the refit's operands
+    size_t lds = 2 * (size_t)((sa.trainRange + 31) / 32) * sizeof(uint32_t) + (size_t)sa.stageCap * 6 * sizeof(float);
     tick(ctx, slot0 + 1, false);
     hipLaunchKernelGGL(ps_select_refit, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream,
                        (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
                        (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
-                       dMatches, dNumMatches, matchStride, pl.ma, pl.sc, pl.sa, (int32_t *)ctx->idxList.p, dPose,
+                       dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
                        dMask, dStats);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
@@ -518,8 +520,8 @@ void ps_context_destroy(PsContext *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->counts, &ctx->mvalid,
-                  &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sPts, &ctx->sNk,
-                  &ctx->sPairs, &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
+                  &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
+                  &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
     for (Buf *b : all) release(*b);
     for (hipEvent_t e : ctx->ev)

@@ -547,6 +547,7 @@ struct SelectArgs {
     const double *usacTab;   // non-increasing; usacTab[k] = smallest p with stopping(p) <= k+1
     int usacTabN;
     int trainRange;      // train indices are < trainRange (size of the uniqueness bitmaps, 0 = skip)
+    int stageCap;        // inlier correspondences staged in LDS for the refit (6 floats each)
 };
 
 // min(Kcap, computeRANSACIteration(r)) through the host-built threshold table (RANSAC.cpp:450-461).
@@ -621,6 +622,8 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
 
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int words = (a.trainRange + 31) >> 5;
+    float *s_stage = reinterpret_cast<float *>(s_bits + 2 * words); // [stageCap][6]: cur xyz (src), prev xyz (dst)
     const int M = mvalid[p];
     const int nIn = numMatches[p];
     const size_t rbase = (size_t)p * a.cap;
@@ -724,10 +727,19 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
             }
             int total;
             int pos = block_scan_flag(in, total, s_wsum);
-            if (in) list[kin + pos] = i;
+            if (in) {
+                const int slot = kin + pos;
+                list[slot] = i;
+                if (slot < a.stageCap) { // the refit's operands, parked in LDS while they are in registers anyway
+                    float4 A = recA[rbase + i], B = recB[rbase + i];
+                    float *d = s_stage + 6 * slot;
+                    d[0] = B.x; d[1] = B.y; d[2] = B.z;
+                    d[3] = A.x; d[4] = A.y; d[5] = A.z;
+                }
+            }
             kin += total;
         }
-        __syncthreads(); // list visible to the whole workgroup (global memory, same CU)
+        __syncthreads(); // list / staged points visible to the whole workgroup
     }
 
     const float ratioF = run ? (float)bestCount / (float)M : 0.0f;
@@ -741,10 +753,16 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
             Rigid ref;
             wave_umeyama(kin,
                          [&](int j, float (&s)[3], float (&d)[3]) {
-                             int i = list[j];
-                             float4 A = recA[rbase + i], B = recB[rbase + i];
-                             d[0] = A.x; d[1] = A.y; d[2] = A.z;
-                             s[0] = B.x; s[1] = B.y; s[2] = B.z;
+                             if (j < a.stageCap) {
+                                 const float *q = s_stage + 6 * j;
+                                 s[0] = q[0]; s[1] = q[1]; s[2] = q[2];
+                                 d[0] = q[3]; d[1] = q[4]; d[2] = q[5];
+                             } else {
+                                 int i = list[j];
+                                 float4 A = recA[rbase + i], B = recB[rbase + i];
+                                 d[0] = A.x; d[1] = A.y; d[2] = A.z;
+                                 s[0] = B.x; s[1] = B.y; s[2] = B.z;
+                             }
                          },
                          ref);
             if (lane == 0) s_model = ref;
@@ -775,7 +793,6 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
     __syncthreads();
 
     // ---- (4) pointInlierRatio: unique trainIdx among final inliers / among all input matches ----
-    const int words = (a.trainRange + 31) >> 5;
     for (int i = tid; i < 2 * words; i += kBlock) s_bits[i] = 0u;
     if (tid == 0) s_uniq[0] = s_uniq[1] = 0;
     __syncthreads();
