@@ -211,6 +211,20 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);
 
+/* ---- A2, streaming form: Matcher::match (src/Matcher/matcher.cpp:452-516) with the previous frame's
+ * descriptors and 3-D points resident in HBM (the prevDescriptors / prevFeatures3D state, matcher.h:379-384).
+ * The first push only stores the frame (detectInitFeatures, matcher.cpp:17-64) and returns *nmatches = -1;
+ * every later push matches previous (query) against the new frame (train), runs the estimator selected by
+ * cfg on the surviving matches and makes the new frame the previous one (:506-513).
+ * Hypothesis stream of every push = cfg->seed (the caller varies it per frame if wanted).
+ * matches / inlierMask: capacity maxKpts; pose column-major 4x4; host pointers. */
+typedef struct PsVoStream PsVoStream;
+int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out);
+void ps_vo_stream_destroy(PsVoStream *s);
+int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                      const uint8_t *desc, size_t descStep, const float *pts, int n,
+                      PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose, PsRansacStats *stats);
+
 /* Algorithmic bytes one call of ps_vo_pairs_device moves per SURVEY.md section 8(d):
  * computed from the per-pair stats already on the host (numMatchesIn, numMatchesValid). */
 uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int numHypotheses);

@@ -220,6 +220,46 @@ class Context:
                                              C.c_void_p(pairs_dev_ptr), int(P), C.byref(res)))
 
 
+class VoStream:
+    """Streaming Matcher::match (matcher.cpp:452-516): previous frame resident in HBM (ps_vo_stream_*)."""
+
+    def __init__(self, ctx: Context, max_kpts):
+        self._ctx = ctx
+        self._cap = int(max_kpts)
+        h = C.c_void_p()
+        ctx._chk(ctx._L.ps_vo_stream_create(ctx._h, self._cap, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._ctx._L.ps_vo_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, params, cfg, K, desc, pts):
+        """Returns None for the first frame, else dict(matches, mask, pose, stats)."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32)
+        K = np.ascontiguousarray(K, np.float32)
+        n = desc.shape[0]
+        matches = np.zeros(max(self._cap, 1), DMATCH_DTYPE)
+        mask = np.zeros(max(self._cap, 1), np.uint8)
+        pose = np.zeros(16, np.float32)
+        stats = np.zeros(1, STATS_DTYPE)
+        nm = C.c_int(0)
+        self._ctx._chk(self._ctx._L.ps_vo_stream_push(self._h, C.byref(params), C.byref(cfg), _p(K), _p(desc), 32, _p(pts),
+                                                      n, _p(matches), C.byref(nm), _p(mask), _p(pose), _p(stats)))
+        if nm.value < 0:
+            return None
+        return dict(matches=matches[: nm.value].copy(), mask=mask[: nm.value].copy(),
+                    pose=pose.reshape(4, 4).T.copy(), stats=stats[0].copy())
+
+
 class DeviceFrames:
     """Raw device pointers of a frame set (PsFrameSet)."""
 

@@ -1036,4 +1036,124 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
                             out->stats, 2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming form of Matcher::match (reference src/Matcher/matcher.cpp:452-516): the previous frame's
+// descriptors and 3-D points stay resident in HBM (the prevDescriptors / prevFeatures3D members,
+// matcher.h:379-384), each push uploads only the new frame.
+struct PsVoStream {
+    PsContext *ctx = nullptr;
+    int cap = 0;
+    long long frames = 0;   // frames pushed so far
+    int curSlot = 0;        // slot of the most recent frame
+    Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot}
+    Buf matches, numM, mask, pose, stats;
+};
+
+int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out || maxKpts < 1 || maxKpts > PS_MAX_KPTS) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_create: bad argument");
+    PsVoStream *s = new PsVoStream();
+    s->ctx = ctx;
+    s->cap = maxKpts;
+    *out = s;
+    const size_t cap = (size_t)maxKpts;
+    PS_ENSURE(s->desc, 2 * cap * 32);
+    PS_ENSURE(s->pts, 2 * cap * 12);
+    PS_ENSURE(s->meta, 4 * sizeof(int32_t));
+    PS_ENSURE(s->matches, cap * sizeof(PsDMatch));
+    PS_ENSURE(s->numM, sizeof(int32_t));
+    PS_ENSURE(s->mask, cap);
+    PS_ENSURE(s->pose, 16 * sizeof(float));
+    PS_ENSURE(s->stats, sizeof(PsRansacStats));
+    PS_HIP(hipMemsetAsync(s->meta.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    return PS_OK;
+}
+
+void ps_vo_stream_destroy(PsVoStream *s)
+{
+    if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    Buf *all[] = {&s->desc, &s->pts, &s->meta, &s->matches, &s->numM, &s->mask, &s->pose, &s->stats};
+    for (Buf *b : all) release(*b);
+    delete s;
+}
+
+int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                      const uint8_t *desc, size_t descStep, const float *pts, int n, PsDMatch *matches, int *nmatches,
+                      uint8_t *inlierMask, float *pose, PsRansacStats *stats)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    PsContext *ctx = s->ctx;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    TimingOff toff(ctx);
+    if (pose) identity16(pose);
+    if (nmatches) *nmatches = 0;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->bestHypothesis = -1;
+        stats->pointInlierRatio = NAN;
+    }
+    if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES || !pose || !nmatches ||
+        (n > 0 && (!matches || !inlierMask)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: bad argument");
+    const int slot = s->frames == 0 ? 0 : 1 - s->curSlot;
+    const size_t cap = (size_t)s->cap;
+    if (n > 0) {
+        PS_HIP(hipMemcpy2DAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, 32, desc, descStep, 32, (size_t)n,
+                                hipMemcpyHostToDevice, ctx->stream));
+        PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, pts, (size_t)n * 12, hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
+    int32_t nk = n;
+    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &nk, sizeof nk, hipMemcpyHostToDevice, ctx->stream));
+    const int prevSlot = s->curSlot;
+    const bool first = s->frames == 0;
+    s->curSlot = slot;
+    s->frames++;
+    if (first) { // detectInitFeatures (matcher.cpp:17-64): nothing to match against yet
+        PS_HIP(hipStreamSynchronize(ctx->stream));
+        *nmatches = -1;
+        return PS_OK;
+    }
+    int32_t pr[2] = {prevSlot, slot}; // query = previous frame, train = current (matcher.cpp:470-471)
+    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, pr, sizeof pr, hipMemcpyHostToDevice, ctx->stream));
+    PsFrameSet fs;
+    fs.desc = (const uint8_t *)s->desc.p;
+    fs.pts = (const float *)s->pts.p;
+    fs.nkpts = (const int32_t *)s->meta.p;
+    fs.numFrames = 2;
+    fs.maxKpts = s->cap;
+    Plan pl;
+    PsRansacConfig c = *cfg;
+    if (c.sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming call");
+    rc = make_plan(ctx, params, &c, K, s->cap, s->cap, pl);
+    if (rc) return rc;
+    rc = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)s->matches.p,
+                         (int32_t *)s->numM.p, 0);
+    if (rc) return rc;
+    rc = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)s->matches.p, (const int32_t *)s->numM.p, s->cap,
+                          (float *)s->pose.p, (uint8_t *)s->mask.p, (PsRansacStats *)s->stats.p, 2);
+    if (rc) return rc;
+    int32_t nm = 0;
+    PsRansacStats st;
+    PS_HIP(hipMemcpyAsync(&nm, s->numM.p, sizeof nm, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(pose, s->pose.p, 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(&st, s->stats.p, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    if (nm > 0) {
+        PS_HIP(hipMemcpyAsync(matches, s->matches.p, (size_t)nm * sizeof(PsDMatch), hipMemcpyDeviceToHost, ctx->stream));
+        PS_HIP(hipMemcpyAsync(inlierMask, s->mask.p, (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
+        PS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *nmatches = nm;
+    if (stats) *stats = st;
+    return PS_OK;
+}
+
 } // extern "C"

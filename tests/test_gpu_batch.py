@@ -131,3 +131,29 @@ def test_stress_config_sizes(ctx, oracle):
         cfgp, _ = make_config(EST_FIXED, int(st["bestHypothesis"]) + 1, seed=9 + p)
         cnt, M = oracle.hypothesis_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], g["matches"][p, :n])
         assert M == st["numMatchesValid"] and cnt[-1] == st["bestInlierCount"] and cnt.max() == cnt[-1]
+
+
+def test_streaming_match_state(ctx, oracle):
+    """ps_vo_stream_*: Matcher::match with the previous frame kept on the GPU; ragged frame sizes."""
+    from putslam_amd import api
+    seq = synth.make_sequence(7, 700, config=3, index=9)
+    nk = [700, 650, 700, 300, 700, 1, 700]
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    st = api.VoStream(ctx, 700)
+    prev = None
+    for f in range(7):
+        cfg, _ = make_config(EST_RANSAC, 487, seed=100 + f)
+        d, p3 = seq["desc"][f][: nk[f]], seq["pts"][f][: nk[f]]
+        r = st.push(prm, cfg, TUM_FR1_K, d, p3)
+        if f == 0:
+            assert r is None
+        else:
+            m = oracle.match_hamming256(prev[0], d)
+            c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, prev[1], p3, m)
+            assert r["matches"].tobytes() == m.tobytes()
+            assert np.array_equal(r["mask"], c["mask"]) and r["pose"].tobytes() == c["pose"].tobytes()
+            for fld in STAT_FIELDS:
+                a, b = r["stats"][fld], c["stats"][fld]
+                assert a == b or (np.isnan(a) and np.isnan(b)), (f, fld, a, b)
+        prev = (d, p3)
+    st.close()
