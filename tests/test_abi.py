@@ -66,3 +66,11 @@ def test_product_never_touches_oracle():
     so = os.path.join(ROOT, "putslam_amd", "libputslam_hip.so")
     syms = os.popen(f"nm -D --undefined-only {so}").read()
     assert "po_" not in syms
+
+
+def test_header_is_plain_c(tmp_path):
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "abi_check.c")
+    out = tmp_path / "abi_check.o"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
+                           "-o", str(out)])

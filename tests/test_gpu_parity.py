@@ -386,3 +386,18 @@ def test_remove_image_distortion_bits(ctx, oracle):
         g = ctx.remove_image_distortion(xy, TUM_FR1_K, dist)
         c = oracle.remove_image_distortion(xy, TUM_FR1_K, dist)
         assert g.tobytes() == c.tobytes()
+
+
+def test_maximum_keypoints_per_frame(ctx, oracle):
+    """PS_MAX_KPTS = 16384 rows per frame: the cross-check keeps best[q] for all of them in LDS (64 KiB)."""
+    n = 16384
+    rng = np.random.default_rng(16384)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = q[rng.permutation(n)] ^ np.packbits(rng.random((n, 256)) < 0.06, axis=1)
+    t[n // 2:] = rng.integers(0, 256, (n - n // 2, 32), dtype=np.uint8)
+    g = ctx.match_hamming256(q, t)
+    c = oracle.match_hamming256(q, t)
+    assert g.tobytes() == c.tobytes() and len(g) > n // 3
+    from putslam_amd import api
+    with pytest.raises(api.PsError):
+        ctx.match_hamming256(np.zeros((n + 1, 32), np.uint8), t)
