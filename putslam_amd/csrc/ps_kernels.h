@@ -464,11 +464,16 @@ __global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restri
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
-#pragma unroll 4
-    for (int m = m0; m < m1; ++m) {
+    auto body = [&](int m) {
         float4 A = pa[m], B = pb[m], C = make_float4(0, 0, 0, 0);
         if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) C = pc[m];
         cnt += inlier_test<MODE, true>(mdl, inv, k, A, B, C) ? 1 : 0;
+    };
+    if (MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR) {
+#pragma unroll 4
+        for (int m = m0; m < m1; ++m) body(m); // straight-line body: batches the scalar record loads
+    } else {
+        for (int m = m0; m < m1; ++m) body(m); // wave-uniform branches inside: not unrollable
     }
     if (h < H) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
