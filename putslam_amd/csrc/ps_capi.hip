@@ -1046,7 +1046,13 @@ struct PsVoStream {
     long long frames = 0;   // frames pushed so far
     int curSlot = 0;        // slot of the most recent frame
     Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot}
-    Buf matches, numM, mask, pose, stats;
+    // One contiguous result block on the device and its pinned host mirror, so a push needs ONE
+    // device-to-host copy and ONE synchronisation: [PsRansacStats][pose 16 f32][numMatches i32 + pad]
+    // [matches cap x 16 B][mask cap B]
+    Buf res;
+    uint8_t *hres = nullptr;   // pinned
+    uint8_t *hin = nullptr;    // pinned staging of the incoming frame: [cap x 32 B][cap x 12 B][4 x i32]
+    size_t offPose = 0, offNum = 0, offMatches = 0, offMask = 0, resBytes = 0;
 };
 
 int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
@@ -1059,14 +1065,17 @@ int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
     s->cap = maxKpts;
     *out = s;
     const size_t cap = (size_t)maxKpts;
+    s->offPose = sizeof(PsRansacStats);
+    s->offNum = s->offPose + 16 * sizeof(float);
+    s->offMatches = s->offNum + 16;
+    s->offMask = s->offMatches + cap * sizeof(PsDMatch);
+    s->resBytes = s->offMask + cap;
     PS_ENSURE(s->desc, 2 * cap * 32);
     PS_ENSURE(s->pts, 2 * cap * 12);
     PS_ENSURE(s->meta, 4 * sizeof(int32_t));
-    PS_ENSURE(s->matches, cap * sizeof(PsDMatch));
-    PS_ENSURE(s->numM, sizeof(int32_t));
-    PS_ENSURE(s->mask, cap);
-    PS_ENSURE(s->pose, 16 * sizeof(float));
-    PS_ENSURE(s->stats, sizeof(PsRansacStats));
+    PS_ENSURE(s->res, s->resBytes);
+    PS_HIP(hipHostMalloc((void **)&s->hres, s->resBytes, hipHostMallocDefault));
+    PS_HIP(hipHostMalloc((void **)&s->hin, cap * 44 + 16, hipHostMallocDefault));
     PS_HIP(hipMemsetAsync(s->meta.p, 0, 4 * sizeof(int32_t), ctx->stream));
     return PS_OK;
 }
@@ -1078,8 +1087,10 @@ void ps_vo_stream_destroy(PsVoStream *s)
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
-    Buf *all[] = {&s->desc, &s->pts, &s->meta, &s->matches, &s->numM, &s->mask, &s->pose, &s->stats};
+    Buf *all[] = {&s->desc, &s->pts, &s->meta, &s->res};
     for (Buf *b : all) release(*b);
+    if (s->hres) (void)hipHostFree(s->hres);
+    if (s->hin) (void)hipHostFree(s->hin);
     delete s;
 }
 
@@ -1100,20 +1111,31 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         stats->pointInlierRatio = NAN;
     }
     if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES || !pose || !nmatches ||
-        (n > 0 && (!matches || !inlierMask)))
+        (n > 0 && (!matches || !inlierMask)) || !cfg)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: bad argument");
-    const int slot = s->frames == 0 ? 0 : 1 - s->curSlot;
+    if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming call");
+    const bool first = s->frames == 0;
+    const int slot = first ? 0 : 1 - s->curSlot;
+    const int prevSlot = s->curSlot;
     const size_t cap = (size_t)s->cap;
+    // incoming frame -> pinned staging -> HBM (asynchronous; the staging area is free again after the
+    // synchronisation that ends the previous push)
+    uint8_t *hd = s->hin;
+    float *hp = reinterpret_cast<float *>(s->hin + cap * 32);
+    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44);
+    for (int i = 0; i < n; ++i) memcpy(hd + (size_t)i * 32, desc + (size_t)i * descStep, 32);
+    if (n > 0) memcpy(hp, pts, (size_t)n * 12);
     if (n > 0) {
-        PS_HIP(hipMemcpy2DAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, 32, desc, descStep, 32, (size_t)n,
-                                hipMemcpyHostToDevice, ctx->stream));
-        PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, pts, (size_t)n * 12, hipMemcpyHostToDevice,
+        PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, (size_t)n * 32, hipMemcpyHostToDevice,
+                              ctx->stream));
+        PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, hp, (size_t)n * 12, hipMemcpyHostToDevice,
                               ctx->stream));
     }
-    int32_t nk = n;
-    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &nk, sizeof nk, hipMemcpyHostToDevice, ctx->stream));
-    const int prevSlot = s->curSlot;
-    const bool first = s->frames == 0;
+    hm[0] = n;
+    hm[1] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
+    hm[2] = slot;
+    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &hm[0], sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, &hm[1], 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     s->curSlot = slot;
     s->frames++;
     if (first) { // detectInitFeatures (matcher.cpp:17-64): nothing to match against yet
@@ -1121,8 +1143,6 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         *nmatches = -1;
         return PS_OK;
     }
-    int32_t pr[2] = {prevSlot, slot}; // query = previous frame, train = current (matcher.cpp:470-471)
-    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, pr, sizeof pr, hipMemcpyHostToDevice, ctx->stream));
     PsFrameSet fs;
     fs.desc = (const uint8_t *)s->desc.p;
     fs.pts = (const float *)s->pts.p;
@@ -1130,29 +1150,26 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     fs.numFrames = 2;
     fs.maxKpts = s->cap;
     Plan pl;
-    PsRansacConfig c = *cfg;
-    if (c.sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming call");
-    rc = make_plan(ctx, params, &c, K, s->cap, s->cap, pl);
+    rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
     if (rc) return rc;
-    rc = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)s->matches.p,
-                         (int32_t *)s->numM.p, 0);
+    uint8_t *dres = (uint8_t *)s->res.p;
+    rc = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)(dres + s->offMatches),
+                         (int32_t *)(dres + s->offNum), 0);
     if (rc) return rc;
-    rc = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)s->matches.p, (const int32_t *)s->numM.p, s->cap,
-                          (float *)s->pose.p, (uint8_t *)s->mask.p, (PsRansacStats *)s->stats.p, 2);
+    rc = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)(dres + s->offMatches), (const int32_t *)(dres + s->offNum),
+                          s->cap, (float *)(dres + s->offPose), dres + s->offMask, (PsRansacStats *)dres, 2);
     if (rc) return rc;
-    int32_t nm = 0;
-    PsRansacStats st;
-    PS_HIP(hipMemcpyAsync(&nm, s->numM.p, sizeof nm, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipMemcpyAsync(pose, s->pose.p, 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipMemcpyAsync(&st, s->stats.p, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(s->hres, dres, s->resBytes, hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));
+    int32_t nm = 0;
+    memcpy(&nm, s->hres + s->offNum, sizeof nm);
+    memcpy(pose, s->hres + s->offPose, 16 * sizeof(float));
+    if (stats) memcpy(stats, s->hres, sizeof *stats);
     if (nm > 0) {
-        PS_HIP(hipMemcpyAsync(matches, s->matches.p, (size_t)nm * sizeof(PsDMatch), hipMemcpyDeviceToHost, ctx->stream));
-        PS_HIP(hipMemcpyAsync(inlierMask, s->mask.p, (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
-        PS_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(matches, s->hres + s->offMatches, (size_t)nm * sizeof(PsDMatch));
+        memcpy(inlierMask, s->hres + s->offMask, (size_t)nm);
     }
     *nmatches = nm;
-    if (stats) *stats = st;
     return PS_OK;
 }
 
