@@ -95,7 +95,7 @@ def test_full_size_properties(ctx, oracle):
     for j, p in enumerate(sample):
         cfgp, _ = make_config(EST_FIXED, 4096, seed=42 + p)
         n = int(g["numMatches"][p])
-        cc = oracle.ransac_rigid3d(prm, cfgp, TUM_FR1_K, seq["desc"] is None or seq["pts"][p], seq["pts"][p + 1],
+        cc = oracle.ransac_rigid3d(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1],
                                    g["matches"][p, :n])
         assert c["matches"][j, :n].tobytes() == g["matches"][p, :n].tobytes()
         assert np.array_equal(cc["mask"], g["inlierMask"][p, :n])
