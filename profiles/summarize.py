@@ -44,16 +44,18 @@ def main():
     summary = {
         "command": "profiles/run_profiles.sh " + tag + "  (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE: "
                    "three separate passes of the same bench.py command)",
-        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch. The reads of these kernels are scalar loads "
-                "(s_load_dwordx4/x8 through the scalar cache) and 16-byte vector loads; the gfx950 x2 correction "
-                "of MI355X_MICROARCH.md is stated for wide coalesced streams only and is NOT applied "
-                "(uncalibrated for this access pattern).",
+        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+                "counts 128-B requests at 64 B, i.e. reports half of the bytes read -> doubled before use. Calibrated on "
+                "this access pattern (scalar s_load_dwordx4/x16 + 16-byte vector loads): the matcher kernel reads every "
+                "descriptor row of the 500-frame sequence (500 x 2000 x 32 B = 32.0 MB unique; re-reads are served by the "
+                "XCD L2 after the XCD-aware ordering) and reports FETCH_SIZE = 16.4 MB = 32.7 MB after doubling. "
+                "WRITE_SIZE is used as is. traffic = 2 x FETCH_SIZE + WRITE_SIZE.",
         "kernels": kern}
     with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
-    allt[key] = {k: int((v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024)
+    allt[key] = {k: int((2.0 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024)
                  for k, v in kern.items()}
     allt[key]["_source"] = f"profiles/{tag}/pmc_summary.json"
     with open(tf, "w") as f:
