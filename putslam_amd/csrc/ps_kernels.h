@@ -431,10 +431,11 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
 // Kernel 3.  RANSAC loop body of RANSAC.cpp:93-135 for ALL hypotheses at once.
 // lane = hypothesis (model in VGPRs); the match records are wave-uniform and arrive through
 // scalar loads.  grid = ceil(H/256) * msplit * P work-groups in XCD-aware order; msplit > 1 splits the
-// match range and merges the integer counts with atomicAdd.
+// match range and merges the integer counts with atomicAdd.  __launch_bounds__(256, 6): 6 waves per SIMD
+// (80 VGPRs; the one-off Jacobi-SVD prologue spills 3-5 dwords) measured 2-3 % faster than 5 waves, 8 is slower.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void ps_ransac_score(const float4 *__restrict__ recA,
+__global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__restrict__ recA,
                                                           const float4 *__restrict__ recB,
                                                           const float4 *__restrict__ recC,
                                                           const int32_t *__restrict__ mvalid, ModelArgs ma,
