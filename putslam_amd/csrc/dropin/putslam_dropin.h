@@ -164,6 +164,13 @@ class Matcher {
     static constexpr double scaleFactor = 1.2; // matcher.h:26-27
     static constexpr int nLevels = 8;
 
+    // Matcher::featureSet (matcher.h:31-37) restricted to what the hot path holds: the image-domain members
+    // (cv::KeyPoint lists, 2-D positions, detection distances) belong to the out-of-scope detect/describe stages.
+    struct featureSet {
+        cv::Mat descriptors;
+        std::vector<Eigen::Vector3f> feature3D;
+    };
+
     Matcher(const std::string _name) : name(_name), frameCounter(0) {}
     virtual ~Matcher() {}
     virtual const std::string &getName() const = 0;
@@ -192,6 +199,13 @@ class Matcher {
                     const std::vector<double> &currentPoseDetDists, Eigen::Matrix4f &estimatedTransformation,
                     std::vector<cv::DMatch> &inlierMatches, int computationNumber = 1);
     int getNumberOfFeatures() const { return (int)prevFeatures3D.size(); }
+    featureSet getFeatures() // matcher.cpp:980-989
+    {
+        featureSet r;
+        r.descriptors = prevDescriptors;
+        r.feature3D = prevFeatures3D;
+        return r;
+    }
     void setSampleSeed(uint64_t s) { seed_ = s; seeded_ = true; }
 
     MatcherParameters matcherParameters;

@@ -102,6 +102,7 @@ int main(int argc, char **argv)
     double r1 = matcher->match(B, cur, Tm, inlm);
     CHECK(std::memcmp(Tm.data(), epose.data(), 64) == 0 && inlm.size() == inl.size() && r1 == ratio);
     CHECK(matcher->getNumberOfFeatures() == N);
+    CHECK(matcher->getFeatures().feature3D.size() == (size_t)N && matcher->getFeatures().descriptors.rows == N);
     double r2 = matcher->match(B, cur, Tm, inlm); // cur vs cur: identity motion, all valid matches inliers
     CHECK(r2 > 0.5 && std::fabs(Tm(0, 3)) < 1e-4f && std::fabs(Tm(0, 0) - 1.0f) < 1e-5f);
 
