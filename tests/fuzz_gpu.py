@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised soak test: HIP path vs oracle over many random configurations (sizes, inlier ratios, noise,
+error modes, estimators, thresholds, seeds).  Not collected by pytest; run on the GPU box:
+
+    python tests/fuzz_gpu.py --iters 3000 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle_py as po  # noqa: E402
+from putslam_amd import api, synth  # noqa: E402
+from putslam_amd._abi import EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-kpts", type=int, default=1500)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    ctx = api.Context(0)
+    t0 = time.time()
+    bad = 0
+    for it in range(a.iters):
+        n = int(rng.integers(4, a.max_kpts))
+        frac = float(rng.uniform(0.05, 0.95))
+        noise = float(10 ** rng.uniform(-4, -1.3))
+        pa, pb = synth.make_pair(n, config=7, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)
+        mode = int(rng.choice([0, 1, 2, 4, 3]))
+        est, H = [(EST_RANSAC, 1157), (EST_USAC, int(rng.integers(50, 3000))), (EST_FIXED, int(rng.integers(1, 3000)))][
+            int(rng.integers(0, 3))]
+        prm = default_ransac_params(mode, lc=bool(rng.integers(0, 2)))
+        prm.inlierThresholdEuclidean = float(10 ** rng.uniform(-3, -0.5))
+        prm.inlierThresholdReprojection = float(10 ** rng.uniform(-1, 1.5))
+        prm.minimalInlierRatioThreshold = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.3, 0.5]))
+        prm.minimalNumberOfMatches = int(rng.choice([3, 8, 10, 15, 40]))
+        K = TUM_FR1_K if rng.random() < 0.9 else TUM_FR1_K * np.float32(10 ** rng.uniform(-3, 3))
+        cfg, _ = make_config(est, H, seed=int(rng.integers(0, 2 ** 62)))
+        mg = ctx.match_hamming256(pa["desc"], pb["desc"])
+        mc = po.match_hamming256(pa["desc"], pb["desc"])
+        ok = mg.tobytes() == mc.tobytes()
+        g = ctx.ransac_rigid3d(prm, cfg, K, pa["pts"], pb["pts"], mc)
+        c = po.ransac_rigid3d(prm, cfg, K, pa["pts"], pb["pts"], mc)
+        ok &= np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+        for f in c["stats"].dtype.names:
+            x, y = g["stats"][f], c["stats"][f]
+            ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+        if not ok:
+            bad += 1
+            print("MISMATCH", dict(it=it, n=n, frac=frac, noise=noise, mode=mode, est=est, H=H), g["stats"], c["stats"], flush=True)
+        if (it + 1) % 200 == 0:
+            print(f"{it + 1} iterations, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz done: {a.iters} iterations, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
