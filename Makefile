@@ -1,0 +1,32 @@
+# Convenience targets; __graft_entry__.build() does the same from Python.
+HIPCC ?= /opt/rocm/bin/hipcc
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+CSRC := putslam_amd/csrc
+LIB := putslam_amd/libputslam_hip.so
+DROPIN := putslam_amd/libputslam_dropin.so
+
+all: $(LIB) $(DROPIN) oracle
+
+$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_device_math.h include/putslam_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
+
+$(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I$(CSRC)/dropin $< -o $@ -Lputslam_amd -lputslam_hip '-Wl,-rpath,$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+test-cpu: all
+	python -m pytest tests -q -m "not gpu"
+
+test-gpu: all
+	python -m pytest tests -q -m gpu
+
+bench: all
+	python bench.py
+
+clean:
+	rm -f $(LIB) $(DROPIN) tests/cpp/test_dropin
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle test-cpu test-gpu bench clean
