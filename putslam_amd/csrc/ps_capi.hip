@@ -36,7 +36,7 @@ struct PsContext {
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, counts, mvalid, idxList, raw;
+    Buf keys, recA, recB, recC, recD, counts, mvalid, cmax, idxList, raw;
     Buf tabR, tabU;
     // staging for the host-pointer entry points (device)
     Buf sDesc, sNk, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
@@ -363,7 +363,7 @@ void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit
 {
     hipLaunchKernelGGL(ps_ransac_score<MODE>, grid, dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p,
                        (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p, (const int32_t *)ctx->mvalid.p,
-                       pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
+                       (const float *)ctx->cmax.p, pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
 }
 
 // Kernels 3 + 4 over records already in the arena.
@@ -420,6 +420,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     const int cap = fs.maxKpts;
     PS_ENSURE(ctx->keys, (size_t)P * cap * sizeof(uint32_t));
     PS_ENSURE(ctx->mvalid, (size_t)P * sizeof(int32_t));
+    PS_ENSURE(ctx->cmax, (size_t)P * sizeof(float));
     if (withRecords) {
         int rc = ensure_records(ctx, (size_t)P * cap);
         if (rc != PS_OK) return rc;
@@ -439,12 +440,12 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         hipLaunchKernelGGL(ps_crosscheck_prep<true>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
                            fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
                            (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
-                           (int32_t *)ctx->mvalid.p);
+                           (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
     else
         hipLaunchKernelGGL(ps_crosscheck_prep<false>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
                            fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
                            (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr,
-                           (int32_t *)ctx->mvalid.p);
+                           (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -520,7 +521,7 @@ void ps_context_destroy(PsContext *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->counts, &ctx->mvalid,
-                  &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
+                  &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
     for (Buf *b : all) release(*b);
@@ -704,6 +705,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->sPose, 16 * sizeof(float));
     PS_ENSURE(ctx->sStats, sizeof(PsRansacStats));
     PS_ENSURE(ctx->mvalid, sizeof(int32_t));
+    PS_ENSURE(ctx->cmax, sizeof(float));
     rc = ensure_records(ctx, (size_t)cap);
     if (rc) return rc;
     if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -716,7 +718,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     hipLaunchKernelGGL(ps_prep_from_matches, dim3(1), dim3(kBlock), 0, ctx->stream, (const float *)ctx->sMisc0.p,
                        (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa,
                        (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
-                       (int32_t *)ctx->mvalid.p);
+                       (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
     PS_HIP(hipGetLastError());
     rc = run_ransac_stage(ctx, pl, 1, cap, (const PsDMatch *)ctx->sMatches.p, (const int32_t *)ctx->sNumM.p, cap,
                           (float *)ctx->sPose.p, (uint8_t *)ctx->sMask.p, (PsRansacStats *)ctx->sStats.p, 2);

@@ -149,6 +149,20 @@ PS_D int block_scan_flag(bool flag, int &total, int *wsum)
     return off + pre;
 }
 
+// workgroup-wide maximum of a non-negative float (4 waves)
+PS_D float block_max(float v, float *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < kBlock / 64; ++i) r = fmaxf(r, red[i]);
+    __syncthreads();
+    return r;
+}
+
 struct PrepArgs {
     float fx, fy, cx, cy;   // camera matrix entries (cv::Mat CV_32FC1, RGBD.cpp:93-96)
     double thrE;            // inlierThresholdEuclidean
@@ -188,10 +202,12 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
                                                              int32_t *__restrict__ numMatches,
                                                              float4 *__restrict__ recA, float4 *__restrict__ recB,
                                                              float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                             int32_t *__restrict__ mvalid)
+                                                             int32_t *__restrict__ mvalid, float *__restrict__ cmaxOut)
 {
     extern __shared__ __align__(16) uint32_t s_best[];
     __shared__ int s_wsum[kBlock / 64];
+    __shared__ float s_red[kBlock / 64];
+    float cm = 0.0f; // largest |coordinate| among this pair's depth-valid matches
     const int p = blockIdx.x;
     const int cap = a.cap;
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
@@ -236,12 +252,18 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
             }
             int vtotal;
             int vpos = block_scan_flag(ok, vtotal, s_wsum);
-            if (ok)
+            if (ok) {
                 write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_, recA,
                               recB, recC, recD);
+                cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
+            }
             vbase += vtotal;
         }
         base += total;
+    }
+    if (WITH_RECORDS) {
+        float c = block_max(cm, s_red);
+        if (threadIdx.x == 0) cmaxOut[p] = c;
     }
     if (threadIdx.x == 0) {
         numMatches[p] = base;
@@ -255,9 +277,11 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
                                                                const PsDMatch *__restrict__ matches, int m, PrepArgs a,
                                                                float4 *__restrict__ recA, float4 *__restrict__ recB,
                                                                float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                               int32_t *__restrict__ mvalid)
+                                                               int32_t *__restrict__ mvalid, float *__restrict__ cmaxOut)
 {
     __shared__ int s_wsum[kBlock / 64];
+    __shared__ float s_red[kBlock / 64];
+    float cm = 0.0f;
     int vbase = 0;
     for (int i0 = 0; i0 < m; i0 += kBlock) {
         const int i = i0 + threadIdx.x;
@@ -273,10 +297,17 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         }
         int vtotal;
         int vpos = block_scan_flag(ok, vtotal, s_wsum);
-        if (ok) write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD);
+        if (ok) {
+            write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD);
+            cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
+        }
         vbase += vtotal;
     }
-    if (threadIdx.x == 0) mvalid[0] = vbase;
+    float c = block_max(cm, s_red);
+    if (threadIdx.x == 0) {
+        mvalid[0] = vbase;
+        cmaxOut[0] = c;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,6 +388,51 @@ PS_D float max3_abs(float a, float b, float c)
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// Wave-level forms: every comparison is balloted on its own (a ballot of a single compare IS the compare's
+// SGPR result) and the masks are combined with scalar ANDs; balloting a compound predicate would first
+// materialise it in a VGPR (v_cndmask + v_cmp_ne).
+// HI_HOISTED: the upper end of the window has been established for every match of the pair from
+// per-hypothesis norms and the pair's largest coordinate (hi_bound_holds), only the lower end is checked here.
+template <bool HI_HOISTED>
+PS_D bool wave_div_window_ok(float a0, float a1, float b, float c0, float c1, float d)
+{
+    unsigned long long m = __builtin_amdgcn_ballot_w64(min3_abs(a0, a1, b) >= kDivLo) &
+                           __builtin_amdgcn_ballot_w64(min3_abs(c0, c1, d) >= kDivLo);
+    if (!HI_HOISTED)
+        m &= __builtin_amdgcn_ballot_w64(max3_abs(a0, a1, b) <= kDivHi) &
+             __builtin_amdgcn_ballot_w64(max3_abs(c0, c1, d) <= kDivHi);
+    return m == __builtin_amdgcn_ballot_w64(true);
+}
+
+// |R x + t| <= 3 max|R_ij| max|x_i| + max|t_i| for every point of the pair (coordinates bounded by cmax),
+// with 1 % slack for the float roundings of the transform and of the multiplication by fx / fy: if that
+// bound times max(|fx|, |fy|, 1) stays below 2^40 no numerator or denominator of this hypothesis can leave the
+// window at its upper end.  NaN / inf anywhere makes the comparison false (the per-match check then applies).
+PS_D bool hi_bound_holds(const Rigid &m, float cmax, float fmaxK)
+{
+    float r = 0.0f, t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r = fmaxf(r, fabsf(m.R[i][j]));
+        t = fmaxf(t, fabsf(m.t[i]));
+    }
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) finite = finite && (m.R[i][j] == m.R[i][j]);
+        finite = finite && (m.t[i] == m.t[i]);
+    }
+    const float e = (3.0f * r * cmax + t) * 1.01f;
+    return finite && (e * fmaxK <= kDivHi);
+}
+// cnt += 1 in the lanes of `mask` (v_addc_co_u32 with the mask as carry-in: one VALU op)
+PS_D void add_mask(int &cnt, unsigned long long mask)
+{
+    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(cnt) : "s"(mask) : "vcc");
+}
+
 // true when every magnitude of both (numerator, numerator, denominator) triples lies in [2^-40, 2^40]
 // (a NaN operand is ignored by min3/max3; it then yields NaN on either division path: same outcome)
 PS_D bool div_window_ok(float a0, float a1, float b, float c0, float c1, float d)
@@ -365,7 +441,9 @@ PS_D bool div_window_ok(float a0, float a1, float b, float c0, float c1, float d
            max3_abs(c0, c1, d) <= kDivHi;
 }
 
-template <int MODE, bool FASTDIV = false>
+// Reference form of the inlier test of one match under one model (RANSAC.cpp:251-281,325-436): used by
+// kernel 4 for the selected hypothesis.  Kernel 3 evaluates the same arithmetic through score_accumulate().
+template <int MODE>
 PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, const float4 &A, const float4 &B,
                       const float4 &C)
 {
@@ -381,50 +459,77 @@ PS_D bool inlier_test(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, 
         float nx, ny, nz;
         xform(inv, A.x, A.y, A.z, nx, ny, nz); // estimatedNewPosition = Rinv * prev[query] + tinv
         float pnu, pnv, pou, pov;
-        if (FASTDIV) {
-            // RGBD::point3Dto2D with the two quotients of each point sharing the reciprocal of z; the whole
-            // wavefront takes this branch only when every lane is inside the division window
-            const float a0 = nx * k.fx, a1 = ny * k.fy, c0 = ex * k.fx, c1 = ey * k.fy;
-            if (wave_all(div_window_ok(a0, a1, nz, c0, c1, ez))) {
-                float q0, q1, q2, q3;
-                div2_shared(a0, a1, nz, q0, q1);
-                div2_shared(c0, c1, ez, q2, q3);
-                pnu = q0 + k.cx; pnv = q1 + k.cy;
-                pou = q2 + k.cx; pov = q3 + k.cy;
-            } else {
-                pnu = a0 / nz + k.cx; pnv = a1 / nz + k.cy;
-                pou = c0 / ez + k.cx; pov = c1 / ez + k.cy;
-            }
-        } else {
-            project(nx, ny, nz, k.fx, k.fy, k.cx, k.cy, pnu, pnv);
-            project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pou, pov);
-        }
+        project(nx, ny, nz, k.fx, k.fy, k.cx, k.cy, pnu, pnv);
+        project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pou, pov);
         float dxn = pnu - C.z, dyn = pnv - C.w; // predictedNew - realNew
         float dxo = pou - C.x, dyo = pov - C.y; // predictedOld - realOld
-        if (FASTDIV) {
-            // cv::norm(Point2f) squares in double.  The float sums f0, f1 are within 2^-22 of the exact values,
-            // so outside the band [bLo, bHi] (half-width 2^-21 around boundR) the float comparison already
-            // decides; the larger of the two (as unsigned bit patterns: sums of squares are >= +0 and any
-            // NaN sorts above +inf) settles both tests at once.  Inside the band, or on NaN, the wave falls
-            // back to the double evaluation below.
-            float f0 = dxn * dxn + dyn * dyn, f1 = dxo * dxo + dyo * dyo;
-            uint32_t u0, u1;
-            memcpy(&u0, &f0, 4);
-            memcpy(&u1, &f1, 4);
-            uint32_t um = u0 > u1 ? u0 : u1;
-            float fm;
-            memcpy(&fm, &um, 4);
-            const bool sureIn = fm < k.bLo, sureOut = fm > k.bHi;
-            if (wave_all(sureIn || sureOut)) return in && sureIn;
-            // keep the double evaluation on the cold side of the branch (the compiler would otherwise
-            // speculate its eight f64 instructions above it)
-            asm volatile("" : "+v"(dxn), "+v"(dyn), "+v"(dxo), "+v"(dyo));
-        }
         double e0 = (double)dxn * (double)dxn + (double)dyn * (double)dyn;
         double e1 = (double)dxo * (double)dxo + (double)dyo * (double)dyo;
         in = in && (e0 < k.boundR) && (e1 < k.boundR);
     }
     return in;
+}
+
+// Kernel 3's form of the same test: cnt += inlier.  Identical values, cheaper instruction stream:
+//  * the two quotients of each projected point share one reciprocal inside the checked division window
+//    (div2_shared), the whole wavefront falling back to '/' otherwise;
+//  * cv::norm's double comparison is settled in float outside the band [bLo, bHi] around boundR: the float
+//    sums f0, f1 are within 2^-22 of the exact values and the band's half-width is 2^-21; the larger of the
+//    two (as unsigned bit patterns: sums of squares are >= +0 and any NaN sorts above +inf) decides both tests
+//    at once; inside the band, or on NaN, the wavefront evaluates in double;
+//  * the count is updated inside each branch, so no boolean has to be carried across the branches in a VGPR.
+template <int MODE, bool HI_HOISTED>
+PS_D void score_accumulate(const Rigid &mdl, const Rigid &inv, const ScoreConsts &k, const float4 &A, const float4 &B,
+                           const float4 &C, int &cnt)
+{
+    float ex, ey, ez;
+    xform(mdl, B.x, B.y, B.z, ex, ey, ez);
+    bool in = true;
+    if (MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+        float d0 = ex - A.x, d1 = ey - A.y, d2 = ez - A.z;
+        float s = d0 * d0 + (d1 * d1 + d2 * d2);
+        in = s < A.w;
+    }
+    if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+        float nx, ny, nz;
+        xform(inv, A.x, A.y, A.z, nx, ny, nz);
+        float pnu, pnv, pou, pov;
+        const float a0 = nx * k.fx, a1 = ny * k.fy, c0 = ex * k.fx, c1 = ey * k.fy;
+        if (wave_div_window_ok<HI_HOISTED>(a0, a1, nz, c0, c1, ez)) {
+            float q0, q1, q2, q3;
+            div2_shared(a0, a1, nz, q0, q1);
+            div2_shared(c0, c1, ez, q2, q3);
+            pnu = q0 + k.cx; pnv = q1 + k.cy;
+            pou = q2 + k.cx; pov = q3 + k.cy;
+        } else {
+            pnu = a0 / nz + k.cx; pnv = a1 / nz + k.cy;
+            pou = c0 / ez + k.cx; pov = c1 / ez + k.cy;
+        }
+        float dxn = pnu - C.z, dyn = pnv - C.w;
+        float dxo = pou - C.x, dyo = pov - C.y;
+        float f0 = dxn * dxn + dyn * dyn, f1 = dxo * dxo + dyo * dyo;
+        uint32_t u0, u1;
+        memcpy(&u0, &f0, 4);
+        memcpy(&u1, &f1, 4);
+        uint32_t um = u0 > u1 ? u0 : u1;
+        float fm;
+        memcpy(&fm, &um, 4);
+        const unsigned long long mIn = __builtin_amdgcn_ballot_w64(fm < k.bLo);
+        const unsigned long long mOut = __builtin_amdgcn_ballot_w64(fm > k.bHi);
+        if ((mIn | mOut) == __builtin_amdgcn_ballot_w64(true)) {
+            if (MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR)
+                add_mask(cnt, mIn & __builtin_amdgcn_ballot_w64(in));
+            else
+                add_mask(cnt, mIn);
+            return;
+        }
+        // cold side: keep the eight f64 instructions from being speculated above the branch
+        asm volatile("" : "+v"(dxn), "+v"(dyn), "+v"(dxo), "+v"(dyo));
+        double e0 = (double)dxn * (double)dxn + (double)dyn * (double)dyn;
+        double e1 = (double)dxo * (double)dxo + (double)dyo * (double)dyo;
+        in = in && (e0 < k.boundR) && (e1 < k.boundR);
+    }
+    cnt += in ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -438,7 +543,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__restrict__ recA,
                                                           const float4 *__restrict__ recB,
                                                           const float4 *__restrict__ recC,
-                                                          const int32_t *__restrict__ mvalid, ModelArgs ma,
+                                                          const int32_t *__restrict__ mvalid,
+                                                          const float *__restrict__ cmaxArr, ModelArgs ma,
                                                           ScoreConsts k, int H, int cap, int minRun, int msplit,
                                                           int32_t *__restrict__ counts)
 {
@@ -465,16 +571,29 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
-    auto body = [&](int m) {
-        float4 A = pa[m], B = pb[m], C = make_float4(0, 0, 0, 0);
-        if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) C = pc[m];
-        cnt += inlier_test<MODE, true>(mdl, inv, k, A, B, C) ? 1 : 0;
-    };
     if (MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR) {
 #pragma unroll 4
-        for (int m = m0; m < m1; ++m) body(m); // straight-line body: batches the scalar record loads
+        for (int m = m0; m < m1; ++m) { // straight-line body: the unrolled loop batches the scalar record loads
+            float4 A = pa[m], B = pb[m];
+            score_accumulate<MODE, false>(mdl, inv, k, A, B, A, cnt);
+        }
     } else {
-        for (int m = m0; m < m1; ++m) body(m); // wave-uniform branches inside: not unrollable
+        // wave-uniform branches inside: not unrollable.  The upper end of the division window is settled here,
+        // once per hypothesis, whenever the pair's coordinate bound allows it.
+        const float cmax = cmaxArr[p];
+        const float fmaxK = fmaxf(fmaxf(fabsf(k.fx), fabsf(k.fy)), 1.0f);
+        const bool hoisted = wave_all(hi_bound_holds(mdl, cmax, fmaxK) && hi_bound_holds(inv, cmax, fmaxK));
+        if (hoisted) {
+            for (int m = m0; m < m1; ++m) {
+                float4 A = pa[m], B = pb[m], C = pc[m];
+                score_accumulate<MODE, true>(mdl, inv, k, A, B, C, cnt);
+            }
+        } else {
+            for (int m = m0; m < m1; ++m) {
+                float4 A = pa[m], B = pb[m], C = pc[m];
+                score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
+            }
+        }
     }
     if (h < H) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
