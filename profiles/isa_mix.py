@@ -82,30 +82,41 @@ def main():
     for mode in (0, 1, 2, 4):
         a = s.index("\n_ZN5psdev15ps_ransac_scoreILi%dEE" % mode)
         body = s[a:s.index(".Lfunc_end", a)]
-        # basic blocks: explicit labels and the fall-through blocks the assembler comments as "; %bb.N:"
+        # basic blocks (explicit labels and the assembler's "; %bb.N:" fall-through blocks), grouped by the loop
+        # header LLVM annotates them with ("in Loop: Header=BBx_y")
         blocks = re.split(r"\n(\.LBB\d+_\d+:|; %bb\.\d+:)", body)
-        names = [blocks[i] for i in range(1, len(blocks), 2)]
-        texts = [blocks[i + 1] for i in range(1, len(blocks), 2)]
-        heads = [i for i, t in enumerate(texts) if "s_load_dwordx4" in t and "v_pk_mul_f32" in t]
-        head = heads[-1]
-        # the loop latch is the labelled block right before the head (it holds the count update and the back edge target)
-        latch = head - 1
-        latch_label = names[latch].rstrip(":")
-        back = [i for i, t in enumerate(texts) if i >= head and re.search(r"s_c?branch\w* " + re.escape(latch_label) + r"\b", t)]
-        tot = Counter()
-        cold = Counter()
-        if not back:  # single-block (unrolled) loop of the Euclidean modes: the head block is the whole body
-            latch, back = head, [head]
-        end = max(back)
-        for i in range(latch, end + 1):
-            t = texts[i]
+        loops = {}
+        for i in range(1, len(blocks), 2):
+            t = blocks[i + 1]
+            first = t.split("\n", 1)[0]
+            m = re.search(r"Header=(BB\d+_\d+)", first)
+            if m and "Depth=1" in first:
+                loops.setdefault(m.group(1), []).append(t)
+            elif "This Inner Loop Header" in first or "This Loop Header" in first:
+                loops.setdefault(blocks[i].strip(".:"), []).append(t)
+        reproj = mode in (1, 2)
+        best = None
+        for hdr, ts in loops.items():
+            alltxt = "\n".join(ts)
+            if reproj:
+                if "v_pk_fma_f32" not in alltxt or "v_max3_f32" in alltxt:
+                    continue  # want the match loop whose upper window bound is hoisted (the common one)
+            else:
+                if "s_load_dwordx4" not in alltxt or "v_pk_mul_f32" not in alltxt:
+                    continue
+            n = sum(valu_of(t).total() for t in ts)
+            if best is None or n > best[0]:
+                best = (n, ts)
+        ts = best[1]
+        tot, cold = Counter(), Counter()
+        for t in ts:
             if "v_div_scale_f32" in t or "v_cvt_f64_f32" in t:
                 cold += valu_of(t)   # '/' fallback and double fallback: taken only outside the window / inside the band
-                continue
-            tot += valu_of(t)
+            else:
+                tot += valu_of(t)
         per = 1.0
-        if mode in (0, 4):
-            per = max(1, texts[head].count("s_load_dwordx4") // 2)  # unrolled: 2 record loads per match
+        if not reproj:
+            per = max(1, "\n".join(ts).count("s_load_dwordx4") // 2)  # unrolled: 2 record loads per match
         out["ps_ransac_score<%d>" % mode] = {"unit": "(hypothesis, match) evaluation per wave",
                                              "valu_per_unit": sum(tot.values()) / per,
                                              "model_cycles_per_unit": sum(price(k, cost) * v for k, v in tot.items()) / per,
