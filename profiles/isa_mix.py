@@ -86,14 +86,20 @@ def main():
         # header LLVM annotates them with ("in Loop: Header=BBx_y")
         blocks = re.split(r"\n(\.LBB\d+_\d+:|; %bb\.\d+:)", body)
         loops = {}
-        for i in range(1, len(blocks), 2):
-            t = blocks[i + 1]
+        names = [blocks[i] for i in range(1, len(blocks), 2)]
+        texts = [blocks[i + 1] for i in range(1, len(blocks), 2)]
+        for i, t in enumerate(texts):
             first = t.split("\n", 1)[0]
-            m = re.search(r"Header=(BB\d+_\d+)", first)
-            if m and "Depth=1" in first:
-                loops.setdefault(m.group(1), []).append(t)
-            elif "This Inner Loop Header" in first or "This Loop Header" in first:
-                loops.setdefault(blocks[i].strip(".:"), []).append(t)
+            if "This Inner Loop Header" in first and "Depth=1" in first:
+                hdr = re.sub(r"^\.L", "", names[i]).rstrip(":")
+                last = i
+                for j in range(i + 1, len(texts)):
+                    f2 = texts[j].split("\n", 1)[0]
+                    if ("Header=" + hdr + " ") in f2 + " ":
+                        last = j
+                    elif "Loop Header" in f2:
+                        break
+                loops[hdr] = texts[i:last + 1]   # contiguous body: header .. last block annotated with this header
         reproj = mode in (1, 2)
         best = None
         for hdr, ts in loops.items():
