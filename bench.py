@@ -45,6 +45,12 @@ def parse():
     ap.add_argument("--preset", default=None, choices=["demoMatching", "sequence", "stress"],
                     help="BASELINE configs: demoMatching = configs[1] (one pair per step), sequence = configs[2] "
                          "(default), stress = configs[4] (5000 kpts, H = 100000, 8 pairs per step)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="sub-batches of the step run concurrently on this many HIP streams (one context each); "
+                         "2 lets the popcount sweep of one half overlap the floating-point sweep of the other")
+    ap.add_argument("--join", default="step", choices=["step", "end"],
+                    help="with --streams > 1: join the streams after every step, or let them free-run until the fence")
+    ap.add_argument("--split", type=float, default=0.5, help="with --streams 2: fraction of the pairs on stream 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
@@ -81,7 +87,9 @@ def main():
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
 
     est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
-    ctx = api.Context(local_rank)
+    S = max(1, args.streams)
+    ctxs = [api.Context(local_rank) for _ in range(S)]
+    ctx = ctxs[0]
     prm = default_ransac_params(args.error_version)
     cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + rank)
 
@@ -90,12 +98,37 @@ def main():
     P = len(seq["pairs"])
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
+    bounds = [P * i // S for i in range(S + 1)]
+    if S == 2:
+        bounds = [0, int(P * args.split), P]
+    side = [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     from putslam_amd import sharding
     gathered = ([torch.zeros((P, sharding.RECORD_FLOATS), dtype=torch.float32, device=dev) for _ in range(world)]
                 if (world > 1 and rank == 0) else None)
 
+    def run_all():
+        if S == 1:
+            run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)             # inputs already in HBM
+            return
+        # S sub-batches of the same step on S streams; outputs land in disjoint slices of the same result
+        # buffers; pair p keeps its hypothesis stream seed + p
+        cur = torch.cuda.current_stream(dev)
+        for i in range(S):
+            lo, hi = bounds[i], bounds[i + 1]
+            st = cur if i == 0 else side[i - 1]
+            if i > 0 and args.join == "step":
+                st.wait_stream(cur)
+            ctxs[i].set_stream(st.cuda_stream)
+            ci, _k = make_config(est, args.hyp, seed=cfg.seed + lo)
+            view = api.DeviceResults(pb.matches[lo:].data_ptr(), pb.num_matches[lo:].data_ptr(), pb.mask[lo:].data_ptr(),
+                                     pb.pose[lo:].data_ptr(), pb.stats[lo:].data_ptr())
+            ctxs[i].vo_pairs_device(prm, ci, TUM_FR1_K, fs.view(), pb.pairs[lo:].data_ptr(), hi - lo, view)
+        if args.join == "step" or world > 1:
+            for st in side:
+                cur.wait_stream(st)
+
     def step():
-        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)                 # inputs already in HBM
+        run_all()
         if world > 1:
             # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI
             st = pb.stats.view(torch.int32).view(P, -1)              # PsRansacStats: [5] numInliers, [0] numMatchesIn
@@ -110,7 +143,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.enable_timing(True)                                            # HIP events on the launch stream
+    for c in ctxs:
+        c.enable_timing(True)                                          # HIP events on the launch stream(s)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -121,8 +155,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    totals = ctx.kernel_time_totals()
-    ctx.enable_timing(False)
+    totals = {}
+    for c in ctxs:
+        for kname, (ms_sum, n) in c.kernel_time_totals().items():
+            a0, n0 = totals.get(kname, (0.0, 0))
+            totals[kname] = (a0 + ms_sum, n0 + n)
+        c.enable_timing(False)
     res = pb.download()
 
     if rank == 0:
@@ -137,7 +175,8 @@ def main():
         kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # average launch duration, ms
         dom = max(kern, key=kern.get)
         dom_ms = kern[dom]
-        achieved = bytes_per_pair * P / (dom_ms * 1e-3) / 1e9
+        pairs_per_launch = P / S
+        achieved = bytes_per_pair * pairs_per_launch / (dom_ms * 1e-3) / 1e9
         # VALU issue model of the two sweeps: static instruction mix of the hot loops (profiles/isa_mix.json,
         # from profiles/isa_mix.py) priced with the per-instruction issue costs measured on this GPU model
         # (profiles/microbench/valu_rates_mi355x.txt).  frac = modelled issue time / measured kernel time.
@@ -145,9 +184,9 @@ def main():
         try:
             mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
             simd_hz = 256 * 4 * 2.4e9
-            waves_match = P * (args.kpts / 64.0)                      # one lane per train row
+            waves_match = (P / S) * (args.kpts / 64.0)                # per launch: one lane per train row
             units_match = waves_match * args.kpts                     # descriptor pairs per wave
-            waves_score = P * (Hs / 64.0)
+            waves_score = (P / S) * (Hs / 64.0)
             units_score = waves_score * m_valid
             km, ks = mix["ps_hamming_nn"], mix["ps_ransac_score<%d>" % (args.error_version if args.error_version in (0, 1, 2, 4) else 0)]
             t_match = units_match * km["model_cycles_per_unit"] / simd_hz * 1e3
@@ -169,7 +208,8 @@ def main():
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
-                key = f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}"
+                key = (f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}" +
+                       (f"xS{S}" if S > 1 else ""))
                 traffic = t.get(key, {}).get(dom)
             except Exception:
                 traffic = None
@@ -187,18 +227,22 @@ def main():
                              ("; configs[3]: one sequence per GPU, RCCL gather of 72 B/pair to rank 0" if world > 1
                               else "")),
                 "pairs_per_step": P * world, "kpts": args.kpts, "hypotheses": args.hyp,
-                "errorVersion": args.error_version, "estimator": args.estimator,
+                "errorVersion": args.error_version, "estimator": args.estimator, "streams": S,
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
                 "mean_inliers": float(stats["numInliers"].mean()),
                 "accepted_pairs": int(stats["accepted"].sum()),
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": P,
+                         "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
                          "avg_launch_ms": dom_ms,
                          "note": "path is VALU-issue-bound, not HBM-bound (DESIGN.md section 4): see valu_issue"},
             "kernel_ms": kern,
             "valu_issue": valu_issue,
+            "streams_note": (None if S == 1 else
+                             f"{S} sub-batches overlap on {S} HIP streams: per-launch durations are measured while the "
+                             "other stream's kernels share the CUs, so kernel_ms sums to more than ms_per_step and the "
+                             "per-kernel fractions are lower than with --streams 1 (DESIGN.md section 5)"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))

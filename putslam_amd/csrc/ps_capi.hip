@@ -50,6 +50,8 @@ struct PsContext {
     long long timedCalls = 0;   // calls recorded since timing was (re)enabled
     int curCall = 0;            // ring slot of the call being recorded
     int nTimed = 0;             // kernels per call
+    // tuning overrides (PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT, read once; 0 = automatic)
+    int forceQsplit = 0, forceMsplit = 0;
 };
 
 namespace {
@@ -376,6 +378,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     PS_ENSURE(ctx->idxList, (size_t)P * cap * sizeof(int32_t));
     const int hb = (H + kBlock - 1) / kBlock;
     int msplit = pick_split((long long)P * hb, 32, 64, cap);
+    if (ctx->forceMsplit > 0) msplit = ctx->forceMsplit;
     if (msplit > 1) PS_HIP(hipMemsetAsync(ctx->counts.p, 0, (size_t)P * H * sizeof(int32_t), ctx->stream));
     dim3 grid((unsigned)hb * (unsigned)msplit * (unsigned)P);
     tick(ctx, slot0, false);
@@ -428,6 +431,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     constexpr int TPL = 2;
     const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
     int qsplit = pick_split((long long)P * tiles, 16, 64, cap);
+    if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
     if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
     tick(ctx, slot0, false);
     hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
@@ -506,6 +510,8 @@ int ps_context_create(int device, PsContext **out)
         return PS_ERR_HIP;
     }
     ctx->stream = ctx->own;
+    if (const char *v = std::getenv("PUTSLAM_HIP_QSPLIT")) ctx->forceQsplit = std::atoi(v);
+    if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
