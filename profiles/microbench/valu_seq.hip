@@ -15,6 +15,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define BCNT(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(sa));
 #define XOR(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(sa));
+#define XORS(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "s"(ss));
+#define XORS2(i) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "s"(ss), "v"(a[(i + 4) & 7]));
+#define ANDS(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "s"(ss));
+#define ADDS(i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "s"(ss));
+#define MULS(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(b[i]) : "s"(sfs));
+#define BCNTS(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "s"(ss));
+#define MOVS(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(ss));
+#define XAD(i) asm volatile("v_xad_u32 %0, %1, %0, 0" : "+v"(a[i]) : "s"(ss));
+#define XORS64(i) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "s"(ss));
 #define ADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(sa));
 #define MINU(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(sa));
 #define MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(sa));
@@ -47,6 +56,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         }                                                                                 \
         for (int i = 0; i < 4; ++i) d[i] = 1.0 + 1e-3 * (double)(threadIdx.x + i);        \
         uint32_t sa = seed | 1;                                                           \
+        uint32_t ss = seed * 2654435761u + 12345u;                                        \
+        float sfs = 1.0f + (float)(seed & 7) * 1e-7f;                                     \
         float sb = 1.0000001f, sc = 0.9999999f + (float)(seed & 1);                       \
         f2 sp = f2{1.0000001f, 0.9999999f};                                               \
         double sd = 1.0000001;                                                            \
@@ -57,6 +68,21 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         out[blockIdx.x * 256 + threadIdx.x] = r;                                          \
     }
 
+SEQ_KERNEL(s_xor8, XOR(0) XOR(1) XOR(2) XOR(3) XOR(4) XOR(5) XOR(6) XOR(7))
+SEQ_KERNEL(s_xors8, XORS(0) XORS(1) XORS(2) XORS(3) XORS(4) XORS(5) XORS(6) XORS(7))
+SEQ_KERNEL(s_xors2_8, XORS2(0) XORS2(1) XORS2(2) XORS2(3) XORS2(4) XORS2(5) XORS2(6) XORS2(7))
+SEQ_KERNEL(s_ands8, ANDS(0) ANDS(1) ANDS(2) ANDS(3) ANDS(4) ANDS(5) ANDS(6) ANDS(7))
+SEQ_KERNEL(s_adds8, ADDS(0) ADDS(1) ADDS(2) ADDS(3) ADDS(4) ADDS(5) ADDS(6) ADDS(7))
+SEQ_KERNEL(s_muls8, MULS(0) MULS(1) MULS(2) MULS(3) MULS(4) MULS(5) MULS(6) MULS(7))
+SEQ_KERNEL(s_bcnts8, BCNTS(0) BCNTS(1) BCNTS(2) BCNTS(3) BCNTS(4) BCNTS(5) BCNTS(6) BCNTS(7))
+SEQ_KERNEL(s_xors_bcnt, XORS(0) BCNT(4) XORS(1) BCNT(5) XORS(2) BCNT(6) XORS(3) BCNT(7))
+SEQ_KERNEL(s_xor_bcnt_dep, XOR(0) BCNT(0) XOR(1) BCNT(1) XOR(2) BCNT(2) XOR(3) BCNT(3))
+SEQ_KERNEL(s_movs8, MOVS(0) MOVS(1) MOVS(2) MOVS(3) MOVS(4) MOVS(5) MOVS(6) MOVS(7))
+SEQ_KERNEL(s_xad8, XAD(0) XAD(1) XAD(2) XAD(3) XAD(4) XAD(5) XAD(6) XAD(7))
+SEQ_KERNEL(s_xors64_8, XORS64(0) XORS64(1) XORS64(2) XORS64(3) XORS64(4) XORS64(5) XORS64(6) XORS64(7))
+SEQ_KERNEL(s_ham_sgpr, XORS(0) BCNT(0) XORS(1) BCNT(1) XORS(2) BCNT(2) XORS(3) BCNT(3) XORS(4) BCNT(4) XORS(5) BCNT(5) XORS(6) BCNT(6) XORS(7) BCNT(7))
+SEQ_KERNEL(s_ham_vgpr, XOR(0) BCNT(0) XOR(1) BCNT(1) XOR(2) BCNT(2) XOR(3) BCNT(3) XOR(4) BCNT(4) XOR(5) BCNT(5) XOR(6) BCNT(6) XOR(7) BCNT(7))
+SEQ_KERNEL(s_ham_mov4, MOVS(0) MOVS(1) XOR(0) BCNT(0) XOR(1) BCNT(1) XOR(2) BCNT(2) XOR(3) BCNT(3) XOR(4) BCNT(4) XOR(5) BCNT(5) XOR(6) BCNT(6) XOR(7) BCNT(7))
 SEQ_KERNEL(s_mul8, MUL(0) MUL(1) MUL(2) MUL(3) MUL(4) MUL(5) MUL(6) MUL(7))
 SEQ_KERNEL(s_bcnt8, BCNT(0) BCNT(1) BCNT(2) BCNT(3) BCNT(4) BCNT(5) BCNT(6) BCNT(7))
 SEQ_KERNEL(s_bcnt_mul, BCNT(0) MUL(0) BCNT(1) MUL(1) BCNT(2) MUL(2) BCNT(3) MUL(3))
@@ -107,6 +133,11 @@ int main(int argc, char **argv)
     uint32_t *out;
     CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     Entry es[] = {
+        {"8 xor (vgpr)", s_xor8}, {"8 xor (sgpr src0)", s_xors8}, {"8 xor d=s^v(other)", s_xors2_8}, {"8 and (sgpr)", s_ands8},
+        {"8 add_u32 (sgpr)", s_adds8}, {"8 mul_f32 (sgpr)", s_muls8}, {"8 bcnt (sgpr)", s_bcnts8},
+        {"4 (xor sgpr, bcnt)", s_xors_bcnt}, {"4 (xor, bcnt) same reg", s_xor_bcnt_dep},
+        {"8 mov (sgpr)", s_movs8}, {"8 xad (sgpr)", s_xad8}, {"8 xor_e64 (sgpr src1)", s_xors64_8},
+        {"8 (xor sgpr, bcnt)", s_ham_sgpr}, {"8 (xor vgpr, bcnt)", s_ham_vgpr}, {"2 mov + 8 (xor vgpr, bcnt)", s_ham_mov4},
         {"8 mul_f32", s_mul8}, {"8 bcnt", s_bcnt8}, {"8 pk_mul", s_pk8}, {"8 fma_f32", s_fma8},
         {"4 (bcnt, mul)", s_bcnt_mul}, {"4 bcnt + 4 mul", s_bcnt4_mul4}, {"4 (bcnt, fmac)", s_bcnt_fmac},
         {"4 (bcnt, fma)", s_bcnt_fma}, {"4 (bcnt, add_f32)", s_bcnt_addf},
