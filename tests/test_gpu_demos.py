@@ -54,3 +54,33 @@ def test_noise_free_pose_within_1e5(ctx):
         r = ctx.ransac_rigid3d(default_ransac_params(mode), cfg, TUM_FR1_K, prev, cur, m)
         assert r["stats"]["numInliers"] == n
         assert np.abs(r["pose"] - T).max() < 1e-5, (mode, np.abs(r["pose"] - T).max())
+
+
+def test_file_grabber_frames_backproject_bit_exact(ctx, oracle, tmp_path):
+    """N4: frames staged in the FileGrabber directory format (fileGrabber.cpp:25-160) -> ps_keypoints2Dto3D and
+    ps_remove_image_distortion on the GPU == oracle, bit for bit."""
+    from putslam_amd import tum_io
+    from putslam_amd._abi import TUM_FR1_K
+    r = np.random.default_rng(7)
+    frames = []
+    for i in range(3):
+        yy, xx = np.mgrid[0:480, 0:640]
+        depth = (4000 + 11 * xx + 7 * yy + r.integers(0, 50, (480, 640))).astype(np.uint16)
+        depth[r.random((480, 640)) < 0.03] = 0
+        rgb = r.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        frames.append((100.0 + i / 30, 100.01 + i / 30, rgb, depth))
+    d = str(tmp_path / "seq")
+    tum_io.write_sequence(d, frames)
+    dist5 = np.array([0.2624, -0.9531, -0.0054, 0.0026, 1.1633])       # TUM fr1 rgb distortion
+    n = 0
+    for fr in tum_io.FileGrabber(d):
+        xy = np.stack([r.uniform(0, 638.4, 2000), r.uniform(0, 478.4, 2000)], axis=1).astype(np.float32)
+        und_g = ctx.remove_image_distortion(xy, TUM_FR1_K, dist5)
+        und_o = oracle.remove_image_distortion(xy, TUM_FR1_K, dist5)
+        assert np.array_equal(und_g.view(np.uint32), und_o.view(np.uint32))
+        got = ctx.keypoints2Dto3D(xy, fr.depthImage, TUM_FR1_K, fr.depthImageScale)
+        exp = oracle.keypoints2Dto3D(xy, fr.depthImage, TUM_FR1_K, fr.depthImageScale)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        assert np.array_equal(fr.depthImage, frames[n][3])
+        n += 1
+    assert n == 3
