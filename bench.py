@@ -75,12 +75,20 @@ def main():
                   file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    dev = torch.device(f"cuda:{local_rank}")
+    # PUTSLAM_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 control flow run with several ranks on ONE GPU
+    # (records staged through the host); the measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("PUTSLAM_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device(f"cuda:{local_rank % ndev if backend != 'nccl' else local_rank}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    xdev = dev if backend == "nccl" else torch.device("cpu")       # where collective payloads live
 
     from putslam_amd import api, synth
     from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config)
@@ -88,7 +96,7 @@ def main():
 
     est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
     S = max(1, args.streams)
-    ctxs = [api.Context(local_rank) for _ in range(S)]
+    ctxs = [api.Context(dev.index) for _ in range(S)]
     ctx = ctxs[0]
     prm = default_ransac_params(args.error_version)
     cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + rank)
@@ -103,7 +111,7 @@ def main():
         bounds = [0, int(P * args.split), P]
     side = [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     from putslam_amd import sharding
-    gathered = ([torch.zeros((P, sharding.RECORD_FLOATS), dtype=torch.float32, device=dev) for _ in range(world)]
+    gathered = ([torch.zeros((P, sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev) for _ in range(world)]
                 if (world > 1 and rank == 0) else None)
 
     def run_all():
@@ -133,7 +141,7 @@ def main():
             # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI
             st = pb.stats.view(torch.int32).view(P, -1)              # PsRansacStats: [5] numInliers, [0] numMatchesIn
             rec = sharding.pack_records(pb.pose, st[:, 5], st[:, 0])
-            sharding.gather_records(rec, dst=0, out=gathered)
+            sharding.gather_records(rec.to(xdev), dst=0, out=gathered)
 
     def fence():
         if world > 1:
@@ -152,7 +160,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     totals = {}
