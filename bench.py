@@ -92,7 +92,7 @@ def main():
 
     from putslam_amd import api, synth
     from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config)
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs, run_pairs_split
 
     est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
     S = max(1, args.streams)
@@ -118,22 +118,9 @@ def main():
         if S == 1:
             run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)             # inputs already in HBM
             return
-        # S sub-batches of the same step on S streams; outputs land in disjoint slices of the same result
-        # buffers; pair p keeps its hypothesis stream seed + p
-        cur = torch.cuda.current_stream(dev)
-        for i in range(S):
-            lo, hi = bounds[i], bounds[i + 1]
-            st = cur if i == 0 else side[i - 1]
-            if i > 0 and args.join == "step":
-                st.wait_stream(cur)
-            ctxs[i].set_stream(st.cuda_stream)
-            ci, _k = make_config(est, args.hyp, seed=cfg.seed + lo)
-            view = api.DeviceResults(pb.matches[lo:].data_ptr(), pb.num_matches[lo:].data_ptr(), pb.mask[lo:].data_ptr(),
-                                     pb.pose[lo:].data_ptr(), pb.stats[lo:].data_ptr())
-            ctxs[i].vo_pairs_device(prm, ci, TUM_FR1_K, fs.view(), pb.pairs[lo:].data_ptr(), hi - lo, view)
-        if args.join == "step" or world > 1:
-            for st in side:
-                cur.wait_stream(st)
+        # S sub-batches of the same step on S streams (device_batch.run_pairs_split)
+        run_pairs_split(ctxs, side, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds,
+                        join=(args.join == "step" or world > 1))
 
     def step():
         run_all()

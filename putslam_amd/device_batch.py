@@ -64,3 +64,35 @@ def run_pairs(ctx, params, cfg, K, frames: FrameSetDevice, batch: PairBatchDevic
     if use_torch_stream:
         ctx.set_stream(torch.cuda.current_stream(frames.device).cuda_stream)
     ctx.vo_pairs_device(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())
+
+
+def run_pairs_split(ctxs, side_streams, params, estimator, num_hypotheses, seed, K, frames: FrameSetDevice,
+                    batch: PairBatchDevice, bounds=None, join=True):
+    """The same batch as `run_pairs`, submitted as len(ctxs) sub-batches on len(ctxs) HIP streams (ctxs[0] on the
+    current torch stream, ctxs[i] on side_streams[i-1]); every context owns its scratch arena, results land in
+    disjoint slices of `batch`.  Pair p keeps its hypothesis stream (seed + p), so the outputs are bit-identical
+    to the single call.  With join=True the current stream waits for the side streams before returning."""
+    from . import api
+    from ._abi import make_config
+    S = len(ctxs)
+    P = batch.P
+    if bounds is None:
+        bounds = [P * i // S for i in range(S + 1)]
+    cur = torch.cuda.current_stream(frames.device)
+    keep = []
+    for i in range(S):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi <= lo:
+            continue
+        st = cur if i == 0 else side_streams[i - 1]
+        if i > 0 and join:
+            st.wait_stream(cur)
+        ctxs[i].set_stream(st.cuda_stream)
+        ci, k = make_config(estimator, num_hypotheses, seed=seed + lo)
+        keep.append(k)
+        view = api.DeviceResults(batch.matches[lo:].data_ptr(), batch.num_matches[lo:].data_ptr(),
+                                 batch.mask[lo:].data_ptr(), batch.pose[lo:].data_ptr(), batch.stats[lo:].data_ptr())
+        ctxs[i].vo_pairs_device(params, ci, K, frames.view(), batch.pairs[lo:].data_ptr(), hi - lo, view)
+    if join:
+        for st in side_streams[:S - 1]:
+            cur.wait_stream(st)

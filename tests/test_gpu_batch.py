@@ -157,3 +157,29 @@ def test_streaming_match_state(ctx, oracle):
                 assert a == b or (np.isnan(a) and np.isnan(b)), (f, fld, a, b)
         prev = (d, p3)
     st.close()
+
+
+@pytest.mark.parametrize("S,est,H", [(2, EST_FIXED, 1024), (3, EST_RANSAC, 487), (2, EST_USAC, 600)])
+def test_split_over_streams_equals_single_call(ctx, S, est, H):
+    """bench.py's default submission (sub-batches on several HIP streams, one context each) must be bit-identical
+    to the single ps_vo_pairs_device call: pair p draws from seed + p wherever its sub-batch starts."""
+    import torch
+    from putslam_amd import api
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs, run_pairs_split
+    seq = synth.make_sequence(24, 700, config=3, index=200 + S)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(est, H, seed=0xABC)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    one = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, one)
+    a = one.download()
+    ctxs = [ctx] + [api.Context(0) for _ in range(S - 1)]
+    side = [torch.cuda.Stream() for _ in range(S - 1)]
+    for join in (True, False):
+        two = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs_split(ctxs, side, prm, est, H, cfg.seed, TUM_FR1_K, fs, two, join=join)
+        b = two.download()                       # synchronises the device, hence every stream
+        _compare(b, a, len(seq["pairs"]))
+    for c in ctxs[1:]:
+        c.close()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
