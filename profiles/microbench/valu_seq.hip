@@ -24,6 +24,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define MOVS(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(ss));
 #define XAD(i) asm volatile("v_xad_u32 %0, %1, %0, 0" : "+v"(a[i]) : "s"(ss));
 #define XORS64(i) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "s"(ss));
+#define XORSD(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "s"(sv[i]));
 #define ADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(sa));
 #define MINU(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(sa));
 #define MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(sa));
@@ -57,6 +58,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         for (int i = 0; i < 4; ++i) d[i] = 1.0 + 1e-3 * (double)(threadIdx.x + i);        \
         uint32_t sa = seed | 1;                                                           \
         uint32_t ss = seed * 2654435761u + 12345u;                                        \
+        uint32_t sv[8];                                                                   \
+        for (int i = 0; i < 8; ++i) sv[i] = __builtin_amdgcn_readfirstlane(seed * (2654435761u + 2 * i) + i); \
         float sfs = 1.0f + (float)(seed & 7) * 1e-7f;                                     \
         float sb = 1.0000001f, sc = 0.9999999f + (float)(seed & 1);                       \
         f2 sp = f2{1.0000001f, 0.9999999f};                                               \
@@ -83,6 +86,8 @@ SEQ_KERNEL(s_xors64_8, XORS64(0) XORS64(1) XORS64(2) XORS64(3) XORS64(4) XORS64(
 SEQ_KERNEL(s_ham_sgpr, XORS(0) BCNT(0) XORS(1) BCNT(1) XORS(2) BCNT(2) XORS(3) BCNT(3) XORS(4) BCNT(4) XORS(5) BCNT(5) XORS(6) BCNT(6) XORS(7) BCNT(7))
 SEQ_KERNEL(s_ham_vgpr, XOR(0) BCNT(0) XOR(1) BCNT(1) XOR(2) BCNT(2) XOR(3) BCNT(3) XOR(4) BCNT(4) XOR(5) BCNT(5) XOR(6) BCNT(6) XOR(7) BCNT(7))
 SEQ_KERNEL(s_ham_mov4, MOVS(0) MOVS(1) XOR(0) BCNT(0) XOR(1) BCNT(1) XOR(2) BCNT(2) XOR(3) BCNT(3) XOR(4) BCNT(4) XOR(5) BCNT(5) XOR(6) BCNT(6) XOR(7) BCNT(7))
+SEQ_KERNEL(s_ham_sgpr_d, XORSD(0) BCNT(0) XORSD(1) BCNT(1) XORSD(2) BCNT(2) XORSD(3) BCNT(3) XORSD(4) BCNT(4) XORSD(5) BCNT(5) XORSD(6) BCNT(6) XORSD(7) BCNT(7))
+SEQ_KERNEL(s_xorsd8, XORSD(0) XORSD(1) XORSD(2) XORSD(3) XORSD(4) XORSD(5) XORSD(6) XORSD(7))
 SEQ_KERNEL(s_mul8, MUL(0) MUL(1) MUL(2) MUL(3) MUL(4) MUL(5) MUL(6) MUL(7))
 SEQ_KERNEL(s_bcnt8, BCNT(0) BCNT(1) BCNT(2) BCNT(3) BCNT(4) BCNT(5) BCNT(6) BCNT(7))
 SEQ_KERNEL(s_bcnt_mul, BCNT(0) MUL(0) BCNT(1) MUL(1) BCNT(2) MUL(2) BCNT(3) MUL(3))
@@ -138,6 +143,7 @@ int main(int argc, char **argv)
         {"4 (xor sgpr, bcnt)", s_xors_bcnt}, {"4 (xor, bcnt) same reg", s_xor_bcnt_dep},
         {"8 mov (sgpr)", s_movs8}, {"8 xad (sgpr)", s_xad8}, {"8 xor_e64 (sgpr src1)", s_xors64_8},
         {"8 (xor sgpr, bcnt)", s_ham_sgpr}, {"8 (xor vgpr, bcnt)", s_ham_vgpr}, {"2 mov + 8 (xor vgpr, bcnt)", s_ham_mov4},
+        {"8 (xor sgpr_i, bcnt) 8 distinct sgprs", s_ham_sgpr_d}, {"8 xor (8 distinct sgprs)", s_xorsd8},
         {"8 mul_f32", s_mul8}, {"8 bcnt", s_bcnt8}, {"8 pk_mul", s_pk8}, {"8 fma_f32", s_fma8},
         {"4 (bcnt, mul)", s_bcnt_mul}, {"4 bcnt + 4 mul", s_bcnt4_mul4}, {"4 (bcnt, fmac)", s_bcnt_fmac},
         {"4 (bcnt, fma)", s_bcnt_fma}, {"4 (bcnt, add_f32)", s_bcnt_addf},
