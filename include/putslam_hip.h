@@ -217,7 +217,10 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
  * every later push matches previous (query) against the new frame (train), runs the estimator selected by
  * cfg on the surviving matches and makes the new frame the previous one (:506-513).
  * Hypothesis stream of every push = cfg->seed (the caller varies it per frame if wanted).
- * matches / inlierMask: capacity maxKpts; pose column-major 4x4; host pointers. */
+ * matches / inlierMask: capacity maxKpts; pose column-major 4x4; host pointers.
+ * A push is launch-bound, so from the third push with unchanged params / estimator / numHypotheses / K on, the
+ * copy-in -> four kernels -> copy-out sequence is replayed from a captured hipGraph (one per frame slot; frame,
+ * row count and seed travel as data).  Results are identical; PUTSLAM_HIP_NO_GRAPH=1 keeps ordinary launches. */
 typedef struct PsVoStream PsVoStream;
 int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out);
 void ps_vo_stream_destroy(PsVoStream *s);

@@ -339,6 +339,7 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
     if (pl.sa.iter0 > H) pl.sa.iter0 = H;
     pl.ma.seed = cfg->seed;
     pl.ma.raw = nullptr;
+    pl.ma.seedDev = nullptr;
     return PS_OK;
 }
 
@@ -1053,7 +1054,7 @@ struct PsVoStream {
     int cap = 0;
     long long frames = 0;   // frames pushed so far
     int curSlot = 0;        // slot of the most recent frame
-    Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot}
+    Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot, seedLo, seedHi}
     // One contiguous result block on the device and its pinned host mirror, so a push needs ONE
     // device-to-host copy and ONE synchronisation: [PsRansacStats][pose 16 f32][numMatches i32 + pad]
     // [matches cap x 16 B][mask cap B]
@@ -1061,6 +1062,20 @@ struct PsVoStream {
     uint8_t *hres = nullptr;   // pinned
     uint8_t *hin = nullptr;    // pinned staging of the incoming frame: [cap x 32 B][cap x 12 B][4 x i32]
     size_t offPose = 0, offNum = 0, offMatches = 0, offMask = 0, resBytes = 0;
+    // A push is launch-bound (three copies in, up to two memsets, four kernels, one copy out): once the scratch
+    // arena has been sized by an ordinary push with the same parameters the sequence is captured into one hipGraph
+    // per frame slot and replayed with a single launch.  Everything that changes between pushes travels as data:
+    // the frame (full-capacity copies from the pinned staging area), its row count and slot (meta) and the seed.
+    bool graphsEnabled = true;
+    bool warm = false;          // an un-captured push has run with `key`
+    struct Key {
+        PsRansacParams prm;
+        int estimator, numHypotheses;
+        float K[9];
+        const void *arena[11]; // scratch and table blocks the captured launches point at (they move when they grow)
+    } key{};
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    long long graphLaunches = 0;
 };
 
 int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
@@ -1080,11 +1095,13 @@ int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
     s->resBytes = s->offMask + cap;
     PS_ENSURE(s->desc, 2 * cap * 32);
     PS_ENSURE(s->pts, 2 * cap * 12);
-    PS_ENSURE(s->meta, 4 * sizeof(int32_t));
+    PS_ENSURE(s->meta, 8 * sizeof(int32_t));
     PS_ENSURE(s->res, s->resBytes);
     PS_HIP(hipHostMalloc((void **)&s->hres, s->resBytes, hipHostMallocDefault));
-    PS_HIP(hipHostMalloc((void **)&s->hin, cap * 44 + 16, hipHostMallocDefault));
-    PS_HIP(hipMemsetAsync(s->meta.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    PS_HIP(hipHostMalloc((void **)&s->hin, cap * 44 + 32, hipHostMallocDefault));
+    memset(s->hin, 0, cap * 44 + 32); // rows beyond a frame's count are copied by the captured graph, never read
+    PS_HIP(hipMemsetAsync(s->meta.p, 0, 8 * sizeof(int32_t), ctx->stream));
+    if (const char *v = std::getenv("PUTSLAM_HIP_NO_GRAPH")) s->graphsEnabled = std::atoi(v) == 0;
     return PS_OK;
 }
 
@@ -1095,6 +1112,11 @@ void ps_vo_stream_destroy(PsVoStream *s)
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    for (hipGraphExec_t &g : s->gexec)
+        if (g) {
+            (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
     Buf *all[] = {&s->desc, &s->pts, &s->meta, &s->res};
     for (Buf *b : all) release(*b);
     if (s->hres) (void)hipHostFree(s->hres);
@@ -1130,23 +1152,31 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     // synchronisation that ends the previous push)
     uint8_t *hd = s->hin;
     float *hp = reinterpret_cast<float *>(s->hin + cap * 32);
-    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44);
+    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44); // {n, prevSlot, slot, pad, seedLo, seedHi}
     for (int i = 0; i < n; ++i) memcpy(hd + (size_t)i * 32, desc + (size_t)i * descStep, 32);
     if (n > 0) memcpy(hp, pts, (size_t)n * 12);
-    if (n > 0) {
-        PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, (size_t)n * 32, hipMemcpyHostToDevice,
-                              ctx->stream));
-        PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, hp, (size_t)n * 12, hipMemcpyHostToDevice,
-                              ctx->stream));
-    }
     hm[0] = n;
     hm[1] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
     hm[2] = slot;
-    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &hm[0], sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, &hm[1], 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hm[3] = 0;
+    memcpy(&hm[4], &cfg->seed, sizeof(uint64_t));
     s->curSlot = slot;
     s->frames++;
+    auto copy_in = [&](size_t rows) -> int {
+        if (rows > 0) {
+            PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, rows * 32, hipMemcpyHostToDevice,
+                                  ctx->stream));
+            PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, hp, rows * 12, hipMemcpyHostToDevice,
+                                  ctx->stream));
+        }
+        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &hm[0], sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, &hm[1], 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 4, &hm[4], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        return PS_OK;
+    };
     if (first) { // detectInitFeatures (matcher.cpp:17-64): nothing to match against yet
+        rc = copy_in((size_t)n);
+        if (rc) return rc;
         PS_HIP(hipStreamSynchronize(ctx->stream));
         *nmatches = -1;
         return PS_OK;
@@ -1160,14 +1190,73 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     Plan pl;
     rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
     if (rc) return rc;
+    pl.ma.seedDev = reinterpret_cast<const uint64_t *>((const int32_t *)s->meta.p + 4);
     uint8_t *dres = (uint8_t *)s->res.p;
-    rc = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)(dres + s->offMatches),
-                         (int32_t *)(dres + s->offNum), 0);
-    if (rc) return rc;
-    rc = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)(dres + s->offMatches), (const int32_t *)(dres + s->offNum),
-                          s->cap, (float *)(dres + s->offPose), dres + s->offMask, (PsRansacStats *)dres, 2);
-    if (rc) return rc;
-    PS_HIP(hipMemcpyAsync(s->hres, dres, s->resBytes, hipMemcpyDeviceToHost, ctx->stream));
+    auto enqueue = [&](size_t rows) -> int {
+        int r = copy_in(rows);
+        if (r) return r;
+        r = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)(dres + s->offMatches),
+                            (int32_t *)(dres + s->offNum), 0);
+        if (r) return r;
+        r = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)(dres + s->offMatches),
+                             (const int32_t *)(dres + s->offNum), s->cap, (float *)(dres + s->offPose), dres + s->offMask,
+                             (PsRansacStats *)dres, 2);
+        if (r) return r;
+        PS_HIP(hipMemcpyAsync(s->hres, dres, s->resBytes, hipMemcpyDeviceToHost, ctx->stream));
+        return PS_OK;
+    };
+    PsVoStream::Key key;
+    memset(&key, 0, sizeof key);
+    key.prm = *params;
+    key.estimator = cfg->estimator;
+    key.numHypotheses = cfg->numHypotheses;
+    if (K) memcpy(key.K, K, sizeof key.K);
+    const void *arena[11] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p};
+    memcpy(key.arena, arena, sizeof arena);
+    const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
+    if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
+        for (hipGraphExec_t &g : s->gexec)
+            if (g) {
+                (void)hipGraphExecDestroy(g);
+                g = nullptr;
+            }
+    }
+    bool launched = false;
+    if (s->graphsEnabled && sameKey) {
+        if (!s->gexec[slot]) {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int r = enqueue(cap);
+                hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
+                if (r == PS_OK && e2 == hipSuccess && graph &&
+                    hipGraphInstantiate(&s->gexec[slot], graph, nullptr, nullptr, 0) != hipSuccess)
+                    s->gexec[slot] = nullptr;
+                if (r != PS_OK || e2 != hipSuccess) s->gexec[slot] = nullptr;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!s->gexec[slot]) {
+                s->graphsEnabled = false; // capture is not available here: stay on ordinary launches
+                (void)hipGetLastError();
+                ctx->err.clear();
+            }
+        }
+        if (s->gexec[slot]) {
+            PS_HIP(hipGraphLaunch(s->gexec[slot], ctx->stream));
+            s->graphLaunches++;
+            launched = true;
+        }
+    }
+    if (!launched) {
+        rc = enqueue((size_t)n);
+        if (rc) return rc;
+        const void *after[11] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p};
+        memcpy(key.arena, after, sizeof after);
+        s->key = key;
+        s->warm = true;
+    }
     PS_HIP(hipStreamSynchronize(ctx->stream));
     int32_t nm = 0;
     memcpy(&nm, s->hres + s->offNum, sizeof nm);

@@ -317,8 +317,10 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
 // ------------------------------------------------------------------------------------------
 struct ModelArgs {
     uint64_t seed;
-    const uint32_t *raw; // optional explicit draws, H x 3 (device)
+    const uint32_t *raw;     // optional explicit draws, H x 3 (device)
+    const uint64_t *seedDev; // optional: the seed lives in device memory (captured graphs replay with a new seed)
 };
+PS_D uint64_t base_seed(const ModelArgs &ma) { return ma.seedDev ? *ma.seedDev : ma.seed; }
 
 PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ recB, size_t rbase, uint32_t M,
                     const ModelArgs &ma, uint64_t pairSeed, uint32_t h, Rigid &mdl)
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
     Rigid mdl, inv;
     bool valid = false;
     if (h < H) {
-        valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, ma.seed + (uint64_t)p, (uint32_t)h, mdl);
+        valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR)
             inverse_rigid_general(mdl, inv);
     }
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
     set_identity(inv);
     int kin = 0;
     if (run && bestIdx >= 0) {
-        gen_model(recA, recB, rbase, (uint32_t)M, ma, ma.seed + (uint64_t)p, (uint32_t)bestIdx, mdl);
+        gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
         const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
         if (needInv) inverse_rigid_general(mdl, inv);
         for (int i0 = 0; i0 < M; i0 += kBlock) {

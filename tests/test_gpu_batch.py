@@ -183,3 +183,38 @@ def test_split_over_streams_equals_single_call(ctx, S, est, H):
     for c in ctxs[1:]:
         c.close()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+def test_streaming_graph_replay_long_sequence(ctx, oracle):
+    """ps_vo_stream_push replays a captured hipGraph from the third push on (one graph per frame slot).  Every push
+    must still equal the oracle: new seed every frame, ragged frame sizes, a parameter change in the middle (graphs
+    are rebuilt), other calls on the same context in between (they resize and rewrite the shared scratch/tables)."""
+    from putslam_amd import api
+    seq = synth.make_sequence(16, 600, config=3, index=31)
+    nk = [600, 600, 590, 600, 420, 600, 600, 1, 600, 600, 333, 600, 600, 600, 0, 600]
+    st = api.VoStream(ctx, 600)
+    prev = None
+    for f in range(16):
+        mode = REPROJECTION_ERROR if f < 9 else EUCLIDEAN_ERROR            # parameter change at frame 9
+        est, H = (EST_RANSAC, 487) if f < 12 else (EST_FIXED, 700)         # estimator / H change at frame 12
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(est, H, seed=1000 + 17 * f)
+        d, p3 = seq["desc"][f][: nk[f]], seq["pts"][f][: nk[f]]
+        r = st.push(prm, cfg, TUM_FR1_K, d, p3)
+        if f == 0:
+            assert r is None
+        else:
+            m = oracle.match_hamming256(prev[0], d)
+            c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, prev[1], p3, m)
+            assert r["matches"].tobytes() == m.tobytes(), f
+            assert np.array_equal(r["mask"], c["mask"]) and r["pose"].tobytes() == c["pose"].tobytes(), f
+            for fld in STAT_FIELDS:
+                a, b = r["stats"][fld], c["stats"][fld]
+                assert a == b or (np.isnan(a) and np.isnan(b)), (f, fld, a, b)
+        if f in (5, 6):   # a foreign call on the same context: bigger scratch, other stop tables
+            big = synth.make_pair(1500, config=2, index=f)
+            mm = ctx.match_hamming256(big[0]["desc"], big[1]["desc"])
+            c2, _ = make_config(EST_USAC, 2000, seed=3)
+            ctx.ransac_rigid3d(default_ransac_params(EUCLIDEAN_ERROR), c2, TUM_FR1_K, big[0]["pts"], big[1]["pts"], mm)
+        prev = (d, p3)
+    st.close()
