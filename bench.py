@@ -122,16 +122,26 @@ def main():
         run_pairs_split(ctxs, side, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds,
                         join=(args.join == "step" or world > 1))
 
+    pending = [None, None]   # in-flight gather of the previous step and the record block it reads
+
     def step():
         run_all()
         if world > 1:
-            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI
+            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI.
+            # Issued asynchronously: it completes beside the next step's kernels and is waited for before the next
+            # gather (or the closing fence) touches the same buffers.
             st = pb.stats.view(torch.int32).view(P, -1)              # PsRansacStats: [5] numInliers, [0] numMatchesIn
-            rec = sharding.pack_records(pb.pose, st[:, 5], st[:, 0])
-            sharding.gather_records(rec.to(xdev), dst=0, out=gathered)
+            rec = sharding.pack_records(pb.pose, st[:, 5], st[:, 0]).to(xdev)
+            if pending[0] is not None:
+                pending[0].wait()
+            work, _ = sharding.gather_records(rec, dst=0, out=gathered, async_op=True)
+            pending[0], pending[1] = work, rec
 
     def fence():
         if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = pending[1] = None
             dist.barrier()
         torch.cuda.synchronize(dev)
 

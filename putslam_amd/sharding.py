@@ -40,8 +40,11 @@ def pack_records(pose, num_inliers, num_matches):
     return rec
 
 
-def gather_records(rec, dst=0, group=None, out=None):
-    """Gather equally sized per-rank record blocks on `dst` (RCCL/gloo gather). Returns the list on dst, else None."""
+def gather_records(rec, dst=0, group=None, out=None, async_op=False):
+    """Gather equally sized per-rank record blocks on `dst` (RCCL/gloo gather).
+    Blocking form: returns the list on dst, else None.  async_op=True: returns (work, list-or-None); the caller
+    waits on `work` before reading the list or reusing `rec` / `out` (lets the gather of one step run beside the
+    kernels of the next)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -49,10 +52,11 @@ def gather_records(rec, dst=0, group=None, out=None):
     if rank == dst:
         if out is None:
             out = [torch.empty_like(rec) for _ in range(world)]
-        dist.gather(rec, out, dst=dst, group=group)
-        return out
-    dist.gather(rec, None, dst=dst, group=group)
-    return None
+        work = dist.gather(rec, out, dst=dst, group=group, async_op=async_op)
+    else:
+        out = None
+        work = dist.gather(rec, None, dst=dst, group=group, async_op=async_op)
+    return (work, out) if async_op else out
 
 
 def _mul4_f32(A, B):

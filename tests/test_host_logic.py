@@ -95,7 +95,17 @@ def _worker(rank, world, port, q):
     res = po.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=1)
     rec = sharding.pack_records(res["pose"], res["stats"]["numInliers"], res["stats"]["numMatchesIn"])
     out = sharding.gather_records(rec, dst=0)
+    # the asynchronous form bench.py uses (gather of step k waited for before step k+1's gather) gives the same blocks
+    import torch
+    bufs = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
+    prev = None
+    for it in range(3):
+        if prev is not None:
+            prev.wait()
+        prev, got = sharding.gather_records(rec + float(it), dst=0, out=bufs, async_op=True)
+    prev.wait()
     if rank == 0:
+        assert all(torch.equal(g, o + 2.0) for g, o in zip(got, out))
         q.put([o.numpy().copy() for o in out])
     else:
         q.put(rec.numpy().copy())
