@@ -1008,13 +1008,24 @@ __global__ __launch_bounds__(kBlock) void ps_match_xyz_kernel(const float *__res
 
     // sweep 1: best value among the candidates (packed (value, index) minimum = first index on ties)
     unsigned long long best = ~0ull;
-    for (int i0 = 0; i0 < ncur; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < ncur) {
-            float d0 = mx - curPos[3 * i], d1 = my - curPos[3 * i + 1], d2 = mz - curPos[3 * i + 2];
+    constexpr int UN = 4; // position / level loads of four 64-keypoint groups are issued before any is used
+    const int lastc = ncur - 1;
+    for (int i0 = 0; i0 < ncur; i0 += 64 * UN) {
+        float px[UN], py[UN], pz[UN];
+        int lv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + 64 * u + lane, ic = i < ncur ? i : lastc;
+            px[u] = curPos[3 * ic]; py[u] = curPos[3 * ic + 1]; pz[u] = curPos[3 * ic + 2];
+            lv[u] = curLevel[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + 64 * u + lane;
+            float d0 = mx - px[u], d1 = my - py[u], d2 = mz - pz[u];
             float s = d0 * d0 + (d1 * d1 + d2 * d2);
-            int li = curLevel[i];
-            if (s < radiusBound && li - 1 <= lj && lj <= li + 1) {
+            int li = lv[u];
+            if (i < ncur && s < radiusBound && li - 1 <= lj && lj <= li + 1) {
                 uint32_t v = satdiff_popc256(a0, a1, curDesc[2 * i], curDesc[2 * i + 1]);
                 unsigned long long key = ((unsigned long long)v << 32) | (unsigned)i;
                 best = key < best ? key : best;
@@ -1036,32 +1047,41 @@ __global__ __launch_bounds__(kBlock) void ps_match_xyz_kernel(const float *__res
     // sweep 2: every candidate within the accept ratio of the best, ascending i
     int n = 0;
     const int base = WRITE ? offsets[j] : 0;
-    for (int i0 = 0; i0 < ncur; i0 += 64) {
-        const int i = i0 + lane;
-        bool acc = false;
-        float value = 0.f;
-        if (i < ncur) {
-            float d0 = mx - curPos[3 * i], d1 = my - curPos[3 * i + 1], d2 = mz - curPos[3 * i + 2];
+    for (int i0 = 0; i0 < ncur; i0 += 64 * UN) {
+        float px[UN], py[UN], pz[UN];
+        int lv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + 64 * u + lane, ic = i < ncur ? i : lastc;
+            px[u] = curPos[3 * ic]; py[u] = curPos[3 * ic + 1]; pz[u] = curPos[3 * ic + 2];
+            lv[u] = curLevel[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + 64 * u + lane;
+            bool acc = false;
+            float value = 0.f;
+            float d0 = mx - px[u], d1 = my - py[u], d2 = mz - pz[u];
             float s = d0 * d0 + (d1 * d1 + d2 * d2);
-            int li = curLevel[i];
-            if (s < radiusBound && li - 1 <= lj && lj <= li + 1) {
+            int li = lv[u];
+            if (i < ncur && s < radiusBound && li - 1 <= lj && lj <= li + 1) {
                 value = (float)satdiff_popc256(a0, a1, curDesc[2 * i], curDesc[2 * i + 1]);
                 acc = acceptRatio * (double)value <= (double)bestVal;
             }
-        }
-        unsigned long long bal = __ballot(acc);
-        if (WRITE && acc) {
-            int pos = base + n + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < cap) {
-                PsDMatch m;
-                m.queryIdx = j;
-                m.trainIdx = i;
-                m.imgIdx = -1; // default-constructed cv::DMatch (matcher.cpp:741)
-                m.distance = value;
-                out[pos] = m;
+            unsigned long long bal = __ballot(acc);
+            if (WRITE && acc) {
+                int pos = base + n + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                    PsDMatch m;
+                    m.queryIdx = j;
+                    m.trainIdx = i;
+                    m.imgIdx = -1; // default-constructed cv::DMatch (matcher.cpp:741)
+                    m.distance = value;
+                    out[pos] = m;
+                }
             }
+            n += __popcll(bal);
         }
-        n += __popcll(bal);
     }
     if (!WRITE && lane == 0) counts[j] = n;
 }
