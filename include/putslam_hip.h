@@ -224,6 +224,8 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
 typedef struct PsVoStream PsVoStream;
 int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out);
 void ps_vo_stream_destroy(PsVoStream *s);
+/* Forget the resident frame: the next push is a first frame again (Matcher::detectInitFeatures, matcher.cpp:17-64). */
+int ps_vo_stream_reset(PsVoStream *s);
 int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
                       const uint8_t *desc, size_t descStep, const float *pts, int n,
                       PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose, PsRansacStats *stats);

@@ -17,7 +17,7 @@ EXPORTED = [
     "ps_last_error", "ps_abi_version", "ps_device_arch",
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
-    "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_push",
+    "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
     "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv",
@@ -94,6 +94,7 @@ def load():
     L.ps_vo_stream_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.ps_vo_stream_destroy.argtypes = [vp]
     L.ps_vo_stream_destroy.restype = None
+    L.ps_vo_stream_reset.argtypes = [vp]
     L.ps_vo_stream_push.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, sz, vp, i32, vp,
                                     C.POINTER(i32), vp, vp, vp]
     L.ps_vo_pairs_device.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp,

@@ -305,20 +305,116 @@ void Matcher::detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3
     prevDescriptors = descriptors;
     prevFeatures3D.swap(features3D);
     frameCounter = 0;
+    fusedSynced_ = false;
+}
+
+// Resident-frame state of one matcher instance: its own context (stream + scratch) and the two-slot frame store.
+struct Matcher::Fused {
+    PsContext *ctx = nullptr;
+    PsVoStream *stream = nullptr;
+    int cap = 0;
+    ~Fused()
+    {
+        if (stream) ps_vo_stream_destroy(stream);
+        if (ctx) ps_context_destroy(ctx);
+    }
+};
+
+bool Matcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
+                             Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
+                             double &pointInlierRatio)
+{
+    const int n = (int)features3D.size(), np = (int)prevFeatures3D.size();
+    if (n > PS_MAX_KPTS || np > PS_MAX_KPTS) return false;
+    if ((n > 0 && (descriptors.cols != PS_DESC_BYTES || descriptors.rows != n)) ||
+        (np > 0 && (prevDescriptors.cols != PS_DESC_BYTES || prevDescriptors.rows != np)))
+        return false; // float descriptors / inconsistent sizes: the generic sequence reports them
+    if (!fused_) fused_ = std::make_shared<Fused>();
+    Fused &f = *fused_;
+    if (!f.ctx) {
+        int dev = 0;
+        if (const char *e = std::getenv("PUTSLAM_HIP_DEVICE")) dev = std::atoi(e);
+        if (ps_context_create(dev, &f.ctx) != PS_OK) {
+            f.ctx = nullptr;
+            return false;
+        }
+    }
+    const int need = std::max(std::max(n, np), 1);
+    if (!f.stream || f.cap < need) {
+        if (f.stream) ps_vo_stream_destroy(f.stream);
+        f.stream = nullptr;
+        f.cap = std::min(PS_MAX_KPTS, std::max(2048, need + need / 4));
+        if (ps_vo_stream_create(f.ctx, f.cap, &f.stream) != PS_OK) {
+            f.stream = nullptr;
+            return false;
+        }
+        fusedSynced_ = false;
+    }
+    RANSAC::parameters rp = matcherParameters.RANSACParams;
+    rp.iterationCount = ransacIterations(0.20); // RANSAC.cpp:30
+    const PsRansacParams prm = toPs(rp);
+    int a = ransacIterations(0.20), b = ransacIterations(rp.minimalInlierRatioThreshold);
+    int H = a > b ? a : b;
+    H = std::max(1, std::min(H, PS_MAX_HYPOTHESES));
+    PsRansacConfig cfg;
+    cfg.estimator = PS_EST_RANSAC;
+    cfg.numHypotheses = H;
+    cfg.seed = seeded_ ? seed_ + (uint64_t)frameCounter : (uint64_t)std::time(nullptr); // RANSAC.cpp:13
+    cfg.sampleIdx = nullptr;
+    float K[9];
+    bool haveK;
+    cameraToK(matcherParameters.cameraMatrixMat, K, haveK);
+    std::vector<cv::DMatch> m((size_t)f.cap);
+    std::vector<uint8_t> mask((size_t)f.cap);
+    Eigen::Matrix4f pose = Eigen::Matrix4f::Identity();
+    PsRansacStats st;
+    int nm = 0;
+    if (!fusedSynced_) { // (re)load the previous frame as the resident one
+        ps_vo_stream_reset(f.stream);
+        int rc = ps_vo_stream_push(f.stream, &prm, &cfg, haveK ? K : nullptr, prevDescriptors.data,
+                                   np > 0 ? (size_t)prevDescriptors.step : (size_t)PS_DESC_BYTES,
+                                   reinterpret_cast<const float *>(prevFeatures3D.data()), np,
+                                   reinterpret_cast<PsDMatch *>(m.data()), &nm, mask.data(), pose.data(), &st);
+        if (rc != PS_OK) return false;
+    }
+    int rc = ps_vo_stream_push(f.stream, &prm, &cfg, haveK ? K : nullptr, descriptors.data,
+                               n > 0 ? (size_t)descriptors.step : (size_t)PS_DESC_BYTES,
+                               reinterpret_cast<const float *>(features3D.data()), n, reinterpret_cast<PsDMatch *>(m.data()),
+                               &nm, mask.data(), pose.data(), &st);
+    if (rc != PS_OK || nm < 0) {
+        if (rc != PS_OK) std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
+        fusedSynced_ = false;
+        return false;
+    }
+    fusedSynced_ = true; // the frame just pushed is the resident "previous" one now
+    inlierMatches.clear();
+    inlierMatches.reserve((size_t)st.numInliers);
+    for (int i = 0; i < nm; ++i)
+        if (mask[(size_t)i]) inlierMatches.push_back(m[(size_t)i]);
+    estimatedTransformation = pose;
+    // RANSAC::pointInlierRatio (RANSAC.h:56-66) was evaluated on the device with two bitmaps over trainIdx
+    // (unique inlier train indices / unique matched train indices, 0/0 = NaN like the reference's set sizes)
+    pointInlierRatio = st.pointInlierRatio;
+    return true;
 }
 
 double Matcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
                       std::vector<cv::DMatch> &inlierMatches)
 {
-    std::vector<cv::DMatch> matches = performMatching(prevDescriptors, descriptors); // matcher.cpp:470
-    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // :491-492
-    RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
-    if (seeded_) ransac.setSampleSeed(seed_ + (uint64_t)frameCounter);
-    estimatedTransformation = ransac.estimateTransformation(prevFeatures3D, features3D, matches, inlierMatches);
+    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // matcher.cpp:491-492
+    double ratio = 0.0;
+    if (!(fusedMatch_ && fusedMatchCall(descriptors, features3D, estimatedTransformation, inlierMatches, ratio))) {
+        std::vector<cv::DMatch> matches = performMatching(prevDescriptors, descriptors); // matcher.cpp:470
+        RANSAC ransac(matcherParameters.RANSACParams, matcherParameters.cameraMatrixMat);
+        if (seeded_) ransac.setSampleSeed(seed_ + (uint64_t)frameCounter);
+        estimatedTransformation = ransac.estimateTransformation(prevFeatures3D, features3D, matches, inlierMatches);
+        fusedSynced_ = false;
+        ratio = RANSAC::pointInlierRatio(inlierMatches, matches); // :515
+    }
     features3D.swap(prevFeatures3D); // :506-513 save computed values for the next iteration
     prevDescriptors = descriptors;
     ++frameCounter;
-    return RANSAC::pointInlierRatio(inlierMatches, matches); // :515
+    return ratio;
 }
 
 double Matcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
@@ -463,9 +559,9 @@ Matcher *createloopClosingMatcherOpenCV(const std::string _parametersFile, const
 } // namespace putslam
 
 // ---------------------------------------------------------------------------------------------
-MatcherOpenCV::MatcherOpenCV(void) : putslam::Matcher("OpenCV Matcher") {}
+MatcherOpenCV::MatcherOpenCV(void) : putslam::Matcher("OpenCV Matcher") { fusedMatch_ = true; }
 // XML parsing (tinyXML, matcher.h:188-357) is outside the path: parameters are plain members to set.
-MatcherOpenCV::MatcherOpenCV(const std::string, const std::string) : putslam::Matcher("OpenCVMatcher") {}
+MatcherOpenCV::MatcherOpenCV(const std::string, const std::string) : putslam::Matcher("OpenCVMatcher") { fusedMatch_ = true; }
 MatcherOpenCV::~MatcherOpenCV(void) {}
 const std::string &MatcherOpenCV::getName() const { return name; }
 

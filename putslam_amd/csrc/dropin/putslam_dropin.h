@@ -217,6 +217,17 @@ class Matcher {
     int frameCounter;
     uint64_t seed_ = 0;
     bool seeded_ = false;
+    // MatcherOpenCV sets fusedMatch_: match() then runs performMatching + RANSAC as ONE call against the previous
+    // frame kept in HBM (ps_vo_stream_push: the prevDescriptors / prevFeatures3D state of matcher.h:379-384 lives on
+    // the GPU as well, one upload and one download per frame) -- same results as the two separate calls.  A class
+    // that overrides performMatching leaves it false and gets the generic sequence.
+    bool fusedMatch_ = false;
+    struct Fused;
+    std::shared_ptr<Fused> fused_;
+    bool fusedSynced_ = false; // the resident frame is prevDescriptors / prevFeatures3D
+    bool fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
+                        Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
+                        double &pointInlierRatio);
 };
 
 Matcher *createMatcherOpenCV(void);

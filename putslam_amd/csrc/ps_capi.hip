@@ -1124,6 +1124,14 @@ void ps_vo_stream_destroy(PsVoStream *s)
     delete s;
 }
 
+int ps_vo_stream_reset(PsVoStream *s)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    s->frames = 0;
+    s->curSlot = 0;
+    return PS_OK;
+}
+
 int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
                       const uint8_t *desc, size_t descStep, const float *pts, int n, PsDMatch *matches, int *nmatches,
                       uint8_t *inlierMask, float *pose, PsRansacStats *stats)

@@ -49,3 +49,20 @@ def test_cpp_dropin(oracle, tmp_path, mode):
     p = subprocess.run([EXE, str(path)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "all checks passed" in p.stdout
+
+
+def test_cpp_demo_matching_sequence(tmp_path):
+    """demos/cpp/demo_matching: the reference's demoMatching loop over the drop-in classes (Matcher factory ->
+    detectInitFeatures / runVO -> VOTrajectory), synthetic frames with known motion; exit code 0 = every increment
+    within 5e-3 of the ground truth; the trajectory file has one TUM line per frame."""
+    exe = os.path.join(ROOT, "demos", "cpp", "demo_matching")
+    if not os.path.exists(exe):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_dropin()
+    traj = tmp_path / "traj.txt"
+    p = subprocess.run([exe, "40", "1200", str(traj)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = traj.read_text().strip().split("\n")
+    assert len(lines) == 40 and all(len(l.split()) == 8 for l in lines)
+    assert "39 increments accepted, 0 rejected" in p.stdout
