@@ -509,7 +509,9 @@ PS_D void score_accumulate(const Rigid &mdl, const Rigid &inv, const ScoreConsts
         }
         float dxn = pnu - C.z, dyn = pnv - C.w;
         float dxo = pou - C.x, dyo = pov - C.y;
-        float f0 = dxn * dxn + dyn * dyn, f1 = dxo * dxo + dyo * dyo;
+        // pre-filter only (the decision inside the band is taken in double below): one product may be fused, the
+        // float sums then sit within 2^-23 of the exact values, inside the 2^-22 the band allows for
+        float f0 = __builtin_fmaf(dxn, dxn, dyn * dyn), f1 = __builtin_fmaf(dxo, dxo, dyo * dyo);
         uint32_t u0, u1;
         memcpy(&u0, &f0, 4);
         memcpy(&u1, &f1, 4);
