@@ -63,6 +63,10 @@ def parse():
 
 def main():
     args = parse()
+    # The sub-batches of a step run on separate HIP streams; with the runtime's default of four hardware queues two
+    # streams can end up sharing one (then they serialise).  Eight queues keep them apart (measured: no effect on two
+    # streams, 105 k -> 117 k pairs/s on three).  Must be set before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
