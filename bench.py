@@ -15,6 +15,12 @@ pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypothes
 thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
 72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
 
+Submission: the step's pairs go out as --streams sub-batch chains (default 3), one HIP stream and one
+context each.  With --join end (default) the chains are ordered only within their own stream, so
+consecutive steps pipeline into each other (one chain's popcount sweep runs beside another's scoring
+sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
+--streams 1 is the single launch chain the per-kernel roofline figures of DESIGN.md section 4 refer to.
+
 Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section "Measurement").
 """
 import argparse
@@ -45,11 +51,12 @@ def parse():
     ap.add_argument("--preset", default=None, choices=["demoMatching", "sequence", "stress"],
                     help="BASELINE configs: demoMatching = configs[1] (one pair per step), sequence = configs[2] "
                          "(default), stress = configs[4] (5000 kpts, H = 100000, 8 pairs per step)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="sub-batches of the step run concurrently on this many HIP streams (one context each); "
-                         "2 lets the popcount sweep of one half overlap the floating-point sweep of the other")
-    ap.add_argument("--join", default="step", choices=["step", "end"],
-                    help="with --streams > 1: join the streams after every step, or let them free-run until the fence")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="sub-batch chains of the step, one HIP stream and one context (scratch arena) each; with "
+                         "--join end they run freely, so one chain's popcount sweep overlaps another's scoring sweep")
+    ap.add_argument("--join", default="end", choices=["step", "end"],
+                    help="step: every step forks from and joins the default stream; end: the sub-batch chains are ordered "
+                         "only within their own stream, consecutive steps pipeline, one synchronisation at the fence")
     ap.add_argument("--split", type=float, default=0.5, help="with --streams 2: fraction of the pairs on stream 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
@@ -96,7 +103,7 @@ def main():
 
     from putslam_amd import api, synth
     from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config)
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs, run_pairs_split
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
 
     est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
     S = max(1, args.streams)
@@ -113,39 +120,40 @@ def main():
     bounds = [P * i // S for i in range(S + 1)]
     if S == 2:
         bounds = [0, int(P * args.split), P]
-    side = [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    # one non-default torch stream per sub-batch chain (the C ABI reads a NULL stream as "the context's private
+    # stream", so the legacy default stream is never handed over)
+    chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    join = args.join == "step"
     from putslam_amd import sharding
-    gathered = ([torch.zeros((P, sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None)
-
-    def run_all():
-        if S == 1:
-            run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)             # inputs already in HBM
-            return
-        # S sub-batches of the same step on S streams (device_batch.run_pairs_split)
-        run_pairs_split(ctxs, side, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds,
-                        join=(args.join == "step" or world > 1))
-
-    pending = [None, None]   # in-flight gather of the previous step and the record block it reads
+    gathered = ([[torch.zeros((bounds[i + 1] - bounds[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
+                  for _ in range(world)] for i in range(S)] if (world > 1 and rank == 0) else [None] * S)
+    pending = [None] * S     # per chain: (in-flight gather of the previous step, the record block it reads)
 
     def step():
-        run_all()
+        # S sub-batches of the step on S streams (device_batch.run_pairs_split); with --join end the chains are
+        # ordered only within their own stream, so consecutive steps pipeline into each other
+        run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds, join=join)
         if world > 1:
-            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI.
-            # Issued asynchronously: it completes beside the next step's kernels and is waited for before the next
-            # gather (or the closing fence) touches the same buffers.
-            st = pb.stats.view(torch.int32).view(P, -1)              # PsRansacStats: [5] numInliers, [0] numMatchesIn
-            rec = sharding.pack_records(pb.pose, st[:, 5], st[:, 0]).to(xdev)
-            if pending[0] is not None:
-                pending[0].wait()
-            work, _ = sharding.gather_records(rec, dst=0, out=gathered, async_op=True)
-            pending[0], pending[1] = work, rec
+            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI -- one
+            # gather per chain, queued behind that chain's kernels and issued asynchronously: it completes beside
+            # the next step's kernels and is waited for before the chain's next gather (or the closing fence)
+            st32 = pb.stats.view(torch.int32).view(P, -1)            # PsRansacStats: [5] numInliers, [0] numMatchesIn
+            for i in range(S):
+                lo, hi = bounds[i], bounds[i + 1]
+                with torch.cuda.stream(chains[i]):
+                    rec = sharding.pack_records(pb.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0]).to(xdev)
+                    if pending[i] is not None:
+                        pending[i][0].wait()
+                    work, _ = sharding.gather_records(rec, dst=0, out=gathered[i], async_op=True)
+                    pending[i] = (work, rec)
 
     def fence():
         if world > 1:
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = pending[1] = None
+            for i in range(S):
+                if pending[i] is not None:
+                    with torch.cuda.stream(chains[i]):
+                        pending[i][0].wait()
+                    pending[i] = None
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -236,7 +244,7 @@ def main():
                              ("; configs[3]: one sequence per GPU, RCCL gather of 72 B/pair to rank 0" if world > 1
                               else "")),
                 "pairs_per_step": P * world, "kpts": args.kpts, "hypotheses": args.hyp,
-                "errorVersion": args.error_version, "estimator": args.estimator, "streams": S,
+                "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "join": args.join,
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
                 "mean_inliers": float(stats["numInliers"].mean()),
                 "accepted_pairs": int(stats["accepted"].sum()),
@@ -249,9 +257,9 @@ def main():
             "kernel_ms": kern,
             "valu_issue": valu_issue,
             "streams_note": (None if S == 1 else
-                             f"{S} sub-batches overlap on {S} HIP streams: per-launch durations are measured while the "
-                             "other stream's kernels share the CUs, so kernel_ms sums to more than ms_per_step and the "
-                             "per-kernel fractions are lower than with --streams 1 (DESIGN.md section 5)"),
+                             f"{S} sub-batch chains on {S} HIP streams (join={args.join}): per-launch durations are measured "
+                             "while the other chains' kernels share the CUs, so kernel_ms sums to more than ms_per_step "
+                             "and the per-kernel fractions are lower than with --streams 1 (DESIGN.md section 5)"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))

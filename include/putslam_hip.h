@@ -106,7 +106,9 @@ typedef struct PsContext PsContext;
  * PUTSLAM.cpp:566,570; featuresMap.cpp:650-652,794). ------------------------- */
 int ps_context_create(int device, PsContext **out);
 void ps_context_destroy(PsContext *ctx);
-/* Use an externally owned hipStream_t (e.g. the caller's current stream); NULL restores the private stream. */
+/* Use an externally owned hipStream_t (e.g. the caller's current stream); NULL restores the private stream, which
+ * is created hipStreamNonBlocking: it is NOT ordered with the legacy default stream, so a caller working on the
+ * default stream hands over an explicit stream (forked from / joined to the default one) or synchronises. */
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);
 const char *ps_last_error(const PsContext *ctx);

@@ -59,40 +59,67 @@ class PairBatchDevice:
                     stats=self.stats.cpu().numpy().view(STATS_DTYPE).reshape(-1)[:P])
 
 
+_SIDE_STREAMS = {}
+
+
+def _work_stream(device):
+    """A non-default torch stream for the calling device.  The C ABI takes a hipStream_t and reads NULL as "the
+    context's private stream", so torch's legacy default stream (handle 0) cannot be handed over: work submitted
+    from the default stream runs on this side stream instead, forked from and joined back to the default stream."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def run_pairs(ctx, params, cfg, K, frames: FrameSetDevice, batch: PairBatchDevice, use_torch_stream=True):
-    """Asynchronous: match -> cross-check -> RANSAC -> refit for every pair of the batch."""
-    if use_torch_stream:
-        ctx.set_stream(torch.cuda.current_stream(frames.device).cuda_stream)
+    """Asynchronous: match -> cross-check -> RANSAC -> refit for every pair of the batch, ordered after the work
+    already queued on torch's current stream; the current stream waits for the results."""
+    if not use_torch_stream:
+        ctx.vo_pairs_device(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())
+        return
+    cur = torch.cuda.current_stream(frames.device)
+    if cur.cuda_stream != 0:
+        ctx.set_stream(cur.cuda_stream)
+        ctx.vo_pairs_device(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())
+        return
+    st = _work_stream(frames.device)
+    st.wait_stream(cur)
+    ctx.set_stream(st.cuda_stream)
     ctx.vo_pairs_device(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())
+    cur.wait_stream(st)
 
 
-def run_pairs_split(ctxs, side_streams, params, estimator, num_hypotheses, seed, K, frames: FrameSetDevice,
+def run_pairs_split(ctxs, streams, params, estimator, num_hypotheses, seed, K, frames: FrameSetDevice,
                     batch: PairBatchDevice, bounds=None, join=True):
-    """The same batch as `run_pairs`, submitted as len(ctxs) sub-batches on len(ctxs) HIP streams (ctxs[0] on the
-    current torch stream, ctxs[i] on side_streams[i-1]); every context owns its scratch arena, results land in
-    disjoint slices of `batch`.  Pair p keeps its hypothesis stream (seed + p), so the outputs are bit-identical
-    to the single call.  With join=True the current stream waits for the side streams before returning."""
+    """The same batch as `run_pairs`, submitted as len(ctxs) sub-batches on len(ctxs) HIP streams (`streams`: one
+    non-default torch stream per context); every context owns its scratch arena, results land in disjoint slices of
+    `batch`.  Pair p keeps its hypothesis stream (seed + p), so the outputs are bit-identical to the single call.
+    join=True: every stream first waits for the current stream and the current stream waits for all of them at the
+    end (the call is then ordered like `run_pairs`).  join=False: the sub-batch chains are only ordered within their
+    own stream -- consecutive calls pipeline into each other and the caller synchronises before reading results."""
     from . import api
     from ._abi import make_config
     S = len(ctxs)
+    assert len(streams) >= S and all(st.cuda_stream != 0 for st in streams[:S])
     P = batch.P
     if bounds is None:
         bounds = [P * i // S for i in range(S + 1)]
     cur = torch.cuda.current_stream(frames.device)
+    if join:
+        for st in streams[:S]:
+            st.wait_stream(cur)
     keep = []
     for i in range(S):
         lo, hi = bounds[i], bounds[i + 1]
         if hi <= lo:
             continue
-        st = cur if i == 0 else side_streams[i - 1]
-        if i > 0 and join:
-            st.wait_stream(cur)
-        ctxs[i].set_stream(st.cuda_stream)
+        ctxs[i].set_stream(streams[i].cuda_stream)
         ci, k = make_config(estimator, num_hypotheses, seed=seed + lo)
         keep.append(k)
         view = api.DeviceResults(batch.matches[lo:].data_ptr(), batch.num_matches[lo:].data_ptr(),
                                  batch.mask[lo:].data_ptr(), batch.pose[lo:].data_ptr(), batch.stats[lo:].data_ptr())
         ctxs[i].vo_pairs_device(params, ci, K, frames.view(), batch.pairs[lo:].data_ptr(), hi - lo, view)
     if join:
-        for st in side_streams[:S - 1]:
+        for st in streams[:S]:
             cur.wait_stream(st)

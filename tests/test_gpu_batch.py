@@ -174,7 +174,7 @@ def test_split_over_streams_equals_single_call(ctx, S, est, H):
     run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, one)
     a = one.download()
     ctxs = [ctx] + [api.Context(0) for _ in range(S - 1)]
-    side = [torch.cuda.Stream() for _ in range(S - 1)]
+    side = [torch.cuda.Stream() for _ in range(S)]
     for join in (True, False):
         two = PairBatchDevice(seq["pairs"], fs.max_kpts)
         run_pairs_split(ctxs, side, prm, est, H, cfg.seed, TUM_FR1_K, fs, two, join=join)
@@ -182,7 +182,7 @@ def test_split_over_streams_equals_single_call(ctx, S, est, H):
         _compare(b, a, len(seq["pairs"]))
     for c in ctxs[1:]:
         c.close()
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream(0)   # back to the context's private stream
 
 
 def test_streaming_graph_replay_long_sequence(ctx, oracle):
