@@ -218,3 +218,30 @@ def test_streaming_graph_replay_long_sequence(ctx, oracle):
             ctx.ransac_rigid3d(default_ransac_params(EUCLIDEAN_ERROR), c2, TUM_FR1_K, big[0]["pts"], big[1]["pts"], mm)
         prev = (d, p3)
     st.close()
+
+
+def test_run_pairs_stream_ordering(ctx):
+    """run_pairs is ordered like a torch op: queued behind the work of the current stream and visible to it afterwards,
+    whether the current stream is the legacy default stream (handle 0, which the C ABI cannot take: a side stream is
+    forked and joined) or an explicit one."""
+    import torch
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(12, 500, config=3, index=61)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=77)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    ref = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, ref)                       # default stream
+    pose_ref = ref.pose.clone()                                         # a default-stream op: must see the results
+    torch.cuda.synchronize()
+    assert pose_ref.abs().sum().item() > 0
+    s = torch.cuda.Stream()
+    other = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    with torch.cuda.stream(s):
+        other.pose.fill_(123.0)                                         # queued before: must not survive
+        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, other)
+        pose_s = other.pose.clone()
+    s.synchronize()
+    assert torch.equal(pose_s, pose_ref)
+    _compare(other.download(), ref.download(), len(seq["pairs"]))
+    ctx.set_stream(0)
