@@ -112,6 +112,12 @@ def main():
     prm = default_ransac_params(args.error_version)
     cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + rank)
 
+    if world > 1:
+        # the run's parameter block comes from rank 0 (one ~120 B broadcast at start, outside the timed region)
+        from putslam_amd import sharding as _sh
+        prm, _K, est, _H, _seed = _sh.broadcast_params(prm, TUM_FR1_K, est, args.hyp, 0xB0B0, src=0, device=xdev)
+        args.hyp = _H
+        cfg, _ = make_config(est, args.hyp, seed=_seed + rank)
     # -- synthetic sequence of this rank (config 3; config 4 = one such sequence per GPU) --
     seq = synth.make_sequence(args.frames, args.kpts, config=3, index=rank)
     P = len(seq["pairs"])

@@ -59,6 +59,31 @@ def gather_records(rec, dst=0, group=None, out=None, async_op=False):
     return (work, out) if async_op else out
 
 
+def broadcast_params(params, K, estimator, num_hypotheses, seed, src=0, group=None, device="cpu"):
+    """The parameter block of the run -- PsRansacParams, the camera matrix, estimator / hypotheses / base seed --
+    from `src` to every rank (~120 B, one broadcast at start; rank `src` is authoritative).
+    Returns (params, K, estimator, num_hypotheses, seed) as received."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from ._abi import PsRansacParams
+    nb = C.sizeof(PsRansacParams)
+    blob = np.zeros(nb + 36 + 16, np.uint8)
+    blob[:nb] = np.frombuffer(bytes(params), np.uint8)
+    blob[nb:nb + 36] = np.frombuffer(np.ascontiguousarray(K, np.float32).tobytes(), np.uint8)
+    blob[nb + 36:] = np.frombuffer(np.array([estimator, num_hypotheses], np.int32).tobytes() +
+                                   np.array([seed], np.uint64).tobytes(), np.uint8)
+    t = torch.from_numpy(blob).to(device)
+    dist.broadcast(t, src=src, group=group)
+    got = t.cpu().numpy()
+    out = PsRansacParams.from_buffer_copy(got[:nb].tobytes())
+    K2 = np.frombuffer(got[nb:nb + 36].tobytes(), np.float32).reshape(3, 3).copy()
+    est, H = (int(v) for v in np.frombuffer(got[nb + 36:nb + 44].tobytes(), np.int32))
+    seed2 = int(np.frombuffer(got[nb + 44:nb + 52].tobytes(), np.uint64)[0])
+    return out, K2, est, H, seed2
+
+
 def _mul4_f32(A, B):
     """Eigen fixed-size 4x4 float product, coefficient-wise with the 4-term sum as (p0+p1)+(p2+p3)."""
     A = np.asarray(A, np.float32)

@@ -93,6 +93,16 @@ def _worker(rank, world, port, q):
     prm = default_ransac_params(EUCLIDEAN_ERROR)
     cfg, _ = make_config(EST_RANSAC, 487, seed=100 + rank)
     res = po.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=1)
+    # rank 0's parameter block is authoritative: the other rank starts from different values and must end up equal
+    mine = default_ransac_params(EUCLIDEAN_ERROR)
+    if rank != 0:
+        mine.inlierThresholdEuclidean = 9.0
+        mine.minimalNumberOfMatches = 99
+    Kmine = np.asarray(TUM_FR1_K, np.float32) * (1.0 if rank == 0 else 2.0)
+    p2, K2, est2, H2, seed2 = sharding.broadcast_params(mine, Kmine, EST_RANSAC if rank == 0 else 2, 487 + rank,
+                                                        0x1234_5678_9ABC_DEF0 + rank, src=0)
+    assert bytes(p2) == bytes(prm) and np.array_equal(K2.ravel(), np.asarray(TUM_FR1_K, np.float32).ravel())
+    assert (est2, H2, seed2) == (EST_RANSAC, 487, 0x1234_5678_9ABC_DEF0)
     rec = sharding.pack_records(res["pose"], res["stats"]["numInliers"], res["stats"]["numMatchesIn"])
     out = sharding.gather_records(rec, dst=0)
     # the asynchronous form bench.py uses (gather of step k waited for before step k+1's gather) gives the same blocks
