@@ -142,6 +142,9 @@ Eigen::Matrix4f RANSAC::estimateTransformation(std::vector<Eigen::Vector3f> prev
                                                std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &bestInlierMatches)
 {
     if (RANSACParams.verbose > 0) std::cout << "RANSAC: original matches.size() = " << matches.size() << std::endl;
+    if (RANSACParams.errorVersion != EUCLIDEAN_ERROR && RANSACParams.errorVersion != REPROJECTION_ERROR &&
+        RANSACParams.errorVersion != EUCLIDEAN_AND_REPROJECTION_ERROR && RANSACParams.errorVersion != ADAPTIVE_ERROR)
+        std::cout << "RANSAC: incorrect error version" << std::endl; // RANSAC.cpp:134-135 (once per call here, not per iteration)
     // enough samples for the longest schedule the reference can run: max(iters(0.2), iters(minRatio))
     int a = ransacIterations(0.20), b = ransacIterations(RANSACParams.minimalInlierRatioThreshold);
     int H = a > b ? a : b;
