@@ -219,6 +219,9 @@ def main():
                                   "frac": t_match / kern.get("ps_hamming_nn", float("nan"))},
                 "ps_ransac_score": {"valu_per_eval": ks["valu_per_unit"], "model_ms": t_score,
                                     "frac": t_score / kern.get("ps_ransac_score", float("nan"))},
+                # the whole step against the same model: S launches of each sweep per step, whatever their overlap
+                "step": {"model_ms": S * (t_match + t_score),
+                         "frac": S * (t_match + t_score) / (elapsed / args.steps * 1e3)},
                 "peak_lane_ops_per_s": VALU_PEAK_TOPS * 1e12,
                 "achieved_lane_ops_per_s": {
                     "ps_hamming_nn": units_match * km["valu_per_unit"] * 64 / (kern.get("ps_hamming_nn", float("nan")) * 1e-3),
