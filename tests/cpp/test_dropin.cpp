@@ -151,6 +151,55 @@ int main(int argc, char **argv)
         CHECK(matcher->matchXYZ(none, curDesc, curF, oct, det, Tx, inlx, 1) == -1.0);
     }
 
+    // ---- fused resident-frame match (MatcherOpenCV) == generic performMatching -> RANSAC sequence ----
+    // A subclass that switches the fused call off must return the same poses, inlier lists and ratios, frame after
+    // frame, including when the frame grows past the resident store's capacity (the store is rebuilt) and when
+    // detectInitFeatures restarts the sequence.
+    {
+        struct GenericMatcher : public MatcherOpenCV {
+            GenericMatcher() { fusedMatch_ = false; }
+        };
+        MatcherOpenCV fusedM;
+        GenericMatcher genericM;
+        for (putslam::Matcher *m : {(putslam::Matcher *)&fusedM, (putslam::Matcher *)&genericM}) {
+            m->setSampleSeed(seed ^ 0x55);
+            m->matcherParameters.RANSACParams.errorVersionVO = mode;
+        }
+        // frames of different sizes cut from the two descriptor / point sets, then one larger than 2048 rows
+        std::vector<uint8_t> bigD;
+        std::vector<Eigen::Vector3f> bigP;
+        for (int rep = 0; rep < 5; ++rep)
+            for (int i = 0; i < N; ++i) {
+                bigD.insert(bigD.end(), db.begin() + (size_t)i * 32, db.begin() + (size_t)(i + 1) * 32);
+                bigD[bigD.size() - 1 - (size_t)(rep % 32)] ^= (uint8_t)(rep * 37 + 1);
+                bigP.push_back(Eigen::Vector3f(cur[(size_t)i].x() + 0.001f * rep, cur[(size_t)i].y(), cur[(size_t)i].z()));
+            }
+        struct Frame { cv::Mat d; std::vector<Eigen::Vector3f> p; };
+        std::vector<Frame> seq;
+        seq.push_back({cv::Mat(N, 32, CV_8U, da.data()), prev});
+        seq.push_back({cv::Mat(N, 32, CV_8U, db.data()), cur});
+        seq.push_back({cv::Mat(N / 2, 32, CV_8U, da.data()), std::vector<Eigen::Vector3f>(prev.begin(), prev.begin() + N / 2)});
+        seq.push_back({cv::Mat(N, 32, CV_8U, db.data()), cur});
+        seq.push_back({cv::Mat((int)bigP.size(), 32, CV_8U, bigD.data()), bigP}); // 5 N rows: beyond the first store
+        seq.push_back({cv::Mat(N, 32, CV_8U, da.data()), prev});
+        seq.push_back({cv::Mat(N, 32, CV_8U, db.data()), cur});
+        bool same = true;
+        for (int pass = 0; pass < 2; ++pass) { // the second pass restarts with detectInitFeatures
+            fusedM.detectInitFeatures(seq[0].d, seq[0].p);
+            genericM.detectInitFeatures(seq[0].d, seq[0].p);
+            for (size_t k = 1; k < seq.size(); ++k) {
+                Eigen::Matrix4f Tf, Tg;
+                std::vector<cv::DMatch> inf, ing;
+                double rf = fusedM.match(seq[k].d, seq[k].p, Tf, inf);
+                double rg = genericM.match(seq[k].d, seq[k].p, Tg, ing);
+                same = same && std::memcmp(Tf.data(), Tg.data(), 64) == 0 && inf.size() == ing.size() &&
+                       (rf == rg || (rf != rf && rg != rg)) &&
+                       (inf.empty() || std::memcmp(inf.data(), ing.data(), inf.size() * sizeof(cv::DMatch)) == 0);
+            }
+        }
+        CHECK(same);
+    }
+
     // ---- USAC wrapper: same signature, no refit, best-count rule ----
     PUTSLAMEstimator::parameters up;
     up.verbose = 0;
