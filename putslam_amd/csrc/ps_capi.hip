@@ -431,7 +431,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     }
     constexpr int TPL = 2;
     const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
-    int qsplit = pick_split((long long)P * tiles, 16, 64, cap);
+    int qsplit = pick_split((long long)P * tiles, 64, 16, cap); // single pair: 256 work-groups of >= 16 query rows
     if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
     if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
     tick(ctx, slot0, false);
