@@ -24,6 +24,7 @@ struct Buf {
     size_t cap = 0;
 };
 
+constexpr int kWidePairs = 16; // batches of at most this many pairs run kernel 2 with 1024-thread work-groups
 constexpr int kMaxTimed = 8;   // kernels timed per call
 constexpr int kTimingRing = 128; // calls kept (HIP events on the launch stream around every kernel)
 
@@ -398,7 +399,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     sa.stageCap = cap < 1536 ? cap : 1536; // 36 KiB of LDS for the refit's operands
     size_t lds = 2 * (size_t)((sa.trainRange + 31) / 32) * sizeof(uint32_t) + (size_t)sa.stageCap * 6 * sizeof(float);
     tick(ctx, slot0 + 1, false);
-    hipLaunchKernelGGL(ps_select_refit, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream,
+    // (1024-thread work-groups were measured for this kernel too: 48 us instead of 40 for a single pair)
+    hipLaunchKernelGGL(ps_select_refit<kBlock>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream,
                        (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
                        (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
                        dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
@@ -441,16 +443,23 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     PS_HIP(hipGetLastError());
     size_t lds = (size_t)cap * sizeof(uint32_t);
     tick(ctx, slot0 + 1, false);
-    if (withRecords)
-        hipLaunchKernelGGL(ps_crosscheck_prep<true>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
-                           fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
-                           (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
-                           (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
-    else
-        hipLaunchKernelGGL(ps_crosscheck_prep<false>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream, fs.pts,
-                           fs.nkpts, dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches,
-                           (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr,
-                           (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
+    const bool wide = P <= kWidePairs; // a handful of pairs: 1024-thread work-groups shorten the per-pair serial walk
+#define PS_LAUNCH_PREP(REC, BLK, A, B, C, D)                                                                          \
+    hipLaunchKernelGGL((ps_crosscheck_prep<REC, BLK>), dim3((unsigned)P), dim3(BLK), lds, ctx->stream, fs.pts, fs.nkpts, \
+                       dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, A, B, C, D,                   \
+                       (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p)
+    if (withRecords) {
+        if (wide)
+            PS_LAUNCH_PREP(true, 1024, (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p);
+        else
+            PS_LAUNCH_PREP(true, kBlock, (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p);
+    } else {
+        if (wide)
+            PS_LAUNCH_PREP(false, 1024, (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr);
+        else
+            PS_LAUNCH_PREP(false, kBlock, (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr);
+    }
+#undef PS_LAUNCH_PREP
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -517,6 +526,10 @@ int ps_context_create(int device, PsContext **out)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true, 1024>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<false, 1024>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
     *out = ctx;
     return PS_OK;

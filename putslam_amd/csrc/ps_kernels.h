@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void ps_hamming_nn(const uint4 *__restrict_
 
 // ---- workgroup-wide ordered compaction helper (4 waves) ----
 // Returns the exclusive prefix of `flag` over the 256 threads; `total` = number of set flags.
-PS_D int block_scan_flag(bool flag, int &total, int *wsum)
+template <int BLOCK = kBlock> PS_D int block_scan_flag(bool flag, int &total, int *wsum)
 {
     unsigned long long bal = __ballot(flag);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -140,7 +140,7 @@ PS_D int block_scan_flag(bool flag, int &total, int *wsum)
     int off = 0;
     total = 0;
 #pragma unroll
-    for (int i = 0; i < kBlock / 64; ++i) {
+    for (int i = 0; i < BLOCK / 64; ++i) {
         int s = wsum[i];
         if (i < w) off += s;
         total += s;
@@ -150,7 +150,7 @@ PS_D int block_scan_flag(bool flag, int &total, int *wsum)
 }
 
 // workgroup-wide maximum of a non-negative float (4 waves)
-PS_D float block_max(float v, float *red)
+template <int BLOCK = kBlock> PS_D float block_max(float v, float *red)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
@@ -158,7 +158,7 @@ PS_D float block_max(float v, float *red)
     __syncthreads();
     float r = red[0];
 #pragma unroll
-    for (int i = 1; i < kBlock / 64; ++i) r = fmaxf(r, red[i]);
+    for (int i = 1; i < BLOCK / 64; ++i) r = fmaxf(r, red[i]);
     __syncthreads();
     return r;
 }
@@ -193,8 +193,9 @@ PS_D void write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t
 // depth filter of RANSAC::estimateTransformation (RANSAC.cpp:65-74) and record building.
 // One workgroup per pair; best[q] lives in LDS (cap x 4 B).
 // ------------------------------------------------------------------------------------------
-template <bool WITH_RECORDS>
-__global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__restrict__ pts,
+// BLOCK = 1024 is the low-latency form for a handful of pairs (one work-group per pair either way).
+template <bool WITH_RECORDS, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restrict__ pts,
                                                              const int32_t *__restrict__ nkpts,
                                                              const int32_t *__restrict__ pairs,
                                                              const uint32_t *__restrict__ keys, PrepArgs a,
@@ -205,18 +206,18 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
                                                              int32_t *__restrict__ mvalid, float *__restrict__ cmaxOut)
 {
     extern __shared__ __align__(16) uint32_t s_best[];
-    __shared__ int s_wsum[kBlock / 64];
-    __shared__ float s_red[kBlock / 64];
+    __shared__ int s_wsum[BLOCK / 64];
+    __shared__ float s_red[BLOCK / 64];
     float cm = 0.0f; // largest |coordinate| among this pair's depth-valid matches
     const int p = blockIdx.x;
     const int cap = a.cap;
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
     const int nq = nkpts[fq], nt = nkpts[ft];
-    for (int q = threadIdx.x; q < nq; q += kBlock) s_best[q] = kNoKey;
+    for (int q = threadIdx.x; q < nq; q += BLOCK) s_best[q] = kNoKey;
     __syncthreads();
     // step 2 of the cross-check: query q keeps the closest train row among those that chose it,
     // ties to the lowest train index (strict '<' while scanning t ascending).
-    for (int t = threadIdx.x; t < nt; t += kBlock) {
+    for (int t = threadIdx.x; t < nt; t += BLOCK) {
         uint32_t key = keys[(size_t)p * cap + t];
         if (key != kNoKey) {
             uint32_t q = key & 0xFFFFu, d = key >> 16;
@@ -227,12 +228,12 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
     const float *pp = pts + (size_t)fq * cap * 3;
     const float *cp = pts + (size_t)ft * cap * 3;
     int base = 0, vbase = 0;
-    for (int q0 = 0; q0 < nq; q0 += kBlock) {
+    for (int q0 = 0; q0 < nq; q0 += BLOCK) {
         const int q = q0 + threadIdx.x;
         uint32_t key = (q < nq) ? s_best[q] : kNoKey;
         const bool has = key != kNoKey;
         int total;
-        int pos = block_scan_flag(has, total, s_wsum);
+        int pos = block_scan_flag<BLOCK>(has, total, s_wsum);
         const int t = (int)(key & 0xFFFFu);
         if (has) {
             PsDMatch m;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
                 ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
             }
             int vtotal;
-            int vpos = block_scan_flag(ok, vtotal, s_wsum);
+            int vpos = block_scan_flag<BLOCK>(ok, vtotal, s_wsum);
             if (ok) {
                 write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_, recA,
                               recB, recC, recD);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void ps_crosscheck_prep(const float *__rest
         base += total;
     }
     if (WITH_RECORDS) {
-        float c = block_max(cm, s_red);
+        float c = block_max<BLOCK>(cm, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = c;
     }
     if (threadIdx.x == 0) {
@@ -729,7 +730,8 @@ PS_D void store_pose(float *pose, const Rigid &m)
 //  (3) Umeyama refit on them and the Euclidean re-selection (RANSAC.cpp:152-158);
 //  (4) ratio gate (RANSAC.cpp:161-164 / USAC_wrapper.cpp:139-141), pointInlierRatio (RANSAC.h:56-66).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restrict__ recA,
+template <int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restrict__ recA,
                                                           const float4 *__restrict__ recB,
                                                           const float4 *__restrict__ recC,
                                                           const int4 *__restrict__ recD,
@@ -743,8 +745,8 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
                                                           PsRansacStats *__restrict__ statsOut)
 {
     extern __shared__ __align__(16) uint32_t s_bits[]; // two bitmaps over train indices: 2 * ceil(trainRange/32) words
-    __shared__ int s_wsum[kBlock / 64];
-    __shared__ unsigned long long s_red[kBlock / 64];
+    __shared__ int s_wsum[BLOCK / 64];
+    __shared__ unsigned long long s_red[BLOCK / 64];
     __shared__ int s_sel[4];
     __shared__ Rigid s_model;
     __shared__ int s_uniq[2];
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
     uint8_t *mask = maskOut + (size_t)p * matchStride;
     int32_t *list = idxList + rbase;
 
-    for (int i = tid; i < nIn; i += kBlock) mask[i] = 0;
+    for (int i = tid; i < nIn; i += BLOCK) mask[i] = 0;
 
     const bool run = !(M < a.minMatches || M < 3);
     int bestIdx = -1, bestCount = 0, trips = 0;
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
     if (run) {
         if (a.estimator == PS_EST_FIXED) {
             unsigned long long key = 0ull;
-            for (int i = tid; i < a.H; i += kBlock) {
+            for (int i = tid; i < a.H; i += BLOCK) {
                 unsigned long long kk = ((unsigned long long)(unsigned)cnts[i] << 32) | (0xFFFFFFFFu - (unsigned)i);
                 key = kk > key ? kk : key;
             }
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
             __syncthreads();
             if (tid == 0) {
                 unsigned long long b = s_red[0];
-                for (int i = 1; i < kBlock / 64; ++i) b = s_red[i] > b ? s_red[i] : b;
+                for (int i = 1; i < BLOCK / 64; ++i) b = s_red[i] > b ? s_red[i] : b;
                 int c = (int)(b >> 32);
                 s_sel[0] = c > 0 ? (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFu)) : -1;
                 s_sel[1] = c;
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
             int pos = 0, limit = a.iter0, best = 0, bIdx = -1;
             for (;;) {
                 unsigned found = 0xFFFFFFFFu;
-                for (int i = pos + tid; i < limit; i += kBlock)
+                for (int i = pos + tid; i < limit; i += BLOCK)
                     if (cnts[i] > best) {
                         found = (unsigned)i;
                         break;
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
                 if (lane == 0) s_red[wv] = found;
                 __syncthreads();
                 unsigned f = (unsigned)s_red[0];
-                for (int i = 1; i < kBlock / 64; ++i) f = (unsigned)s_red[i] < f ? (unsigned)s_red[i] : f;
+                for (int i = 1; i < BLOCK / 64; ++i) f = (unsigned)s_red[i] < f ? (unsigned)s_red[i] : f;
                 __syncthreads();
                 if (f == 0xFFFFFFFFu) break;
                 bIdx = (int)f;
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
         gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
         const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
         if (needInv) inverse_rigid_general(mdl, inv);
-        for (int i0 = 0; i0 < M; i0 += kBlock) {
+        for (int i0 = 0; i0 < M; i0 += BLOCK) {
             const int i = i0 + tid;
             bool in = false;
             if (i < M) {
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
                 }
             }
             int total;
-            int pos = block_scan_flag(in, total, s_wsum);
+            int pos = block_scan_flag<BLOCK>(in, total, s_wsum);
             if (in) {
                 const int slot = kin + pos;
                 list[slot] = i;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
         }
         __syncthreads();
         mdl = s_model;
-        for (int j0 = 0; j0 < kin; j0 += kBlock) {
+        for (int j0 = 0; j0 < kin; j0 += BLOCK) {
             const int j = j0 + tid;
             bool in = false;
             int i = 0;
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
                 in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, A); // s < A.w : plain or adaptive bound
             }
             int total;
-            block_scan_flag(in, total, s_wsum);
+            block_scan_flag<BLOCK>(in, total, s_wsum);
             if (in && accepted) mask[recD[rbase + i].x] = 1;
             nfinal += total;
         }
@@ -916,18 +918,18 @@ __global__ __launch_bounds__(kBlock) void ps_select_refit(const float4 *__restri
     } else if (run) {
         // USAC: no refit (USAC_wrapper.cpp:204-222 commented out); the loop's inliers are returned even
         // when the ratio gate replaces the pose by identity (USAC_wrapper.cpp:139-141).
-        for (int j = tid; j < kin; j += kBlock) mask[recD[rbase + list[j]].x] = 1;
+        for (int j = tid; j < kin; j += BLOCK) mask[recD[rbase + list[j]].x] = 1;
         nfinal = kin;
     }
     __syncthreads();
 
     // ---- (4) pointInlierRatio: unique trainIdx among final inliers / among all input matches ----
-    for (int i = tid; i < 2 * words; i += kBlock) s_bits[i] = 0u;
+    for (int i = tid; i < 2 * words; i += BLOCK) s_bits[i] = 0u;
     if (tid == 0) s_uniq[0] = s_uniq[1] = 0;
     __syncthreads();
     const PsDMatch *mm = matches + (size_t)p * matchStride;
     int ua = 0, ui = 0;
-    for (int i = tid; i < nIn; i += kBlock) {
+    for (int i = tid; i < nIn; i += BLOCK) {
         int t = mm[i].trainIdx;
         if (t >= 0 && t < a.trainRange) {
             uint32_t bit = 1u << (t & 31);
