@@ -4,6 +4,8 @@ host cores, achieved bytes/s against the 8 TB/s HBM peak):
   N2  ps_match_xyz                 guided map matching (matcher.cpp:694-746), nmap map features x ncur keypoints
   N4  ps_remove_image_distortion   cv::undistortPoints, 5 Brown-model iterations per point (RGBD.cpp:254-314)
   A3  ps_keypoints2Dto3D           back-projection from a 640x480 depth image (RGBD.cpp:30-65)
+  A10 ps_kabsch_f64                double N-point Kabsch (kabschEst.cpp:24-68): one wavefront up to 16384 points,
+                                   G wavefronts in two passes above
 The entry points take host pointers, so the call time includes both PCIe directions and one synchronisation; run the
 script under `rocprofv3 --kernel-trace --stats` for the kernel-only durations (profiles/run_next_rows.sh).
 Prints one JSON line per row."""
@@ -67,6 +69,15 @@ def main():
         assert g.tobytes() == c.tobytes()
         rows.append(dict(row="A3 ps_keypoints2Dto3D", n=n, gpu_call_ms=tg * 1e3, cpu_oracle_ms=tc * 1e3, cpu_threads=1,
                          algorithmic_bytes=n * (8 + 2 + 12), depth_image_bytes=int(depth.nbytes)))
+    # ---- A10: double Kabsch on n correspondences (config 1: n = 500) ----
+    for n in (500, 100000):
+        A = rng.uniform(-1.5, 1.5, (n, 3))
+        B = A + [0.1, 0.2, -0.3] + rng.normal(0, 1, (n, 3)) * [0.01, 0.02, 0.03]
+        tg, g = timed(lambda: ctx.kabsch_f64(A, B), 20)
+        tc, c = timed(lambda: orc.kabsch_f64(A, B), 5)
+        assert np.abs(g - np.asarray(c, np.float64)).max() < 1e-12      # summation tree differs (tests: same bound)
+        rows.append(dict(row="A10 ps_kabsch_f64", n=n, gpu_call_ms=tg * 1e3, cpu_oracle_ms=tc * 1e3, cpu_threads=1,
+                         algorithmic_bytes=n * 48 + 128))
     for r in rows:
         print(json.dumps(r))
 

@@ -960,11 +960,23 @@ int ps_kabsch_f64(PsContext *ctx, const double *A, const double *B, int n, int l
     size_t bytes = (size_t)3 * ld * sizeof(double);
     PS_ENSURE(ctx->sMisc0, bytes);
     PS_ENSURE(ctx->sMisc1, bytes);
-    PS_ENSURE(ctx->sMisc2, 16 * sizeof(double));
+    PS_ENSURE(ctx->sMisc2, (16 + (size_t)15 * 1024) * sizeof(double)); // pose + per-wave partial sums
     PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, A, bytes - (size_t)(ld - n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, B, bytes - (size_t)(ld - n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(ps_kabsch_f64_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->sMisc0.p,
-                       (const double *)ctx->sMisc1.p, n, ld, (double *)ctx->sMisc2.p);
+    if (n <= 16384) { // one wavefront: lowest latency (config 1 has 500 points)
+        hipLaunchKernelGGL(ps_kabsch_f64_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->sMisc0.p,
+                           (const double *)ctx->sMisc1.p, n, ld, (double *)ctx->sMisc2.p);
+    } else { // G wavefronts, two passes over the points + a finishing wave
+        int G = (n + 4095) / 4096;
+        if (G > 1024) G = 1024;
+        double *part = (double *)ctx->sMisc2.p + 16, *part2 = part + (size_t)6 * 1024;
+        hipLaunchKernelGGL(ps_kabsch_f64_sums, dim3((unsigned)G), dim3(64), 0, ctx->stream, (const double *)ctx->sMisc0.p,
+                           (const double *)ctx->sMisc1.p, n, ld, part);
+        hipLaunchKernelGGL(ps_kabsch_f64_cov, dim3((unsigned)G), dim3(64), 0, ctx->stream, (const double *)ctx->sMisc0.p,
+                           (const double *)ctx->sMisc1.p, n, ld, (const double *)part, part2);
+        hipLaunchKernelGGL(ps_kabsch_f64_finish, dim3(1), dim3(64), 0, ctx->stream, (const double *)part,
+                           (const double *)part2, G, n, (double *)ctx->sMisc2.p);
+    }
     PS_HIP(hipGetLastError());
     PS_HIP(hipMemcpyAsync(T, ctx->sMisc2.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));

@@ -1261,6 +1261,117 @@ __global__ __launch_bounds__(64) void ps_kabsch_f64_kernel(const double *__restr
     }
 }
 
+// Large point sets: the same arithmetic spread over G wavefronts (one 64-lane work-group each, strided like the
+// single-wave kernel's lanes), partial sums combined in wave order by every wave / by the finishing wave.  The
+// summation tree is a function of (n, G) only, so results are reproducible; versus the oracle's sequential sums the
+// bound is the 1e-12 of the single-wave form.
+//   pass 1: part[g][0..5]  = column sums of A, B over the wave's points
+//   pass 2: part2[g][0..8] = sum (a - cA)(b - cB)^T over the wave's points, cA / cB from all part[] in order
+//   finish: one wave adds part2[] in order, SVD, pose
+__global__ __launch_bounds__(64) void ps_kabsch_f64_sums(const double *__restrict__ A, const double *__restrict__ B, int n,
+                                                         int ld, double *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63, g = blockIdx.x, G = gridDim.x;
+    double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+    for (long long i = (long long)g * 64 + lane; i < n; i += (long long)G * 64) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sa[c] += A[(size_t)c * ld + i];
+            sb[c] += B[(size_t)c * ld + i];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double va = wave_tree_sum_f64(sa[c]), vb = wave_tree_sum_f64(sb[c]);
+        if (lane == 0) {
+            part[(size_t)g * 6 + c] = va;
+            part[(size_t)g * 6 + 3 + c] = vb;
+        }
+    }
+}
+
+PS_D void kabsch_means(const double *__restrict__ part, int G, int n, double (&cA)[3], double (&cB)[3])
+{
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int g = 0; g < G; ++g) // every lane of every wave: the same order, the same values
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[c] += part[(size_t)g * 6 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cA[c] = s[c] / (double)n;
+        cB[c] = s[3 + c] / (double)n;
+    }
+}
+
+__global__ __launch_bounds__(64) void ps_kabsch_f64_cov(const double *__restrict__ A, const double *__restrict__ B, int n,
+                                                        int ld, const double *__restrict__ part,
+                                                        double *__restrict__ part2)
+{
+    const int lane = threadIdx.x & 63, g = blockIdx.x, G = gridDim.x;
+    double cA[3], cB[3];
+    kabsch_means(part, G, n, cA, cB);
+    double acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = 0.0;
+    for (long long i = (long long)g * 64 + lane; i < n; i += (long long)G * 64) {
+        double a[3], b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = A[(size_t)c * ld + i] - cA[c];
+            b[c] = B[(size_t)c * ld + i] - cB[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[r][c] += a[r] * b[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = wave_tree_sum_f64(acc[r][c]);
+            if (lane == 0) part2[(size_t)g * 9 + 3 * r + c] = v;
+        }
+}
+
+__global__ __launch_bounds__(64) void ps_kabsch_f64_finish(const double *__restrict__ part, const double *__restrict__ part2,
+                                                           int G, int n, double *__restrict__ T)
+{
+    const int lane = threadIdx.x & 63;
+    double cA[3], cB[3];
+    kabsch_means(part, G, n, cA, cB);
+    double Am[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            for (int g = 0; g < G; ++g) v += part2[(size_t)g * 9 + 3 * r + c];
+            Am[r][c] = v;
+        }
+    double V[3][3], W[3][3], S[3];
+    jacobi_svd3<double>(Am, V, S, W);
+    double det = det3_lu(Am);
+    double dsg = (det != 0.0) ? det : 1.0;
+    double d = (double)((dsg > 0.0) - (dsg < 0.0));
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double R[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R[j] = (W[i][0] * V[j][0] + W[i][1] * V[j][1]) + (W[i][2] * d) * V[j][2];
+            double ti = (R[0] * (-cA[0]) + (R[1] * (-cA[1]) + R[2] * (-cA[2]))) + cB[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) T[4 * j + i] = R[j];
+            T[12 + i] = ti;
+        }
+    }
+}
+
 // RGBD::keypoints2Dto3D / point2Dto3D / roundSize (reference src/RGBD/RGBD.cpp:10-16,30-65).
 PS_D int round_size(double x, int size)
 {

@@ -281,7 +281,7 @@ def test_usac_limit_table(ctx, oracle):
 
 
 # ---------------------------------------------------------------- A10 Kabsch (double)
-@pytest.mark.parametrize("n", [3, 100, 500, 4097])
+@pytest.mark.parametrize("n", [3, 100, 500, 4097, 16384, 16385, 100003, 5000000])  # > 16384: multi-wave reduction
 def test_kabsch_f64(ctx, oracle, n):
     rng = np.random.default_rng(n)
     A = rng.uniform(-1.5, 1.5, (n, 3))
@@ -290,6 +290,7 @@ def test_kabsch_f64(ctx, oracle, n):
     Tg = ctx.kabsch_f64(A, B)
     To = oracle.kabsch_f64(A, B)
     assert np.abs(Tg - To).max() < 1e-12  # summation tree differs from the oracle's sequential sums
+    assert np.array_equal(Tg, ctx.kabsch_f64(A, B))  # and is reproducible
     assert abs(np.linalg.det(Tg[:3, :3]) - 1) < 1e-12
     assert np.array_equal(ctx.kabsch_f64(np.zeros((0, 3)), np.zeros((0, 3))), np.eye(4))
 
