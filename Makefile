@@ -1,13 +1,13 @@
 # Convenience targets; __graft_entry__.build() does the same from Python.
 HIPCC ?= /opt/rocm/bin/hipcc
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
 CSRC := putslam_amd/csrc
 LIB := putslam_amd/libputslam_hip.so
 DROPIN := putslam_amd/libputslam_dropin.so
 
 all: $(LIB) $(DROPIN) oracle
 
-$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_device_math.h include/putslam_hip.h
+$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_device_math.h include/putslam_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
 
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)

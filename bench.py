@@ -205,6 +205,8 @@ def main():
         # (profiles/microbench/valu_rates_mi355x.txt).  frac = modelled issue time / measured kernel time.
         valu_issue = None
         try:
+            if "ps_hamming_nn" not in kern:
+                raise KeyError("matrix-core matcher: the VALU issue model does not apply")
             mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
             simd_hz = 256 * 4 * 2.4e9
             waves_match = (P / S) * (args.kpts / 64.0)                # per launch: one lane per train row

@@ -111,6 +111,14 @@ void ps_context_destroy(PsContext *ctx);
  * default stream hands over an explicit stream (forked from / joined to the default one) or synchronises. */
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);
+/* Kernel variants kept side by side for A/B measurements and as tested twins (results are identical):
+ *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma (default), 0 = integer VALU sweep ps_hamming_nn
+ *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu, read at context creation).
+ *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
+ *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).
+ * ps_context_get_option returns the value or a negative PsStatus. */
+int ps_context_set_option(PsContext *ctx, const char *name, int value);
+int ps_context_get_option(const PsContext *ctx, const char *name);
 const char *ps_last_error(const PsContext *ctx);
 int ps_abi_version(void);
 /* Name of the device the context runs on, e.g. "gfx950". */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libputslam_hip.so")
 # every symbol include/putslam_hip.h declares
 EXPORTED = [
     "ps_context_create", "ps_context_destroy", "ps_context_set_stream", "ps_context_synchronize",
+    "ps_context_set_option", "ps_context_get_option",
     "ps_last_error", "ps_abi_version", "ps_device_arch",
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
@@ -39,7 +40,7 @@ def _try_build():
     if not (os.path.exists(hipcc) and os.path.exists(src)):
         return
     import subprocess
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared", src, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", src, "-o", LIB_PATH]
     try:
         subprocess.check_call(cmd)
     except (OSError, subprocess.CalledProcessError):
@@ -72,6 +73,8 @@ def load():
     L.ps_context_destroy.restype = None
     L.ps_context_set_stream.argtypes = [vp, vp]
     L.ps_context_synchronize.argtypes = [vp]
+    L.ps_context_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.ps_context_get_option.argtypes = [vp, C.c_char_p]
     L.ps_last_error.argtypes = [vp]
     L.ps_last_error.restype = C.c_char_p
     L.ps_device_arch.argtypes = [vp]

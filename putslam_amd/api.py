@@ -59,6 +59,16 @@ class Context:
     def synchronize(self):
         self._chk(self._L.ps_context_synchronize(self._h))
 
+    def set_option(self, name, value):
+        """Kernel variant switches (include/putslam_hip.h: ps_context_set_option), e.g. ("matcher", 0 | 1)."""
+        self._chk(self._L.ps_context_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = self._L.ps_context_get_option(self._h, name.encode())
+        if v < 0:
+            raise ValueError(f"unknown option {name!r}")
+        return v
+
     def enable_timing(self, on=True):
         self._chk(self._L.ps_context_enable_timing(self._h, 1 if on else 0))
 
@@ -78,7 +88,7 @@ class Context:
         if n < 0:
             self._chk(n)
         names = kernel_names()
-        return {names[i]: (float(sums[i]), int(cnt[i])) for i in range(n)}
+        return {names[i]: (float(sums[i]), int(cnt[i])) for i in range(n) if cnt[i] > 0}
 
     # ---- A1 ----
     def match_hamming256(self, query, train):

@@ -5,6 +5,7 @@
 // There is no CPU fallback anywhere in this file: every entry point launches the HIP kernels
 // of ps_kernels.h or fails with a negative PsStatus.
 #include "ps_kernels.h"
+#include "ps_matcher_mfma.h"
 
 #include <cfloat>
 #include <climits>
@@ -38,6 +39,7 @@ struct PsContext {
     char arch[64] = {0};
     // scratch arena (device)
     Buf keys, recA, recB, recC, recD, counts, mvalid, cmax, idxList, raw;
+    Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
     // staging for the host-pointer entry points (device)
     Buf sDesc, sNk, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
@@ -50,9 +52,12 @@ struct PsContext {
     std::vector<hipEvent_t> ev; // [kTimingRing][kMaxTimed][2], created when timing is first enabled
     long long timedCalls = 0;   // calls recorded since timing was (re)enabled
     int curCall = 0;            // ring slot of the call being recorded
-    int nTimed = 0;             // kernels per call
+    int nTimed = 0;             // highest timed slot + 1
+    unsigned slotMask[kTimingRing] = {0}; // per kept call: which slots were recorded
     // tuning overrides (PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT, read once; 0 = automatic)
     int forceQsplit = 0, forceMsplit = 0;
+    // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher
+    int matcher = 1;
 };
 
 namespace {
@@ -348,7 +353,10 @@ void tick(PsContext *ctx, int slot, bool stop)
 {
     if (!ctx->timing || slot >= kMaxTimed || ctx->ev.empty()) return;
     (void)hipEventRecord(ctx->ev[((size_t)ctx->curCall * kMaxTimed + slot) * 2 + (stop ? 1 : 0)], ctx->stream);
-    if (stop && slot + 1 > ctx->nTimed) ctx->nTimed = slot + 1;
+    if (stop) {
+        ctx->slotMask[ctx->curCall] |= 1u << slot;
+        if (slot + 1 > ctx->nTimed) ctx->nTimed = slot + 1;
+    }
 }
 
 int pick_split(long long blocksWithout, int maxSplit, int minChunkOf, int total)
@@ -431,16 +439,39 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         int rc = ensure_records(ctx, (size_t)P * cap);
         if (rc != PS_OK) return rc;
     }
-    constexpr int TPL = 2;
-    const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
-    int qsplit = pick_split((long long)P * tiles, 64, 16, cap); // single pair: 256 work-groups of >= 16 query rows
-    if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
-    if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
-    tick(ctx, slot0, false);
-    hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                       (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, tiles, qsplit, (uint32_t *)ctx->keys.p);
-    tick(ctx, slot0, true);
-    PS_HIP(hipGetLastError());
+    if (ctx->matcher == 1) {
+        // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
+        constexpr int TT = 4;
+        const int tpf = (cap + kTileRows - 1) / kTileRows;
+        const int groups = (tpf + kWavesPerWG * TT - 1) / (kWavesPerWG * TT);
+        PS_ENSURE(ctx->xq, (size_t)P * tpf * kTileU4 * sizeof(uint4));
+        int qsplit = pick_split((long long)P * groups, tpf, 1, tpf);
+        if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
+        if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+        int xchunks = tpf < 8 ? tpf : 8;
+        if ((long long)P * xchunks < 1024) xchunks = tpf < 64 ? tpf : 64;
+        tick(ctx, 4, false);
+        hipLaunchKernelGGL(ps_expand_query_fp4, dim3((unsigned)xchunks, (unsigned)P), dim3(kBlock), 0, ctx->stream,
+                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, (uint4 *)ctx->xq.p);
+        tick(ctx, 4, true);
+        tick(ctx, 5, false);
+        hipLaunchKernelGGL(ps_hamming_mfma<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
+                           ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                           (const uint4 *)ctx->xq.p, (uint32_t *)ctx->keys.p);
+        tick(ctx, 5, true);
+        PS_HIP(hipGetLastError());
+    } else {
+        constexpr int TPL = 2;
+        const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
+        int qsplit = pick_split((long long)P * tiles, 64, 16, cap); // single pair: 256 work-groups of >= 16 query rows
+        if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
+        if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+        tick(ctx, slot0, false);
+        hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
+                           (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, tiles, qsplit, (uint32_t *)ctx->keys.p);
+        tick(ctx, slot0, true);
+        PS_HIP(hipGetLastError());
+    }
     size_t lds = (size_t)cap * sizeof(uint32_t);
     tick(ctx, slot0 + 1, false);
     const bool wide = P <= kWidePairs; // a handful of pairs: 1024-thread work-groups shorten the per-pair serial walk
@@ -522,6 +553,7 @@ int ps_context_create(int device, PsContext **out)
     ctx->stream = ctx->own;
     if (const char *v = std::getenv("PUTSLAM_HIP_QSPLIT")) ctx->forceQsplit = std::atoi(v);
     if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
+    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER")) ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
@@ -541,7 +573,7 @@ void ps_context_destroy(PsContext *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->counts, &ctx->mvalid,
-                  &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
+                  &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
     for (Buf *b : all) release(*b);
@@ -556,6 +588,31 @@ int ps_context_set_stream(PsContext *ctx, void *s)
     if (!ctx) return PS_ERR_BAD_ARG;
     ctx->stream = s ? (hipStream_t)s : ctx->own;
     return PS_OK;
+}
+
+int ps_context_set_option(PsContext *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return PS_ERR_BAD_ARG;
+    if (strcmp(name, "matcher") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "matcher: 0 (VALU) or 1 (MFMA)");
+        ctx->matcher = value;
+        return PS_OK;
+    }
+    if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
+        if (value < 0 || value > 1024) return fail(ctx, PS_ERR_BAD_ARG, "split: 0..1024");
+        (name[0] == 'q' ? ctx->forceQsplit : ctx->forceMsplit) = value;
+        return PS_OK;
+    }
+    return fail(ctx, PS_ERR_BAD_ARG, "unknown option");
+}
+
+int ps_context_get_option(const PsContext *ctx, const char *name)
+{
+    if (!ctx || !name) return PS_ERR_BAD_ARG;
+    if (strcmp(name, "matcher") == 0) return ctx->matcher;
+    if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
+    if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
+    return PS_ERR_BAD_ARG;
 }
 
 int ps_context_synchronize(PsContext *ctx)
@@ -581,6 +638,7 @@ int ps_context_enable_timing(PsContext *ctx, int enable)
     ctx->timedCalls = 0;
     ctx->curCall = 0;
     ctx->nTimed = 0;
+    memset(ctx->slotMask, 0, sizeof ctx->slotMask);
     return PS_OK;
 }
 
@@ -593,7 +651,7 @@ int ps_last_kernel_times_ms(PsContext *ctx, float *ms)
     for (int i = 0; i < ctx->nTimed; ++i) {
         float t = 0.f;
         size_t b = ((size_t)ctx->curCall * kMaxTimed + i) * 2;
-        PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
+        if (ctx->slotMask[ctx->curCall] & (1u << i)) PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
         ms[i] = t;
     }
     return ctx->nTimed;
@@ -612,6 +670,7 @@ int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches)
     long long n = ctx->timedCalls < kTimingRing ? ctx->timedCalls : kTimingRing;
     for (long long c = 0; c < n; ++c)
         for (int i = 0; i < ctx->nTimed; ++i) {
+            if (!(ctx->slotMask[c] & (1u << i))) continue;
             float t = 0.f;
             size_t b = ((size_t)c * kMaxTimed + i) * 2;
             PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
@@ -623,7 +682,7 @@ int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches)
 
 const char *ps_kernel_names(void)
 {
-    return "ps_hamming_nn\0ps_crosscheck_prep\0ps_ransac_score\0ps_select_refit\0";
+    return "ps_hamming_nn\0ps_crosscheck_prep\0ps_ransac_score\0ps_select_refit\0ps_expand_query_fp4\0ps_hamming_mfma\0";
 }
 
 uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int H)
@@ -1062,6 +1121,7 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     if (rc) return rc;
     if (ctx->timing) {
         ctx->curCall = (int)(ctx->timedCalls % kTimingRing);
+        ctx->slotMask[ctx->curCall] = 0;
         ctx->timedCalls++;
     }
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
@@ -1095,9 +1155,9 @@ struct PsVoStream {
     bool warm = false;          // an un-captured push has run with `key`
     struct Key {
         PsRansacParams prm;
-        int estimator, numHypotheses;
+        int estimator, numHypotheses, variant;
         float K[9];
-        const void *arena[11]; // scratch and table blocks the captured launches point at (they move when they grow)
+        const void *arena[12]; // scratch and table blocks the captured launches point at (they move when they grow)
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1240,12 +1300,24 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     };
     PsVoStream::Key key;
     memset(&key, 0, sizeof key);
-    key.prm = *params;
+    // field by field: the caller's struct may carry indeterminate padding bytes, the key is compared with memcmp
+    key.prm.verbose = params->verbose;
+    key.prm.errorVersion = params->errorVersion;
+    key.prm.errorVersionVO = params->errorVersionVO;
+    key.prm.errorVersionMap = params->errorVersionMap;
+    key.prm.inlierThresholdEuclidean = params->inlierThresholdEuclidean;
+    key.prm.inlierThresholdReprojection = params->inlierThresholdReprojection;
+    key.prm.inlierThresholdMahalanobis = params->inlierThresholdMahalanobis;
+    key.prm.minimalInlierRatioThreshold = params->minimalInlierRatioThreshold;
+    key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
+    key.prm.usedPairs = params->usedPairs;
+    key.prm.iterationCount = params->iterationCount;
+    key.variant = ctx->matcher;
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[11] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p};
+    const void *arena[12] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1284,8 +1356,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[11] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p};
+        const void *after[12] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

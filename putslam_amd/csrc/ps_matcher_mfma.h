@@ -1,0 +1,220 @@
+// ps_matcher_mfma.h -- kernel 1 of the path on the matrix cores of gfx950.
+//
+// cv::batchDistance(train, query, K=1) inside BFMatcher's cross-check (reference call site
+// src/Matcher/matcherOpenCV.cpp:198-206): for each train row the nearest query row under the 256-bit
+// Hamming distance, ties to the lowest query index.
+//
+// The N x N x 256 popcount sweep is an exact small-integer contraction: with every descriptor bit b
+// written as s = 4 - 8b (+4 / -4), sum_k s_q[k] * s_t[k] = 16 * (256 - 2 * hamming).  +-4 are FP4 (e2m1) values, so
+// v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (the densest matrix format of CDNA4: K = 64 per 32-cycle
+// instruction) computes a 32 x 32 tile of distances in 4 instructions; every partial sum is an integer below
+// 2^13, hence exact in the f32 accumulator whatever the internal summation order.  The accumulator is
+// initialised with 2^23 + 4127 - (row of the tile), so each entry ends as
+//       2^23 + D,   D = 8223 - 32 * hamming - row = 32 * (256 - hamming) + (31 - row)   in [0, 8223]
+// Every value (and every partial sum) lies in [2^23, 2^24), where f32 has unit spacing: the mantissa field of
+// the result IS the integer D and the bit patterns order like integers.  Within a tile the nearest query, lowest
+// row first, is the MAXIMUM pattern: v_max3_i32 over the 16 accumulator registers a lane holds (its column = its
+// train descriptor).  Across tiles (ascending query index) a later tile wins only with a strictly smaller
+// distance, i.e. when its maximum exceeds the running best with the row field saturated (best | 31): one v_or,
+// one compare, two selects per tile.  Query rows beyond the frame start from -1e30 (a negative pattern).
+//
+// Operand traffic: the previous frame (query side) of every pair is expanded once per call into the
+// fragment-major FP4 image  Xq[pair][tile of 32 rows][k-step 0..3][lane 0..63][16 B]  by ps_expand_query_fp4
+// (N work, not N^2); a work-group stages one 4-KiB query tile at a time through LDS (double-buffered, one
+// barrier per tile, contiguous conflict-free ds_read_b128) and shares it between its 4 waves; every wave
+// expands its own TT train tiles in registers once and keeps them as B operands for the whole sweep.
+// Any consistent assignment of descriptor bits to (k-step, lane half, element) is valid because both
+// operands use the same one: lane (r = lane & 31, h = lane >> 5) holds, for k-step s, the 32 bits of dword
+// 2s + h of row r.
+//
+// The integer VALU kernel ps_hamming_nn (ps_kernels.h) is kept as the tested twin
+// (PUTSLAM_HIP_MATCHER=valu / ps_context_set_option("matcher", 0)).
+#pragma once
+
+#include "ps_kernels.h"
+
+namespace psdev {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+constexpr int kTileRows = 32;            // rows of one MFMA tile
+constexpr int kTileU4 = 256;             // uint4 (16 B) pieces of one expanded tile: 4 k-steps x 64 lanes = 4 KiB
+constexpr int kWavesPerWG = kBlock / 64; // 4
+
+// 8 descriptor bits -> 8 FP4 nibbles (bit i -> nibble i): 0 -> 0x6 = +4.0, 1 -> 0xE = -4.0
+PS_D uint32_t fp4_from_byte(uint32_t x)
+{
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return (x << 3) | 0x66666666u;
+}
+PS_D v4i_t fp4_from_dword(uint32_t w)
+{
+    v4i_t r;
+    r.x = (int)fp4_from_byte(w & 0xFFu);
+    r.y = (int)fp4_from_byte((w >> 8) & 0xFFu);
+    r.z = (int)fp4_from_byte((w >> 16) & 0xFFu);
+    r.w = (int)fp4_from_byte(w >> 24);
+    return r;
+}
+
+// row of the 32 x 32 tile held in accumulator register `reg` by lane half h (C/D layout of every
+// 32x32 MFMA of gfx950: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+PS_D int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------
+// Query-side expansion: one work-group per (pair, chunk of tiles).  Thread o of a tile writes piece
+// o = s * 64 + h * 32 + r (the layout the MFMA kernel reads back linearly), i.e. dword 2s + h of row r.
+// Rows beyond the frame's count are written as zeros (0.0 in FP4); the MFMA kernel masks them anyway.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ps_expand_query_fp4(const uint32_t *__restrict__ desc,
+                                                              const int32_t *__restrict__ nkpts,
+                                                              const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                              uint4 *__restrict__ Xq)
+{
+    const int p = blockIdx.y;
+    const int fq = pairs[2 * p];
+    const int nq = nkpts[fq];
+    const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
+    uint4 *__restrict__ out = Xq + (size_t)p * tpf * kTileU4;
+    const int o = threadIdx.x, s = o >> 6, h = (o >> 5) & 1, r = o & 31;
+    for (int tile = blockIdx.x; tile < tpf; tile += gridDim.x) {
+        const int row = tile * kTileRows + r;
+        v4i_t e = {0, 0, 0, 0};
+        if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * s + h]);
+        out[(size_t)tile * kTileU4 + o] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+    }
+}
+
+PS_D v16f_t mfma_fp4(const v4i_t &a, const v4i_t &b, const v16f_t &c)
+{
+    // FP4 operands occupy the first 4 of the 8 operand registers (cbsz = blgp = 4 selects e2m1); scale
+    // operands 0 with op_sel 0 select the unscaled form (scale 2^0 on both sides)
+    const v8i_t a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+    const v8i_t b8 = __builtin_shufflevector(b, b, 0, 1, 2, 3, -1, -1, -1, -1);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);
+}
+
+PS_D int fbits(float f) { return __builtin_bit_cast(int, f); }
+PS_D int imax3(int a, int b, int c) { return max(max(a, b), c); }
+// maximum of the 16 accumulator entries as integer bit patterns (valid entries are >= +0.0f)
+PS_D int max16(const v16f_t &d)
+{
+    int m = imax3(fbits(d[0]), fbits(d[1]), fbits(d[2]));
+    m = imax3(m, fbits(d[3]), fbits(d[4]));
+    m = imax3(m, fbits(d[5]), fbits(d[6]));
+    m = imax3(m, fbits(d[7]), fbits(d[8]));
+    m = imax3(m, fbits(d[9]), fbits(d[10]));
+    m = imax3(m, fbits(d[11]), fbits(d[12]));
+    m = imax3(m, fbits(d[13]), fbits(d[14]));
+    return max(m, fbits(d[15]));
+}
+
+constexpr float kMfmaNoRow = -1.0e30f; // accumulator start of a query row beyond the frame: never the maximum
+constexpr int kMfmaBias = 8223;        // 32 * 256 + 31
+constexpr float kMfmaBase = 8388608.0f; // 2^23: unit spacing up to 2^24
+
+// ------------------------------------------------------------------------------------------
+// grid = groups * qsplit * P work-groups in XCD-aware order; a work-group owns 4 * TT train tiles (one
+// wave each TT of them) and sweeps the query tiles [T0, T1) of its split.  qsplit > 1 merges with atomicMin
+// on the packed key (hamming << 16 | query), the same key kernel 2 reads from ps_hamming_nn.
+// ------------------------------------------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(kBlock) void ps_hamming_mfma(const uint32_t *__restrict__ desc,
+                                                          const int32_t *__restrict__ nkpts,
+                                                          const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                          int groups, int qsplit, const uint4 *__restrict__ Xq,
+                                                          uint32_t *__restrict__ keys)
+{
+    __shared__ uint4 s_a[2][kTileU4];
+    const unsigned perPair = (unsigned)(groups * qsplit);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = (int)(L / perPair);
+    const int inner = (int)(L - (unsigned)p * perPair);
+    const int g = inner / qsplit, qs = inner - g * qsplit;
+    const int fq = pairs[2 * p], ft = pairs[2 * p + 1]; // query = previous frame, train = current
+    const int nq = nkpts[fq], nt = nkpts[ft];
+    if (g * (kWavesPerWG * TT * kTileRows) >= nt) return; // whole work-group beyond the train rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile0 = (g * kWavesPerWG + wave) * TT;
+    const int nqTiles = (nq + kTileRows - 1) / kTileRows;
+    const int T0 = (int)(((long long)nqTiles * qs) / qsplit), T1 = (int)(((long long)nqTiles * (qs + 1)) / qsplit);
+
+    // B operands: this wave's train tiles, expanded in registers (rows beyond nt repeat the last row; never stored)
+    const uint32_t *__restrict__ t32 = desc + (size_t)ft * cap * 8;
+    v4i_t B[TT][4];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        int t = (tile0 + i) * kTileRows + r;
+        t = t < nt ? t : nt - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) B[i][s] = fp4_from_dword(t32[(size_t)t * 8 + 2 * s + h]);
+    }
+    v16f_t C;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)(kMfmaBias - 4096 - tile_row(reg, h));
+    int best[TT], bestT[TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        best[i] = 0; // below every valid entry (their patterns are >= 0x4B000000)
+        bestT[i] = 0;
+    }
+
+    const uint4 *__restrict__ xq = Xq + (size_t)p * tpf * kTileU4;
+    if (T0 < T1) s_a[0][tid] = xq[(size_t)T0 * kTileU4 + tid];
+    __syncthreads();
+    for (int T = T0; T < T1; ++T) {
+        const int buf = (T - T0) & 1;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (T + 1 < T1) nxt = xq[(size_t)(T + 1) * kTileU4 + tid];
+        v4i_t A[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 a = s_a[buf][s * 64 + lane];
+            A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
+        }
+        v16f_t Cin = C;
+        if (T * kTileRows + kTileRows > nq) { // last, partial query tile: rows beyond nq can never win
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (T * kTileRows + tile_row(reg, h) >= nq) Cin[reg] = kMfmaNoRow;
+        }
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            v16f_t acc = mfma_fp4(A[0], B[i][0], Cin);
+            acc = mfma_fp4(A[1], B[i][1], acc);
+            acc = mfma_fp4(A[2], B[i][2], acc);
+            acc = mfma_fp4(A[3], B[i][3], acc);
+            const int m = max16(acc);
+            if (m > (best[i] | 31)) { // strictly smaller distance only: the earlier (lower) query tile keeps a tie
+                best[i] = m;
+                bestT[i] = T;
+            }
+        }
+        if (T + 1 < T1) s_a[buf ^ 1][tid] = nxt;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int t = (tile0 + i) * kTileRows + r;
+        uint32_t key = kNoKey;
+        if (best[i] > 0) {
+            const int v = kMfmaBias - (best[i] & 0x7FFFFF); // 32 * hamming + row of the tile
+            key = ((uint32_t)(v >> 5) << 16) | (uint32_t)(bestT[i] * kTileRows + (v & 31));
+        }
+        const uint32_t other = (uint32_t)__shfl_xor((int)key, 32, 64); // the other half's 16 rows of every tile
+        key = other < key ? other : key;
+        if (h == 0 && t < nt) {
+            if (qsplit == 1)
+                keys[(size_t)p * cap + t] = key;
+            else
+                atomicMin(&keys[(size_t)p * cap + t], key);
+        }
+    }
+}
+
+} // namespace psdev

@@ -37,7 +37,8 @@ def test_struct_layout_matches_library():
 
 def test_kernel_names_and_bytes_formula():
     from putslam_amd import api
-    assert api.kernel_names() == ["ps_hamming_nn", "ps_crosscheck_prep", "ps_ransac_score", "ps_select_refit"]
+    assert api.kernel_names() == ["ps_hamming_nn", "ps_crosscheck_prep", "ps_ransac_score", "ps_select_refit",
+                                  "ps_expand_query_fp4", "ps_hamming_mfma"]
     # SURVEY.md section 8(d) reference points
     assert api.algorithmic_bytes(2000, 1200, 1200, 4096) == 271600
     assert api.algorithmic_bytes(2000, 1200, 1200, 487) == 213856

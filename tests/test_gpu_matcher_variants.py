@@ -1,0 +1,116 @@
+"""Kernel 1 twins: the FP4 matrix-core sweep (ps_hamming_mfma, default) and the integer VALU sweep
+(ps_hamming_nn) must both reproduce the oracle's BFMatcher(NORM_HAMMING, crossCheck=true) list bit for bit
+(reference src/Matcher/matcherOpenCV.cpp:100-105,198-206)."""
+import numpy as np
+import pytest
+
+from putslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [("mfma", 1), ("valu", 0)]
+
+
+@pytest.fixture(scope="module", params=VARIANTS, ids=[v[0] for v in VARIANTS])
+def vctx(request):
+    c = api.Context(0)
+    c.set_option("matcher", request.param[1])
+    assert c.get_option("matcher") == request.param[1]
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 500, 1999, 2000, 2017, 5000])
+def test_variant_match_bit_exact(vctx, oracle, n):
+    a, b = synth.make_pair(n, config=2, index=1000 + n)
+    assert vctx.match_hamming256(a["desc"], b["desc"]).tobytes() == oracle.match_hamming256(a["desc"], b["desc"]).tobytes()
+
+
+@pytest.mark.parametrize("nq,nt", [(300, 1000), (1000, 300), (1, 700), (700, 1), (513, 511), (33, 4097), (4097, 33)])
+def test_variant_match_ragged(vctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 11 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    if k:
+        t[:k] = q[rng.permutation(nq)[:k]] ^ np.packbits(rng.random((k, 256)) < 0.05, axis=1)
+    assert vctx.match_hamming256(q, t).tobytes() == oracle.match_hamming256(q, t).tobytes()
+
+
+def test_variant_extreme_distances_and_ties(vctx, oracle):
+    # distance 0, distance 256, every row identical (ties resolve to the lowest index in both passes), and a
+    # block of rows that differ from their query in exactly one bit at every bit position (0..255)
+    z, o = np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8)
+    assert vctx.match_hamming256(z, o)[0]["distance"] == 256.0
+    assert vctx.match_hamming256(o, o)[0]["distance"] == 0.0
+    q = np.tile(np.arange(32, dtype=np.uint8), (70, 1))
+    t = np.tile(np.arange(32, dtype=np.uint8), (45, 1))
+    g = vctx.match_hamming256(q, t)
+    assert g.tobytes() == oracle.match_hamming256(q, t).tobytes() and len(g) == 1
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (256, 32), dtype=np.uint8)
+    flip = np.zeros((256, 256), np.uint8)
+    flip[np.arange(256), np.arange(256)] = 1
+    t = base ^ np.packbits(flip, axis=1)
+    g = vctx.match_hamming256(base, t)
+    assert g.tobytes() == oracle.match_hamming256(base, t).tobytes()
+    assert np.all(g["distance"] == 1.0) and np.array_equal(g["queryIdx"], g["trainIdx"])
+
+
+def test_variant_low_entropy_descriptors(vctx, oracle):
+    # few distinct bytes -> many equal distances: the tie rule (lowest query, then lowest train) decides almost everything
+    rng = np.random.default_rng(77)
+    q = rng.integers(0, 2, (900, 32), dtype=np.uint8) * 255
+    t = rng.integers(0, 2, (1100, 32), dtype=np.uint8) * 255
+    assert vctx.match_hamming256(q, t).tobytes() == oracle.match_hamming256(q, t).tobytes()
+
+
+@pytest.mark.parametrize("qsplit", [1, 2, 5])
+def test_variant_ties_across_query_tiles(vctx, oracle, qsplit):
+    """One work-group sweeps many 32-row query tiles: equal distances in different tiles must resolve to the lowest
+    query index whatever the row inside the tile (a later tile's lower row must not win)."""
+    rng = np.random.default_rng(2024 + qsplit)
+    base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    q = base[rng.integers(0, 40, 1500)]                      # 1500 queries drawn from 40 distinct rows: many exact ties
+    t = base[rng.integers(0, 40, 1300)] ^ np.packbits(rng.random((1300, 256)) < 0.02, axis=1)
+    vctx.set_option("qsplit", qsplit)
+    try:
+        g = vctx.match_hamming256(q, t)
+    finally:
+        vctx.set_option("qsplit", 0)
+    assert g.tobytes() == oracle.match_hamming256(q, t).tobytes()
+
+
+def test_variants_agree_on_a_batch(oracle):
+    """ps_vo_pairs_device with either matcher: identical matches / masks / poses / stats for a 9-pair batch with
+    ragged keypoint counts; three sampled pairs are also compared with the oracle."""
+    from putslam_amd._abi import EST_RANSAC, REPROJECTION_ERROR, TUM_FR1_K, default_ransac_params, make_config
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(10, 700, config=3, index=5)
+    seq["nkpts"][3] = 517
+    seq["nkpts"][7] = 64
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=4242)
+    outs = []
+    for kind in (1, 0):
+        c = api.Context(0)
+        c.set_option("matcher", kind)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb, use_torch_stream=False)
+        c.synchronize()
+        outs.append(pb.download())
+        c.close()
+    a, b = outs
+    assert np.array_equal(a["numMatches"], b["numMatches"])
+    for p in range(len(seq["pairs"])):
+        n = int(a["numMatches"][p])
+        assert a["matches"][p][:n].tobytes() == b["matches"][p][:n].tobytes()
+        assert np.array_equal(a["inlierMask"][p][:n], b["inlierMask"][p][:n])
+    assert a["pose"].tobytes() == b["pose"].tobytes()
+    assert a["stats"].tobytes() == b["stats"].tobytes()
+    for p in (0, 3, 7):
+        f0, f1 = seq["pairs"][p]
+        n0, n1 = int(seq["nkpts"][f0]), int(seq["nkpts"][f1])
+        m = oracle.match_hamming256(seq["desc"][f0][:n0], seq["desc"][f1][:n1])
+        assert a["matches"][p][:len(m)].tobytes() == m.tobytes() and int(a["numMatches"][p]) == len(m)
