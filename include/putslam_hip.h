@@ -114,6 +114,10 @@ int ps_context_synchronize(PsContext *ctx);
 /* Kernel variants kept side by side for A/B measurements and as tested twins (results are identical):
  *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma (default), 0 = integer VALU sweep ps_hamming_nn
  *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu, read at context creation).
+ *   "score":   1 = decision-exact fast scoring kernel for errorVersion 1 (ps_ransac_score_fast: cheap evaluation with a
+ *              proven error band, in-band evaluations re-done by the value-exact code; default), 0 = value-exact
+ *              ps_ransac_score<1> for every evaluation (PUTSLAM_HIP_SCORE=fast|exact).  Counts are identical.
+ *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
  *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).
  * ps_context_get_option returns the value or a negative PsStatus. */
@@ -271,6 +275,9 @@ int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M
 /* Runs blocks*256*perThread random (a0, a1, b) triples through the scoring kernel's shared-reciprocal
  * division and through the '/' operator; *mismatches must come back 0 (bitwise comparison). */
 int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, uint64_t *mismatches, uint64_t *tested);
+/* After a scoring launch with option "score_stats" = 1: evaluations the fast kernel parked for the value-exact
+ * code, and (hypothesis, match) evaluations it made in all (lanes of partially filled wavefronts included). */
+int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations);
 /* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
 size_t ps_abi_sizeof_dmatch(void);
 size_t ps_abi_sizeof_params(void);

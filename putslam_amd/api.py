@@ -63,6 +63,12 @@ class Context:
         """Kernel variant switches (include/putslam_hip.h: ps_context_set_option), e.g. ("matcher", 0 | 1)."""
         self._chk(self._L.ps_context_set_option(self._h, name.encode(), int(value)))
 
+    def score_stats(self):
+        """(parked, evaluations) of the last fast scoring launch (needs set_option("score_stats", 1))."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.ps_debug_score_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def get_option(self, name):
         v = self._L.ps_context_get_option(self._h, name.encode())
         if v < 0:

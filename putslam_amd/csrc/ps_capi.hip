@@ -6,6 +6,7 @@
 // of ps_kernels.h or fails with a negative PsStatus.
 #include "ps_kernels.h"
 #include "ps_matcher_mfma.h"
+#include "ps_score_fast.h"
 
 #include <cfloat>
 #include <climits>
@@ -38,7 +39,8 @@ struct PsContext {
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, counts, mvalid, cmax, idxList, raw;
+    Buf keys, recA, recB, recC, recD, recE, counts, mvalid, cmax, idxList, raw;
+    Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
     // staging for the host-pointer entry points (device)
@@ -58,6 +60,9 @@ struct PsContext {
     int forceQsplit = 0, forceMsplit = 0;
     // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher
     int matcher = 1;
+    // 1 = decision-exact fast scoring for the reprojection metric (ps_score_fast.h), 0 = value-exact ps_ransac_score
+    int scoreFast = 1;
+    int scoreStats = 0;
 };
 
 namespace {
@@ -286,6 +291,7 @@ struct Plan {
     int H = 0;        // hypotheses scored
     int minRun = 3;
     ScoreConsts sc{};
+    FastConsts fc{};
     PrepArgs pa{};
     SelectArgs sa{};
     ModelArgs ma{};
@@ -316,6 +322,25 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
         if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
         pl.sc.bLo = flo;
         pl.sc.bHi = fhi;
+    }
+    // constants of the decision-exact fast path (ps_score_fast.h); directed roundings keep every bound on its safe side
+    {
+        FastConsts &fc = pl.fc;
+        const double fm = std::fmax(std::fmax(std::fabs((double)k[0]), std::fabs((double)k[4])), 1.0);
+        const double cm = std::fmax(std::fabs((double)k[2]), std::fabs((double)k[5]));
+        const double bR = pl.sc.boundR;
+        fc.enabled = (bR >= 1e-12 && bR <= 1e12 && fm <= 1e6 && cm <= 1e6) ? 1 : 0; // false for NaN
+        if (fc.enabled) {
+            const double T = std::sqrt(bR);
+            auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; };
+            auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; };
+            fc.fmaxK = up(fm);
+            fc.cmaxK = up(cm);
+            fc.thrUp = up(T * (1.0 + 1e-5));
+            fc.bIn0 = down(bR * (1.0 - 8.0 * 5.9604644775390625e-08));
+            fc.cIn = up(2.0 * std::sqrt(2.0) * T * (1.0 + 1e-5));
+            fc.cOut = up(std::sqrt(2.0) * (1.0 + 1e-5));
+        }
     }
     pl.pa.fx = k[0]; pl.pa.fy = k[4]; pl.pa.cx = k[2]; pl.pa.cy = k[5];
     pl.pa.thrE = prm->inlierThresholdEuclidean;
@@ -375,7 +400,7 @@ void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit
 {
     hipLaunchKernelGGL(ps_ransac_score<MODE>, grid, dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p,
                        (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p, (const int32_t *)ctx->mvalid.p,
-                       (const float *)ctx->cmax.p, pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
+                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
 }
 
 // Kernels 3 + 4 over records already in the arena.
@@ -394,7 +419,21 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     tick(ctx, slot0, false);
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR: launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit); break;
-    case PS_REPROJECTION_ERROR: launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit); break;
+    case PS_REPROJECTION_ERROR:
+        if (ctx->scoreFast) {
+            unsigned long long *dbg = nullptr;
+            if (ctx->scoreStats) {
+                PS_ENSURE(ctx->dbgCnt, 2 * sizeof(unsigned long long));
+                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                dbg = (unsigned long long *)ctx->dbgCnt.p;
+            }
+            hipLaunchKernelGGL(ps_ransac_score_fast<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
+                               (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
+                               (const float4 *)ctx->recE.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,
+                               pl.ma, pl.sc, pl.fc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p, dbg);
+        } else
+            launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
+        break;
     case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
         launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
@@ -424,6 +463,7 @@ int ensure_records(PsContext *ctx, size_t n)
     PS_ENSURE(ctx->recB, n * 16);
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
+    PS_ENSURE(ctx->recE, n * 16);
     return PS_OK;
 }
 
@@ -434,7 +474,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     const int cap = fs.maxKpts;
     PS_ENSURE(ctx->keys, (size_t)P * cap * sizeof(uint32_t));
     PS_ENSURE(ctx->mvalid, (size_t)P * sizeof(int32_t));
-    PS_ENSURE(ctx->cmax, (size_t)P * sizeof(float));
+    PS_ENSURE(ctx->cmax, (size_t)P * sizeof(float2));
     if (withRecords) {
         int rc = ensure_records(ctx, (size_t)P * cap);
         if (rc != PS_OK) return rc;
@@ -478,7 +518,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
 #define PS_LAUNCH_PREP(REC, BLK, A, B, C, D)                                                                          \
     hipLaunchKernelGGL((ps_crosscheck_prep<REC, BLK>), dim3((unsigned)P), dim3(BLK), lds, ctx->stream, fs.pts, fs.nkpts, \
                        dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, A, B, C, D,                   \
-                       (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p)
+                       (float4 *)ctx->recE.p, (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p)
     if (withRecords) {
         if (wide)
             PS_LAUNCH_PREP(true, 1024, (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p);
@@ -553,6 +593,7 @@ int ps_context_create(int device, PsContext **out)
     ctx->stream = ctx->own;
     if (const char *v = std::getenv("PUTSLAM_HIP_QSPLIT")) ctx->forceQsplit = std::atoi(v);
     if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
+    if (const char *v = std::getenv("PUTSLAM_HIP_SCORE")) ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER")) ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
@@ -572,7 +613,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -598,6 +639,11 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->matcher = value;
         return PS_OK;
     }
+    if (strcmp(name, "score") == 0 || strcmp(name, "score_stats") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "score / score_stats: 0 or 1");
+        (name[5] == 0 ? ctx->scoreFast : ctx->scoreStats) = value;
+        return PS_OK;
+    }
     if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
         if (value < 0 || value > 1024) return fail(ctx, PS_ERR_BAD_ARG, "split: 0..1024");
         (name[0] == 'q' ? ctx->forceQsplit : ctx->forceMsplit) = value;
@@ -610,6 +656,8 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;
     if (strcmp(name, "matcher") == 0) return ctx->matcher;
+    if (strcmp(name, "score") == 0) return ctx->scoreFast;
+    if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
     if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
     if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
     return PS_ERR_BAD_ARG;
@@ -784,7 +832,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->sPose, 16 * sizeof(float));
     PS_ENSURE(ctx->sStats, sizeof(PsRansacStats));
     PS_ENSURE(ctx->mvalid, sizeof(int32_t));
-    PS_ENSURE(ctx->cmax, sizeof(float));
+    PS_ENSURE(ctx->cmax, sizeof(float2));
     rc = ensure_records(ctx, (size_t)cap);
     if (rc) return rc;
     if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -797,7 +845,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     hipLaunchKernelGGL(ps_prep_from_matches, dim3(1), dim3(kBlock), 0, ctx->stream, (const float *)ctx->sMisc0.p,
                        (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa,
                        (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
-                       (int32_t *)ctx->mvalid.p, (float *)ctx->cmax.p);
+                       (float4 *)ctx->recE.p, (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p);
     PS_HIP(hipGetLastError());
     rc = run_ransac_stage(ctx, pl, 1, cap, (const PsDMatch *)ctx->sMatches.p, (const int32_t *)ctx->sNumM.p, cap,
                           (float *)ctx->sPose.p, (uint8_t *)ctx->sMask.p, (PsRansacStats *)ctx->sStats.p, 2);
@@ -886,6 +934,22 @@ int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, u
     PS_HIP(hipStreamSynchronize(ctx->stream));
     *mismatches = h[0];
     *tested = h[1];
+    return PS_OK;
+}
+
+// Diagnostic: how many evaluations the last fast scoring launch parked for the value-exact code (option "score_stats").
+int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!parked || !evaluations) return PS_ERR_BAD_ARG;
+    *parked = *evaluations = 0;
+    if (!ctx->dbgCnt.p) return PS_OK;
+    unsigned long long h[2] = {0, 0};
+    PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    *parked = h[0];
+    *evaluations = h[1];
     return PS_OK;
 }
 
@@ -1157,7 +1221,7 @@ struct PsVoStream {
         PsRansacParams prm;
         int estimator, numHypotheses, variant;
         float K[9];
-        const void *arena[12]; // scratch and table blocks the captured launches point at (they move when they grow)
+        const void *arena[13]; // scratch and table blocks the captured launches point at (they move when they grow)
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1312,12 +1376,12 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher;
+    key.variant = ctx->matcher | (ctx->scoreFast << 1) | (ctx->scoreStats << 2);
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[12] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p};
+    const void *arena[13] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1356,8 +1420,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[12] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p};
+        const void *after[13] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

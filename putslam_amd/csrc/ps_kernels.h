@@ -170,9 +170,10 @@ struct PrepArgs {
     int cap;
 };
 
-// Builds the four 16-byte records of one depth-valid match.
-PS_D void write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t, float px, float py, float pz,
-                        float cx_, float cy_, float cz_, float4 *recA, float4 *recB, float4 *recC, int4 *recD)
+// Builds the five 16-byte records of one depth-valid match; returns the largest |offset| of recE.
+PS_D float write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t, float px, float py, float pz,
+                         float cx_, float cy_, float cz_, float4 *recA, float4 *recB, float4 *recC, int4 *recD,
+                         float4 *recE)
 {
     // Euclid rule of RANSAC.cpp:268-272: thr = inlierThresholdEuclidean (* prev.z in ADAPTIVE mode),
     // turned into its exact squared-domain bound.
@@ -186,6 +187,10 @@ PS_D void write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t
     recB[slot] = make_float4(cx_, cy_, cz_, 0.0f);
     recC[slot] = make_float4(ou, ov, nu, nv);
     recD[slot] = make_int4(srcIdx, q, t, 0);
+    // offsets of the decision-exact fast scoring path (ps_score_fast.h): predicted - real = quotient + (c - real)
+    const float4 e = make_float4(a.cx - ou, a.cy - ov, a.cx - nu, a.cy - nv);
+    recE[slot] = e;
+    return fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -203,12 +208,14 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
                                                              int32_t *__restrict__ numMatches,
                                                              float4 *__restrict__ recA, float4 *__restrict__ recB,
                                                              float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                             int32_t *__restrict__ mvalid, float *__restrict__ cmaxOut)
+                                                             float4 *__restrict__ recE,
+                                                             int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut)
 {
     extern __shared__ __align__(16) uint32_t s_best[];
     __shared__ int s_wsum[BLOCK / 64];
     __shared__ float s_red[BLOCK / 64];
     float cm = 0.0f; // largest |coordinate| among this pair's depth-valid matches
+    float um = 0.0f; // largest |c - projection| among them (NaN offsets are skipped by fmaxf; they only ever score "out")
     const int p = blockIdx.x;
     const int cap = a.cap;
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
@@ -254,8 +261,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             int vtotal;
             int vpos = block_scan_flag<BLOCK>(ok, vtotal, s_wsum);
             if (ok) {
-                write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_, recA,
-                              recB, recC, recD);
+                um = fmaxf(um, write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_,
+                                             recA, recB, recC, recD, recE));
                 cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
             }
             vbase += vtotal;
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
     }
     if (WITH_RECORDS) {
         float c = block_max<BLOCK>(cm, s_red);
-        if (threadIdx.x == 0) cmaxOut[p] = c;
+        float u = block_max<BLOCK>(um, s_red);
+        if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
     }
     if (threadIdx.x == 0) {
         numMatches[p] = base;
@@ -278,11 +286,12 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
                                                                const PsDMatch *__restrict__ matches, int m, PrepArgs a,
                                                                float4 *__restrict__ recA, float4 *__restrict__ recB,
                                                                float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                               int32_t *__restrict__ mvalid, float *__restrict__ cmaxOut)
+                                                               float4 *__restrict__ recE,
+                                                               int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut)
 {
     __shared__ int s_wsum[kBlock / 64];
     __shared__ float s_red[kBlock / 64];
-    float cm = 0.0f;
+    float cm = 0.0f, um = 0.0f;
     int vbase = 0;
     for (int i0 = 0; i0 < m; i0 += kBlock) {
         const int i = i0 + threadIdx.x;
@@ -299,15 +308,17 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         int vtotal;
         int vpos = block_scan_flag(ok, vtotal, s_wsum);
         if (ok) {
-            write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD);
+            um = fmaxf(um, write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD,
+                                         recE));
             cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
         }
         vbase += vtotal;
     }
     float c = block_max(cm, s_red);
+    float u = block_max(um, s_red);
     if (threadIdx.x == 0) {
         mvalid[0] = vbase;
-        cmaxOut[0] = c;
+        cmaxOut[0] = make_float2(c, u);
     }
 }
 
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
                                                           const float4 *__restrict__ recB,
                                                           const float4 *__restrict__ recC,
                                                           const int32_t *__restrict__ mvalid,
-                                                          const float *__restrict__ cmaxArr, ModelArgs ma,
+                                                          const float2 *__restrict__ cmaxArr, ModelArgs ma,
                                                           ScoreConsts k, int H, int cap, int minRun, int msplit,
                                                           int32_t *__restrict__ counts)
 {
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
     } else {
         // wave-uniform branches inside: not unrollable.  The upper end of the division window is settled here,
         // once per hypothesis, whenever the pair's coordinate bound allows it.
-        const float cmax = cmaxArr[p];
+        const float cmax = cmaxArr[p].x;
         const float fmaxK = fmaxf(fmaxf(fabsf(k.fx), fabsf(k.fy)), 1.0f);
         const bool hoisted = wave_all(hi_bound_holds(mdl, cmax, fmaxK) && hi_bound_holds(inv, cmax, fmaxK));
         if (hoisted) {

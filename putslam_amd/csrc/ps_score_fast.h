@@ -1,0 +1,235 @@
+// ps_score_fast.h -- kernel 3 for the reprojection metric, decision-exact instead of value-exact.
+//
+// RANSAC::computeInlierRatioReprojection (reference src/TransformEst/RANSAC.cpp:325-375) decides, for every
+// (hypothesis, match), whether two reprojection errors stay below inlierThresholdReprojection.  Only that
+// DECISION has to equal the reference's; ps_ransac_score<1> (ps_kernels.h) reproduces every intermediate VALUE
+// bit for bit (two rigid transforms without FMA, four IEEE quotients, two cv::norm tests: 61 VALU instructions
+// per evaluation).  This kernel takes the decision from a cheap evaluation with a proven error band and hands the
+// evaluations that fall inside the band to the value-exact code:
+//
+//   fast evaluation (38 VALU instructions): both transforms as FMA chains with the camera constants folded into
+//   the model rows (X~ = fx * (R p + t)_x ...), one v_rcp_f32 per projected point, offsets c - real taken from a
+//   per-match record: d~u = X~ * rcp(Z~) + (cx - u_real), s~ = d~u^2 + d~v^2 for the two directions.
+//
+//   error band.  u = 2^-24.  For one hypothesis let S >= sum_j |R_ij| |p_j| + |t_i| for every row of the model and of
+//   its inverse and every point of the pair (S = 1.001 (rho * cmax + tau), rho = largest row sum of |R|, tau = largest
+//   |t|, cmax = the pair's largest coordinate).  Standard running-error bounds give, against the real-valued
+//   transform E:  reference numerator fl(fl(E_x) * fx) within g6 |fx| S, reference denominator within g4 S, FMA-chain
+//   numerator within g4 |fx| S, FMA-chain denominator within g3 S  (g_k = k u / (1 - k u)); taken together
+//   eta = 16 u fmaxK S and zeta = 8 u S cover numerators and denominators of both paths.  With
+//   |Z~| >= 2^-14 S (= 128 zeta: the lane is "uncertain" otherwise) both quotients are within
+//   1.01 (eta + |Q| zeta) |rcp(Z~)| of the real quotient Q; the remaining roundings (the reference's quotient, + c,
+//   - real; here rcp's 1 ulp, the offset record, the fma) add at most 1.01 u (8 |Q| + 2 cmaxK + 2 |D| + |c - real|).
+//   When the reference calls the match an inlier, |Q| <= Qin = 1.02 (Umax + thr + 0.016 fmaxK + 1) (Umax = the
+//   pair's largest |c - real|), so each of the four differences the reference squares is within
+//       delta = kap1 * rmax + kap0,    kap1 = 1.02 * 8 u (2 fmaxK + Qin) * S,    rmax = max |rcp(Z~)| of the two points,
+//                                      kap0 = 1.02 u (8 Qin + 2 cmaxK + 2 thr + 2 + Umax)
+//   of the fast value, hence (triangle inequality on the 2-vector, T = sqrt(boundR)):
+//       max s~ < boundR (1 - 8u) - 2 sqrt2 T delta            =>  the reference's two tests pass      (certain inlier)
+//       max s~ > (T (1 + 1e-5) + sqrt2 (1 + 1e-5) delta)^2    =>  at least one of them fails          (certain outlier:
+//                                                                  had both passed, the first bound would hold)
+//   Anything else -- inside the band, |Z~| below the floor, NaN -- is "uncertain".
+//
+//   uncertain evaluations are parked as (match, lane) in a wave-private LDS queue and evaluated later by the
+//   value-exact inlier_test<MODE>() (the model is parked in LDS at the start), densely packed: one lane per parked
+//   evaluation instead of one whole wavefront per uncertain match.  Counts therefore equal ps_ransac_score<1>'s
+//   for every hypothesis (tests: test_hypothesis_counts_bit_exact, test_score_variants_*, the fuzz slice).
+//
+// A wavefront whose bounds do not hold (non-finite model, S fmaxK > 2^40, threshold outside [1e-10, 1e15]) runs
+// the value-exact loop of ps_kernels.h instead.
+#pragma once
+
+#include "ps_kernels.h"
+
+namespace psdev {
+
+struct FastConsts {
+    float fmaxK;  // max(|fx|, |fy|, 1)
+    float cmaxK;  // max(|cx|, |cy|)
+    float thrUp;  // sqrt(boundR) (1 + 1e-5), rounded up
+    float bIn0;   // boundR (1 - 8u), rounded down
+    float cIn;    // 2 sqrt2 sqrt(boundR) (1 + 1e-5), rounded up
+    float cOut;   // sqrt2 (1 + 1e-5), rounded up
+    int enabled;  // thresholds and camera constants inside the range the bounds were derived for
+};
+
+constexpr int kQueueCap = 256; // parked evaluations per wave (drained by the wave itself when full)
+constexpr float kEpsU = 5.9604644775390625e-08f; // 2^-24
+
+struct FastModel {
+    float r0[3], t0; // fx * row 0, fx * t_0
+    float r1[3], t1; // fy * row 1, fy * t_1
+    float r2[3], t2; // row 2, t_2
+};
+
+PS_D void make_fast(const Rigid &m, float fx, float fy, FastModel &f)
+{
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        f.r0[j] = fx * m.R[0][j];
+        f.r1[j] = fy * m.R[1][j];
+        f.r2[j] = m.R[2][j];
+    }
+    f.t0 = fx * m.t[0];
+    f.t1 = fy * m.t[1];
+    f.t2 = m.t[2];
+}
+
+// largest row sum of |R| and largest |t| (NaN anywhere makes the sums NaN: the caller's comparison then fails)
+PS_D void model_norms(const Rigid &m, float &rho, float &tau)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float rs = (fabsf(m.R[i][0]) + fabsf(m.R[i][1])) + fabsf(m.R[i][2]);
+        rho = rs > rho ? rs : (rs == rs ? rho : rs); // propagate NaN
+        const float ta = fabsf(m.t[i]);
+        tau = ta > tau ? ta : (ta == ta ? tau : ta);
+    }
+}
+
+// squared reprojection offset of one point under one folded model; rz = rcp of the projected depth
+PS_D float fast_sq(const FastModel &f, float x, float y, float z, float ku, float kv, float &rz)
+{
+    const float X = __builtin_fmaf(f.r0[0], x, __builtin_fmaf(f.r0[1], y, __builtin_fmaf(f.r0[2], z, f.t0)));
+    const float Y = __builtin_fmaf(f.r1[0], x, __builtin_fmaf(f.r1[1], y, __builtin_fmaf(f.r1[2], z, f.t1)));
+    const float Z = __builtin_fmaf(f.r2[0], x, __builtin_fmaf(f.r2[1], y, __builtin_fmaf(f.r2[2], z, f.t2)));
+    rz = __builtin_amdgcn_rcpf(Z);
+    const float du = __builtin_fmaf(X, rz, ku);
+    const float dv = __builtin_fmaf(Y, rz, kv);
+    return __builtin_fmaf(du, du, dv * dv);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
+    const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
+    const float4 *__restrict__ recE, const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound,
+    ModelArgs ma, ScoreConsts k, FastConsts fc, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
+    unsigned long long *__restrict__ dbg)
+{
+    static_assert(MODE == PS_REPROJECTION_ERROR, "the fast path covers the reprojection metric");
+    __shared__ float s_mdl[12][kBlock];
+    __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
+    __shared__ int s_cnt[kBlock];
+
+    const unsigned hb = (unsigned)((H + kBlock - 1) / kBlock);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
+    const int p = (int)(L / (hb * (unsigned)msplit));
+    const int M = mvalid[p];
+    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = (int)bx * kBlock + tid;
+    const size_t rbase = (size_t)p * cap;
+    const int m0 = (int)(((long long)M * by) / msplit);
+    const int m1 = (int)(((long long)M * (by + 1)) / msplit);
+
+    Rigid mdl, inv;
+    set_identity(mdl);
+    bool valid = false;
+    if (h < H) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+    inverse_rigid_general(mdl, inv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s_mdl[3 * i + j][tid] = mdl.R[i][j];
+        s_mdl[9 + i][tid] = mdl.t[i];
+    }
+    s_cnt[tid] = 0;
+
+    const float4 *__restrict__ pa = recA + rbase;
+    const float4 *__restrict__ pb = recB + rbase;
+    const float4 *__restrict__ pc = recC + rbase;
+    const float4 *__restrict__ pe = recE + rbase;
+    const float2 pbnd = pairBound[p];
+    const float cmax = pbnd.x, umax = pbnd.y;
+
+    float rho = 0.0f, tau = 0.0f;
+    model_norms(mdl, rho, tau);
+    model_norms(inv, rho, tau);
+    const float S = (rho * cmax + tau) * 1.001f;
+    // (comparisons are false for NaN: a non-finite model, cmax or umax sends the wavefront to the value-exact loop)
+    const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f;
+    int cnt = 0;
+
+    if (!wave_all(boundsOk)) {
+        for (int m = m0; m < m1; ++m) {
+            const float4 A = pa[m], B = pb[m], C = pc[m];
+            score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
+        }
+    } else {
+        FastModel F, G;
+        make_fast(mdl, k.fx, k.fy, F); // current point -> previous image   (estimatedOldPosition, RANSAC.cpp:346)
+        make_fast(inv, k.fx, k.fy, G); // previous point -> current image   (estimatedNewPosition, RANSAC.cpp:348)
+        const float Qin = 1.02f * (umax + fc.thrUp + 0.016f * fc.fmaxK + 1.0f);
+        const float kap1 = S * (1.02f * 8.0f * kEpsU * (2.0f * fc.fmaxK + Qin));
+        const float kap0 = 1.02f * kEpsU * (8.0f * Qin + 2.0f * fc.cmaxK + 2.0f * fc.thrUp + 2.0f + umax);
+        const float rcap = 16384.0f / S; // |rcp(Z~)| above this: |Z~| < 2^-14 S, the band is not valid
+        int qn = 0;                      // parked evaluations of this wave (wave-uniform)
+        unsigned long long parked = 0;
+
+        // value-exact evaluation of the parked (match, lane) pairs, one lane each
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int e = lane; e < qn; e += 64) {
+                const uint32_t ent = s_q[wv][e];
+                const int t = wv * 64 + (int)(ent & 63u), m = (int)(ent >> 6);
+                Rigid md, iv;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][t];
+                    md.t[i] = s_mdl[9 + i][t];
+                }
+                inverse_rigid_general(md, iv);
+                const float4 A = pa[m], B = pb[m], C = pc[m];
+                if (inlier_test<MODE>(md, iv, k, A, B, C)) atomicAdd(&s_cnt[t], 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            parked += (unsigned long long)qn;
+            qn = 0;
+        };
+
+        const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
+        for (int m = m0; m < m1; ++m) {
+            const float4 A = pa[m], B = pb[m], E = pe[m];
+            float ro, rn;
+            const float so = fast_sq(F, B.x, B.y, B.z, E.x, E.y, ro); // predictedOld - realOld
+            const float sn = fast_sq(G, A.x, A.y, A.z, E.z, E.w, rn); // predictedNew - realNew
+            // sums of squares are >= +0 and any NaN sorts above +inf as an unsigned pattern: the larger decides both tests
+            const uint32_t uo = __builtin_bit_cast(uint32_t, so), un = __builtin_bit_cast(uint32_t, sn);
+            const float sm = __builtin_bit_cast(float, max(uo, un));
+            const float rm = fmaxf(fabsf(ro), fabsf(rn));
+            const float dl = __builtin_fmaf(kap1, rm, kap0);
+            const float lo2 = __builtin_fmaf(-fc.cIn, dl, fc.bIn0);
+            const float hO = __builtin_fmaf(fc.cOut, dl, fc.thrUp);
+            const float hi2 = hO * hO;
+            const unsigned long long mZ = __builtin_amdgcn_ballot_w64(rm <= rcap);
+            const unsigned long long mIn = __builtin_amdgcn_ballot_w64(sm < lo2) & mZ;
+            const unsigned long long mOut = __builtin_amdgcn_ballot_w64(sm > hi2) & mZ;
+            add_mask(cnt, mIn);
+            const unsigned long long mU = execAll & ~(mIn | mOut);
+            if (mU != 0ull) {
+                const int n = __popcll(mU);
+                if (qn + n > kQueueCap) drain();
+                if ((mU >> lane) & 1ull)
+                    s_q[wv][qn + __popcll(mU & ((1ull << lane) - 1ull))] = ((uint32_t)m << 6) | (uint32_t)lane;
+                qn += n;
+            }
+        }
+        drain();
+        cnt += s_cnt[tid];
+        if (dbg != nullptr && lane == 0) {
+            atomicAdd(&dbg[0], parked);
+            atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
+        }
+    }
+    if (h < H) {
+        if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
+        if (msplit == 1)
+            counts[(size_t)p * H + h] = cnt;
+        else if (cnt)
+            atomicAdd(&counts[(size_t)p * H + h], cnt);
+    }
+}
+
+} // namespace psdev
