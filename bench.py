@@ -184,6 +184,20 @@ def main():
             a0, n0 = totals.get(kname, (0.0, 0))
             totals[kname] = (a0 + ms_sum, n0 + n)
         c.enable_timing(False)
+    # one extra, untimed pass with the fast scoring kernel's statistics switched on: the share of (hypothesis, match)
+    # evaluations that fell inside the error band and were re-done by the value-exact code
+    parked_frac = None
+    if world == 1 and args.error_version == 1 and ctxs[0].get_option("score") == 1:
+        pk = ev = 0
+        for c in ctxs:
+            c.set_option("score_stats", 1)
+        step()
+        fence()
+        for c in ctxs:
+            a_, b_ = c.score_stats()
+            pk, ev = pk + a_, ev + b_
+            c.set_option("score_stats", 0)
+        parked_frac = pk / ev if ev else None
     res = pb.download()
 
     if rank == 0:
@@ -266,6 +280,7 @@ def main():
                          "avg_launch_ms": dom_ms,
                          "note": "path is VALU-issue-bound, not HBM-bound (DESIGN.md section 4): see valu_issue"},
             "kernel_ms": kern,
+            "score_parked_frac": parked_frac,
             "valu_issue": valu_issue,
             "streams_note": (None if S == 1 else
                              f"{S} sub-batch chains on {S} HIP streams (join={args.join}): per-launch durations are measured "

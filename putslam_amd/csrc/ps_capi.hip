@@ -337,9 +337,11 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
             fc.fmaxK = up(fm);
             fc.cmaxK = up(cm);
             fc.thrUp = up(T * (1.0 + 1e-5));
-            fc.bIn0 = down(bR * (1.0 - 8.0 * 5.9604644775390625e-08));
+            fc.bIn0 = down(bR * (1.0 - 16.0 * 5.9604644775390625e-08));
             fc.cIn = up(2.0 * std::sqrt(2.0) * T * (1.0 + 1e-5));
-            fc.cOut = up(std::sqrt(2.0) * (1.0 + 1e-5));
+            const double c = std::sqrt(2.0) * (1.0 + 1e-5);
+            fc.thr2Up = up((double)fc.thrUp * (double)fc.thrUp);
+            fc.cHi = up((2.0 * c + c * c) * (double)fc.thrUp);
         }
     }
     pl.pa.fx = k[0]; pl.pa.fy = k[4]; pl.pa.cx = k[2]; pl.pa.cy = k[5];

@@ -188,7 +188,8 @@ PS_D float write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int 
     recC[slot] = make_float4(ou, ov, nu, nv);
     recD[slot] = make_int4(srcIdx, q, t, 0);
     // offsets of the decision-exact fast scoring path (ps_score_fast.h): predicted - real = quotient + (c - real)
-    const float4 e = make_float4(a.cx - ou, a.cy - ov, a.cx - nu, a.cy - nv);
+    // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
+    const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
     recE[slot] = e;
     return fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)));
 }

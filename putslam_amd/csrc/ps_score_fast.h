@@ -25,9 +25,12 @@
 //       delta = kap1 * rmax + kap0,    kap1 = 1.02 * 8 u (2 fmaxK + Qin) * S,    rmax = max |rcp(Z~)| of the two points,
 //                                      kap0 = 1.02 u (8 Qin + 2 cmaxK + 2 thr + 2 + Umax)
 //   of the fast value, hence (triangle inequality on the 2-vector, T = sqrt(boundR)):
-//       max s~ < boundR (1 - 8u) - 2 sqrt2 T delta            =>  the reference's two tests pass      (certain inlier)
+//       max s~ < boundR (1 - 16u) - 2 sqrt2 T delta           =>  the reference's two tests pass      (certain inlier)
 //       max s~ > (T (1 + 1e-5) + sqrt2 (1 + 1e-5) delta)^2    =>  at least one of them fails          (certain outlier:
 //                                                                  had both passed, the first bound would hold)
+//   Both limits are evaluated as affine functions of rmax (one fma each, coefficients rounded to the safe side): the
+//   first is affine already; for delta <= T' = T (1 + 1e-5) the square is at most T'^2 + (2 c + c^2) T' delta with
+//   c = sqrt2 (1 + 1e-5), and lanes with a larger delta (|Z~| of a few millimetres) count as uncertain.
 //   Anything else -- inside the band, |Z~| below the floor, NaN -- is "uncertain".
 //
 //   uncertain evaluations are parked as (match, lane) in a wave-private LDS queue and evaluated later by the
@@ -47,32 +50,37 @@ struct FastConsts {
     float fmaxK;  // max(|fx|, |fy|, 1)
     float cmaxK;  // max(|cx|, |cy|)
     float thrUp;  // sqrt(boundR) (1 + 1e-5), rounded up
-    float bIn0;   // boundR (1 - 8u), rounded down
+    float bIn0;   // boundR (1 - 16u), rounded down
     float cIn;    // 2 sqrt2 sqrt(boundR) (1 + 1e-5), rounded up
-    float cOut;   // sqrt2 (1 + 1e-5), rounded up
+    float thr2Up; // thrUp^2, rounded up
+    float cHi;    // (2 c + c^2) thrUp with c = sqrt2 (1 + 1e-5), rounded up
     int enabled;  // thresholds and camera constants inside the range the bounds were derived for
 };
 
 constexpr int kQueueCap = 256; // parked evaluations per wave (drained by the wave itself when full)
 constexpr float kEpsU = 5.9604644775390625e-08f; // 2^-24
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+// Both folded models of one hypothesis, packed across the two directions for v_pk_fma_f32:
+// .x = current point -> previous image (model), .y = previous point -> current image (inverse model).
 struct FastModel {
-    float r0[3], t0; // fx * row 0, fx * t_0
-    float r1[3], t1; // fy * row 1, fy * t_1
-    float r2[3], t2; // row 2, t_2
+    v2f_t r0[3], t0; // fx * row 0, fx * t_0
+    v2f_t r1[3], t1; // fy * row 1, fy * t_1
+    v2f_t r2[3], t2; // row 2, t_2
 };
 
-PS_D void make_fast(const Rigid &m, float fx, float fy, FastModel &f)
+PS_D void make_fast(const Rigid &m, const Rigid &inv, float fx, float fy, FastModel &f)
 {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        f.r0[j] = fx * m.R[0][j];
-        f.r1[j] = fy * m.R[1][j];
-        f.r2[j] = m.R[2][j];
+        f.r0[j] = v2f_t{fx * m.R[0][j], fx * inv.R[0][j]};
+        f.r1[j] = v2f_t{fy * m.R[1][j], fy * inv.R[1][j]};
+        f.r2[j] = v2f_t{m.R[2][j], inv.R[2][j]};
     }
-    f.t0 = fx * m.t[0];
-    f.t1 = fy * m.t[1];
-    f.t2 = m.t[2];
+    f.t0 = v2f_t{fx * m.t[0], fx * inv.t[0]};
+    f.t1 = v2f_t{fy * m.t[1], fy * inv.t[1]};
+    f.t2 = v2f_t{m.t[2], inv.t[2]};
 }
 
 // largest row sum of |R| and largest |t| (NaN anywhere makes the sums NaN: the caller's comparison then fails)
@@ -87,16 +95,21 @@ PS_D void model_norms(const Rigid &m, float &rho, float &tau)
     }
 }
 
-// squared reprojection offset of one point under one folded model; rz = rcp of the projected depth
-PS_D float fast_sq(const FastModel &f, float x, float y, float z, float ku, float kv, float &rz)
+PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+// squared reprojection offsets of the two directions (.x: predictedOld - realOld, .y: predictedNew - realNew) and the
+// reciprocals of the two projected depths.  cur = B (current point), prev = A (previous point), E = offsets
+// (cx - uOld, cx - uNew, cy - vOld, cy - vNew).
+PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const float4 &E, v2f_t &rz)
 {
-    const float X = __builtin_fmaf(f.r0[0], x, __builtin_fmaf(f.r0[1], y, __builtin_fmaf(f.r0[2], z, f.t0)));
-    const float Y = __builtin_fmaf(f.r1[0], x, __builtin_fmaf(f.r1[1], y, __builtin_fmaf(f.r1[2], z, f.t1)));
-    const float Z = __builtin_fmaf(f.r2[0], x, __builtin_fmaf(f.r2[1], y, __builtin_fmaf(f.r2[2], z, f.t2)));
-    rz = __builtin_amdgcn_rcpf(Z);
-    const float du = __builtin_fmaf(X, rz, ku);
-    const float dv = __builtin_fmaf(Y, rz, kv);
-    return __builtin_fmaf(du, du, dv * dv);
+    const v2f_t px = {B.x, A.x}, py = {B.y, A.y}, pz = {B.z, A.z};
+    const v2f_t X = pk_fma(f.r0[0], px, pk_fma(f.r0[1], py, pk_fma(f.r0[2], pz, f.t0)));
+    const v2f_t Y = pk_fma(f.r1[0], px, pk_fma(f.r1[1], py, pk_fma(f.r1[2], pz, f.t1)));
+    const v2f_t Z = pk_fma(f.r2[0], px, pk_fma(f.r2[1], py, pk_fma(f.r2[2], pz, f.t2)));
+    rz = v2f_t{__builtin_amdgcn_rcpf(Z.x), __builtin_amdgcn_rcpf(Z.y)};
+    const v2f_t du = pk_fma(X, rz, v2f_t{E.x, E.y});
+    const v2f_t dv = pk_fma(Y, rz, v2f_t{E.z, E.w});
+    return pk_fma(du, du, dv * dv);
 }
 
 template <int MODE>
@@ -157,13 +170,21 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
             score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
         }
     } else {
-        FastModel F, G;
-        make_fast(mdl, k.fx, k.fy, F); // current point -> previous image   (estimatedOldPosition, RANSAC.cpp:346)
-        make_fast(inv, k.fx, k.fy, G); // previous point -> current image   (estimatedNewPosition, RANSAC.cpp:348)
+        // mdl: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
+        // inv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
+        FastModel F;
+        make_fast(mdl, inv, k.fx, k.fy, F);
         const float Qin = 1.02f * (umax + fc.thrUp + 0.016f * fc.fmaxK + 1.0f);
         const float kap1 = S * (1.02f * 8.0f * kEpsU * (2.0f * fc.fmaxK + Qin));
         const float kap0 = 1.02f * kEpsU * (8.0f * Qin + 2.0f * fc.cmaxK + 2.0f * fc.thrUp + 2.0f + umax);
-        const float rcap = 16384.0f / S; // |rcp(Z~)| above this: |Z~| < 2^-14 S, the band is not valid
+        // |rcp(Z~)| above rcap: |Z~| < 2^-14 S (the band is not valid) or delta > thrUp (the affine upper limit is not)
+        const float rcap2 = fc.thrUp > kap0 ? ((fc.thrUp - kap0) / kap1) * 0.99999f : -1.0f;
+        const float rcap = fminf(16384.0f / S, rcap2);
+        const float up4 = 1.0f + 4.0f * kEpsU;
+        const float a1 = (fc.cIn * kap1) * up4;                                   // lower limit: a0 - a1 * rmax
+        const float a0 = (fc.bIn0 - fc.cIn * kap0) - 4.0f * kEpsU * fc.bIn0;
+        const float b1 = (fc.cHi * kap1) * up4;                                   // upper limit: b0 + b1 * rmax
+        const float b0 = (fc.thr2Up + fc.cHi * kap0) * up4;
         int qn = 0;                      // parked evaluations of this wave (wave-uniform)
         unsigned long long parked = 0;
 
@@ -192,17 +213,16 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
         for (int m = m0; m < m1; ++m) {
             const float4 A = pa[m], B = pb[m], E = pe[m];
-            float ro, rn;
-            const float so = fast_sq(F, B.x, B.y, B.z, E.x, E.y, ro); // predictedOld - realOld
-            const float sn = fast_sq(G, A.x, A.y, A.z, E.z, E.w, rn); // predictedNew - realNew
+            v2f_t rz;
+            const v2f_t ss = fast_sq2(F, A, B, E, rz);
             // sums of squares are >= +0 and any NaN sorts above +inf as an unsigned pattern: the larger decides both tests
+            // (scalar copies first: __builtin_bit_cast applied to a vector-element expression reads element 0 for both)
+            const float so = ss.x, sn = ss.y;
             const uint32_t uo = __builtin_bit_cast(uint32_t, so), un = __builtin_bit_cast(uint32_t, sn);
             const float sm = __builtin_bit_cast(float, max(uo, un));
-            const float rm = fmaxf(fabsf(ro), fabsf(rn));
-            const float dl = __builtin_fmaf(kap1, rm, kap0);
-            const float lo2 = __builtin_fmaf(-fc.cIn, dl, fc.bIn0);
-            const float hO = __builtin_fmaf(fc.cOut, dl, fc.thrUp);
-            const float hi2 = hO * hO;
+            const float rm = fmaxf(fabsf(rz.x), fabsf(rz.y));
+            const float lo2 = __builtin_fmaf(-a1, rm, a0);
+            const float hi2 = __builtin_fmaf(b1, rm, b0);
             const unsigned long long mZ = __builtin_amdgcn_ballot_w64(rm <= rcap);
             const unsigned long long mIn = __builtin_amdgcn_ballot_w64(sm < lo2) & mZ;
             const unsigned long long mOut = __builtin_amdgcn_ballot_w64(sm > hi2) & mZ;
