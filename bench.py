@@ -35,7 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one non-FMA op per lane-cycle)
+VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one wave64 instruction per SIMD every 2 cycles)
+MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md)
+# VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane),
+# counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
+VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
+                 "ps_ransac_score_fast<1>": 24}
 
 
 def parse():
@@ -58,6 +63,10 @@ def parse():
                     help="step: every step forks from and joins the default stream; end: the sub-batch chains are ordered "
                          "only within their own stream, consecutive steps pipeline, one synchronisation at the fence")
     ap.add_argument("--split", type=float, default=0.5, help="with --streams 2: fraction of the pairs on stream 0")
+    ap.add_argument("--dump-records", default=None,
+                    help="test hook: write the per-pair records rank 0 holds after the last step (numpy .npy)")
+    ap.add_argument("--as-rank", type=int, default=None,
+                    help="test hook: single-rank run with the sequence and seed of this rank of a multi-rank run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
@@ -110,7 +119,8 @@ def main():
     ctxs = [api.Context(dev.index) for _ in range(S)]
     ctx = ctxs[0]
     prm = default_ransac_params(args.error_version)
-    cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + rank)
+    vrank = rank if args.as_rank is None else args.as_rank   # which rank's sequence / seed this process works on
+    cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + vrank)
 
     if world > 1:
         # the run's parameter block comes from rank 0 (one ~120 B broadcast at start, outside the timed region)
@@ -119,7 +129,7 @@ def main():
         args.hyp = _H
         cfg, _ = make_config(est, args.hyp, seed=_seed + rank)
     # -- synthetic sequence of this rank (config 3; config 4 = one such sequence per GPU) --
-    seq = synth.make_sequence(args.frames, args.kpts, config=3, index=rank)
+    seq = synth.make_sequence(args.frames, args.kpts, config=3, index=vrank)
     P = len(seq["pairs"])
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
@@ -184,21 +194,49 @@ def main():
             a0, n0 = totals.get(kname, (0.0, 0))
             totals[kname] = (a0 + ms_sum, n0 + n)
         c.enable_timing(False)
-    # one extra, untimed pass with the fast scoring kernel's statistics switched on: the share of (hypothesis, match)
-    # evaluations that fell inside the error band and were re-done by the value-exact code
+    # ---- single-chain leg (untimed for `value`): the same step as ONE launch chain on one stream, so that every kernel
+    # runs alone on the chip.  Its HIP-event durations are the kernels' own (the timed region above runs S chains
+    # side by side: there a launch's duration includes the time it shares the CUs with the other chains' kernels).
+    # `roofline` is computed from this leg; profiles/ holds the rocprofv3 kernel trace of `--streams 1`.
+    solo = {}
     parked_frac = None
-    if world == 1 and args.error_version == 1 and ctxs[0].get_option("score") == 1:
-        pk = ev = 0
-        for c in ctxs:
-            c.set_option("score_stats", 1)
-        step()
-        fence()
-        for c in ctxs:
-            a_, b_ = c.score_stats()
-            pk, ev = pk + a_, ev + b_
-            c.set_option("score_stats", 0)
-        parked_frac = pk / ev if ev else None
+    if world == 1:
+        c0 = ctxs[0]
+        solo_steps = max(3, min(8, args.steps))
+
+        def solo_step():
+            run_pairs_split([c0], [chains[0]], prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=[0, P], join=False)
+
+        solo_step()
+        torch.cuda.synchronize(dev)
+        c0.enable_timing(True)
+        ts0 = time.perf_counter()
+        for _ in range(solo_steps):
+            solo_step()
+        torch.cuda.synchronize(dev)
+        solo_ms_per_step = (time.perf_counter() - ts0) / solo_steps * 1e3
+        solo = {k: v[0] / max(v[1], 1) for k, v in c0.kernel_time_totals().items()}
+        c0.enable_timing(False)
+        # one more pass with the fast scoring kernel's statistics on: the share of (hypothesis, match) evaluations
+        # that fell inside the error band and were re-done by the value-exact code
+        if args.error_version == 1 and c0.get_option("score") == 1:
+            c0.set_option("score_stats", 1)
+            solo_step()
+            torch.cuda.synchronize(dev)
+            pk, ev = c0.score_stats()
+            c0.set_option("score_stats", 0)
+            parked_frac = pk / ev if ev else None
     res = pb.download()
+    if args.dump_records:
+        # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
+        if world > 1 and rank == 0:
+            blocks = [np.concatenate([gathered[i][r].cpu().numpy() for i in range(S)]) for r in range(world)]
+            np.save(args.dump_records, np.stack(blocks))
+        elif world == 1:
+            st32 = res["stats"].view(np.int32).reshape(P, -1)
+            rec = sharding.pack_records(torch.from_numpy(res["pose"]), torch.from_numpy(st32[:, 5].copy()),
+                                        torch.from_numpy(st32[:, 0].copy()))
+            np.save(args.dump_records, rec.numpy()[None])
 
     if rank == 0:
         stats = res["stats"]
@@ -209,49 +247,43 @@ def main():
         Hs = args.hyp
         bytes_per_pair = float(np.mean([api.algorithmic_bytes(args.kpts, int(s["numMatchesIn"]),
                                                               int(s["numMatchesValid"]), Hs) for s in stats]))
-        kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # average launch duration, ms
-        dom = max(kern, key=kern.get)
-        dom_ms = kern[dom]
-        pairs_per_launch = P / S
-        achieved = bytes_per_pair * pairs_per_launch / (dom_ms * 1e-3) / 1e9
-        # VALU issue model of the two sweeps: static instruction mix of the hot loops (profiles/isa_mix.json,
-        # from profiles/isa_mix.py) priced with the per-instruction issue costs measured on this GPU model
-        # (profiles/microbench/valu_rates_mi355x.txt).  frac = modelled issue time / measured kernel time.
-        valu_issue = None
-        try:
-            if "ps_hamming_nn" not in kern:
-                raise KeyError("matrix-core matcher: the VALU issue model does not apply")
-            mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
-            simd_hz = 256 * 4 * 2.4e9
-            waves_match = (P / S) * (args.kpts / 64.0)                # per launch: one lane per train row
-            units_match = waves_match * args.kpts                     # descriptor pairs per wave
-            waves_score = (P / S) * (Hs / 64.0)
-            units_score = waves_score * m_valid
-            km, ks = mix["ps_hamming_nn"], mix["ps_ransac_score<%d>" % (args.error_version if args.error_version in (0, 1, 2, 4) else 0)]
-            t_match = units_match * km["model_cycles_per_unit"] / simd_hz * 1e3
-            t_score = units_score * ks["model_cycles_per_unit"] / simd_hz * 1e3
-            valu_issue = {
-                "ps_hamming_nn": {"valu_per_pair": km["valu_per_unit"], "model_ms": t_match,
-                                  "frac": t_match / kern.get("ps_hamming_nn", float("nan"))},
-                "ps_ransac_score": {"valu_per_eval": ks["valu_per_unit"], "model_ms": t_score,
-                                    "frac": t_score / kern.get("ps_ransac_score", float("nan"))},
-                # the whole step against the same model: S launches of each sweep per step, whatever their overlap
-                "step": {"model_ms": S * (t_match + t_score),
-                         "frac": S * (t_match + t_score) / (elapsed / args.steps * 1e3)},
-                "peak_lane_ops_per_s": VALU_PEAK_TOPS * 1e12,
-                "achieved_lane_ops_per_s": {
-                    "ps_hamming_nn": units_match * km["valu_per_unit"] * 64 / (kern.get("ps_hamming_nn", float("nan")) * 1e-3),
-                    "ps_ransac_score": units_score * ks["valu_per_unit"] * 64 / (kern.get("ps_ransac_score", float("nan")) * 1e-3)},
-            }
-        except Exception:
-            valu_issue = None
+        kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # timed region: average launch duration, ms
+        matcher = "mfma" if ctx.get_option("matcher") == 1 else "valu"
+        score = "fast" if (ctx.get_option("score") == 1 and args.error_version == 1) else "exact"
+
+        def kernel_bounds(kms, pairs_per_launch):
+            """What actually bounds the two sweeps (the path is compute-bound, not HBM-bound): achieved rate of the
+            bounding unit / its nominal peak (MI355X_MICROARCH.md).  Instruction counts: profiles/isa_mix.json."""
+            out = {}
+            if "ps_hamming_mfma" in kms:
+                flops = 2.0 * 256.0 * args.kpts * args.kpts * pairs_per_launch
+                ach = flops / (kms["ps_hamming_mfma"] * 1e-3) / 1e12
+                out["ps_hamming_mfma"] = {"bound": "mfma", "dtype": "fp4 (e2m1) x fp4 -> f32", "achieved": ach,
+                                          "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": ach / MFMA_FP4_PEAK_TFLOPS}
+            vk = {"ps_hamming_nn": (VALU_PER_UNIT["ps_hamming_nn"], args.kpts * float(args.kpts) * pairs_per_launch / 64.0),
+                  "ps_ransac_score": (VALU_PER_UNIT["ps_ransac_score_%s<%d>" % (score, args.error_version)]
+                                      if ("ps_ransac_score_%s<%d>" % (score, args.error_version)) in VALU_PER_UNIT else None,
+                                      Hs * m_valid * pairs_per_launch / 64.0)}
+            for name, (per_unit, wave_units) in vk.items():
+                if name in kms and per_unit:
+                    ach = wave_units * per_unit * 64.0 / (kms[name] * 1e-3) / 1e12
+                    out[name] = {"bound": "valu", "valu_instructions_per_unit": per_unit, "achieved": ach,
+                                 "peak": VALU_PEAK_TOPS, "unit": "T lane-instructions/s", "frac": ach / VALU_PEAK_TOPS}
+            return out
+
+        rk = solo if solo else kern                      # kernels' own durations when the single-chain leg ran
+        r_pairs = P if solo else P / S
+        dom = max((k for k in rk if k != "ps_expand_query_fp4"), key=rk.get)
+        dom_ms = rk[dom]
+        achieved = bytes_per_pair * r_pairs / (dom_ms * 1e-3) / 1e9
+        bounds_solo = kernel_bounds(rk, r_pairs)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
-                key = (f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}" +
-                       (f"xS{S}" if S > 1 else ""))
+                key = f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}x{matcher}x{score}"
                 traffic = t.get(key, {}).get(dom)
             except Exception:
                 traffic = None
@@ -270,22 +302,33 @@ def main():
                               else "")),
                 "pairs_per_step": P * world, "kpts": args.kpts, "hypotheses": args.hyp,
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "join": args.join,
+                "matcher_kernel": matcher, "score_kernel": score,
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
                 "mean_inliers": float(stats["numInliers"].mean()),
                 "accepted_pairs": int(stats["accepted"].sum()),
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": pairs_per_launch,
+                         "algorithmic_bytes_per_pair": bytes_per_pair, "pairs_per_launch": r_pairs,
                          "avg_launch_ms": dom_ms,
-                         "note": "path is VALU-issue-bound, not HBM-bound (DESIGN.md section 4): see valu_issue"},
-            "kernel_ms": kern,
+                         "leg": ("single launch chain (--streams 1 equivalent), run inside this process after the timed "
+                                 "region: the kernel alone on the chip" if solo else "timed region"),
+                         "bound_actual": bounds_solo.get(dom, {}).get("bound"),
+                         "bound_actual_frac": bounds_solo.get(dom, {}).get("frac"),
+                         "note": "the path is compute-bound (VALU issue for the scoring sweep, MFMA for the Hamming "
+                                 "sweep), not HBM-bound: see kernel_bounds"},
+            "kernel_ms": rk,
+            "kernel_bounds": bounds_solo,
+            "single_chain": ({"ms_per_step": solo_ms_per_step, "pairs_per_s": P / (solo_ms_per_step * 1e-3),
+                              "kernel_ms_sum": sum(solo.values())} if solo else None),
+            "timed_region_kernel_ms": kern,
             "score_parked_frac": parked_frac,
-            "valu_issue": valu_issue,
             "streams_note": (None if S == 1 else
-                             f"{S} sub-batch chains on {S} HIP streams (join={args.join}): per-launch durations are measured "
-                             "while the other chains' kernels share the CUs, so kernel_ms sums to more than ms_per_step "
-                             "and the per-kernel fractions are lower than with --streams 1 (DESIGN.md section 5)"),
+                             f"value / ms_per_step: {S} sub-batch chains on {S} HIP streams (join={args.join}); "
+                             "timed_region_kernel_ms are per-launch durations of sub-batches measured while the other "
+                             "chains' kernels share the CUs (they sum to more than ms_per_step); kernel_ms / roofline / "
+                             "kernel_bounds come from the single-chain leg (DESIGN.md section 5)"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))
@@ -322,13 +365,15 @@ def cpu_baseline(args, seq, prm, cfg, est):
 
     n0 = min(len(pairs), max(cores, 2))
     t = run(cfg, n0, cores)                                   # calibration (also warms the pages)
-    n = int(min(len(pairs), max(n0, n0 * args.cpu_seconds / max(t, 1e-3))))
-    reps = int(max(1, min(8, round(args.cpu_seconds / max(t * n / n0, 1e-3)))))   # whole sequence too short: repeat it
-    t = sum(run(cfg, n, cores) for _ in range(reps))
-    out = {"cpu_baseline": {"value": reps * n / t, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                            "sample": f"first {n} of {len(pairs)} pairs of the same sequence x {reps} passes, same H/"
-                                      f"errorVersion/estimator as the GPU run, OpenMP over pairs, {t:.1f} s wall = "
-                                      f"{t * cores:.0f} core-seconds"}}
+    passes = 5
+    n = int(min(len(pairs), max(n0, n0 * (args.cpu_seconds / passes) / max(t, 1e-3))))
+    times = sorted(run(cfg, n, cores) for _ in range(passes))
+    med = times[passes // 2]
+    out = {"cpu_baseline": {"value": n / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                            "passes": passes, "pass_seconds": times,
+                            "sample": f"first {n} of {len(pairs)} pairs of the same sequence, {passes} passes, median; same "
+                                      f"H/errorVersion/estimator as the GPU run, OpenMP over pairs on {cores} threads, "
+                                      f"{sum(times):.1f} s wall in all"}}
     # what the reference itself would do: sequential adaptive schedule, <= 487 iterations (RANSAC.cpp:30,450-453)
     cfg_ref, _ = make_config(EST_RANSAC, 487, seed=cfg.seed)
     n2 = min(len(pairs), max(n, 4 * cores))

@@ -108,7 +108,10 @@ int ps_context_create(int device, PsContext **out);
 void ps_context_destroy(PsContext *ctx);
 /* Use an externally owned hipStream_t (e.g. the caller's current stream); NULL restores the private stream, which
  * is created hipStreamNonBlocking: it is NOT ordered with the legacy default stream, so a caller working on the
- * default stream hands over an explicit stream (forked from / joined to the default one) or synchronises. */
+ * default stream hands over an explicit stream (forked from / joined to the default one) or synchronises.
+ * The scratch arena belongs to the context: when the stream changes, the new stream is made to wait (event) for
+ * the work already queued on the previous one, so consecutive calls on different streams never overlap on it.
+ * One context still serves one caller thread at a time; concurrent chains use one context each. */
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);
 /* Kernel variants kept side by side for A/B measurements and as tested twins (results are identical):

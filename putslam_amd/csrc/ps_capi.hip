@@ -36,6 +36,7 @@ struct PsContext {
     int device = 0;
     hipStream_t own = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t handoff = nullptr; // orders a newly selected stream behind the work queued on the previous one
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
@@ -622,6 +623,7 @@ void ps_context_destroy(PsContext *ctx)
     for (Buf *b : all) release(*b);
     for (hipEvent_t e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->handoff) (void)hipEventDestroy(ctx->handoff);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
 }
@@ -629,7 +631,16 @@ void ps_context_destroy(PsContext *ctx)
 int ps_context_set_stream(PsContext *ctx, void *s)
 {
     if (!ctx) return PS_ERR_BAD_ARG;
-    ctx->stream = s ? (hipStream_t)s : ctx->own;
+    hipStream_t next = s ? (hipStream_t)s : ctx->own;
+    if (next == ctx->stream) return PS_OK;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    // The scratch arena and the stop tables belong to the context, not to a stream: work queued on the new stream
+    // must not start before the work already queued on the old one has finished with them.
+    if (!ctx->handoff) PS_HIP(hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming));
+    PS_HIP(hipEventRecord(ctx->handoff, ctx->stream));
+    PS_HIP(hipStreamWaitEvent(next, ctx->handoff, 0));
+    ctx->stream = next;
     return PS_OK;
 }
 
@@ -1319,8 +1330,12 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     hm[2] = slot;
     hm[3] = 0;
     memcpy(&hm[4], &cfg->seed, sizeof(uint64_t));
-    s->curSlot = slot;
-    s->frames++;
+    // The stream's state (curSlot, frames) is committed only when the push has succeeded: after a failed push
+    // (bad parameters, a HIP error) the resident frame is still the previous one and the next push matches against it.
+    auto commit = [&]() {
+        s->curSlot = slot;
+        s->frames++;
+    };
     auto copy_in = [&](size_t rows) -> int {
         if (rows > 0) {
             PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, rows * 32, hipMemcpyHostToDevice,
@@ -1337,6 +1352,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         rc = copy_in((size_t)n);
         if (rc) return rc;
         PS_HIP(hipStreamSynchronize(ctx->stream));
+        commit();
         *nmatches = -1;
         return PS_OK;
     }
@@ -1429,6 +1445,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         s->warm = true;
     }
     PS_HIP(hipStreamSynchronize(ctx->stream));
+    commit();
     int32_t nm = 0;
     memcpy(&nm, s->hres + s->offNum, sizeof nm);
     memcpy(pose, s->hres + s->offPose, 16 * sizeof(float));

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak test: HIP path vs oracle over many random configurations (sizes, inlier ratios, noise,
-error modes, estimators, thresholds, seeds).  Not collected by pytest; run on the GPU box:
+error modes, estimators, thresholds, seeds).  tests/test_gpu_fuzz_slice.py collects a 300-configuration slice under
+`-m gpu`; longer soaks are run by hand on the GPU box:
 
     python tests/fuzz_gpu.py --iters 3000 --seed 1
 """
@@ -19,18 +20,14 @@ from putslam_amd import api, synth  # noqa: E402
 from putslam_amd._abi import EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=1000)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--max-kpts", type=int, default=1500)
-    a = ap.parse_args()
-    rng = np.random.default_rng(a.seed)
-    ctx = api.Context(0)
+def run(iters, seed, max_kpts=1500, ctx=None, verbose=True):
+    """Returns the number of configurations in which the HIP path and the oracle disagree."""
+    rng = np.random.default_rng(seed)
+    ctx = ctx or api.Context(0)
     t0 = time.time()
     bad = 0
-    for it in range(a.iters):
-        n = int(rng.integers(4, a.max_kpts))
+    for it in range(iters):
+        n = int(rng.integers(4, max_kpts))
         frac = float(rng.uniform(0.05, 0.95))
         noise = float(10 ** rng.uniform(-4, -1.3))
         pa, pb = synth.make_pair(n, config=7, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)
@@ -56,8 +53,18 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH", dict(it=it, n=n, frac=frac, noise=noise, mode=mode, est=est, H=H), g["stats"], c["stats"], flush=True)
-        if (it + 1) % 200 == 0:
+        if verbose and (it + 1) % 200 == 0:
             print(f"{it + 1} iterations, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-kpts", type=int, default=1500)
+    a = ap.parse_args()
+    bad = run(a.iters, a.seed, a.max_kpts)
     print(f"fuzz done: {a.iters} iterations, {bad} mismatches")
     return 1 if bad else 0
 

@@ -245,3 +245,118 @@ def test_run_pairs_stream_ordering(ctx):
     assert torch.equal(pose_s, pose_ref)
     _compare(other.download(), ref.download(), len(seq["pairs"]))
     ctx.set_stream(0)
+
+
+def test_full_length_sequence_sampled_against_oracle(ctx, oracle):
+    """BASELINE configs[2] at full length -- the 500-frame x 2000-keypoint sequence bench.py times, H = 4096 fixed,
+    reprojection error -- through the default submission (three chains on three streams): 20 sampled pairs are compared
+    field by field with the oracle (matches, mask, pose bytes, statistics), every pair is checked for the
+    size-independent properties, and the composed trajectory stays next to the ground truth."""
+    import torch
+    from putslam_amd import api, sharding
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
+    seq = synth.make_sequence(500, 2000, config=3, index=0)
+    P = len(seq["pairs"])
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    H, seed = 4096, 0xB0B0
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    ctxs = [ctx, api.Context(0), api.Context(0)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    run_pairs_split(ctxs, streams, prm, EST_FIXED, H, seed, TUM_FR1_K, fs, pb, join=False)
+    g = pb.download()
+    for c in ctxs[1:]:
+        c.close()
+    ctx.set_stream(0)
+    assert int(g["stats"]["accepted"].sum()) == P
+    for p in range(P):
+        n = int(g["numMatches"][p])
+        st = g["stats"][p]
+        assert st["numMatchesIn"] == n and st["numInliers"] == int(g["inlierMask"][p, :n].sum())
+        assert st["numInliers"] <= st["bestInlierCount"] <= st["numMatchesValid"] <= n and st["iterationsRun"] == H
+        assert np.abs(g["pose"][p].reshape(4, 4).T - seq["gt"][p]).max() < 5e-3
+    sample = sorted(set(np.random.default_rng(7).integers(0, P, 19).tolist() + [0, P - 1]))[:20]
+    for p in sample:
+        f0, f1 = seq["pairs"][p]
+        m = oracle.match_hamming256(seq["desc"][f0], seq["desc"][f1])
+        n = int(g["numMatches"][p])
+        assert n == len(m) and g["matches"][p, :n].tobytes() == m.tobytes(), p
+        cfgp, _ = make_config(EST_FIXED, H, seed=seed + p)          # pair p draws from seed + p
+        c = oracle.ransac_rigid3d(prm, cfgp, TUM_FR1_K, seq["pts"][f0], seq["pts"][f1], m)
+        assert np.array_equal(c["mask"], g["inlierMask"][p, :n]), p
+        assert c["pose"].T.astype(np.float32).tobytes() == g["pose"][p].tobytes(), p
+        for fld in STAT_FIELDS:
+            a, b = g["stats"][p][fld], c["stats"][fld]
+            assert a == b or (np.isnan(a) and np.isnan(b)), (p, fld, a, b)
+    traj = sharding.compose_trajectory(g["pose"].reshape(P, 4, 4).transpose(0, 2, 1))
+    gt = sharding.compose_trajectory(seq["gt"].astype(np.float32))
+    assert np.abs(traj[-1][:3, 3] - gt[-1][:3, 3]).max() < 0.05
+
+
+def test_stream_push_failure_leaves_the_resident_frame_alone(ctx, oracle):
+    """A push that fails (unsupported parameters, hypothesis count out of range) must not advance the stream: the next
+    good push still matches against the last frame that was really uploaded, exactly like the uninterrupted sequence."""
+    from putslam_amd import api
+    seq = synth.make_sequence(5, 500, config=3, index=77)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+
+    def run(inject):
+        st = api.VoStream(ctx, 500)
+        out = []
+        for f in range(5):
+            cfg, _ = make_config(EST_RANSAC, 487, seed=9 + f)
+            if inject and f in (2, 3):
+                bad = default_ransac_params(EUCLIDEAN_ERROR)
+                bad.usedPairs = 4                                     # PS_ERR_UNSUPPORTED
+                with pytest.raises(api.PsError):
+                    st.push(bad, cfg, TUM_FR1_K, seq["desc"][4], seq["pts"][4])   # a different frame: must not stick
+                cbad, _ = make_config(EST_RANSAC, 0, seed=1)          # numHypotheses out of range
+                with pytest.raises(api.PsError):
+                    st.push(prm, cbad, TUM_FR1_K, seq["desc"][0], seq["pts"][0])
+            out.append(st.push(prm, cfg, TUM_FR1_K, seq["desc"][f], seq["pts"][f]))
+        st.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a[0] is None and b[0] is None
+    for f in range(1, 5):
+        assert a[f]["matches"].tobytes() == b[f]["matches"].tobytes(), f
+        assert a[f]["pose"].tobytes() == b[f]["pose"].tobytes() and np.array_equal(a[f]["mask"], b[f]["mask"])
+        m = oracle.match_hamming256(seq["desc"][f - 1], seq["desc"][f])
+        assert b[f]["matches"].tobytes() == m.tobytes()
+    # the first frame failing leaves the stream empty: the next push is still a first frame
+    st = api.VoStream(ctx, 500)
+    bad = default_ransac_params(EUCLIDEAN_ERROR)
+    bad.usedPairs = 5
+    cfg, _ = make_config(EST_RANSAC, 487, seed=1)
+    assert st.push(bad, cfg, TUM_FR1_K, seq["desc"][0], seq["pts"][0]) is None   # first frames are only stored
+    assert st.push(prm, cfg, TUM_FR1_K, seq["desc"][1], seq["pts"][1]) is not None
+    st.close()
+
+
+def test_one_context_called_from_two_streams_is_ordered(oracle):
+    """ps_context_set_stream orders the new stream behind the work queued on the previous one: two run_pairs calls on ONE
+    context from two different torch streams share the scratch arena and must still both be right."""
+    import torch
+    from putslam_amd import api
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    c = api.Context(0)
+    seqs = [synth.make_sequence(40, 900, config=3, index=300 + i) for i in range(2)]
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 2048, seed=5)
+    fss = [FrameSetDevice(s["desc"], s["pts"], s["nkpts"]) for s in seqs]
+    ref = []
+    for s, fs in zip(seqs, fss):
+        pb = PairBatchDevice(s["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        ref.append(pb.download())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        pbs = [PairBatchDevice(s["pairs"], fs.max_kpts) for s, fs in zip(seqs, fss)]
+        for i in (0, 1, 0, 1):                                        # alternate streams without synchronising
+            with torch.cuda.stream(streams[i]):
+                run_pairs(c, prm, cfg, TUM_FR1_K, fss[i], pbs[i])
+        torch.cuda.synchronize()
+        for i in range(2):
+            _compare(pbs[i].download(), ref[i], len(seqs[i]["pairs"]))
+    c.close()
