@@ -26,7 +26,7 @@ bench: all
 	python bench.py
 
 clean:
-	rm -f $(LIB) $(DROPIN) tests/cpp/test_dropin
+	rm -f $(LIB) $(DROPIN) tests/cpp/test_dropin tests/cpp/test_reference_shaped
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle test-cpu test-gpu bench clean

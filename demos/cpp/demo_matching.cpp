@@ -1,6 +1,6 @@
 // demo_matching.cpp -- C++ counterpart of the reference's demos/demoMatching.cpp for the part of its loop that
 // lies on the hot path: frames enter with descriptors + back-projected 3-D points (detection is out of scope),
-// go through putslam::Matcher (createMatcherOpenCV -> detectInitFeatures / match, src/PUTSLAM/PUTSLAM.cpp:718-740),
+// go through putslam_hip::FrameMatcher (createMatcherOpenCV -> detectInitFeatures / match, src/PUTSLAM/PUTSLAM.cpp:718-740),
 // the pose increments are composed with the 0.1 m gate and written as a TUM trajectory (PUTSLAM.cpp:1006-1016).
 // Frames are synthetic (a static cloud seen from a camera on a smooth path, shuffled keypoint order, descriptor
 // bit noise, outliers), so the estimated trajectory can be checked against the ground truth it was made from.
@@ -84,9 +84,9 @@ int main(int argc, char **argv)
     }
     for (auto &b : wdesc) b = (uint8_t)rng.next();
 
-    putslam::Matcher *matcher = putslam::createMatcherOpenCV();
+    putslam_hip::FrameMatcher *matcher = putslam_hip::createFrameMatcher();
     matcher->setSampleSeed(42);
-    putslam::VOTrajectory vo;
+    putslam_hip::VOTrajectory vo;
     FILE *traj = trajPath ? std::fopen(trajPath, "w") : nullptr;
     Pose prevPose = camera_pose(0);
     double worstT = 0, worstR = 0, seconds = 0;
@@ -155,7 +155,7 @@ int main(int argc, char **argv)
             if (k % 20 == 0 || k == frames - 1)
                 std::printf("frame %4d: %4zu inliers, point inlier ratio %.3f\n", k, inliers.size(), ratio);
         }
-        if (traj) std::fprintf(traj, "%s\n", putslam::VOTrajectory::freiburgLine(vo.VOPoseEstimate, 1305031102.175304 + k / 30.0).c_str());
+        if (traj) std::fprintf(traj, "%s\n", putslam_hip::VOTrajectory::freiburgLine(vo.VOPoseEstimate, 1305031102.175304 + k / 30.0).c_str());
         prevPose = P;
     }
     if (traj) std::fclose(traj);

@@ -48,6 +48,13 @@ struct Point2f {
     Point2f(float x_, float y_) : x(x_), y(y_) {}
 };
 
+// what the hot path reads of a cv::KeyPoint: the pyramid octave (matcher.cpp:641,783); same field order as OpenCV's
+struct KeyPoint {
+    Point2f pt;
+    float size = 0, angle = -1, response = 0;
+    int octave = 0, class_id = -1;
+};
+
 // Header + shared pixel buffer, like cv::Mat: copies are shallow.
 class Mat {
   public:

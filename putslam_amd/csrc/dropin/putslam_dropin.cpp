@@ -55,6 +55,7 @@ void cameraToK(const cv::Mat &cameraMatrix, float K[9], bool &have)
 PsRansacParams toPs(const RANSAC::parameters &p)
 {
     PsRansacParams q;
+    std::memset(&q, 0, sizeof q); // padding bytes too: the C ABI may compare parameter blocks bytewise
     q.verbose = p.verbose;
     q.errorVersion = p.errorVersion;
     q.errorVersionVO = p.errorVersionVO;
@@ -282,8 +283,12 @@ TransformEst *createKabschEstimator(void)
     return kabsch.get();
 }
 
+} // namespace putslam
+
+namespace putslam_hip {
+
 // ---------------------------------------------------------------------------------------------
-Matcher::MatcherParameters::MatcherParameters()
+FrameMatcher::MatcherParameters::MatcherParameters()
 {
     // shipped defaults, resources/putslammatcherOpenCVParameters.xml:29-37
     RANSACParams.verbose = 0;
@@ -303,7 +308,7 @@ Matcher::MatcherParameters::MatcherParameters()
     for (int i = 0; i < 9; ++i) cameraMatrixMat.at<float>(i / 3, i % 3) = K[i];
 }
 
-void Matcher::detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
+void FrameMatcher::detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
 {
     prevDescriptors = descriptors;
     prevFeatures3D.swap(features3D);
@@ -312,7 +317,7 @@ void Matcher::detectInitFeatures(cv::Mat descriptors, std::vector<Eigen::Vector3
 }
 
 // Resident-frame state of one matcher instance: its own context (stream + scratch) and the two-slot frame store.
-struct Matcher::Fused {
+struct FrameMatcher::Fused {
     PsContext *ctx = nullptr;
     PsVoStream *stream = nullptr;
     int cap = 0;
@@ -323,7 +328,10 @@ struct Matcher::Fused {
     }
 };
 
-bool Matcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
+FrameMatcher::FrameMatcher(const std::string _name) : name(_name), frameCounter(0) {}
+FrameMatcher::~FrameMatcher() {}
+
+bool FrameMatcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
                              Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
                              double &pointInlierRatio)
 {
@@ -332,7 +340,7 @@ bool Matcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen
     if ((n > 0 && (descriptors.cols != PS_DESC_BYTES || descriptors.rows != n)) ||
         (np > 0 && (prevDescriptors.cols != PS_DESC_BYTES || prevDescriptors.rows != np)))
         return false; // float descriptors / inconsistent sizes: the generic sequence reports them
-    if (!fused_) fused_ = std::make_shared<Fused>();
+    if (!fused_) fused_.reset(new Fused());
     Fused &f = *fused_;
     if (!f.ctx) {
         int dev = 0;
@@ -401,7 +409,7 @@ bool Matcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen
     return true;
 }
 
-double Matcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
+double FrameMatcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,
                       std::vector<cv::DMatch> &inlierMatches)
 {
     matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // matcher.cpp:491-492
@@ -420,7 +428,7 @@ double Matcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features
     return ratio;
 }
 
-double Matcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
+double FrameMatcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector3f> pts0, cv::Mat desc1,
                                         std::vector<Eigen::Vector3f> pts1, Eigen::Matrix4f &estimatedTransformation,
                                         std::vector<cv::DMatch> &inlierMatches)
 {
@@ -434,7 +442,7 @@ double Matcher::matchFeatureLoopClosure(cv::Mat desc0, std::vector<Eigen::Vector
     return RANSAC::pointInlierRatio(inlierMatches, matches);
 }
 
-double Matcher::matchXYZ(const std::vector<MapFeatureXYZ> &mapFeatures, cv::Mat currentPoseDescriptors,
+double FrameMatcher::matchXYZ(const std::vector<MapFeatureXYZ> &mapFeatures, cv::Mat currentPoseDescriptors,
                          std::vector<Eigen::Vector3f> &currentPoseFeatures3D, const std::vector<int> &currentPoseOctaves,
                          const std::vector<double> &currentPoseDetDists, Eigen::Matrix4f &estimatedTransformation,
                          std::vector<cv::DMatch> &inlierMatches, int computationNumber)
@@ -540,35 +548,40 @@ std::string VOTrajectory::freiburgLine(const Eigen::Matrix4f &T, double timestam
     return o.str();
 }
 
-// "A single instance of OpenCV matcher", matcherOpenCV.cpp:20
-MatcherOpenCV::Ptr matcherClass, loopClosingMatcherClass;
+// "A single instance of OpenCV matcher", matcherOpenCV.cpp:20 -- the same ownership rule for the hot-path matcher
+FrameMatcherHIP::Ptr matcherClass, loopClosingMatcherClass;
 
-Matcher *createMatcherOpenCV(void)
+FrameMatcher *createFrameMatcher(void)
 {
-    matcherClass.reset(new MatcherOpenCV());
+    matcherClass.reset(new FrameMatcherHIP());
     return matcherClass.get();
 }
-Matcher *createMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile)
+FrameMatcher *createFrameMatcher(const std::string _parametersFile, const std::string _grabberParametersFile)
 {
-    matcherClass.reset(new MatcherOpenCV(_parametersFile, _grabberParametersFile));
+    matcherClass.reset(new FrameMatcherHIP(_parametersFile, _grabberParametersFile));
     return matcherClass.get();
 }
-Matcher *createloopClosingMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile)
+FrameMatcher *createLoopClosingFrameMatcher(const std::string _parametersFile, const std::string _grabberParametersFile)
 {
-    loopClosingMatcherClass.reset(new MatcherOpenCV(_parametersFile, _grabberParametersFile));
+    loopClosingMatcherClass.reset(new FrameMatcherHIP(_parametersFile, _grabberParametersFile));
     return loopClosingMatcherClass.get();
 }
 
-} // namespace putslam
-
 // ---------------------------------------------------------------------------------------------
-MatcherOpenCV::MatcherOpenCV(void) : putslam::Matcher("OpenCV Matcher") { fusedMatch_ = true; }
+FrameMatcherHIP::FrameMatcherHIP(void) : FrameMatcher("OpenCV Matcher") { fusedMatch_ = true; }
 // XML parsing (tinyXML, matcher.h:188-357) is outside the path: parameters are plain members to set.
-MatcherOpenCV::MatcherOpenCV(const std::string, const std::string) : putslam::Matcher("OpenCVMatcher") { fusedMatch_ = true; }
-MatcherOpenCV::~MatcherOpenCV(void) {}
-const std::string &MatcherOpenCV::getName() const { return name; }
+FrameMatcherHIP::FrameMatcherHIP(const std::string, const std::string) : FrameMatcher("OpenCVMatcher") { fusedMatch_ = true; }
+FrameMatcherHIP::~FrameMatcherHIP(void) {}
+const std::string &FrameMatcherHIP::getName() const { return name; }
 
-std::vector<cv::DMatch> MatcherOpenCV::performMatching(cv::Mat prevDescriptors, cv::Mat descriptors)
+std::vector<cv::DMatch> FrameMatcherHIP::performMatching(cv::Mat prevDescriptors, cv::Mat descriptors)
+{
+    return hammingCrossCheckMatch(prevDescriptors, descriptors);
+}
+
+// MatcherOpenCV::performMatching (matcherOpenCV.cpp:198-206) as a free function: the body the reference's own class
+// gets in a PUTSLAM build.
+std::vector<cv::DMatch> hammingCrossCheckMatch(cv::Mat prevDescriptors, cv::Mat descriptors)
 {
     std::vector<cv::DMatch> matches;
     if (prevDescriptors.empty() || descriptors.empty()) return matches;
@@ -591,3 +604,5 @@ std::vector<cv::DMatch> MatcherOpenCV::performMatching(cv::Mat prevDescriptors, 
     matches.resize((size_t)n);
     return matches;
 }
+
+} // namespace putslam_hip

@@ -6,8 +6,16 @@
 //   ::RANSAC_USAC                  include/putslam/USAC/USAC_wrapper.h:16-65, src/USAC/USAC_wrapper.cpp
 //   putslam::TransformEst          include/putslam/TransformEst/transformEst.h:16-26
 //   putslam::KabschEst + factory   include/putslam/TransformEst/kabschEst.h, src/TransformEst/kabschEst.cpp
-//   putslam::Matcher (hot-path part) include/putslam/Matcher/matcher.h:24,100-151,405-422
-//   MatcherOpenCV factories        include/putslam/Matcher/matcherOpenCV.h:17-22, src/Matcher/matcherOpenCV.cpp:20-47
+//
+// The Matcher plugin itself (putslam::Matcher / ::MatcherOpenCV, include/putslam/Matcher/matcher.h:24,100-151,405-422)
+// keeps ITS OWN class in a PUTSLAM build: detection, description and tracking are image-domain OpenCV stages outside the
+// path.  This library therefore defines no symbol of that name.  What it provides for the plugin is
+//   putslam_hip::FrameMatcher / FrameMatcherHIP   the hot-path state machine behind Matcher::match / runVO /
+//                                  matchXYZ / matchFeatureLoopClosure (matcher.cpp:452-516,606-861) on descriptors and
+//                                  3-D points, which the reference's methods call after their detect / describe part;
+//   putslam_matcher_glue.h         the same entry points with the reference's own argument types (SensorFrame-derived
+//                                  descriptors, std::vector<MapFeature>, framesIds[2], pairedFeatures), as templates;
+//   INTEGRATION.md section 2       the bodies a maintainer puts into matcher.cpp / matcherOpenCV.cpp.
 //   RGBD helpers                   include/putslam/RGBD/RGBD.h:38-51, src/RGBD/RGBD.cpp:10-16,30-65,92-98
 //
 // Everything computes on the GPU through libputslam_hip.so; there is no host fallback.
@@ -20,6 +28,8 @@
 #include <vector>
 
 #include "putslam_compat_types.h"
+
+#define PUTSLAM_HIP_DESC_BYTES 32 // ORB / LDB rows (matcherOpenCV.cpp:90, ldb.cpp:61,657)
 
 // ---------------------------------------------------------------------------------------------
 class RANSAC {
@@ -135,11 +145,17 @@ class KabschEst : public TransformEst {
 // library-owned singleton, raw pointer returned, a second call replaces the instance (kabschEst.cpp:8,70-73)
 TransformEst *createKabschEstimator(void);
 
+} // namespace putslam
+
+namespace putslam_hip {
+
 // ---------------------------------------------------------------------------------------------
 // Hot-path part of the Matcher plugin.  Detection / description / tracking are image-domain OpenCV
 // stages outside the path: their pure virtuals are not part of this class; the
 // frame enters at the point where Matcher::match has descriptors and 3-D points (matcher.cpp:467-480).
-class Matcher {
+// Deliberately NOT named putslam::Matcher: the reference's class of that name stays in a PUTSLAM build and
+// delegates to this one, so the two can be linked into one program.
+class FrameMatcher {
   public:
     struct MatcherParameters {
         int verbose = 0;
@@ -171,8 +187,11 @@ class Matcher {
         std::vector<Eigen::Vector3f> feature3D;
     };
 
-    Matcher(const std::string _name) : name(_name), frameCounter(0) {}
-    virtual ~Matcher() {}
+    FrameMatcher(const std::string _name);
+    virtual ~FrameMatcher();
+    // one resident frame store (context + stream + HBM slots) per instance: not copyable
+    FrameMatcher(const FrameMatcher &) = delete;
+    FrameMatcher &operator=(const FrameMatcher &) = delete;
     virtual const std::string &getName() const = 0;
     virtual std::vector<cv::DMatch> performMatching(cv::Mat prevDescriptors, cv::Mat descriptors) = 0;
 
@@ -223,16 +242,21 @@ class Matcher {
     // that overrides performMatching leaves it false and gets the generic sequence.
     bool fusedMatch_ = false;
     struct Fused;
-    std::shared_ptr<Fused> fused_;
+    std::unique_ptr<Fused> fused_;
     bool fusedSynced_ = false; // the resident frame is prevDescriptors / prevFeatures3D
     bool fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
                         Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
                         double &pointInlierRatio);
 };
 
-Matcher *createMatcherOpenCV(void);
-Matcher *createMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
-Matcher *createloopClosingMatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
+// MatcherOpenCV::performMatching (matcherOpenCV.cpp:198-206) as a free function over the calling thread's context.
+std::vector<cv::DMatch> hammingCrossCheckMatch(cv::Mat prevDescriptors, cv::Mat descriptors);
+
+// Library-owned singletons with the reference factories' ownership rules (raw pointer returned, a second call
+// replaces the instance: matcherOpenCV.cpp:20-47): one for the VO thread, one for the loop-closure thread.
+FrameMatcher *createFrameMatcher(void);
+FrameMatcher *createFrameMatcher(const std::string _parametersFile, const std::string _grabberParametersFile);
+FrameMatcher *createLoopClosingFrameMatcher(const std::string _parametersFile, const std::string _grabberParametersFile);
 
 // ---------------------------------------------------------------------------------------------
 // VO driver (PUTSLAM::startProcessing, src/PUTSLAM/PUTSLAM.cpp:733-740,1006-1016): pose composition with
@@ -243,16 +267,17 @@ struct VOTrajectory {
     static std::string freiburgLine(const Eigen::Matrix4f &pose, double timestamp);
 };
 
-} // namespace putslam
-
-// The reference declares its concrete matcher in the global namespace (matcherOpenCV.h:26-30).
-class MatcherOpenCV : public putslam::Matcher {
+// The concrete matcher: performMatching = cv::BFMatcher(NORM_HAMMING, crossCheck = true).match(prev, cur) on the GPU
+// (the body MatcherOpenCV::performMatching gets in a PUTSLAM build, matcherOpenCV.cpp:198-206), match() fused with the
+// RANSAC against the frame resident in HBM.
+class FrameMatcherHIP : public FrameMatcher {
   public:
-    typedef std::unique_ptr<MatcherOpenCV> Ptr;
-    MatcherOpenCV(void);
-    MatcherOpenCV(const std::string _parametersFile, const std::string _grabberParametersFile);
-    ~MatcherOpenCV(void);
+    typedef std::unique_ptr<FrameMatcherHIP> Ptr;
+    FrameMatcherHIP(void);
+    FrameMatcherHIP(const std::string _parametersFile, const std::string _grabberParametersFile);
+    ~FrameMatcherHIP(void);
     virtual const std::string &getName() const;
-    // cv::BFMatcher(NORM_HAMMING, crossCheck = true).match(prevDescriptors, descriptors) on the GPU
     virtual std::vector<cv::DMatch> performMatching(cv::Mat prevDescriptors, cv::Mat descriptors);
 };
+
+} // namespace putslam_hip

@@ -54,8 +54,8 @@ int main(int argc, char **argv)
     std::fclose(f);
 
     // ---- Matcher plugin + factories (singleton ownership like matcherOpenCV.cpp:20-47) ----
-    putslam::Matcher *matcher = putslam::createMatcherOpenCV();
-    putslam::Matcher *lc = putslam::createloopClosingMatcherOpenCV("", "");
+    putslam_hip::FrameMatcher *matcher = putslam_hip::createFrameMatcher();
+    putslam_hip::FrameMatcher *lc = putslam_hip::createLoopClosingFrameMatcher("", "");
     CHECK(matcher != nullptr && lc != nullptr && matcher != lc);
     CHECK(matcher->getName() == "OpenCV Matcher");
     cv::Mat A(N, 32, CV_8U, da.data()), B(N, 32, CV_8U, db.data());
@@ -67,7 +67,7 @@ int main(int argc, char **argv)
     std::vector<Eigen::Vector3f> prev((size_t)N), cur((size_t)N);
     std::memcpy((void *)prev.data(), pa.data(), (size_t)N * 12);
     std::memcpy((void *)cur.data(), pb.data(), (size_t)N * 12);
-    putslam::Matcher::MatcherParameters mp;
+    putslam_hip::FrameMatcher::MatcherParameters mp;
     mp.RANSACParams.errorVersion = mode;
     RANSAC ransac(mp.RANSACParams, mp.cameraMatrixMat);
     ransac.setSampleSeed(seed);
@@ -120,14 +120,14 @@ int main(int argc, char **argv)
 
     // ---- guided map matching (matchXYZ, matcher.cpp:606-798): previous frame's features as the "map" ----
     {
-        std::vector<putslam::Matcher::MapFeatureXYZ> mapF;
+        std::vector<putslam_hip::FrameMatcher::MapFeatureXYZ> mapF;
         std::vector<Eigen::Vector3f> curF;
         std::vector<int> oct;
         std::vector<double> det;
         std::vector<uint8_t> curD;
         for (int i = 0; i < N; ++i) {
             if (!(prev[(size_t)i].z() > 0.1f)) continue;
-            putslam::Matcher::MapFeatureXYZ f;
+            putslam_hip::FrameMatcher::MapFeatureXYZ f;
             f.id = (unsigned)i;
             for (int c = 0; c < 3; ++c) f.position[c] = prev[(size_t)i][c];
             f.descriptor = cv::Mat(1, 32, CV_8U, da.data() + (size_t)i * 32);
@@ -147,7 +147,7 @@ int main(int argc, char **argv)
         double rx = matcher->matchXYZ(mapF, curDesc, curF, oct, det, Tx, inlx, 1);
         CHECK(rx > 0.9 && inlx.size() > mapF.size() / 2);
         CHECK(std::fabs(Tx(0, 3) + 0.01f) < 1e-4f && std::fabs(Tx(1, 3)) < 1e-4f && std::fabs(Tx(0, 0) - 1.0f) < 1e-5f);
-        std::vector<putslam::Matcher::MapFeatureXYZ> none;
+        std::vector<putslam_hip::FrameMatcher::MapFeatureXYZ> none;
         CHECK(matcher->matchXYZ(none, curDesc, curF, oct, det, Tx, inlx, 1) == -1.0);
     }
 
@@ -156,12 +156,12 @@ int main(int argc, char **argv)
     // frame, including when the frame grows past the resident store's capacity (the store is rebuilt) and when
     // detectInitFeatures restarts the sequence.
     {
-        struct GenericMatcher : public MatcherOpenCV {
+        struct GenericMatcher : public putslam_hip::FrameMatcherHIP {
             GenericMatcher() { fusedMatch_ = false; }
         };
-        MatcherOpenCV fusedM;
+        putslam_hip::FrameMatcherHIP fusedM;
         GenericMatcher genericM;
-        for (putslam::Matcher *m : {(putslam::Matcher *)&fusedM, (putslam::Matcher *)&genericM}) {
+        for (putslam_hip::FrameMatcher *m : {(putslam_hip::FrameMatcher *)&fusedM, (putslam_hip::FrameMatcher *)&genericM}) {
             m->setSampleSeed(seed ^ 0x55);
             m->matcherParameters.RANSACParams.errorVersionVO = mode;
         }
@@ -244,13 +244,13 @@ int main(int argc, char **argv)
 #endif
 
     // ---- VO trajectory driver (PUTSLAM.cpp:735-740,1006-1016) ----
-    putslam::VOTrajectory vo;
+    putslam_hip::VOTrajectory vo;
     vo.addIncrement(T);
     Eigen::Matrix4f big = Eigen::Matrix4f::Identity();
     big(0, 3) = 0.5f; // > 0.1 m: ignored
     vo.addIncrement(big);
     CHECK(std::memcmp(vo.VOPoseEstimate.data(), T.data(), 64) == 0);
-    std::string line = putslam::VOTrajectory::freiburgLine(Eigen::Matrix4f::Identity(), 1305031102.175304);
+    std::string line = putslam_hip::VOTrajectory::freiburgLine(Eigen::Matrix4f::Identity(), 1305031102.175304);
     CHECK(line == "1305031102.1753039 0 0 0 0 0 0 1");
 
     // ---- RGBD helpers ----
