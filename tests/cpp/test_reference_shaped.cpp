@@ -330,6 +330,65 @@ int main(int argc, char **argv)
         std::vector<cv::DMatch> inl;
         CHECK(hm.matchFeatureLoopClosure(wide0, p0, wide1, p1, Tlc, inl) == -1.0);
     }
+    // matchXYZ with the reference's argument types == the FrameMatcher call it unpacks into (which the oracle checks in
+    // tests/cpp/test_dropin.cpp): the previous set's features as the "map", the other set as the current pose
+    {
+        std::vector<putslam::MapFeature> mapF;
+        std::vector<putslam_hip::FrameMatcher::MapFeatureXYZ> xyz;
+        std::vector<int> viewOf;
+        for (int k = 0; k < n0; ++k) {
+            putslam::MapFeature mf = sets[0][(size_t)k];
+            mf.position = putslam::Vec3(p0[(size_t)k][0], p0[(size_t)k][1], p0[(size_t)k][2]);
+            auto &ext = mf.descriptors[(unsigned)frames[0]];
+            ext.octave = k % 3;
+            ext.detDist = std::sqrt(mf.position.x() * mf.position.x() + mf.position.y() * mf.position.y() +
+                                    mf.position.z() * mf.position.z());
+            mapF.push_back(mf);
+            viewOf.push_back(frames[0]);
+            putslam_hip::FrameMatcher::MapFeatureXYZ x;
+            x.id = mf.id;
+            x.position[0] = mf.position.x(); x.position[1] = mf.position.y(); x.position[2] = mf.position.z();
+            x.descriptor = ext.descriptor;
+            x.octave = ext.octave;
+            x.detDist = ext.detDist;
+            xyz.push_back(x);
+        }
+        std::vector<cv::KeyPoint> kps((size_t)n0);
+        std::vector<double> det((size_t)n0);
+        std::vector<int> oct((size_t)n0);
+        std::vector<cv::Point2f> und((size_t)n0), dis((size_t)n0);
+        std::vector<Eigen::Vector3f> curF = p0; // same positions, descriptors of the other frame where they correspond
+        for (int k = 0; k < n0; ++k) {
+            kps[(size_t)k].octave = oct[(size_t)k] = k % 3;
+            det[(size_t)k] = std::sqrt((double)p0[(size_t)k][0] * p0[(size_t)k][0] + (double)p0[(size_t)k][1] * p0[(size_t)k][1] +
+                                       (double)p0[(size_t)k][2] * p0[(size_t)k][2]);
+            und[(size_t)k] = cv::Point2f(3.0f * k, 1.0f);
+            dis[(size_t)k] = cv::Point2f(3.0f * k + 0.5f, 1.5f);
+        }
+        putslam_hip::FrameMatcherHIP h1, h2;
+        for (putslam_hip::FrameMatcherHIP *h : {&h1, &h2}) {
+            h->matcherParameters.RANSACParams = rlc;
+            h->matcherParameters.cameraMatrixMat = K;
+            h->setSampleSeed(77);
+        }
+        std::vector<putslam::MapFeature> found;
+        Eigen::Matrix4f T1, T2;
+        std::vector<cv::DMatch> inl2;
+        const double r1 = putslam_hip::matchXYZ(h1, mapF, 42, found, T1, A, curF, kps, det, und, dis, viewOf, 1);
+        const double r2 = h2.matchXYZ(xyz, A, curF, oct, det, T2, inl2, 1);
+        CHECK(r1 == r2 && r1 > 0.5 && found.size() == inl2.size() && std::memcmp(T1.data(), T2.data(), 64) == 0);
+        bool conv = found.size() == inl2.size();
+        for (size_t i = 0; conv && i < found.size(); ++i) {
+            const int mapId = inl2[i].queryIdx, cur = inl2[i].trainIdx;
+            const putslam::MapFeature &mf = found[i];
+            conv = mf.id == mapF[(size_t)mapId].id && mf.u == und[(size_t)cur].x && mf.posesIds.size() == 1 &&
+                   mf.posesIds[0] == 42u && mf.descriptors.count(42u) == 1 &&
+                   mf.descriptors.at(42u).octave == kps[(size_t)cur].octave &&
+                   mf.position.z() == (double)curF[(size_t)cur][2] &&
+                   std::memcmp(mf.descriptors.at(42u).descriptor.data, A.data + (size_t)cur * A.step, 32) == 0;
+        }
+        CHECK(conv);
+    }
     if (failures == 0) std::printf("all checks passed\n");
     return failures ? 1 : 0;
 }
