@@ -40,7 +40,7 @@ MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1
 # VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane),
 # counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
 VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
-                 "ps_ransac_score_fast<1>": 24}
+                 "ps_ransac_score_fast<1>": 24, "ps_ransac_score_mfma<1>": 13}
 
 
 def parse():
@@ -219,7 +219,7 @@ def main():
         c0.enable_timing(False)
         # one more pass with the fast scoring kernel's statistics on: the share of (hypothesis, match) evaluations
         # that fell inside the error band and were re-done by the value-exact code
-        if args.error_version == 1 and c0.get_option("score") == 1:
+        if args.error_version == 1 and c0.get_option("score") >= 1:
             c0.set_option("score_stats", 1)
             solo_step()
             torch.cuda.synchronize(dev)
@@ -249,7 +249,7 @@ def main():
                                                               int(s["numMatchesValid"]), Hs) for s in stats]))
         kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # timed region: average launch duration, ms
         matcher = "mfma" if ctx.get_option("matcher") == 1 else "valu"
-        score = "fast" if (ctx.get_option("score") == 1 and args.error_version == 1) else "exact"
+        score = ({1: "fast", 2: "mfma"}.get(ctx.get_option("score"), "exact") if args.error_version == 1 else "exact")
 
         def kernel_bounds(kms, pairs_per_launch):
             """What actually bounds the two sweeps (the path is compute-bound, not HBM-bound): achieved rate of the

@@ -118,8 +118,10 @@ int ps_context_synchronize(PsContext *ctx);
  *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma (default), 0 = integer VALU sweep ps_hamming_nn
  *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu, read at context creation).
  *   "score":   1 = decision-exact fast scoring kernel for errorVersion 1 (ps_ransac_score_fast: cheap evaluation with a
- *              proven error band, in-band evaluations re-done by the value-exact code; default), 0 = value-exact
- *              ps_ransac_score<1> for every evaluation (PUTSLAM_HIP_SCORE=fast|exact).  Counts are identical.
+ *              proven error band, in-band evaluations re-done by the value-exact code; default), 2 = the same scheme
+ *              with the two rigid transforms on the matrix cores (ps_ransac_score_mfma, v_mfma_f32_16x16x4_f32),
+ *              0 = value-exact ps_ransac_score<1> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
+ *              Counts are identical.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
  *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).

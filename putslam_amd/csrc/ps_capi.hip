@@ -7,6 +7,7 @@
 #include "ps_kernels.h"
 #include "ps_matcher_mfma.h"
 #include "ps_score_fast.h"
+#include "ps_score_mfma.h"
 
 #include <cfloat>
 #include <climits>
@@ -40,7 +41,7 @@ struct PsContext {
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, recE, counts, mvalid, cmax, idxList, raw;
+    Buf keys, recA, recB, recC, recD, recE, recP, recE4, counts, mvalid, cmax, idxList, raw;
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
@@ -61,7 +62,9 @@ struct PsContext {
     int forceQsplit = 0, forceMsplit = 0;
     // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher
     int matcher = 1;
-    // 1 = decision-exact fast scoring for the reprojection metric (ps_score_fast.h), 0 = value-exact ps_ransac_score
+    // errorVersion 1: 1 = decision-exact VALU kernel (ps_score_fast.h, default), 2 = decision-exact scoring with the
+    // transforms on the matrix cores (ps_score_mfma.h: correct, measured 8 % slower, profiles/r02f),
+    // 0 = value-exact ps_ransac_score<1>
     int scoreFast = 1;
     int scoreStats = 0;
 };
@@ -387,6 +390,17 @@ void tick(PsContext *ctx, int slot, bool stop)
     }
 }
 
+int cap_e(int cap) { return (cap + 15) & ~15; } // per-pair row count of recE4: cap rounded up to whole 16-match tiles
+
+RecPtrs rec_ptrs(PsContext *ctx, int cap)
+{
+    RecPtrs r;
+    r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
+    r.E = (float4 *)ctx->recE.p; r.P = (float4 *)ctx->recP.p; r.E4 = (float *)ctx->recE4.p;
+    r.capE = cap_e(cap);
+    return r;
+}
+
 int pick_split(long long blocksWithout, int maxSplit, int minChunkOf, int total)
 {
     // Few pairs and many CUs: split the inner range so that ~8 workgroups per CU are in flight.
@@ -423,7 +437,19 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR: launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit); break;
     case PS_REPROJECTION_ERROR:
-        if (ctx->scoreFast) {
+        if (ctx->scoreFast == 2) {
+            unsigned long long *dbg = nullptr;
+            if (ctx->scoreStats) {
+                PS_ENSURE(ctx->dbgCnt, 2 * sizeof(unsigned long long));
+                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                dbg = (unsigned long long *)ctx->dbgCnt.p;
+            }
+            hipLaunchKernelGGL(ps_ransac_score_mfma<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
+                               (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
+                               (const float4 *)ctx->recP.p, (const float *)ctx->recE4.p, (const int32_t *)ctx->mvalid.p,
+                               (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, cap_e(cap), pl.minRun, msplit,
+                               (int32_t *)ctx->counts.p, dbg);
+        } else if (ctx->scoreFast == 1) {
             unsigned long long *dbg = nullptr;
             if (ctx->scoreStats) {
                 PS_ENSURE(ctx->dbgCnt, 2 * sizeof(unsigned long long));
@@ -467,6 +493,7 @@ int ensure_records(PsContext *ctx, size_t n)
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
     PS_ENSURE(ctx->recE, n * 16);
+    PS_ENSURE(ctx->recP, n * 16);
     return PS_OK;
 }
 
@@ -481,6 +508,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     if (withRecords) {
         int rc = ensure_records(ctx, (size_t)P * cap);
         if (rc != PS_OK) return rc;
+        PS_ENSURE(ctx->recE4, (size_t)P * cap_e(cap) * 16 + 256);
     }
     if (ctx->matcher == 1) {
         // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
@@ -518,20 +546,22 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     size_t lds = (size_t)cap * sizeof(uint32_t);
     tick(ctx, slot0 + 1, false);
     const bool wide = P <= kWidePairs; // a handful of pairs: 1024-thread work-groups shorten the per-pair serial walk
-#define PS_LAUNCH_PREP(REC, BLK, A, B, C, D)                                                                          \
+#define PS_LAUNCH_PREP(REC, BLK)                                                                                       \
     hipLaunchKernelGGL((ps_crosscheck_prep<REC, BLK>), dim3((unsigned)P), dim3(BLK), lds, ctx->stream, fs.pts, fs.nkpts, \
-                       dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, A, B, C, D,                   \
-                       (float4 *)ctx->recE.p, (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p)
+                       dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, rp,                           \
+                       (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p)
+    RecPtrs rp{};
     if (withRecords) {
+        rp = rec_ptrs(ctx, cap);
         if (wide)
-            PS_LAUNCH_PREP(true, 1024, (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p);
+            PS_LAUNCH_PREP(true, 1024);
         else
-            PS_LAUNCH_PREP(true, kBlock, (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p);
+            PS_LAUNCH_PREP(true, kBlock);
     } else {
         if (wide)
-            PS_LAUNCH_PREP(false, 1024, (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr);
+            PS_LAUNCH_PREP(false, 1024);
         else
-            PS_LAUNCH_PREP(false, kBlock, (float4 *)nullptr, (float4 *)nullptr, (float4 *)nullptr, (int4 *)nullptr);
+            PS_LAUNCH_PREP(false, kBlock);
     }
 #undef PS_LAUNCH_PREP
     tick(ctx, slot0 + 1, true);
@@ -596,7 +626,8 @@ int ps_context_create(int device, PsContext **out)
     ctx->stream = ctx->own;
     if (const char *v = std::getenv("PUTSLAM_HIP_QSPLIT")) ctx->forceQsplit = std::atoi(v);
     if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
-    if (const char *v = std::getenv("PUTSLAM_HIP_SCORE")) ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
+    if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
+        ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER")) ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
@@ -616,7 +647,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recP, &ctx->recE4, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -652,9 +683,14 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->matcher = value;
         return PS_OK;
     }
-    if (strcmp(name, "score") == 0 || strcmp(name, "score_stats") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "score / score_stats: 0 or 1");
-        (name[5] == 0 ? ctx->scoreFast : ctx->scoreStats) = value;
+    if (strcmp(name, "score") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "score: 0 (value-exact), 1 (fast VALU) or 2 (MFMA)");
+        ctx->scoreFast = value;
+        return PS_OK;
+    }
+    if (strcmp(name, "score_stats") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "score_stats: 0 or 1");
+        ctx->scoreStats = value;
         return PS_OK;
     }
     if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
@@ -848,6 +884,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->cmax, sizeof(float2));
     rc = ensure_records(ctx, (size_t)cap);
     if (rc) return rc;
+    PS_ENSURE(ctx->recE4, (size_t)cap_e(cap) * 16 + 256);
     if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
     if (ncur > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, cur, (size_t)ncur * 12, hipMemcpyHostToDevice, ctx->stream));
     if (m > 0)
@@ -856,9 +893,8 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     int32_t mm = m;
     PS_HIP(hipMemcpyAsync(ctx->sNumM.p, &mm, sizeof mm, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(ps_prep_from_matches, dim3(1), dim3(kBlock), 0, ctx->stream, (const float *)ctx->sMisc0.p,
-                       (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa,
-                       (float4 *)ctx->recA.p, (float4 *)ctx->recB.p, (float4 *)ctx->recC.p, (int4 *)ctx->recD.p,
-                       (float4 *)ctx->recE.p, (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p);
+                       (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa, rec_ptrs(ctx, cap),
+                       (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p);
     PS_HIP(hipGetLastError());
     rc = run_ransac_stage(ctx, pl, 1, cap, (const PsDMatch *)ctx->sMatches.p, (const int32_t *)ctx->sNumM.p, cap,
                           (float *)ctx->sPose.p, (uint8_t *)ctx->sMask.p, (PsRansacStats *)ctx->sStats.p, 2);
@@ -1234,7 +1270,7 @@ struct PsVoStream {
         PsRansacParams prm;
         int estimator, numHypotheses, variant;
         float K[9];
-        const void *arena[13]; // scratch and table blocks the captured launches point at (they move when they grow)
+        const void *arena[15]; // scratch and table blocks the captured launches point at (they move when they grow)
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1394,12 +1430,12 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 1) | (ctx->scoreStats << 2);
+    key.variant = ctx->matcher | (ctx->scoreFast << 1) | (ctx->scoreStats << 3);
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[13] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p};
+    const void *arena[15] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1438,8 +1474,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[13] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p};
+        const void *after[15] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

@@ -170,10 +170,21 @@ struct PrepArgs {
     int cap;
 };
 
-// Builds the five 16-byte records of one depth-valid match; returns the largest |offset| of recE.
-PS_D float write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int t, float px, float py, float pz,
-                         float cx_, float cy_, float cz_, float4 *recA, float4 *recB, float4 *recC, int4 *recD,
-                         float4 *recE)
+// Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
+struct RecPtrs {
+    float4 *A;  // prev xyz + squared Euclid bound
+    float4 *B;  // cur xyz, w = 1   (also the A operand "current point" of the matrix-core scoring kernel)
+    float4 *C;  // projections of prev and cur (realOld u v, realNew u v)
+    int4 *D;    // (index in the match list, queryIdx, trainIdx, 0)
+    float4 *E;  // offsets c - real of the fast scoring path: (cx - uOld, cx - uNew, cy - vOld, cy - vNew)
+    float4 *P;  // prev xyz, w = 1  (A operand "previous point" of the matrix-core scoring kernel)
+    float *E4;  // the offsets of E transposed in groups of four matches, [P][capE / 4][4 components][4 matches]
+    int capE;   // cap rounded up to a multiple of 16
+};
+
+// Builds the records of depth-valid match number v of pair p; returns the largest |offset| of E.
+PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int srcIdx, int q, int t, float px, float py,
+                         float pz, float cx_, float cy_, float cz_)
 {
     // Euclid rule of RANSAC.cpp:268-272: thr = inlierThresholdEuclidean (* prev.z in ADAPTIVE mode),
     // turned into its exact squared-domain bound.
@@ -183,14 +194,18 @@ PS_D float write_records(const PrepArgs &a, size_t slot, int srcIdx, int q, int 
     float ou, ov, nu, nv;
     project(px, py, pz, a.fx, a.fy, a.cx, a.cy, ou, ov);    // realOld  (RANSAC.cpp:357-358)
     project(cx_, cy_, cz_, a.fx, a.fy, a.cx, a.cy, nu, nv); // realNew  (RANSAC.cpp:352-353)
-    recA[slot] = make_float4(px, py, pz, bound);
-    recB[slot] = make_float4(cx_, cy_, cz_, 0.0f);
-    recC[slot] = make_float4(ou, ov, nu, nv);
-    recD[slot] = make_int4(srcIdx, q, t, 0);
-    // offsets of the decision-exact fast scoring path (ps_score_fast.h): predicted - real = quotient + (c - real)
+    const size_t slot = (size_t)p * a.cap + (size_t)v;
+    r.A[slot] = make_float4(px, py, pz, bound);
+    r.B[slot] = make_float4(cx_, cy_, cz_, 1.0f);
+    r.C[slot] = make_float4(ou, ov, nu, nv);
+    r.D[slot] = make_int4(srcIdx, q, t, 0);
+    r.P[slot] = make_float4(px, py, pz, 1.0f);
+    // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
-    recE[slot] = e;
+    r.E[slot] = e;
+    float *e4 = r.E4 + ((size_t)p * r.capE + (size_t)(v & ~3)) * 4 + (v & 3);
+    e4[0] = e.x; e4[4] = e.y; e4[8] = e.z; e4[12] = e.w;
     return fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)));
 }
 
@@ -206,10 +221,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
                                                              const int32_t *__restrict__ pairs,
                                                              const uint32_t *__restrict__ keys, PrepArgs a,
                                                              PsDMatch *__restrict__ matches,
-                                                             int32_t *__restrict__ numMatches,
-                                                             float4 *__restrict__ recA, float4 *__restrict__ recB,
-                                                             float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                             float4 *__restrict__ recE,
+                                                             int32_t *__restrict__ numMatches, RecPtrs rec,
                                                              int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut)
 {
     extern __shared__ __align__(16) uint32_t s_best[];
@@ -262,8 +274,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             int vtotal;
             int vpos = block_scan_flag<BLOCK>(ok, vtotal, s_wsum);
             if (ok) {
-                um = fmaxf(um, write_records(a, (size_t)p * cap + vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_,
-                                             recA, recB, recC, recD, recE));
+                um = fmaxf(um, write_records(a, rec, p, vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_));
                 cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
             }
             vbase += vtotal;
@@ -285,10 +296,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
 __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__restrict__ prev,
                                                                const float *__restrict__ cur,
                                                                const PsDMatch *__restrict__ matches, int m, PrepArgs a,
-                                                               float4 *__restrict__ recA, float4 *__restrict__ recB,
-                                                               float4 *__restrict__ recC, int4 *__restrict__ recD,
-                                                               float4 *__restrict__ recE,
-                                                               int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut)
+                                                               RecPtrs rec, int32_t *__restrict__ mvalid,
+                                                               float2 *__restrict__ cmaxOut)
 {
     __shared__ int s_wsum[kBlock / 64];
     __shared__ float s_red[kBlock / 64];
@@ -309,8 +318,7 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         int vtotal;
         int vpos = block_scan_flag(ok, vtotal, s_wsum);
         if (ok) {
-            um = fmaxf(um, write_records(a, (size_t)vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, recA, recB, recC, recD,
-                                         recE));
+            um = fmaxf(um, write_records(a, rec, 0, vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_));
             cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
         }
         vbase += vtotal;

@@ -1,5 +1,6 @@
-"""Kernel 3 twins for the reprojection metric: the decision-exact fast kernel (ps_ransac_score_fast, default) and the
-value-exact kernel (ps_ransac_score<1>) must give the oracle's inlier count for EVERY hypothesis
+"""Kernel 3 triplets for the reprojection metric: the decision-exact kernel with the transforms on the matrix cores
+(ps_ransac_score_mfma), the decision-exact VALU kernel (ps_ransac_score_fast, default) and the value-exact kernel
+(ps_ransac_score<1>) must give the oracle's inlier count for EVERY hypothesis
 (reference src/TransformEst/RANSAC.cpp:325-375), over thresholds, camera scales, noise levels and degenerate data."""
 import numpy as np
 import pytest
@@ -21,6 +22,15 @@ def fctx():
 
 
 @pytest.fixture(scope="module")
+def mctx():
+    c = api.Context(0)
+    c.set_option("score", 2)
+    c.set_option("score_stats", 1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
 def ectx():
     c = api.Context(0)
     c.set_option("score", 0)
@@ -28,13 +38,25 @@ def ectx():
     c.close()
 
 
+MCTX = {}
+
+
 def _counts(fctx, ectx, oracle, prm, cfg, K, a, b, m):
+    if "c" not in MCTX:
+        MCTX["c"] = api.Context(0)
+        MCTX["c"].set_option("score", 2)
+        MCTX["c"].set_option("score_stats", 1)
+    mctx = MCTX["c"]
     g = fctx.debug_ransac_counts(prm, cfg, K, a["pts"], b["pts"], m)
     parked, evals = fctx.score_stats()
+    x = mctx.debug_ransac_counts(prm, cfg, K, a["pts"], b["pts"], m)
+    parked2, evals2 = mctx.score_stats()
     e = ectx.debug_ransac_counts(prm, cfg, K, a["pts"], b["pts"], m)
     c, M = oracle.hypothesis_counts(prm, cfg, K, a["pts"], b["pts"], m)
     assert np.array_equal(e, c), "value-exact kernel differs from the oracle"
-    assert np.array_equal(g, c), "decision-exact kernel differs from the oracle"
+    assert np.array_equal(g, c), "decision-exact VALU kernel differs from the oracle"
+    assert np.array_equal(x, c), "decision-exact matrix-core kernel differs from the oracle"
+    assert evals2 == 0 or parked2 <= 4 * max(parked, 64) + evals2 // 200, (parked, evals, parked2, evals2)
     return parked, evals, M
 
 
@@ -105,7 +127,7 @@ def test_score_variants_full_results(fctx, ectx, oracle):
         prm = default_ransac_params(REPROJECTION_ERROR)
         cfg, _ = make_config(EST_RANSAC, 1157, seed=idx)
         c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
-        for ctx in (fctx, ectx):
+        for ctx in (fctx, ectx, MCTX.get("c", fctx)):
             g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
             assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
             assert g["stats"]["bestHypothesis"] == c["stats"]["bestHypothesis"]
