@@ -42,6 +42,7 @@ struct PsContext {
     char arch[64] = {0};
     // scratch arena (device)
     Buf keys, recA, recB, recC, recD, recE, recP, recE4, counts, mvalid, cmax, idxList, raw;
+    Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches only)
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
@@ -299,6 +300,7 @@ struct Plan {
     PrepArgs pa{};
     SelectArgs sa{};
     ModelArgs ma{};
+    int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -420,6 +422,26 @@ void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit
                        (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p);
 }
 
+// Decisions of the scoring stage that the preceding kernels need to know: how the match range is split (kernel 2 then
+// clears the counts, instead of a memset launch) and whether kernel 3 parks its models for kernel 4.
+int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
+{
+    const int H = pl.H;
+    PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
+    const int hb = (H + kBlock - 1) / kBlock;
+    pl.msplit = pick_split((long long)P * hb, 32, 64, cap);
+    if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
+    pl.pa.zeroCounts = pl.msplit > 1 ? (int32_t *)ctx->counts.p : nullptr;
+    pl.pa.zeroH = H;
+    pl.ma.models = nullptr;
+    const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
+    if (P <= kWidePairs && mbytes <= ((size_t)64 << 20)) {
+        PS_ENSURE(ctx->models, mbytes);
+        pl.ma.models = (float *)ctx->models.p;
+    }
+    return PS_OK;
+}
+
 // Kernels 3 + 4 over records already in the arena.
 int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMatch *dMatches,
                      const int32_t *dNumMatches, int matchStride, float *dPose, uint8_t *dMask, PsRansacStats *dStats,
@@ -429,9 +451,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
     PS_ENSURE(ctx->idxList, (size_t)P * cap * sizeof(int32_t));
     const int hb = (H + kBlock - 1) / kBlock;
-    int msplit = pick_split((long long)P * hb, 32, 64, cap);
-    if (ctx->forceMsplit > 0) msplit = ctx->forceMsplit;
-    if (msplit > 1) PS_HIP(hipMemsetAsync(ctx->counts.p, 0, (size_t)P * H * sizeof(int32_t), ctx->stream));
+    const int msplit = pl.msplit; // counts were cleared by kernel 2 when the range is split (prepare_score)
     dim3 grid((unsigned)hb * (unsigned)msplit * (unsigned)P);
     tick(ctx, slot0, false);
     switch (pl.mode) {
@@ -518,12 +538,12 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         PS_ENSURE(ctx->xq, (size_t)P * tpf * kTileU4 * sizeof(uint4));
         int qsplit = pick_split((long long)P * groups, tpf, 1, tpf);
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
-        if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
         int xchunks = tpf < 8 ? tpf : 8;
         if ((long long)P * xchunks < 1024) xchunks = tpf < 64 ? tpf : 64;
         tick(ctx, 4, false);
         hipLaunchKernelGGL(ps_expand_query_fp4, dim3((unsigned)xchunks, (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, (uint4 *)ctx->xq.p);
+                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, (uint4 *)ctx->xq.p,
+                           qsplit > 1 ? (uint32_t *)ctx->keys.p : (uint32_t *)nullptr); // also clears the keys
         tick(ctx, 4, true);
         tick(ctx, 5, false);
         hipLaunchKernelGGL(ps_hamming_mfma<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
@@ -647,7 +667,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recP, &ctx->recE4, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recP, &ctx->recE4, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -873,6 +893,8 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
                               ctx->stream));
         pl.ma.raw = (const uint32_t *)ctx->raw.p;
     }
+    rc = prepare_score(ctx, pl, 1, cap);
+    if (rc) return rc;
     PS_ENSURE(ctx->sMisc0, (size_t)(nprev > 0 ? nprev : 1) * 12);
     PS_ENSURE(ctx->sMisc1, (size_t)(ncur > 0 ? ncur : 1) * 12);
     PS_ENSURE(ctx->sMatches, (size_t)cap * sizeof(PsDMatch));
@@ -1237,6 +1259,8 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
         ctx->slotMask[ctx->curCall] = 0;
         ctx->timedCalls++;
     }
+    rc = prepare_score(ctx, pl, P, cap);
+    if (rc) return rc;
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     return run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask,
@@ -1270,7 +1294,7 @@ struct PsVoStream {
         PsRansacParams prm;
         int estimator, numHypotheses, variant;
         float K[9];
-        const void *arena[15]; // scratch and table blocks the captured launches point at (they move when they grow)
+        const void *arena[16]; // scratch and table blocks the captured launches point at (they move when they grow)
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1402,6 +1426,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
     if (rc) return rc;
     pl.ma.seedDev = reinterpret_cast<const uint64_t *>((const int32_t *)s->meta.p + 4);
+    rc = prepare_score(ctx, pl, 1, s->cap);
+    if (rc) return rc;
     uint8_t *dres = (uint8_t *)s->res.p;
     auto enqueue = [&](size_t rows) -> int {
         int r = copy_in(rows);
@@ -1434,8 +1460,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[15] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p};
+    const void *arena[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p, ctx->models.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1474,8 +1500,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[15] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p};
+        const void *after[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p, ctx->models.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

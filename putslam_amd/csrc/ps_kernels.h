@@ -168,6 +168,8 @@ struct PrepArgs {
     double thrE;            // inlierThresholdEuclidean
     int mode;               // RANSAC::ERROR_VERSION
     int cap;
+    int32_t *zeroCounts;    // optional: counts[P][zeroH] to clear for kernel 3's split-range atomics (saves a memset launch)
+    int zeroH;
 };
 
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
@@ -285,6 +287,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         float c = block_max<BLOCK>(cm, s_red);
         float u = block_max<BLOCK>(um, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
+        if (a.zeroCounts)
+            for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroH + i] = 0;
     }
     if (threadIdx.x == 0) {
         numMatches[p] = base;
@@ -329,6 +333,8 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         mvalid[0] = vbase;
         cmaxOut[0] = make_float2(c, u);
     }
+    if (a.zeroCounts)
+        for (int i = threadIdx.x; i < a.zeroH; i += kBlock) a.zeroCounts[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,7 +346,26 @@ struct ModelArgs {
     uint64_t seed;
     const uint32_t *raw;     // optional explicit draws, H x 3 (device)
     const uint64_t *seedDev; // optional: the seed lives in device memory (captured graphs replay with a new seed)
+    float *models;           // optional [P][H][12]: kernel 3 parks every hypothesis model here and kernel 4 reads the
+                             // winner's instead of repeating its sample -> Umeyama -> Jacobi-SVD chain (small batches:
+                             // the chain is ~10 us of latency on the critical path of a single frame pair)
 };
+
+PS_D void store_model(const ModelArgs &ma, size_t slot, const Rigid &m)
+{
+    float4 *d = reinterpret_cast<float4 *>(ma.models + slot * 12);
+    d[0] = make_float4(m.R[0][0], m.R[0][1], m.R[0][2], m.R[1][0]);
+    d[1] = make_float4(m.R[1][1], m.R[1][2], m.R[2][0], m.R[2][1]);
+    d[2] = make_float4(m.R[2][2], m.t[0], m.t[1], m.t[2]);
+}
+PS_D void load_model(const ModelArgs &ma, size_t slot, Rigid &m)
+{
+    const float4 *d = reinterpret_cast<const float4 *>(ma.models + slot * 12);
+    const float4 a = d[0], b = d[1], c = d[2];
+    m.R[0][0] = a.x; m.R[0][1] = a.y; m.R[0][2] = a.z; m.R[1][0] = a.w;
+    m.R[1][1] = b.x; m.R[1][2] = b.y; m.R[2][0] = b.z; m.R[2][1] = b.w;
+    m.R[2][2] = c.x; m.t[0] = c.y; m.t[1] = c.z; m.t[2] = c.w;
+}
 PS_D uint64_t base_seed(const ModelArgs &ma) { return ma.seedDev ? *ma.seedDev : ma.seed; }
 
 PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ recB, size_t rbase, uint32_t M,
@@ -588,6 +613,7 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
     bool valid = false;
     if (h < H) {
         valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        if (ma.models && by == 0) store_model(ma, (size_t)p * H + h, mdl);
         if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR)
             inverse_rigid_general(mdl, inv);
     }
@@ -858,7 +884,10 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
     set_identity(inv);
     int kin = 0;
     if (run && bestIdx >= 0) {
-        gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
+        if (ma.models)
+            load_model(ma, (size_t)p * a.H + bestIdx, mdl); // parked by kernel 3 (an invalid sample parks the identity)
+        else
+            gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
         const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
         if (needInv) inverse_rigid_general(mdl, inv);
         for (int i0 = 0; i0 < M; i0 += BLOCK) {

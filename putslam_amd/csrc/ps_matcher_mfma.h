@@ -73,9 +73,11 @@ PS_D int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 __global__ __launch_bounds__(kBlock) void ps_expand_query_fp4(const uint32_t *__restrict__ desc,
                                                               const int32_t *__restrict__ nkpts,
                                                               const int32_t *__restrict__ pairs, int cap, int tpf,
-                                                              uint4 *__restrict__ Xq)
+                                                              uint4 *__restrict__ Xq, uint32_t *__restrict__ keysInit)
 {
     const int p = blockIdx.y;
+    if (keysInit) // the matcher merges query splits with atomicMin: start every key at "no query" (saves a memset launch)
+        for (int t = blockIdx.x * kBlock + threadIdx.x; t < cap; t += gridDim.x * kBlock) keysInit[(size_t)p * cap + t] = kNoKey;
     const int fq = pairs[2 * p];
     const int nq = nkpts[fq];
     const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;

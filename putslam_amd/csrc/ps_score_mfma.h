@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kBlock, 3) void ps_ransac_score_mfma(
     set_identity(mdl);
     bool valid = false;
     if (h < H) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+    if (ma.models && by == 0 && h < H) store_model(ma, (size_t)p * H + h, mdl);
     inverse_rigid_general(mdl, inv);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
