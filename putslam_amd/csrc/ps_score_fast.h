@@ -173,19 +173,41 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
     } else {
         // mdl: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
         // inv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
+        // Everything the hot loop keeps in registers per hypothesis -- the folded models and the band coefficients -- is
+        // (re)built here from the model parked in LDS: once before the loop and again after every in-loop drain, so that
+        // none of it has to stay alive across the drain's register-hungry code (kept alive it was spilled to scratch on
+        // every launch: 40 dwords per lane, 349 MB of writes per 499 pairs, profiles/r02d).
         FastModel F;
-        make_fast(mdl, inv, k.fx, k.fy, F);
+        float a1, b1, rcap;
         const float Qin = 1.02f * (umax + fc.thrUp + 0.016f * fc.fmaxK + 1.0f);
-        const float kap1 = S * (1.02f * 8.0f * kEpsU * (2.0f * fc.fmaxK + Qin));
         const float kap0 = 1.02f * kEpsU * (8.0f * Qin + 2.0f * fc.cmaxK + 2.0f * fc.thrUp + 2.0f + umax);
-        // |rcp(Z~)| above rcap: |Z~| < 2^-14 S (the band is not valid) or delta > thrUp (the affine upper limit is not)
-        const float rcap2 = fc.thrUp > kap0 ? ((fc.thrUp - kap0) / kap1) * 0.99999f : -1.0f;
-        const float rcap = fminf(16384.0f / S, rcap2);
         const float up4 = 1.0f + 4.0f * kEpsU;
-        const float a1 = (fc.cIn * kap1) * up4;                                   // lower limit: a0 - a1 * rmax
-        const float a0 = (fc.bIn0 - fc.cIn * kap0) - 4.0f * kEpsU * fc.bIn0;
-        const float b1 = (fc.cHi * kap1) * up4;                                   // upper limit: b0 + b1 * rmax
-        const float b0 = (fc.thr2Up + fc.cHi * kap0) * up4;
+        const float a0 = (fc.bIn0 - fc.cIn * kap0) - 4.0f * kEpsU * fc.bIn0;     // lower limit: a0 - a1 * rmax
+        const float b0 = (fc.thr2Up + fc.cHi * kap0) * up4;                       // upper limit: b0 + b1 * rmax
+        auto rebuild = [&]() {
+            Rigid md, iv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
+                md.t[i] = s_mdl[9 + i][tid];
+            }
+            // md: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
+            // iv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
+            inverse_rigid_general(md, iv);
+            make_fast(md, iv, k.fx, k.fy, F);
+            float rho2 = 0.0f, tau2 = 0.0f;
+            model_norms(md, rho2, tau2);
+            model_norms(iv, rho2, tau2);
+            const float S2 = (rho2 * cmax + tau2) * 1.001f;
+            const float kap1 = S2 * (1.02f * 8.0f * kEpsU * (2.0f * fc.fmaxK + Qin));
+            // |rcp(Z~)| above rcap: |Z~| < 2^-14 S (the band is not valid) or delta > thrUp (the affine upper limit is not)
+            const float rcap2 = fc.thrUp > kap0 ? ((fc.thrUp - kap0) / kap1) * 0.99999f : -1.0f;
+            rcap = fminf(16384.0f / S2, rcap2);
+            a1 = (fc.cIn * kap1) * up4;
+            b1 = (fc.cHi * kap1) * up4;
+        };
+        rebuild();
         int qn = 0;                      // parked evaluations of this wave (wave-uniform)
         unsigned long long parked = 0;
 
@@ -231,7 +253,10 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
             const unsigned long long mU = execAll & ~(mIn | mOut);
             if (mU != 0ull) {
                 const int n = __popcll(mU);
-                if (qn + n > kQueueCap) drain();
+                if (qn + n > kQueueCap) {
+                    drain();
+                    rebuild();
+                }
                 if ((mU >> lane) & 1ull)
                     s_q[wv][qn + __popcll(mU & ((1ull << lane) - 1ull))] = ((uint32_t)m << 6) | (uint32_t)lane;
                 qn += n;
