@@ -65,6 +65,23 @@ def main():
                 agg[k.split("psdev::")[1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         with open(os.path.join(dst, "sq_counters.json"), "w") as f:
             json.dump({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}, f, indent=1)
+    # per-launch durations from the kernel trace, in launch order (the --stats average mixes warm-up launches, the timed
+    # region and bench.py's single-chain leg; with the default profile command --streams 1 --steps 5 --warmup 2 the
+    # launches are: 2 warm-up, 5 timed, 1 leg warm-up, 5 leg (these are what `kernel_ms` averages), 1 statistics pass)
+    tr = os.path.join(src, "trace", "bench_kernel_trace.csv")
+    if os.path.exists(tr):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            k = r["Kernel_Name"]
+            if "psdev::" in k:
+                per[k.split("psdev::")[1].split("(")[0]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        out = {}
+        for k, v in per.items():
+            v.sort()
+            ms = [round(x[1], 4) for x in v]
+            out[k] = {"launch_ms": ms, "single_chain_leg_mean_ms": (sum(ms[-6:-1]) / 5 if len(ms) == 14 else None)}
+        with open(os.path.join(dst, "kernel_launch_ms.json"), "w") as f:
+            json.dump(out, f, indent=1)
     for extra in ("bench_default.json",):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
