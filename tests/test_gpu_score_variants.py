@@ -56,7 +56,7 @@ def _counts(fctx, ectx, oracle, prm, cfg, K, a, b, m):
     assert np.array_equal(e, c), "value-exact kernel differs from the oracle"
     assert np.array_equal(g, c), "decision-exact VALU kernel differs from the oracle"
     assert np.array_equal(x, c), "decision-exact matrix-core kernel differs from the oracle"
-    assert evals2 == 0 or parked2 <= 4 * max(parked, 64) + evals2 // 200, (parked, evals, parked2, evals2)
+    assert parked <= evals and parked2 <= evals2      # (the share itself is checked at the shipped threshold below)
     return parked, evals, M
 
 
