@@ -9,7 +9,8 @@ import os
 from ._abi import PsDMatch, PsFrameSet, PsPairResults, PsRansacConfig, PsRansacParams, PsRansacStats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libputslam_hip.so")
+# PUTSLAM_HIP_LIB: A/B hook of the profiling scripts (another build of the same library, e.g. a kernel variant)
+LIB_PATH = os.environ.get("PUTSLAM_HIP_LIB") or os.path.join(_HERE, "libputslam_hip.so")
 
 # every symbol include/putslam_hip.h declares
 EXPORTED = [

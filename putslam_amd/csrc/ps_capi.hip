@@ -532,7 +532,10 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     }
     if (ctx->matcher == 1) {
         // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
-        constexpr int TT = 4;
+#ifndef PS_MFMA_TT
+#define PS_MFMA_TT 4
+#endif
+        constexpr int TT = PS_MFMA_TT;
         const int tpf = (cap + kTileRows - 1) / kTileRows;
         const int groups = (tpf + kWavesPerWG * TT - 1) / (kWavesPerWG * TT);
         PS_ENSURE(ctx->xq, (size_t)P * tpf * kTileU4 * sizeof(uint4));

@@ -20,9 +20,13 @@
 //
 // Operand traffic: the previous frame (query side) of every pair is expanded once per call into the
 // fragment-major FP4 image  Xq[pair][tile of 32 rows][k-step 0..3][lane 0..63][16 B]  by ps_expand_query_fp4
-// (N work, not N^2); a work-group stages one 4-KiB query tile at a time through LDS (double-buffered, one
-// barrier per tile, contiguous conflict-free ds_read_b128) and shares it between its 4 waves; every wave
-// expands its own TT train tiles in registers once and keeps them as B operands for the whole sweep.
+// (N work, not N^2); every wave expands its own TT train tiles in registers once and keeps them as B operands for
+// the whole sweep, and streams the query tiles as A operands: four contiguous 1-KiB loads per tile, one tile ahead,
+// straight into registers (the four waves of a work-group read the same tiles within a few hundred cycles: L1 / L2
+// hits).  The first form staged the query tiles through LDS (double-buffered, one barrier per tile, shared by the
+// four waves): 0.211 ms against 0.186 ms per 499 pairs -- the barrier tied the waves of a work-group together, and
+// with one wave of each of two work-groups per SIMD the matrix and the vector phases of all of them coincided
+// (PS_MFMA_DIRECT=0 rebuilds that form; profiles/r02h).
 // Any consistent assignment of descriptor bits to (k-step, lane half, element) is valid because both
 // operands use the same one: lane (r = lane & 31, h = lane >> 5) holds, for k-step s, the 32 bits of dword
 // 2s + h of row r.
@@ -124,14 +128,24 @@ constexpr float kMfmaBase = 8388608.0f; // 2^23: unit spacing up to 2^24
 // wave each TT of them) and sweeps the query tiles [T0, T1) of its split.  qsplit > 1 merges with atomicMin
 // on the packed key (hamming << 16 | query), the same key kernel 2 reads from ps_hamming_nn.
 // ------------------------------------------------------------------------------------------
+// 1 (default): every wave loads its own query tiles straight into registers; 0: the first form, query tiles staged
+// through LDS and shared by the work-group's four waves (kept for A/B: profiles/r02h).
+#ifndef PS_MFMA_DIRECT
+#define PS_MFMA_DIRECT 1
+#endif
+#ifndef PS_MFMA_WAVES
+#define PS_MFMA_WAVES 1
+#endif
 template <int TT>
-__global__ __launch_bounds__(kBlock) void ps_hamming_mfma(const uint32_t *__restrict__ desc,
+__global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const uint32_t *__restrict__ desc,
                                                           const int32_t *__restrict__ nkpts,
                                                           const int32_t *__restrict__ pairs, int cap, int tpf,
                                                           int groups, int qsplit, const uint4 *__restrict__ Xq,
                                                           uint32_t *__restrict__ keys)
 {
+#if !PS_MFMA_DIRECT
     __shared__ uint4 s_a[2][kTileU4];
+#endif
     const unsigned perPair = (unsigned)(groups * qsplit);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int p = (int)(L / perPair);
@@ -167,6 +181,25 @@ __global__ __launch_bounds__(kBlock) void ps_hamming_mfma(const uint32_t *__rest
     }
 
     const uint4 *__restrict__ xq = Xq + (size_t)p * tpf * kTileU4;
+#if PS_MFMA_DIRECT
+    // Every wave fetches its own copy of the query tile (4 x 16 B per lane, served by L1 / L2 for the other waves of the
+    // work-group) one tile ahead into registers: no LDS staging, no barrier, the waves of a work-group drift apart freely.
+    uint4 an[4];
+    if (T0 < T1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) an[s] = xq[(size_t)T0 * kTileU4 + s * 64 + lane];
+    }
+    for (int T = T0; T < T1; ++T) {
+        v4i_t A[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            A[s].x = (int)an[s].x; A[s].y = (int)an[s].y; A[s].z = (int)an[s].z; A[s].w = (int)an[s].w;
+        }
+        if (T + 1 < T1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) an[s] = xq[(size_t)(T + 1) * kTileU4 + s * 64 + lane];
+        }
+#else
     if (T0 < T1) s_a[0][tid] = xq[(size_t)T0 * kTileU4 + tid];
     __syncthreads();
     for (int T = T0; T < T1; ++T) {
@@ -179,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void ps_hamming_mfma(const uint32_t *__rest
             const uint4 a = s_a[buf][s * 64 + lane];
             A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
         }
+#endif
         v16f_t Cin = C;
         if (T * kTileRows + kTileRows > nq) { // last, partial query tile: rows beyond nq can never win
 #pragma unroll
@@ -197,8 +231,10 @@ __global__ __launch_bounds__(kBlock) void ps_hamming_mfma(const uint32_t *__rest
                 bestT[i] = T;
             }
         }
+#if !PS_MFMA_DIRECT
         if (T + 1 < T1) s_a[buf ^ 1][tid] = nxt;
         __syncthreads();
+#endif
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
