@@ -5,7 +5,7 @@ Compiles ps_capi.hip to gfx950 assembly, finds the hot loop of ps_hamming_nn<2> 
 ps_ransac_score<MODE>, counts VALU instructions per unit of work (descriptor pair / (hypothesis, match)
 evaluation per wave) and prices them with the per-instruction issue costs measured on the MI355X box by
 profiles/microbench/valu_rates (cycles per wave64 instruction per SIMD, normalised to 2.4 GHz).
-Writes profiles/isa_mix.json, which bench.py uses for its `valu_issue` block.
+Writes profiles/isa_mix.json; bench.py's VALU_PER_UNIT table (instructions per unit of the hot loops) is taken from it.
 """
 import json
 import os
@@ -67,7 +67,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                               "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
+                               "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
                               stderr=subprocess.DEVNULL)
         s = open(asm).read()
     out = {"cost_source": "profiles/microbench/valu_rates_mi355x.txt (cycles per wave64 instruction per SIMD @ 2.4 GHz)"}
@@ -127,11 +127,39 @@ def main():
                                              "valu_per_unit": sum(tot.values()) / per,
                                              "model_cycles_per_unit": sum(price(k, cost) * v for k, v in tot.items()) / per,
                                              "mix": dict(tot), "cold_fallback_valu": sum(cold.values()) / per}
+    # ---- round 2 kernels ----
+    # decision-exact scoring kernel: the hot path of one evaluation runs from the loop header to the add-with-carry
+    a = s.index("\n_ZN5psdev20ps_ransac_score_fastILi1EE")
+    body = s[a:s.index(".Lfunc_end", a)]
+    end = body.rindex("v_addc_co_u32")
+    start = body.rindex("This Loop Header", 0, end)
+    c = valu_of(body[start:body.index("\n", end)])
+    out["ps_ransac_score_fast<1>"] = {"unit": "(hypothesis, match) evaluation per wave", "valu_per_unit": sum(c.values()),
+                                      "model_cycles_per_unit": sum(price(k, cost) * v for k, v in c.items()), "mix": dict(c)}
+    # matrix-core Hamming sweep: the main loop = the innermost loop with 16 MFMAs (4 train tiles x 4 k-steps) per trip
+    a = s.index("\n_ZN5psdev15ps_hamming_mfmaILi4EE")
+    body = s[a:s.index(".Lfunc_end", a)]
+    hdrs = [m.start() for m in re.finditer(r"=>This Inner Loop Header", body)]
+    best = None
+    for h0 in hdrs:
+        seg = body[h0:]
+        m = re.search(r"s_cbranch_\w+ \.LBB\d+_\d+\n(?=\.LBB|; %bb)", seg)
+        nxt = body.find("Loop Header", h0 + 40)
+        seg = body[h0:nxt if nxt > 0 else len(body)]
+        n = seg.count("v_mfma_f32_32x32x64_f8f6f4")
+        if n and (best is None or n > best[0]):
+            best = (n, seg)
+    c = valu_of(best[1])
+    nm = c.pop("v_mfma_f32_32x32x64_f8f6f4")
+    out["ps_hamming_mfma<4>"] = {"unit": "query tile x 4 train tiles per wave (4096 distances)", "mfma_per_unit": nm,
+                                 "valu_per_unit": sum(c.values()), "valu_per_mfma": sum(c.values()) / nm,
+                                 "note": "the block includes the cold partial-last-tile masking (16 compares/selects)",
+                                 "mix": dict(c)}
     with open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():
         if isinstance(v, dict):
-            print(k, round(v["valu_per_unit"], 1), "VALU,", round(v["model_cycles_per_unit"], 1), "cycles per", v["unit"])
+            print(k, round(v["valu_per_unit"], 1), "VALU,", round(v.get("model_cycles_per_unit", float("nan")), 1), "cycles per", v["unit"])
 
 
 if __name__ == "__main__":
