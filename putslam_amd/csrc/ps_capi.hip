@@ -544,8 +544,8 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         int xchunks = tpf < 8 ? tpf : 8;
         if ((long long)P * xchunks < 1024) xchunks = tpf < 64 ? tpf : 64;
         tick(ctx, 4, false);
-        hipLaunchKernelGGL(ps_expand_query_fp4, dim3((unsigned)xchunks, (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, (uint4 *)ctx->xq.p,
+        hipLaunchKernelGGL(ps_expand_query_fp4, dim3((unsigned)xchunks * (unsigned)P), dim3(kBlock), 0, ctx->stream,
+                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, xchunks, (uint4 *)ctx->xq.p,
                            qsplit > 1 ? (uint32_t *)ctx->keys.p : (uint32_t *)nullptr); // also clears the keys
         tick(ctx, 4, true);
         tick(ctx, 5, false);

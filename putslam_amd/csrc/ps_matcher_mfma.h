@@ -77,17 +77,19 @@ PS_D int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 __global__ __launch_bounds__(kBlock) void ps_expand_query_fp4(const uint32_t *__restrict__ desc,
                                                               const int32_t *__restrict__ nkpts,
                                                               const int32_t *__restrict__ pairs, int cap, int tpf,
-                                                              uint4 *__restrict__ Xq, uint32_t *__restrict__ keysInit)
+                                                              int chunks, uint4 *__restrict__ Xq,
+                                                              uint32_t *__restrict__ keysInit)
 {
-    const int p = blockIdx.y;
+    // grid = chunks x P work-groups in one dimension (no 65535 limit on the number of pairs)
+    const int p = (int)(blockIdx.x / (unsigned)chunks), chunk = (int)(blockIdx.x % (unsigned)chunks);
     if (keysInit) // the matcher merges query splits with atomicMin: start every key at "no query" (saves a memset launch)
-        for (int t = blockIdx.x * kBlock + threadIdx.x; t < cap; t += gridDim.x * kBlock) keysInit[(size_t)p * cap + t] = kNoKey;
+        for (int t = chunk * kBlock + threadIdx.x; t < cap; t += chunks * kBlock) keysInit[(size_t)p * cap + t] = kNoKey;
     const int fq = pairs[2 * p];
     const int nq = nkpts[fq];
     const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
     uint4 *__restrict__ out = Xq + (size_t)p * tpf * kTileU4;
     const int o = threadIdx.x, s = o >> 6, h = (o >> 5) & 1, r = o & 31;
-    for (int tile = blockIdx.x; tile < tpf; tile += gridDim.x) {
+    for (int tile = chunk; tile < tpf; tile += chunks) {
         const int row = tile * kTileRows + r;
         v4i_t e = {0, 0, 0, 0};
         if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * s + h]);
