@@ -17,9 +17,16 @@ thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (
 
 Submission: the step's pairs go out as --streams sub-batch chains (default 3), one HIP stream and one
 context each.  With --join end (default) the chains are ordered only within their own stream, so
-consecutive steps pipeline into each other (one chain's popcount sweep runs beside another's scoring
-sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
---streams 1 is the single launch chain the per-kernel roofline figures of DESIGN.md section 4 refer to.
+consecutive steps pipeline into each other (one chain's matrix-core Hamming sweep runs beside another's vector
+scoring sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
+
+After the timed region (never part of `value`) rank 0 of a single-GPU run adds three short legs:
+  * a single-chain leg -- the same step as ONE launch chain on one stream, HIP events around every kernel: the
+    kernels' own durations.  `kernel_ms`, `roofline`, `kernel_bounds`, `single_chain` come from it (the timed region's
+    per-launch figures, measured while three chains share the CUs, are kept as `timed_region_kernel_ms`);
+  * one pass with the fast scoring kernel's statistics on (`score_parked_frac`);
+  * `cpu_baseline`: the oracle on the same workload on all host cores, 5 passes, median (+ the reference's own
+    <= 487-iteration schedule as `cpu_reference_schedule`).
 
 Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section "Measurement").
 """
