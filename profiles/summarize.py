@@ -76,10 +76,23 @@ def main():
             if "psdev::" in k:
                 per[k.split("psdev::")[1].split("(")[0]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
         out = {}
+        # launch order of bench.py --streams 1: W warm-up, K timed, 1 leg warm-up, L = max(3, min(8, K)) leg launches
+        # (what `kernel_ms` averages), 1 statistics pass
+        K = W = None
+        try:
+            line = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())
+            K, W = int(line["steps"]), int(line["warmup"])
+        except Exception:
+            pass
         for k, v in per.items():
             v.sort()
             ms = [round(x[1], 4) for x in v]
-            out[k] = {"launch_ms": ms, "single_chain_leg_mean_ms": (sum(ms[-6:-1]) / 5 if len(ms) == 14 else None)}
+            leg = None
+            if K is not None:
+                L = max(3, min(8, K))
+                if len(ms) == W + K + 1 + L + 1:
+                    leg = sum(ms[-(L + 1):-1]) / L
+            out[k] = {"launch_ms": ms, "all_launches_mean_ms": sum(ms) / len(ms), "single_chain_leg_mean_ms": leg}
         with open(os.path.join(dst, "kernel_launch_ms.json"), "w") as f:
             json.dump(out, f, indent=1)
     for extra in ("bench_default.json",):
