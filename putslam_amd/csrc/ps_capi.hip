@@ -41,7 +41,7 @@ struct PsContext {
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, recE, recP, recE4, counts, mvalid, cmax, idxList, raw;
+    Buf keys, recA, recB, recC, recD, recE, recH, recS, counts, mvalid, cmax, idxList, raw;
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches only)
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
@@ -392,14 +392,27 @@ void tick(PsContext *ctx, int slot, bool stop)
     }
 }
 
-int cap_e(int cap) { return (cap + 15) & ~15; } // per-pair row count of recE4: cap rounded up to whole 16-match tiles
+int cap_h(int cap) { return (cap + 31) & ~31; } // per-pair row count of recH: cap rounded up to whole 32-match tiles
 
-RecPtrs rec_ptrs(PsContext *ctx, int cap)
+// The f16 operands of the matrix-core scoring kernel are written (by kernel 2) only when that kernel will read them.
+bool with_split(const PsContext *ctx, int mode) { return ctx->scoreFast == 2 && mode == PS_REPROJECTION_ERROR; }
+
+int ensure_split(PsContext *ctx, int P, int cap)
+{
+    PS_ENSURE(ctx->recH, (size_t)P * 6 * cap_h(cap) * 32);
+    PS_ENSURE(ctx->recS, (size_t)P * sizeof(int2));
+    return PS_OK;
+}
+
+RecPtrs rec_ptrs(PsContext *ctx, int cap, int mode)
 {
     RecPtrs r;
     r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
-    r.E = (float4 *)ctx->recE.p; r.P = (float4 *)ctx->recP.p; r.E4 = (float *)ctx->recE4.p;
-    r.capE = cap_e(cap);
+    r.E = (float4 *)ctx->recE.p;
+    const bool split = with_split(ctx, mode);
+    r.H = split ? (uint4 *)ctx->recH.p : nullptr;
+    r.S = split ? (int2 *)ctx->recS.p : nullptr;
+    r.capH = cap_h(cap);
     return r;
 }
 
@@ -460,20 +473,20 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (ctx->scoreFast == 2) {
             unsigned long long *dbg = nullptr;
             if (ctx->scoreStats) {
-                PS_ENSURE(ctx->dbgCnt, 2 * sizeof(unsigned long long));
-                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
+                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             hipLaunchKernelGGL(ps_ransac_score_mfma<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
                                (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
-                               (const float4 *)ctx->recP.p, (const float *)ctx->recE4.p, (const int32_t *)ctx->mvalid.p,
-                               (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, cap_e(cap), pl.minRun, msplit,
+                               (const uint4 *)ctx->recH.p, (const int2 *)ctx->recS.p, (const int32_t *)ctx->mvalid.p,
+                               (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, cap_h(cap), pl.minRun, msplit,
                                (int32_t *)ctx->counts.p, dbg);
         } else if (ctx->scoreFast == 1) {
             unsigned long long *dbg = nullptr;
             if (ctx->scoreStats) {
-                PS_ENSURE(ctx->dbgCnt, 2 * sizeof(unsigned long long));
-                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
+                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             hipLaunchKernelGGL(ps_ransac_score_fast<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
@@ -513,7 +526,6 @@ int ensure_records(PsContext *ctx, size_t n)
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
     PS_ENSURE(ctx->recE, n * 16);
-    PS_ENSURE(ctx->recP, n * 16);
     return PS_OK;
 }
 
@@ -528,7 +540,10 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     if (withRecords) {
         int rc = ensure_records(ctx, (size_t)P * cap);
         if (rc != PS_OK) return rc;
-        PS_ENSURE(ctx->recE4, (size_t)P * cap_e(cap) * 16 + 256);
+        if (with_split(ctx, pa.mode)) {
+            rc = ensure_split(ctx, P, cap);
+            if (rc != PS_OK) return rc;
+        }
     }
     if (ctx->matcher == 1) {
         // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
@@ -575,7 +590,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
                        (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p)
     RecPtrs rp{};
     if (withRecords) {
-        rp = rec_ptrs(ctx, cap);
+        rp = rec_ptrs(ctx, cap, pa.mode);
         if (wide)
             PS_LAUNCH_PREP(true, 1024);
         else
@@ -670,7 +685,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recP, &ctx->recE4, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recH, &ctx->recS, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -909,7 +924,10 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->cmax, sizeof(float2));
     rc = ensure_records(ctx, (size_t)cap);
     if (rc) return rc;
-    PS_ENSURE(ctx->recE4, (size_t)cap_e(cap) * 16 + 256);
+    if (with_split(ctx, pl.pa.mode)) {
+        rc = ensure_split(ctx, 1, cap);
+        if (rc) return rc;
+    }
     if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
     if (ncur > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, cur, (size_t)ncur * 12, hipMemcpyHostToDevice, ctx->stream));
     if (m > 0)
@@ -918,7 +936,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     int32_t mm = m;
     PS_HIP(hipMemcpyAsync(ctx->sNumM.p, &mm, sizeof mm, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(ps_prep_from_matches, dim3(1), dim3(kBlock), 0, ctx->stream, (const float *)ctx->sMisc0.p,
-                       (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa, rec_ptrs(ctx, cap),
+                       (const float *)ctx->sMisc1.p, (const PsDMatch *)ctx->sMatches.p, m, pl.pa, rec_ptrs(ctx, cap, pl.pa.mode),
                        (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p);
     PS_HIP(hipGetLastError());
     rc = run_ransac_stage(ctx, pl, 1, cap, (const PsDMatch *)ctx->sMatches.p, (const int32_t *)ctx->sNumM.p, cap,
@@ -1019,7 +1037,7 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
     if (!parked || !evaluations) return PS_ERR_BAD_ARG;
     *parked = *evaluations = 0;
     if (!ctx->dbgCnt.p) return PS_OK;
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));
     *parked = h[0];
@@ -1464,7 +1482,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
     const void *arena[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p, ctx->models.p};
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1504,7 +1522,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         rc = enqueue((size_t)n);
         if (rc) return rc;
         const void *after[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recP.p, ctx->recE4.p, ctx->models.p};
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

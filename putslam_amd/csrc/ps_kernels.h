@@ -175,14 +175,84 @@ struct PrepArgs {
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
 struct RecPtrs {
     float4 *A;  // prev xyz + squared Euclid bound
-    float4 *B;  // cur xyz, w = 1   (also the A operand "current point" of the matrix-core scoring kernel)
+    float4 *B;  // cur xyz, w = 1
     float4 *C;  // projections of prev and cur (realOld u v, realNew u v)
     int4 *D;    // (index in the match list, queryIdx, trainIdx, 0)
     float4 *E;  // offsets c - real of the fast scoring path: (cx - uOld, cx - uNew, cy - vOld, cy - vNew)
-    float4 *P;  // prev xyz, w = 1  (A operand "previous point" of the matrix-core scoring kernel)
-    float *E4;  // the offsets of E transposed in groups of four matches, [P][capE / 4][4 components][4 matches]
-    int capE;   // cap rounded up to a multiple of 16
+    uint4 *H;   // f16 match operands of the matrix-core scoring kernel, [P][6 kinds][capH][2 K-blocks] (ps_score_mfma.h)
+    int2 *S;    // per pair: (eP, kappa), the power-of-two scales those operands were written with
+    int capH;   // cap rounded up to whole 32-match tiles
 };
+
+// ---- f16 operand split of the matrix-core scoring kernel (ps_score_mfma.h) ----
+// A scaled f32 value v (|v| <= 2^14) as hi + lo with hi = f16(v), lo = f16(v - hi):  |v - hi - lo| <= 2^-22 |v| + 2^-25
+// (v - hi is exact in f32; subnormal halfs are produced by v_cvt_f16_f32 and honoured by the f16 MFMA on gfx950,
+// profiles/microbench/mfma_f16_denorm.hip).
+PS_D void split_f16(float v, uint32_t &hi, uint32_t &lo)
+{
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    lo = (uint32_t)__builtin_bit_cast(unsigned short, l);
+}
+// x <= 2^n for finite x > 0 (0 -> 0)
+PS_D int exp_ceil(float x)
+{
+    int n;
+    (void)frexpf(x, &n);
+    return n;
+}
+// The pair-level scales: points are written times 2^eP (largest |coordinate| or the constant 1 -> at most 2^13), the
+// offset-times-point rows times 2^(eP - kappa) with 2^kappa >= max(Umax, fx, fy, 1).
+PS_D int2 split_scales(float cmax, float umax, float fx, float fy)
+{
+    const int nC = exp_ceil(fmaxf(cmax, 1.0f));
+    const int nU = umax > 0.0f ? exp_ceil(umax) : -126;
+    const int nF = exp_ceil(fmaxf(fmaxf(fabsf(fx), fabsf(fy)), 1.0f));
+    int kap = nU > nF ? nU : nF;
+    kap = kap < 1 ? 1 : (kap > 60 ? 60 : kap);
+    int eP = 13 - nC;
+    eP = eP < -100 ? -100 : eP; // (non-finite bounds: the scoring kernel does not use the operands of such a pair)
+    return make_int2(eP, kap);
+}
+// One K-block (two coordinates) of a match-side operand row: slots (hi, hi, lo, lo) per coordinate.
+PS_D uint4 match_block(float c0, float c1)
+{
+    uint32_t h0, l0, h1, l1;
+    split_f16(c0, h0, l0);
+    split_f16(c1, h1, l1);
+    return make_uint4(h0 | (h0 << 16), l0 | (l0 << 16), h1 | (h1 << 16), l1 | (l1 << 16));
+}
+// Second pass of kernel 2 (all threads of the pair's work-group, after the records and the pair bounds are known):
+// the six f16 operand rows of every depth-valid match -- for each direction the point (x, y, z, 1) and the point times
+// the two image offsets k = c - real, so that the matrix cores produce  A~ = fx X + k Z  directly (ps_score_mfma.h).
+template <int BLOCK>
+PS_D void write_split_operands(const PrepArgs &a, const RecPtrs &r, int p, int M, float cmax, float umax)
+{
+    if (r.H == nullptr) return;
+    const int2 sc = split_scales(cmax, umax, a.fx, a.fy);
+    if (threadIdx.x == 0) r.S[p] = sc;
+    const int eP = sc.x, eK = sc.x - sc.y;
+    uint4 *base = r.H + (size_t)p * 6 * r.capH * 2;
+    for (int v = threadIdx.x; v < M; v += BLOCK) {
+        const size_t slot = (size_t)p * a.cap + (size_t)v;
+        const float4 prev = r.A[slot], cur = r.B[slot], e = r.E[slot];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            // direction 0: current point -> previous image (offsets of realOld); 1: previous point -> current image
+            const float px = d ? prev.x : cur.x, py = d ? prev.y : cur.y, pz = d ? prev.z : cur.z;
+            const float kx = d ? e.y : e.x, ky = d ? e.w : e.z;
+            uint4 *row = base + ((size_t)(3 * d) * r.capH + v) * 2;
+            const size_t kind = (size_t)r.capH * 2;
+            row[0] = match_block(ldexpf(px, eP), ldexpf(py, eP));
+            row[1] = match_block(ldexpf(pz, eP), ldexpf(1.0f, eP));
+            row[kind + 0] = match_block(ldexpf(kx * px, eK), ldexpf(kx * py, eK));
+            row[kind + 1] = match_block(ldexpf(kx * pz, eK), ldexpf(kx, eK));
+            row[2 * kind + 0] = match_block(ldexpf(ky * px, eK), ldexpf(ky * py, eK));
+            row[2 * kind + 1] = match_block(ldexpf(ky * pz, eK), ldexpf(ky, eK));
+        }
+    }
+}
 
 // Builds the records of depth-valid match number v of pair p; returns the largest |offset| of E.
 PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int srcIdx, int q, int t, float px, float py,
@@ -201,14 +271,13 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
     r.B[slot] = make_float4(cx_, cy_, cz_, 1.0f);
     r.C[slot] = make_float4(ou, ov, nu, nv);
     r.D[slot] = make_int4(srcIdx, q, t, 0);
-    r.P[slot] = make_float4(px, py, pz, 1.0f);
     // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
     r.E[slot] = e;
-    float *e4 = r.E4 + ((size_t)p * r.capE + (size_t)(v & ~3)) * 4 + (v & 3);
-    e4[0] = e.x; e4[4] = e.y; e4[8] = e.z; e4[12] = e.w;
-    return fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)));
+    // (a NaN offset reports an infinite bound: the decision-exact kernels then leave the pair to the value-exact code)
+    const bool num = e.x == e.x && e.y == e.y && e.z == e.z && e.w == e.w;
+    return num ? fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))) : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -287,6 +356,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         float c = block_max<BLOCK>(cm, s_red);
         float u = block_max<BLOCK>(um, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
+        write_split_operands<BLOCK>(a, rec, p, vbase, c, u); // (block_max ends with a barrier: the records are visible)
         if (a.zeroCounts)
             for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroH + i] = 0;
     }
@@ -333,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         mvalid[0] = vbase;
         cmaxOut[0] = make_float2(c, u);
     }
+    write_split_operands<kBlock>(a, rec, 0, vbase, c, u);
     if (a.zeroCounts)
         for (int i = threadIdx.x; i < a.zeroH; i += kBlock) a.zeroCounts[i] = 0;
 }

@@ -1,0 +1,28 @@
+"""Device characterisation behind ps_ransac_score_mfma's error band (putslam_amd/csrc/ps_score_mfma.h): the ISA does not
+state how accurately v_mfma_f32_32x32x16_f16 accumulates, the kernel ASSUMES |D - (c + sum a_k b_k)| <= 12 u (|c| + sum |a_k b_k|)
+per instruction (u = 2^-24; the adder model read off profiles/microbench/mfma_f16_probe*.hip gives 8.75 u).  This test
+measures it on the device under test: 3 M dot products from six adversarial families against 128-bit integer arithmetic."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "profiles", "microbench", "mfma_f16_acc")
+
+
+def test_mfma_f16_accumulation_error_within_the_assumed_bound():
+    if not os.path.exists(EXE):
+        pytest.fail("profiles/microbench/mfma_f16_acc is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"worst gamma over all families: ([0-9.]+) u", out.stdout)
+    assert m, out.stdout
+    worst = float(m.group(1))
+    # one MFMA and two chained ones (what the kernel issues) both stay below the model bound; the kernel assumes 12 u / 24 u
+    assert 0.5 < worst <= 8.75, out.stdout
+    # the layout the kernel relies on: the cancellation family is exact
+    assert re.search(r"heavy cancellation\s+0\.000\s+0\.000", out.stdout), out.stdout

@@ -132,3 +132,42 @@ def test_score_variants_full_results(fctx, ectx, oracle):
             assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
             assert g["stats"]["bestHypothesis"] == c["stats"]["bestHypothesis"]
             assert g["stats"]["bestInlierCount"] == c["stats"]["bestInlierCount"]
+
+
+def test_score_variants_batch_on_a_full_chip(oracle):
+    """The three kernels over a batch large enough that several work-groups share every CU (two waves per SIMD for the
+    matrix-core kernel): identical results, run to run and kernel to kernel.  This is the configuration that exposed the
+    MFMA source-operand hazard documented in ps_score_mfma.h (counts wrong and different from run to run, while every
+    single-pair test -- at most one work-group per CU -- passed)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(33, 2000, config=3, index=1)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=42)
+    outs = {}
+    for score in (1, 2, 2, 2, 0):
+        c = api.Context(0)
+        c.set_option("score", score)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        c.close()
+        if "ref" not in outs:
+            outs["ref"] = g
+            continue
+        r = outs["ref"]
+        assert g["pose"].tobytes() == r["pose"].tobytes(), "score=%d" % score
+        assert np.array_equal(g["inlierMask"], r["inlierMask"]), "score=%d" % score
+        for k in ("bestHypothesis", "bestInlierCount", "numInliers", "numMatchesValid"):
+            assert np.array_equal(g["stats"][k], r["stats"][k]), (score, k)
+    # and one pair of the batch against the oracle, every hypothesis, at the automatic (large) match-range split
+    p = 11
+    cfgp, _ = make_config(EST_FIXED, 4096, seed=42 + p)
+    c = api.Context(0)
+    c.set_option("score", 2)
+    m = c.match_hamming256(seq["desc"][p], seq["desc"][p + 1])
+    want, _ = oracle.hypothesis_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], m)
+    for _ in range(3):
+        got = c.debug_ransac_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], m)
+        assert np.array_equal(got, want)
+    c.close()
