@@ -47,7 +47,7 @@ MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1
 # VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane),
 # counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
 VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
-                 "ps_ransac_score_fast<1>": 24, "ps_ransac_score_mfma<1>": 16.6}
+                 "ps_ransac_score_fast<1>": 23, "ps_ransac_score_mfma<1>": 16.6}
 
 
 def parse():

@@ -343,7 +343,7 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
             fc.fmaxK = up(fm);
             fc.cmaxK = up(cm);
             fc.thrUp = up(T * (1.0 + 1e-5));
-            fc.bIn0 = down(bR * (1.0 - 16.0 * 5.9604644775390625e-08));
+            fc.bIn0 = down(bR * (1.0 - 20.0 * 5.9604644775390625e-08));
             fc.cIn = up(2.0 * std::sqrt(2.0) * T * (1.0 + 1e-5));
             const double c = std::sqrt(2.0) * (1.0 + 1e-5);
             fc.thr2Up = up((double)fc.thrUp * (double)fc.thrUp);

@@ -7,7 +7,7 @@
 // per evaluation).  This kernel takes the decision from a cheap evaluation with a proven error band and hands the
 // evaluations that fall inside the band to the value-exact code:
 //
-//   fast evaluation (23 VALU instructions, 18 of them v_pk_*_f32 over the two directions): both transforms as FMA
+//   fast evaluation (23 VALU instructions, 16 of them v_pk_*_f32 over the two directions): both transforms as FMA
 //   chains with the camera constants folded into the model rows (X~ = fx (R p + t)_x, ..., Z~ = (R p + t)_z) and the
 //   test taken in the MULTIPLIED domain, without any division:
 //       reference:  dx = fl(fl(fl(e_x fx) / e_z) + cx) - u_real,   inlier <=> dx^2 + dy^2 < boundR  (both directions)
@@ -30,7 +30,10 @@
 //       s~ < w (T^2 (1 - 16u) w - 2 T' G)                   =>  the reference's test passes      (certain inlier)
 //       s~ > w (T'^2 w + 2 T' G) + G^2 (1 + 1e-4)           =>  it fails                          (certain outlier:
 //                                                                had it passed, s~ would be below this limit)
-//   with T' = T (1 + 1e-5); both limits are two packed FMAs each in w, the constants rounded to the safe side.  No
+//   with T' = T (1 + 1e-5).  Evaluated as  T^2 (1 - 20u) q - band  and  T'^2 q + band  with  q = Z~^2  and ONE
+//   band = fl(2 T' G |Z~| + G^2 (1 + 1e-4)) for both (the lower limit only gets stricter by G^2; 4u more on the
+//   quadratic coefficient for the rounding of q and of the band): one packed multiply, two plain FMAs with the |.|
+//   source modifier and two packed FMAs, the constants rounded to the safe side.  No
 //   depth floor is needed: the errors are absolute, not divided by Z~; for |Z~| -> 0 the lower limit turns negative
 //   (never "inlier") and the upper one tends to G^2, the noise level of s~ itself (then "uncertain", not "outlier").
 //   Anything else -- inside the band, NaN -- is "uncertain".
@@ -52,7 +55,7 @@ struct FastConsts {
     float fmaxK;  // max(|fx|, |fy|, 1)
     float cmaxK;  // max(|cx|, |cy|)
     float thrUp;  // sqrt(boundR) (1 + 1e-5), rounded up
-    float bIn0;   // boundR (1 - 16u), rounded down
+    float bIn0;   // boundR (1 - 20u), rounded down
     float cIn;    // 2 sqrt2 sqrt(boundR) (1 + 1e-5), rounded up
     float thr2Up; // thrUp^2, rounded up
     float cHi;    // (2 c + c^2) thrUp with c = sqrt2 (1 + 1e-5), rounded up
@@ -103,7 +106,7 @@ PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(
 // (cx - uOld, cx - uNew, cy - vOld, cy - vNew).
 // Division-free form: A~ = X~ + k Z~ ~ (predicted - real) * depth; returns s~ = A~^2 + B~^2 of the two directions and
 // w = |Z~| of the two projected depths.
-PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const float4 &E, v2f_t &w)
+PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const float4 &E, v2f_t &Zout)
 {
     const v2f_t px = {B.x, A.x}, py = {B.y, A.y}, pz = {B.z, A.z};
     const v2f_t X = pk_fma(f.r0[0], px, pk_fma(f.r0[1], py, pk_fma(f.r0[2], pz, f.t0)));
@@ -111,7 +114,7 @@ PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const 
     const v2f_t Z = pk_fma(f.r2[0], px, pk_fma(f.r2[1], py, pk_fma(f.r2[2], pz, f.t2)));
     const v2f_t Au = pk_fma(v2f_t{E.x, E.y}, Z, X);
     const v2f_t Bv = pk_fma(v2f_t{E.z, E.w}, Z, Y);
-    w = __builtin_elementwise_max(Z, -Z);
+    Zout = Z;
     return pk_fma(Au, Au, Bv * Bv);
 }
 
@@ -234,10 +237,19 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
         for (int m = m0; m < m1; ++m) {
             const float4 A = pa[m], B = pb[m], E = pe[m];
-            v2f_t w;
-            const v2f_t ss = fast_sq2(F, A, B, E, w);
-            const v2f_t lo = pk_fma(v2f_t{fc.bIn0, fc.bIn0}, w, v2f_t{-cL, -cL}) * w;
-            const v2f_t hi = pk_fma(pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, w, v2f_t{cL, cL}), w, v2f_t{G2, G2});
+            v2f_t Z;
+            const v2f_t ss = fast_sq2(F, A, B, E, Z);
+            // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
+            // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
+            const v2f_t q = Z * Z;
+            // (inline asm: written with fabsf() the compiler packs the two FMAs again and spends two v_and on |Z~|)
+            const float zx = Z.x, zy = Z.y;
+            float bx, by;
+            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(bx) : "v"(cL), "v"(zx), "v"(G2));
+            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(by) : "v"(cL), "v"(zy), "v"(G2));
+            const v2f_t band = {bx, by};
+            const v2f_t lo = pk_fma(v2f_t{fc.bIn0, fc.bIn0}, q, -band);
+            const v2f_t hi = pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, q, band);
             // (scalar copies: comparisons on vector-element expressions; any NaN makes all four comparisons false)
             const float se = ss.x, sn = ss.y, loe = lo.x, lon = lo.y, hie = hi.x, hin = hi.y;
             const unsigned long long mIn =

@@ -2,7 +2,7 @@
 // matrix cores, in split f16.
 //
 // Same decision-exact scheme as ps_ransac_score_fast (ps_score_fast.h: cheap evaluation + proven error band, in-band
-// evaluations parked and re-done by the value-exact code).  The cheap evaluation there spends 11 of its 17 packed
+// evaluations parked and re-done by the value-exact code).  The cheap evaluation there spends 11 of its 16 packed
 // instructions on        X~ = fx (R p + t)_x,  Y~,  Z~        and        A~ = X~ + (cx - u_real) Z~,  B~ = Y~ + (cy - v_real) Z~.
 // With k = c - real folded into the MATCH side these are three plain dot products over eight "coordinates":
 //
@@ -29,10 +29,11 @@
 // fields, and inlier / certain / uncertain are three integer instructions per 16 evaluations:
 //       in = inE & inN;   certain = in | outE | outN;   count += popcount(in);   uncertain = ~certain
 // (logic instructions issue at 2.4 cycles against 4.3 for a compare, and no SGPR masks have to be kept).  That needs every
-// value of the hot loop to be finite -- see boundsOk.  Per 1024 evaluations: 10 MFMA + ~265 VALU against 24 x 16 = 384.
+// value of the hot loop to be finite -- see boundsOk.  Per 1024 evaluations: 10 MFMA + ~265 VALU against 23 x 16 = 368.
 //
-// What it achieves (499 pairs, 2000 keypoints, H = 4096, single chain): 1.64 ms against 1.87 ms for ps_ransac_score_fast
-// -- and no gain in the three-chain timed region, so it is a tested option (PUTSLAM_HIP_SCORE=mfma), not the default.
+// What it achieves (499 pairs, 2000 keypoints, H = 4096; profiles/r02i): 1.57 ms against 1.76 ms for ps_ransac_score_fast
+// single-chain, 260.0 k against 248.9 k frame-pairs/s in the three-chain timed region: a tested option
+// (PUTSLAM_HIP_SCORE=mfma), not the default.
 // Why not more (profiles/microbench/mfma_valu_coissue.hip, valu_dep.hip):
 //   * on one gfx950 SIMD a v_mfma_f32_32x32x16_f16 stream and a v_pk_fma_f32 stream do NOT overlap (one wave or two:
 //     the times add); 10 MFMAs cost 400 cycles per 1024 evaluations on top of the vector work;
@@ -56,7 +57,7 @@
 //   with the reference's own distance to A* (ps_score_fast.h: 8.03 fmaxK + 5.02 Umax + 3.02 cmaxK, and 5 u S for e_z):
 //       E = 1.05 u (42 fmaxK + 40 Umax + 4 cmaxK) S + 2^-6 / s1,     |e_z - Z~| <= 26 u S + 2^-7 / s2,
 //       G = sqrt2 E + T' (26 u S + 2^-7 / s2)
-//   and the same two limits  s~ < w (T^2 (1 - 16u) w - 2 T' G)  /  s~ > w (T'^2 w + 2 T' G) + G^2 (1 + 1e-4), evaluated on the
+//   and the same two limits  s~ < w (T^2 (1 - 20u) w - 2 T' G)  /  s~ > w (T'^2 w + 2 T' G) + G^2 (1 + 1e-4), evaluated on the
 //   SCALED accumulators (all scale factors are powers of two: no further rounding).  The band is ~3 times wider than the
 //   f32 chain's: 0.21 % instead of 0.07 % of the evaluations are parked.
 #pragma once
