@@ -134,14 +134,17 @@ def test_score_variants_full_results(fctx, ectx, oracle):
             assert g["stats"]["bestInlierCount"] == c["stats"]["bestInlierCount"]
 
 
-def test_score_variants_batch_on_a_full_chip(oracle):
+@pytest.mark.parametrize("thr", [2.0, 0.05])
+def test_score_variants_batch_on_a_full_chip(oracle, thr):
     """The three kernels over a batch large enough that several work-groups share every CU (two waves per SIMD for the
     matrix-core kernel): identical results, run to run and kernel to kernel.  This is the configuration that exposed the
     MFMA source-operand hazard documented in ps_score_mfma.h (counts wrong and different from run to run, while every
-    single-pair test -- at most one work-group per CU -- passed)."""
+    single-pair test -- at most one work-group per CU -- passed).  At 0.05 px so many evaluations fall inside the band
+    that the matrix-core kernel drains its queue from inside the pipelined loop, with MFMAs in flight."""
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     seq = synth.make_sequence(33, 2000, config=3, index=1)
     prm = default_ransac_params(REPROJECTION_ERROR)
+    prm.inlierThresholdReprojection = thr
     cfg, _ = make_config(EST_FIXED, 4096, seed=42)
     outs = {}
     for score in (1, 2, 2, 2, 0):
