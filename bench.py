@@ -292,8 +292,20 @@ def main():
                 t = json.load(open(tf))
                 key = f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}x{matcher}x{score}"
                 traffic = t.get(key, {}).get(dom)
+                # pipe-busy fractions of the same profiled workload (SQ counters of the rocprofv3 pass next to the
+                # traffic pass): share of the kernel's cycles in which the vector ALU / the matrix pipe of a SIMD is busy
+                sq = json.load(open(os.path.join(ROOT, os.path.dirname(t[key]["_source"]), "sq_counters.json")))
+                for kname, c in sq.items():
+                    short = kname.split("<")[0]
+                    short = {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_mfma": "ps_ransac_score"}.get(short, short)
+                    if short in bounds_solo and c.get("GRBM_GUI_ACTIVE"):
+                        cyc = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0      # kernel cycles x SIMDs (8 XCDs report separately)
+                        bounds_solo[short]["pipe_busy_pmc"] = {
+                            "valu_active_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / cyc,
+                            "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / cyc,
+                            "source": os.path.dirname(t[key]["_source"]) + "/sq_counters.json (profiled run, not this one)"}
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
