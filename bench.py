@@ -255,7 +255,7 @@ def main():
         bytes_per_pair = float(np.mean([api.algorithmic_bytes(args.kpts, int(s["numMatchesIn"]),
                                                               int(s["numMatchesValid"]), Hs) for s in stats]))
         kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # timed region: average launch duration, ms
-        matcher = "mfma" if ctx.get_option("matcher") == 1 else "valu"
+        matcher = "mfma" if ctx.get_option("matcher_used") == 1 else "valu"   # what this workload's calls ran
         score = ({1: "fast", 2: "mfma"}.get(ctx.get_option("score"), "exact") if args.error_version == 1 else "exact")
 
         def kernel_bounds(kms, pairs_per_launch):

@@ -115,8 +115,10 @@ void ps_context_destroy(PsContext *ctx);
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);
 /* Kernel variants kept side by side for A/B measurements and as tested twins (results are identical):
- *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma (default), 0 = integer VALU sweep ps_hamming_nn
- *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu, read at context creation).
+ *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma, 0 = integer VALU sweep ps_hamming_nn, 2 = by batch size
+ *              (default: the matrix-core form, one launch more, from about five 2000-keypoint pairs per call on)
+ *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu|auto, read at context creation); "matcher_used" (read only)
+ *              tells which of the two the last matching call ran.
  *   "score":   1 = decision-exact fast scoring kernel for errorVersion 1 (ps_ransac_score_fast: cheap evaluation with a
  *              proven error band, in-band evaluations re-done by the value-exact code; default), 2 = the same scheme
  *              with the two rigid transforms and the image-offset products on the matrix cores in split f16

@@ -61,8 +61,11 @@ struct PsContext {
     unsigned slotMask[kTimingRing] = {0}; // per kept call: which slots were recorded
     // tuning overrides (PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT, read once; 0 = automatic)
     int forceQsplit = 0, forceMsplit = 0;
-    // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher
-    int matcher = 1;
+    // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher,
+    // 2 = by batch size (default): the MFMA form costs one more launch (the FP4 expansion), which a handful of pairs does
+    // not earn back
+    int matcher = 2;
+    int matcherUsed = 1; // what the last matching call ran (1 MFMA, 0 VALU)
     // errorVersion 1: 1 = decision-exact VALU kernel (ps_score_fast.h, default), 2 = decision-exact scoring with the
     // transforms on the matrix cores (ps_score_mfma.h: correct, measured 8 % slower, profiles/r02f),
     // 0 = value-exact ps_ransac_score<1>
@@ -545,7 +548,10 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
             if (rc != PS_OK) return rc;
         }
     }
-    if (ctx->matcher == 1) {
+    // by batch size: VALU sweep 1.85 us, MFMA sweep 0.43 us per 2000 x 2000 pair on a full chip, + ~7 us for the extra launch
+    const bool useMfma = ctx->matcher == 1 || (ctx->matcher == 2 && (double)P * cap * cap > 2.0e7);
+    ctx->matcherUsed = useMfma ? 1 : 0;
+    if (useMfma) {
         // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
 #ifndef PS_MFMA_TT
 #define PS_MFMA_TT 4
@@ -666,7 +672,8 @@ int ps_context_create(int device, PsContext **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
     if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
-    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER")) ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : 1;
+    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER"))
+        ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
@@ -717,7 +724,7 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;
     if (strcmp(name, "matcher") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "matcher: 0 (VALU) or 1 (MFMA)");
+        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)");
         ctx->matcher = value;
         return PS_OK;
     }
@@ -743,6 +750,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;
     if (strcmp(name, "matcher") == 0) return ctx->matcher;
+    if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
     if (strcmp(name, "score") == 0) return ctx->scoreFast;
     if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
     if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
