@@ -48,6 +48,9 @@ MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1
 # counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
 VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
                  "ps_ransac_score_fast<1>": 23, "ps_ransac_score_mfma<1>": 16.6}
+# of those, packed two-lane f32 instructions (v_pk_*_f32: two f32 operations per lane, issued over 4 cycles -- the same
+# f32 rate as two plain instructions at 2 cycles): counted twice in `lane_ops`
+PK_PER_UNIT = {"ps_ransac_score_fast<1>": 16, "ps_ransac_score_mfma<1>": 7.0}
 
 
 def parse():
@@ -277,6 +280,12 @@ def main():
                     ach = wave_units * per_unit * 64.0 / (kms[name] * 1e-3) / 1e12
                     out[name] = {"bound": "valu", "valu_instructions_per_unit": per_unit, "achieved": ach,
                                  "peak": VALU_PEAK_TOPS, "unit": "T lane-instructions/s", "frac": ach / VALU_PEAK_TOPS}
+                    pk = PK_PER_UNIT.get("%s_%s<%d>" % (name, score, args.error_version)) if name == "ps_ransac_score" else None
+                    if pk:
+                        # f32 lane OPERATIONS (a packed instruction = two): the figure to hold against the f32 vector peak
+                        out[name]["lane_ops_per_unit"] = per_unit + pk
+                        out[name]["achieved_lane_ops"] = ach * (per_unit + pk) / per_unit
+                        out[name]["frac_lane_ops"] = out[name]["achieved_lane_ops"] / VALU_PEAK_TOPS
             return out
 
         rk = solo if solo else kern                      # kernels' own durations when the single-chain leg ran
