@@ -360,3 +360,37 @@ def test_one_context_called_from_two_streams_is_ordered(oracle):
         for i in range(2):
             _compare(pbs[i].download(), ref[i], len(seqs[i]["pairs"]))
     c.close()
+
+
+def test_maximum_keypoints_batch_with_coresident_workgroups(ctx, oracle):
+    """PS_MAX_KPTS rows per frame in a batch large enough (299 pairs on 256 CUs) that two cross-check work-groups, 64 KiB
+    of LDS each, share a CU: match lists identical run to run and equal to the oracle's on sampled pairs."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    n, F = 16384, 300
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    desc = np.empty((F, n, 32), np.uint8)
+    for f in range(F):
+        d = base[rng.permutation(n)] ^ np.packbits(rng.random((n, 256)) < 0.05, axis=1)
+        d[n // 2:] = rng.integers(0, 256, (n - n // 2, 32), dtype=np.uint8)
+        desc[f] = d
+    pts = rng.uniform(-1, 1, (F, n, 3)).astype(np.float32)
+    pts[..., 2] = rng.uniform(0.5, 5.0, (F, n)).astype(np.float32)
+    nk = np.full(F, n, np.int32)
+    pairs = np.array([[i, i + 1] for i in range(F - 1)], np.int32)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 256, seed=1)
+    fs = FrameSetDevice(desc, pts, nk)
+    outs = []
+    for _ in range(2):
+        pb = PairBatchDevice(pairs, fs.max_kpts)
+        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+        outs.append(pb.download())
+    assert np.array_equal(outs[0]["numMatches"], outs[1]["numMatches"])
+    for p in range(len(pairs)):
+        k = int(outs[0]["numMatches"][p])
+        assert outs[0]["matches"][p, :k].tobytes() == outs[1]["matches"][p, :k].tobytes(), p
+    for p in (0, 150, 298):
+        c = oracle.match_hamming256(desc[p], desc[p + 1])
+        k = int(outs[0]["numMatches"][p])
+        assert k == len(c) and outs[0]["matches"][p, :k].tobytes() == c.tobytes(), p
