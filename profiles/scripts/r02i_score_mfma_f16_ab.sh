@@ -11,7 +11,7 @@ for s in mfma fast exact; do
   PUTSLAM_HIP_SCORE=$s python bench.py --no-cpu-baseline > $O/bench_s3_$s.json 2> $O/err_s3_$s.txt
 done
 export PUTSLAM_HIP_SCORE=mfma
-rocprofv3 --kernel-trace --stats -d $O/trace -o mfma -- python3 bench.py --streams 1 --steps 20 --warmup 20 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o mfma -- python3 bench.py --streams 1 --steps 20 --warmup 20 --no-cpu-baseline > $O/trace_bench.json 2> $O/trace_err.txt
 unset PUTSLAM_HIP_SCORE
 find $O/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_mfma.csv
 rm -rf $O/trace
