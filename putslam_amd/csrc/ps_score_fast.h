@@ -119,7 +119,7 @@ PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock, 6) void ps_ransac_score_fast(
+__global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound,
     ModelArgs ma, ScoreConsts k, FastConsts fc, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
