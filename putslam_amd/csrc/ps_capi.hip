@@ -528,7 +528,7 @@ int ensure_records(PsContext *ctx, size_t n)
     PS_ENSURE(ctx->recB, n * 16);
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
-    PS_ENSURE(ctx->recE, n * 16);
+    PS_ENSURE(ctx->recE, n * 40);
     return PS_OK;
 }
 

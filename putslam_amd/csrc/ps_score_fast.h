@@ -106,14 +106,16 @@ PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(
 // (cx - uOld, cx - uNew, cy - vOld, cy - vNew).
 // Division-free form: A~ = X~ + k Z~ ~ (predicted - real) * depth; returns s~ = A~^2 + B~^2 of the two directions and
 // w = |Z~| of the two projected depths.
-PS_D v2f_t fast_sq2(const FastModel &f, const float4 &A, const float4 &B, const float4 &E, v2f_t &Zout)
+PS_D v2f_t fast_sq2(const FastModel &f, const float2 *__restrict__ e, v2f_t &Zout)
 {
-    const v2f_t px = {B.x, A.x}, py = {B.y, A.y}, pz = {B.z, A.z};
+    // the 40-byte record IS the operand pairs: (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew) (cy - vOld, cy - vNew)
+    const float2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+    const v2f_t px = {e0.x, e0.y}, py = {e1.x, e1.y}, pz = {e2.x, e2.y};
     const v2f_t X = pk_fma(f.r0[0], px, pk_fma(f.r0[1], py, pk_fma(f.r0[2], pz, f.t0)));
     const v2f_t Y = pk_fma(f.r1[0], px, pk_fma(f.r1[1], py, pk_fma(f.r1[2], pz, f.t1)));
     const v2f_t Z = pk_fma(f.r2[0], px, pk_fma(f.r2[1], py, pk_fma(f.r2[2], pz, f.t2)));
-    const v2f_t Au = pk_fma(v2f_t{E.x, E.y}, Z, X);
-    const v2f_t Bv = pk_fma(v2f_t{E.z, E.w}, Z, Y);
+    const v2f_t Au = pk_fma(v2f_t{e3.x, e3.y}, Z, X);
+    const v2f_t Bv = pk_fma(v2f_t{e4.x, e4.y}, Z, Y);
     Zout = Z;
     return pk_fma(Au, Au, Bv * Bv);
 }
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
-    const float4 *__restrict__ pe = recE + rbase;
+    const float2 *__restrict__ pe = reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(recE) + rbase * 10);
     const float2 pbnd = pairBound[p];
     const float cmax = pbnd.x, umax = pbnd.y;
 
@@ -236,9 +238,8 @@ __global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
 
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
         for (int m = m0; m < m1; ++m) {
-            const float4 A = pa[m], B = pb[m], E = pe[m];
             v2f_t Z;
-            const v2f_t ss = fast_sq2(F, A, B, E, Z);
+            const v2f_t ss = fast_sq2(F, pe + 5 * m, Z);
             // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
             // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
             const v2f_t q = Z * Z;
