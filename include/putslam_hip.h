@@ -122,7 +122,7 @@ int ps_context_synchronize(PsContext *ctx);
  *   "score":   1 = decision-exact fast scoring kernel for errorVersion 1 (ps_ransac_score_fast: cheap evaluation with a
  *              proven error band, in-band evaluations re-done by the value-exact code; default), 2 = the same scheme
  *              with the two rigid transforms and the image-offset products on the matrix cores in split f16
- *              (ps_ransac_score_mfma, v_mfma_f32_32x32x16_f16; 10 % faster, relies on a measured MFMA accumulation bound),
+ *              (ps_ransac_score_mfma, v_mfma_f32_32x32x16_f16; 5 % faster on its own, relies on a measured MFMA accumulation bound),
  *              0 = value-exact ps_ransac_score<1> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
  *              Counts are identical.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).

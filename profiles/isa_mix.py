@@ -129,7 +129,7 @@ def main():
                                              "mix": dict(tot), "cold_fallback_valu": sum(cold.values()) / per}
     # ---- round 2 kernels ----
     # decision-exact scoring kernel: the hot path of one evaluation runs from the loop header to the add-with-carry
-    a = s.index("\n_ZN5psdev20ps_ransac_score_fastILi1EE")
+    a = s.index("\n_ZN5psdev20ps_ransac_score_fastILi1ELb1EE")
     body = s[a:s.index(".Lfunc_end", a)]
     end = body.rindex("v_addc_co_u32")
     start = body.rindex("This Loop Header", 0, end)

@@ -41,7 +41,7 @@ struct PsContext {
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, recE, recH, recS, counts, mvalid, cmax, idxList, raw;
+    Buf keys, recA, recB, recC, recD, recE, recF, recH, recS, counts, mvalid, cmax, idxList, raw;
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches only)
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
@@ -412,6 +412,7 @@ RecPtrs rec_ptrs(PsContext *ctx, int cap, int mode)
     RecPtrs r;
     r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
     r.E = (float4 *)ctx->recE.p;
+    r.F = (float2 *)ctx->recF.p;
     const bool split = with_split(ctx, mode);
     r.H = split ? (uint4 *)ctx->recH.p : nullptr;
     r.S = split ? (int2 *)ctx->recS.p : nullptr;
@@ -492,10 +493,18 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
-            hipLaunchKernelGGL(ps_ransac_score_fast<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
-                               (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
-                               (const float4 *)ctx->recE.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,
-                               pl.ma, pl.sc, pl.fc, pl.H, cap, pl.minRun, msplit, (int32_t *)ctx->counts.p, dbg);
+            // more work-groups than fit at once (256 CUs x 6): the build for big launches (ps_score_fast.h)
+#define PS_LAUNCH_FAST(BIG)                                                                                            \
+    hipLaunchKernelGGL((ps_ransac_score_fast<PS_REPROJECTION_ERROR, BIG>), grid, dim3(kBlock), 0, ctx->stream,         \
+                       (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,          \
+                       (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,       \
+                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, pl.minRun, msplit,                 \
+                       (int32_t *)ctx->counts.p, dbg)
+            if (grid.x > 1536u)
+                PS_LAUNCH_FAST(true);
+            else
+                PS_LAUNCH_FAST(false);
+#undef PS_LAUNCH_FAST
         } else
             launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
@@ -528,7 +537,8 @@ int ensure_records(PsContext *ctx, size_t n)
     PS_ENSURE(ctx->recB, n * 16);
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
-    PS_ENSURE(ctx->recE, n * 40);
+    PS_ENSURE(ctx->recE, n * 16);
+    PS_ENSURE(ctx->recF, n * 40);
     return PS_OK;
 }
 
@@ -692,7 +702,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recH, &ctx->recS, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -1323,7 +1333,7 @@ struct PsVoStream {
         PsRansacParams prm;
         int estimator, numHypotheses, variant;
         float K[9];
-        const void *arena[16]; // scratch and table blocks the captured launches point at (they move when they grow)
+        const void *arena[17]; // scratch and table blocks the captured launches point at (they move when they grow)
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1489,8 +1499,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
+    const void *arena[17] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recF.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
     memcpy(key.arena, arena, sizeof arena);
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
@@ -1529,8 +1539,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[16] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
+        const void *after[17] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
+                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recF.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
         memcpy(key.arena, after, sizeof after);
         s->key = key;
         s->warm = true;

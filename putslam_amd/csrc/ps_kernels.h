@@ -178,9 +178,11 @@ struct RecPtrs {
     float4 *B;  // cur xyz, w = 1
     float4 *C;  // projections of prev and cur (realOld u v, realNew u v)
     int4 *D;    // (index in the match list, queryIdx, trainIdx, 0)
-    float4 *E;  // the fast scoring path's match record, 40 B = 5 float2 per match, laid out as the SGPR pairs its packed
-                // instructions take (one s_load_dwordx8 + one dwordx2, no repacking; 8 B less scalar-cache footprint per match
-                // than prev + cur + offsets): (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew) (cy - vOld, cy - vNew)
+    float4 *E;  // offsets c - real of the decision-exact scoring paths: (cx - uOld, cx - uNew, cy - vOld, cy - vNew)
+    float2 *F;  // the fast scoring kernel's packed match record for large launches, 40 B = 5 float2 per match, laid out as
+                // the SGPR pairs its packed instructions take (one s_load_dwordx8 + one dwordx2, no repacking; 8 B less
+                // scalar-cache footprint per match than prev + cur + offsets):
+                // (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew) (cy - vOld, cy - vNew)
     uint4 *H;   // f16 match operands of the matrix-core scoring kernel, [P][6 kinds][capH][2 K-blocks] (ps_score_mfma.h)
     int2 *S;    // per pair: (eP, kappa), the power-of-two scales those operands were written with
     int capH;   // cap rounded up to whole 32-match tiles
@@ -238,9 +240,7 @@ PS_D void write_split_operands(const PrepArgs &a, const RecPtrs &r, int p, int M
     uint4 *base = r.H + (size_t)p * 6 * r.capH * 2;
     for (int v = threadIdx.x; v < M; v += BLOCK) {
         const size_t slot = (size_t)p * a.cap + (size_t)v;
-        const float4 prev = r.A[slot], cur = r.B[slot];
-        const float *er = reinterpret_cast<const float *>(r.E) + 10 * slot;
-        const float4 e = make_float4(er[6], er[7], er[8], er[9]); // (cx - uOld, cx - uNew, cy - vOld, cy - vNew)
+        const float4 prev = r.A[slot], cur = r.B[slot], e = r.E[slot];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             // direction 0: current point -> previous image (offsets of realOld); 1: previous point -> current image
@@ -278,10 +278,11 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
     // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
+    r.E[slot] = e;
     {
-        float2 *er = reinterpret_cast<float2 *>(reinterpret_cast<float *>(r.E) + 10 * slot);
-        er[0] = make_float2(cx_, px); er[1] = make_float2(cy_, py); er[2] = make_float2(cz_, pz);
-        er[3] = make_float2(e.x, e.y); er[4] = make_float2(e.z, e.w);
+        float2 *f = r.F + 5 * slot;
+        f[0] = make_float2(cx_, px); f[1] = make_float2(cy_, py); f[2] = make_float2(cz_, pz);
+        f[3] = make_float2(e.x, e.y); f[4] = make_float2(e.z, e.w);
     }
     // (a NaN offset reports an infinite bound: the decision-exact kernels then leave the pair to the value-exact code)
     const bool num = e.x == e.x && e.y == e.y && e.z == e.z && e.w == e.w;

@@ -102,28 +102,31 @@ PS_D void model_norms(const Rigid &m, float &rho, float &tau)
 
 PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(a, b, c); }
 
-// The two directions are .x: predictedOld - realOld and .y: predictedNew - realNew.  cur = B (current point), prev = A (previous point), E = offsets
-// (cx - uOld, cx - uNew, cy - vOld, cy - vNew).
+// The two directions are .x: predictedOld - realOld and .y: predictedNew - realNew.  Operand pairs (cur, prev) of the three
+// coordinates and the offset pairs (cx - uOld, cx - uNew), (cy - vOld, cy - vNew).
 // Division-free form: A~ = X~ + k Z~ ~ (predicted - real) * depth; returns s~ = A~^2 + B~^2 of the two directions and
-// w = |Z~| of the two projected depths.
-PS_D v2f_t fast_sq2(const FastModel &f, const float2 *__restrict__ e, v2f_t &Zout)
+// Z~ of the two projected depths.
+PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, v2f_t ky, v2f_t &Zout)
 {
-    // the 40-byte record IS the operand pairs: (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew) (cy - vOld, cy - vNew)
-    const float2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
-    const v2f_t px = {e0.x, e0.y}, py = {e1.x, e1.y}, pz = {e2.x, e2.y};
     const v2f_t X = pk_fma(f.r0[0], px, pk_fma(f.r0[1], py, pk_fma(f.r0[2], pz, f.t0)));
     const v2f_t Y = pk_fma(f.r1[0], px, pk_fma(f.r1[1], py, pk_fma(f.r1[2], pz, f.t1)));
     const v2f_t Z = pk_fma(f.r2[0], px, pk_fma(f.r2[1], py, pk_fma(f.r2[2], pz, f.t2)));
-    const v2f_t Au = pk_fma(v2f_t{e3.x, e3.y}, Z, X);
-    const v2f_t Bv = pk_fma(v2f_t{e4.x, e4.y}, Z, Y);
+    const v2f_t Au = pk_fma(kx, Z, X);
+    const v2f_t Bv = pk_fma(ky, Z, Y);
     Zout = Z;
     return pk_fma(Au, Au, Bv * Bv);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
+// Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
+// a few prologue values spilled) and the packed 40-byte match record (RecPtrs::F: the loop is sensitive to the
+// scalar-cache footprint of the records every wave streams; 1.77 -> 1.70 -> 1.68 ms per 499 pairs).  Small launches are bound
+// by the latency of ONE prologue and of cold record loads: 6 waves (80 VGPRs, no spills) and the three 16-byte records,
+// whose loads go out side by side (single pair: 31 against 36 us).
+template <int MODE, bool BIG>
+__global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
-    const float4 *__restrict__ recE, const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound,
+    const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
+    const float2 *__restrict__ pairBound,
     ModelArgs ma, ScoreConsts k, FastConsts fc, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
     unsigned long long *__restrict__ dbg)
 {
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
-    const float2 *__restrict__ pe = reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(recE) + rbase * 10);
+    const float4 *__restrict__ pe = recE + rbase;
+    const float2 *__restrict__ pf = recF + rbase * 5;
     const float2 pbnd = pairBound[p];
     const float cmax = pbnd.x, umax = pbnd.y;
 
@@ -238,8 +242,15 @@ __global__ __launch_bounds__(kBlock, 7) void ps_ransac_score_fast(
 
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
         for (int m = m0; m < m1; ++m) {
-            v2f_t Z;
-            const v2f_t ss = fast_sq2(F, pe + 5 * m, Z);
+            v2f_t Z, ss;
+            if (BIG) {
+                const float2 *__restrict__ e = pf + 5 * m;
+                const float2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+                ss = fast_sq2(F, v2f_t{e0.x, e0.y}, v2f_t{e1.x, e1.y}, v2f_t{e2.x, e2.y}, v2f_t{e3.x, e3.y}, v2f_t{e4.x, e4.y}, Z);
+            } else {
+                const float4 A = pa[m], B = pb[m], E = pe[m];
+                ss = fast_sq2(F, v2f_t{B.x, A.x}, v2f_t{B.y, A.y}, v2f_t{B.z, A.z}, v2f_t{E.x, E.y}, v2f_t{E.z, E.w}, Z);
+            }
             // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
             // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
             const v2f_t q = Z * Z;

@@ -31,8 +31,8 @@
 // (logic instructions issue at 2.4 cycles against 4.3 for a compare, and no SGPR masks have to be kept).  That needs every
 // value of the hot loop to be finite -- see boundsOk.  Per 1024 evaluations: 10 MFMA + ~265 VALU against 23 x 16 = 368.
 //
-// What it achieves (499 pairs, 2000 keypoints, H = 4096; profiles/r02i): 1.57 ms against 1.69 ms for ps_ransac_score_fast
-// single-chain, 260 k against 250 k frame-pairs/s in the three-chain timed region: a tested option
+// What it achieves (499 pairs, 2000 keypoints, H = 4096; profiles/r02i): 1.61 ms against 1.69 ms for ps_ransac_score_fast
+// single-chain, 249 k against 253 k frame-pairs/s in the three-chain timed region: a tested option
 // (PUTSLAM_HIP_SCORE=mfma), not the default.
 // Why not more (profiles/microbench/mfma_valu_coissue.hip, valu_dep.hip):
 //   * on one gfx950 SIMD a v_mfma_f32_32x32x16_f16 stream and a v_pk_fma_f32 stream do NOT overlap (one wave or two:
