@@ -20,13 +20,21 @@ context each.  With --join end (default) the chains are ordered only within thei
 consecutive steps pipeline into each other (one chain's matrix-core Hamming sweep runs beside another's vector
 scoring sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
 
-After the timed region (never part of `value`) rank 0 of a single-GPU run adds three short legs:
+The timed region of K steps is run --repeats times (default 5, each bracketed by barrier + synchronize, max over
+ranks); `value` / `ms_per_step` are the MEDIAN region, `value_min` / `value_max` the spread, `timed_regions_ms_per_step`
+all of them.
+
+After the timed regions (never part of `value`) rank 0 of a single-GPU run adds short legs:
   * a single-chain leg -- the same step as ONE launch chain on one stream, HIP events around every kernel: the
     kernels' own durations.  `kernel_ms`, `roofline`, `kernel_bounds`, `single_chain` come from it (the timed region's
     per-launch figures, measured while three chains share the CUs, are kept as `timed_region_kernel_ms`);
   * one pass with the fast scoring kernel's statistics on (`score_parked_frac`);
-  * `cpu_baseline`: the oracle on the same workload on all host cores, 5 passes, median (+ the reference's own
-    <= 487-iteration schedule as `cpu_reference_schedule`).
+  * `other_modes`: the same sequence as ONE launch chain in the regimes every shipped reference config runs --
+    errorVersion 0 with H = 4096 fixed, and errorVersion 0 with the reference's own adaptive <= 487-iteration schedule
+    (RANSAC.cpp:30,450-453) -- `ms_per_step`, `pairs_per_s` and the kernels' own durations;
+  * `cpu_baseline`: the oracle on the same workload on all host cores, 5 passes, median, with the SIMD popcount
+    matcher (OpenCV's normHamming is vectorised; the scalar-popcnt figure is kept as `scalar_matcher_value`)
+    (+ the reference's own <= 487-iteration schedule as `cpu_reference_schedule`).
 
 Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section "Measurement").
 """
@@ -47,10 +55,13 @@ MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1
 # VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane),
 # counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
 VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
+                 "ps_ransac_score_exact<4>": 19, "ps_ransac_score_exact<2>": 61,
+                 "ps_ransac_score_fast<0>": 9.5, "ps_ransac_score_fast<4>": 9.5,
                  "ps_ransac_score_fast<1>": 23, "ps_ransac_score_mfma<1>": 16.6}
 # of those, packed two-lane f32 instructions (v_pk_*_f32: two f32 operations per lane, issued over 4 cycles -- the same
 # f32 rate as two plain instructions at 2 cycles): counted twice in `lane_ops`
-PK_PER_UNIT = {"ps_ransac_score_fast<1>": 16, "ps_ransac_score_mfma<1>": 7.0}
+PK_PER_UNIT = {"ps_ransac_score_fast<1>": 16, "ps_ransac_score_mfma<1>": 7.0, "ps_ransac_score_fast<0>": 9.0,
+               "ps_ransac_score_fast<4>": 9.0}
 
 
 def parse():
@@ -77,6 +88,13 @@ def parse():
                     help="test hook: write the per-pair records rank 0 holds after the last step (numpy .npy)")
     ap.add_argument("--as-rank", type=int, default=None,
                     help="test hook: single-rank run with the sequence and seed of this rank of a multi-rank run")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps each; value = the median region, value_min/max = the spread")
+    ap.add_argument("--shard", default="pairs", choices=["pairs", "sequence"],
+                    help="N > 1: 'pairs' = one sequence per GPU (BASELINE configs[3], weak scaling); 'sequence' = ONE "
+                         "sequence of --frames frames split over the ranks with a one-frame halo "
+                         "(sharding.shard_sequence; strong scaling)")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
@@ -139,8 +157,25 @@ def main():
         args.hyp = _H
         cfg, _ = make_config(est, args.hyp, seed=_seed + rank)
     # -- synthetic sequence of this rank (config 3; config 4 = one such sequence per GPU) --
-    seq = synth.make_sequence(args.frames, args.kpts, config=3, index=vrank)
+    from putslam_amd import sharding
+    shard_seq = args.shard == "sequence" and world > 1
+    if shard_seq:
+        # ONE sequence for the whole job; this rank uploads frames [frame_lo, frame_hi) (the last one is the halo the
+        # next rank uploads too) and works on pairs [pair_lo, pair_hi); pair p keeps its global hypothesis stream seed + p
+        full = synth.make_sequence(args.frames, args.kpts, config=3, index=0)
+        sh = sharding.shard_sequence(args.frames, world, rank)
+        f0, f1 = sh["frame_lo"], sh["frame_hi"]
+        npairs = sh["pair_hi"] - sh["pair_lo"]
+        seq = dict(desc=full["desc"][f0:max(f1, f0 + 1)], pts=full["pts"][f0:max(f1, f0 + 1)],
+                   nkpts=full["nkpts"][f0:max(f1, f0 + 1)],
+                   pairs=np.stack([np.arange(npairs), np.arange(1, npairs + 1)], axis=1).astype(np.int32).reshape(-1, 2))
+        cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + sh["pair_lo"])
+        Pmax = -(-(args.frames - 1) // world)           # largest shard: gather blocks are padded to it
+    else:
+        seq = synth.make_sequence(args.frames, args.kpts, config=3, index=vrank)
     P = len(seq["pairs"])
+    if not shard_seq:
+        Pmax = P
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
     bounds = [P * i // S for i in range(S + 1)]
@@ -150,8 +185,13 @@ def main():
     # stream", so the legacy default stream is never handed over)
     chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
     join = args.join == "step"
-    from putslam_amd import sharding
-    gathered = ([[torch.zeros((bounds[i + 1] - bounds[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
+    # gather blocks: chain i carries pairs [bounds[i], bounds[i+1]) of this rank; with --shard sequence the shards differ
+    # by at most one pair and every rank pads its LAST chain's block to the size of the largest shard's
+    gsize = [bounds[i + 1] - bounds[i] for i in range(S)]
+    if shard_seq:
+        gsize = [(Pmax * (i + 1) // S) - (Pmax * i // S) for i in range(S)]
+        bounds = [min(P, Pmax * i // S) for i in range(S)] + [P]
+    gathered = ([[torch.zeros((gsize[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
                   for _ in range(world)] for i in range(S)] if (world > 1 and rank == 0) else [None] * S)
     pending = [None] * S     # per chain: (in-flight gather of the previous step, the record block it reads)
 
@@ -167,7 +207,11 @@ def main():
             for i in range(S):
                 lo, hi = bounds[i], bounds[i + 1]
                 with torch.cuda.stream(chains[i]):
-                    rec = sharding.pack_records(pb.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0]).to(xdev)
+                    rec = sharding.pack_records(pb.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0])
+                    if rec.shape[0] < gsize[i]:          # --shard sequence: pad to the common block size
+                        rec = torch.cat([rec, torch.zeros((gsize[i] - rec.shape[0], sharding.RECORD_FLOATS),
+                                                          dtype=rec.dtype, device=rec.device)])
+                    rec = rec.to(xdev)
                     if pending[i] is not None:
                         pending[i][0].wait()
                     work, _ = sharding.gather_records(rec, dst=0, out=gathered[i], async_op=True)
@@ -188,16 +232,21 @@ def main():
     fence()
     for c in ctxs:
         c.enable_timing(True)                                          # HIP events on the launch stream(s)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # --repeats timed regions of exactly --steps steps, each bracketed by barrier + synchronize on both sides; the
+    # region time is the max over ranks; the line reports the median region (and the spread)
+    region_s = []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        region_s.append(el)
+    elapsed = float(np.median(region_s))
     totals = {}
     for c in ctxs:
         for kname, (ms_sum, n) in c.kernel_time_totals().items():
@@ -229,7 +278,7 @@ def main():
         c0.enable_timing(False)
         # one more pass with the fast scoring kernel's statistics on: the share of (hypothesis, match) evaluations
         # that fell inside the error band and were re-done by the value-exact code
-        if args.error_version == 1 and c0.get_option("score") >= 1:
+        if args.error_version in (0, 1, 4) and c0.get_option("score") >= 1:
             c0.set_option("score_stats", 1)
             solo_step()
             torch.cuda.synchronize(dev)
@@ -237,6 +286,40 @@ def main():
             c0.set_option("score_stats", 0)
             parked_frac = pk / ev if ev else None
     res = pb.download()
+    # ---- the regimes the reference's shipped configs run (errorVersion 0: resources/putslammatcherOpenCVParameters.xml:30-31
+    # and all configs/*), same sequence, ONE launch chain, HIP events around every kernel; results go to a second output
+    # block so that `res` above stays the timed workload's
+    other_modes = None
+    if world == 1 and not args.no_other_modes:
+        other_modes = {}
+        pb2 = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
+        prm0 = default_ransac_params(0)
+        for name, est2, hyp2 in (("E0/fixed/4096", EST_FIXED, 4096), ("E0/ransac/487", EST_RANSAC, 487)):
+            if args.preset == "stress" and est2 == EST_FIXED:
+                hyp2, name = args.hyp, "E0/fixed/%d" % args.hyp
+            cfg2, _ = make_config(est2, hyp2, seed=cfg.seed)
+
+            def leg_step():
+                run_pairs_split([c0], [chains[0]], prm0, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=[0, P], join=False)
+
+            leg_step()
+            torch.cuda.synchronize(dev)
+            c0.enable_timing(True)
+            n_leg = 5
+            tl0 = time.perf_counter()
+            for _ in range(n_leg):
+                leg_step()
+            torch.cuda.synchronize(dev)
+            leg_ms = (time.perf_counter() - tl0) / n_leg * 1e3
+            kms = {k: v[0] / max(v[1], 1) for k, v in c0.kernel_time_totals().items()}
+            c0.enable_timing(False)
+            st2 = pb2.download()["stats"]
+            other_modes[name] = {"ms_per_step": leg_ms, "pairs_per_s": P / (leg_ms * 1e-3), "kernel_ms": kms,
+                                 "kernel_ms_sum": sum(kms.values()), "steps": n_leg,
+                                 "mean_iterations_run": float(st2["iterationsRun"].mean()),
+                                 "mean_inliers": float(st2["numInliers"].mean()),
+                                 "accepted_pairs": int(st2["accepted"].sum()),
+                                 "score_kernel": "fast" if c0.get_option("score") >= 1 else "exact"}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if world > 1 and rank == 0:
@@ -250,7 +333,8 @@ def main():
 
     if rank == 0:
         stats = res["stats"]
-        pairs_total = P * world * args.steps
+        P_total_per_step = (args.frames - 1) if shard_seq else P * world
+        pairs_total = P_total_per_step * args.steps
         value = pairs_total / elapsed
         m_in = float(stats["numMatchesIn"].mean())
         m_valid = float(stats["numMatchesValid"].mean())
@@ -259,7 +343,8 @@ def main():
                                                               int(s["numMatchesValid"]), Hs) for s in stats]))
         kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # timed region: average launch duration, ms
         matcher = "mfma" if ctx.get_option("matcher_used") == 1 else "valu"   # what this workload's calls ran
-        score = ({1: "fast", 2: "mfma"}.get(ctx.get_option("score"), "exact") if args.error_version == 1 else "exact")
+        score = ({1: "fast", 2: "mfma"}.get(ctx.get_option("score"), "exact") if args.error_version == 1 else
+                 ("fast" if (args.error_version in (0, 4) and ctx.get_option("score") >= 1) else "exact"))
 
         def kernel_bounds(kms, pairs_per_launch):
             """What actually bounds the two sweeps (the path is compute-bound, not HBM-bound): achieved rate of the
@@ -318,7 +403,10 @@ def main():
         out = {
             "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if shard_seq else "weak",
+            "value_min": P_total_per_step * args.steps / max(region_s), "value_max": P_total_per_step * args.steps / min(region_s),
+            "timed_regions_ms_per_step": [r / args.steps * 1e3 for r in region_s], "repeats": len(region_s),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[2]: TUM fr1/desk-style synthetic sequence, "
@@ -328,7 +416,9 @@ def main():
                              f"{args.error_version} -> refit; inputs resident in HBM" +
                              ("; configs[3]: one sequence per GPU, RCCL gather of 72 B/pair to rank 0" if world > 1
                               else "")),
-                "pairs_per_step": P * world, "kpts": args.kpts, "hypotheses": args.hyp,
+                "pairs_per_step": P_total_per_step, "kpts": args.kpts, "hypotheses": args.hyp,
+                "world_size": (dist.get_world_size() if world > 1 else 1),
+                "backend": (dist.get_backend() if world > 1 else None), "shard": args.shard,
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "join": args.join,
                 "matcher_kernel": matcher, "score_kernel": score,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
@@ -352,6 +442,7 @@ def main():
                               "kernel_ms_sum": sum(solo.values())} if solo else None),
             "timed_region_kernel_ms": kern,
             "score_parked_frac": parked_frac,
+            "other_modes": other_modes,
             "streams_note": (None if S == 1 else
                              f"value / ms_per_step: {S} sub-batch chains on {S} HIP streams (join={args.join}); "
                              "timed_region_kernel_ms are per-launch durations of sub-batches measured while the other "
@@ -391,6 +482,8 @@ def cpu_baseline(args, seq, prm, cfg, est):
         po.vo_pairs(prm, cfg_, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], pairs[:n], threads=threads)
         return time.perf_counter() - t0
 
+    # the matcher half runs the SIMD popcount sweep (what OpenCV's vectorised normHamming amounts to): the generous figure
+    po.set_matcher_simd(True)
     n0 = min(len(pairs), max(cores, 2))
     t = run(cfg, n0, cores)                                   # calibration (also warms the pages)
     passes = 5
@@ -398,10 +491,13 @@ def cpu_baseline(args, seq, prm, cfg, est):
     times = sorted(run(cfg, n, cores) for _ in range(passes))
     med = times[passes // 2]
     out = {"cpu_baseline": {"value": n / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                            "passes": passes, "pass_seconds": times,
+                            "passes": passes, "pass_seconds": times, "matcher": po.matcher_simd_kind(),
                             "sample": f"first {n} of {len(pairs)} pairs of the same sequence, {passes} passes, median; same "
                                       f"H/errorVersion/estimator as the GPU run, OpenMP over pairs on {cores} threads, "
                                       f"{sum(times):.1f} s wall in all"}}
+    po.set_matcher_simd(False)
+    out["cpu_baseline"]["scalar_matcher_value"] = n / run(cfg, n, cores)     # one pass with the scalar popcnt sweep
+    po.set_matcher_simd(True)
     # what the reference itself would do: sequential adaptive schedule, <= 487 iterations (RANSAC.cpp:30,450-453)
     cfg_ref, _ = make_config(EST_RANSAC, 487, seed=cfg.seed)
     n2 = min(len(pairs), max(n, 4 * cores))
@@ -409,7 +505,7 @@ def cpu_baseline(args, seq, prm, cfg, est):
     t1 = run(cfg_ref, min(n2, 16), 1)
     out["cpu_reference_schedule"] = {
         "value": n2 / t2, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-        "single_thread_value": min(n2, 16) / t1,
+        "single_thread_value": min(n2, 16) / t1, "matcher": po.matcher_simd_kind(),
         "sample": f"{n2} pairs, adaptive RANSAC schedule of the reference (<=487 iterations), all cores; "
                   f"single_thread_value on {min(n2, 16)} pairs"}
     return out

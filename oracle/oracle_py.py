@@ -94,6 +94,16 @@ def match_hamming256(query, train):
     return out[: n.value].copy()
 
 
+def set_matcher_simd(on):
+    """Timed-baseline switch: SIMD popcount sweep (default when the host has AVX2) or the scalar popcnt loop."""
+    lib().po_set_matcher_simd(int(bool(on)))
+
+
+def matcher_simd_kind():
+    """0 = scalar only, 1 = AVX2 nibble lookup, 2 = AVX-512 VPOPCNTQ (what -march=native gave this build)."""
+    return {0: "scalar", 1: "avx2-lut", 2: "avx512-vpopcnt"}[lib().po_matcher_simd_kind()]
+
+
 def round_size(x, size):
     return lib().po_round_size(float(x), int(size))
 
@@ -163,6 +173,35 @@ def is_inlier(mode, T, K, prev_pt, cur_pt, thrE, thrR):
     pp = np.ascontiguousarray(prev_pt, np.float32)
     cp = np.ascontiguousarray(cur_pt, np.float32)
     return lib().po_is_inlier(int(mode), _p(Tc), _p(Ti), _p(K), _p(pp), _p(cp), float(thrE), float(thrR))
+
+
+def eval_errors(T, K, prev_pt, cur_pt):
+    """(Euclid norm, reprojection error new, reprojection error old) of one match under model T (4x4), as the
+    reference computes them (RANSAC.cpp:266-272,346-366)."""
+    Tc = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(16))
+    Ti = np.zeros(16, np.float32)
+    lib().po_inverse4_f32(_p(Tc), _p(Ti))
+    K = np.ascontiguousarray(K, np.float32)
+    pp = np.ascontiguousarray(prev_pt, np.float32)
+    cp = np.ascontiguousarray(cur_pt, np.float32)
+    err = np.zeros(3, np.float64)
+    lib().po_eval_errors(_p(Tc), _p(Ti), _p(K), _p(pp), _p(cp), _p(err))
+    return err
+
+
+def hypothesis_model(cfg, prev, cur, matches, h):
+    """Model of hypothesis h as hypothesis_counts builds it: (T 4x4 or None when invalid, valid-match indices, sample)."""
+    prev = np.ascontiguousarray(prev, np.float32)
+    cur = np.ascontiguousarray(cur, np.float32)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    m = matches.shape[0]
+    T = np.zeros(16, np.float32)
+    valid = np.zeros(max(m, 1), np.int32)
+    M = C.c_int(0)
+    idx = np.zeros(3, np.int32)
+    ok = lib().po_hypothesis_model(C.byref(cfg), _p(prev), _p(cur), _p(matches), m, int(h), _p(T), _p(valid),
+                                   C.byref(M), _p(idx))
+    return (T.reshape(4, 4).T.copy() if ok else None), valid[: M.value].copy(), idx
 
 
 def ransac_rigid3d(params, cfg, K, prev, cur, matches, want_counts=False):

@@ -33,6 +33,78 @@ int po_hamming256(const uint8_t *a, const uint8_t *b)
            __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
+/* SIMD form of the same sweep for the TIMED baseline: OpenCV's hal::normHamming is vectorised (universal intrinsics:
+ * per-nibble lookup + byte sums on AVX2, VPOPCNT where the CPU has it), so a scalar popcnt loop would not be the
+ * "most generous to the CPU" figure BASELINE.md promises.  Distances are integers: the result is identical to the
+ * scalar path by construction (asserted in tests/test_oracle_kat.py::test_simd_matcher_equals_scalar). */
+#if defined(__AVX2__)
+#include <immintrin.h>
+#define PO_HAVE_SIMD 1
+static inline int ham256_simd(__m256i t, const uint8_t *q)
+{
+    __m256i x = _mm256_xor_si256(t, _mm256_loadu_si256((const __m256i *)q));
+#if defined(__AVX512VPOPCNTDQ__) && defined(__AVX512VL__)
+    __m256i c = _mm256_popcnt_epi64(x);
+#else
+    const __m256i lut = _mm256_setr_epi8(0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4, 0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3,
+                                         2, 3, 3, 4);
+    const __m256i mask = _mm256_set1_epi8(0x0F);
+    __m256i lo = _mm256_and_si256(x, mask), hi = _mm256_and_si256(_mm256_srli_epi16(x, 4), mask);
+    __m256i c = _mm256_sad_epu8(_mm256_add_epi8(_mm256_shuffle_epi8(lut, lo), _mm256_shuffle_epi8(lut, hi)),
+                                _mm256_setzero_si256());
+#endif
+    __m128i s2 = _mm_add_epi64(_mm256_castsi256_si128(c), _mm256_extracti128_si256(c, 1));
+    return (int)(_mm_cvtsi128_si64(s2) + _mm_extract_epi64(s2, 1));
+}
+int po_matcher_simd_kind(void)
+{
+#if defined(__AVX512VPOPCNTDQ__) && defined(__AVX512VL__)
+    return 2; /* VPOPCNTQ on 256-bit vectors */
+#else
+    return 1; /* AVX2 nibble lookup + psadbw */
+#endif
+}
+#else
+#define PO_HAVE_SIMD 0
+int po_matcher_simd_kind(void) { return 0; }
+#endif
+
+static int g_matcher_simd = PO_HAVE_SIMD; /* which sweep po_match_hamming256 runs (po_set_matcher_simd) */
+void po_set_matcher_simd(int on) { g_matcher_simd = (on && PO_HAVE_SIMD) ? 1 : 0; }
+int po_get_matcher_simd(void) { return g_matcher_simd; }
+
+static void nearest_query(const uint8_t *tr, const uint8_t *query, int nq, size_t qstep, int simd, int *bestOut,
+                          int *bqOut)
+{
+    int best = INT_MAX, bq = -1;
+#if PO_HAVE_SIMD
+    if (simd) {
+        const __m256i t = _mm256_loadu_si256((const __m256i *)tr);
+        for (int q = 0; q < nq; ++q) {
+            int d = ham256_simd(t, query + (size_t)q * qstep);
+            if (d < best) {
+                best = d;
+                bq = q;
+            }
+        }
+        *bestOut = best;
+        *bqOut = bq;
+        return;
+    }
+#else
+    (void)simd;
+#endif
+    for (int q = 0; q < nq; ++q) {
+        int d = po_hamming256(tr, query + (size_t)q * qstep);
+        if (d < best) {
+            best = d;
+            bq = q;
+        }
+    }
+    *bestOut = best;
+    *bqOut = bq;
+}
+
 int po_match_hamming256(const uint8_t *query, int nq, size_t qstep, const uint8_t *train, int nt,
                         size_t tstep, PsDMatch *out, int *nout)
 {
@@ -49,16 +121,10 @@ int po_match_hamming256(const uint8_t *query, int nq, size_t qstep, const uint8_
         dist[q] = INT_MAX;
         idx[q] = -1;
     }
+    const int simd = g_matcher_simd;
     for (int t = 0; t < nt; ++t) {
-        const uint8_t *tr = train + (size_t)t * tstep;
-        int best = INT_MAX, bq = -1;
-        for (int q = 0; q < nq; ++q) {
-            int d = po_hamming256(tr, query + (size_t)q * qstep);
-            if (d < best) {
-                best = d;
-                bq = q;
-            }
-        }
+        int best, bq;
+        nearest_query(train + (size_t)t * tstep, query, nq, qstep, simd, &best, &bq);
         if (bq >= 0 && best < dist[bq]) {
             dist[bq] = best;
             idx[bq] = t;
@@ -312,6 +378,25 @@ int po_is_inlier(int mode, const float *T, const float *Tinv, const float *K, co
     return 0; /* Mahalanobis (dead, RANSAC.cpp:301-303) and unknown modes (RANSAC.cpp:134-135) score 0 */
 }
 
+/* The error VALUES behind po_is_inlier, as the reference computes them (RANSAC.cpp:266-272,346-366): err[0] = the float
+ * Euclidean norm (as double), err[1] = cv::norm(predictedNew - realNew), err[2] = cv::norm(predictedOld - realOld).
+ * For the directed band-edge tests: a threshold set to one of these values (or its neighbours) puts that evaluation
+ * exactly on the decision boundary. */
+void po_eval_errors(const float *T, const float *Tinv, const float *K, const float *pp, const float *cp, double *err)
+{
+    float estOld[3], estNew[3];
+    xform(T, cp, estOld);
+    err[0] = (double)norm3(estOld, pp);
+    xform(Tinv, pp, estNew);
+    float pnu, pnv, rnu, rnv, pou, pov, rou, rov;
+    project_pt(estNew, K, &pnu, &pnv);
+    project_pt(cp, K, &rnu, &rnv);
+    project_pt(estOld, K, &pou, &pov);
+    project_pt(pp, K, &rou, &rov);
+    err[1] = cvnorm2(pnu, pnv, rnu, rnv);
+    err[2] = cvnorm2(pou, pov, rou, rov);
+}
+
 /* ------------------------------------------------------------------------------------------
  * A6  iteration schedule
  * ------------------------------------------------------------------------------------------ */
@@ -455,6 +540,21 @@ int po_hypothesis_counts(const PsRansacParams *params, const PsRansacConfig *cfg
     }
     free(valid);
     return 0;
+}
+
+/* The model of hypothesis h exactly as po_hypothesis_counts builds it (sample -> 3-point Umeyama); returns 0 when the
+ * model is invalid (iteration skipped, RANSAC.cpp:107), M through *Mvalid, the sampled valid-match indices in idx3. */
+int po_hypothesis_model(const PsRansacConfig *cfg, const float *prev, const float *cur, const PsDMatch *matches, int m,
+                        int h, float *T, int *validOut, int *Mvalid, int *idx3)
+{
+    int M = 0;
+    for (int i = 0; i < m; ++i)
+        if (depth_ok(&prev[3 * (size_t)matches[i].queryIdx]) && depth_ok(&cur[3 * (size_t)matches[i].trainIdx]))
+            validOut[M++] = i;
+    *Mvalid = M;
+    if (M < 3) return 0;
+    po_sample_triplet(cfg, cfg->seed, h, M, idx3);
+    return fit_sample(prev, cur, matches, validOut, idx3, T);
 }
 
 double po_point_inlier_ratio(const PsDMatch *inl, int ninl, const PsDMatch *all, int nall)

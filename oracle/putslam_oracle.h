@@ -37,6 +37,11 @@ int po_match_hamming256(const uint8_t *query, int nq, size_t qstep,
                         PsDMatch *out, int *nout);
 
 /* RGBD::roundSize (RGBD.cpp:10-16), point2Dto3D (:47-65), keypoints2Dto3D (:30-45), point3Dto2D (:92-98). */
+/* timed-baseline switch: SIMD popcount sweep (OpenCV's normHamming is vectorised) vs the scalar popcnt loop; identical results */
+void po_set_matcher_simd(int on);
+int po_get_matcher_simd(void);
+int po_matcher_simd_kind(void); /* 0 none (scalar only), 1 AVX2 nibble lookup, 2 AVX-512 VPOPCNTQ */
+
 int po_round_size(double x, int size);
 void po_keypoints2Dto3D(const float *xy, int n, const uint16_t *depth, int rows, int cols,
                         size_t depthStep, const float *K, double depthImageScale, float *out);
@@ -71,6 +76,12 @@ int po_is_inlier(int mode, const float *T, const float *Tinv, const float *K,
  * (USAC_wrapper.cpp:104-151) / fixed-H variant, selected by cfg->estimator.
  * hypCounts (may be NULL): receives the inlier count of every hypothesis that the
  * sequential loop evaluated (others -1); length cfg->numHypotheses. */
+/* error values behind po_is_inlier (Euclid norm, reprojection new, reprojection old) and the model of hypothesis h:
+ * used by the directed band-edge tests */
+void po_eval_errors(const float *T, const float *Tinv, const float *K, const float *pp, const float *cp, double *err);
+int po_hypothesis_model(const PsRansacConfig *cfg, const float *prev, const float *cur, const PsDMatch *matches, int m,
+                        int h, float *T, int *validOut, int *Mvalid, int *idx3);
+
 int po_ransac_rigid3d(const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
                       const float *prev, int nprev, const float *cur, int ncur,
                       const PsDMatch *matches, int m,

@@ -8,6 +8,7 @@
 #include "ps_matcher_mfma.h"
 #include "ps_score_fast.h"
 #include "ps_score_mfma.h"
+#include "ps_score_euclid.h"
 
 #include <cfloat>
 #include <climits>
@@ -300,6 +301,7 @@ struct Plan {
     int minRun = 3;
     ScoreConsts sc{};
     FastConsts fc{};
+    EuclidConsts ec{};
     PrepArgs pa{};
     SelectArgs sa{};
     ModelArgs ma{};
@@ -351,6 +353,28 @@ int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *c
             const double c = std::sqrt(2.0) * (1.0 + 1e-5);
             fc.thr2Up = up((double)fc.thrUp * (double)fc.thrUp);
             fc.cHi = up((2.0 * c + c * c) * (double)fc.thrUp);
+        }
+    }
+    // constants of the decision-exact Euclidean path (ps_score_euclid.h): the threshold in the root domain, pushed
+    // 6u (7u) to the safe side; errorVersion 0 works against the exact float bound B the value-exact code compares with,
+    // errorVersion 4 against thr itself (the record is normalised by the match's depth)
+    {
+        EuclidConsts &ec = pl.ec;
+        const double thr = prm->inlierThresholdEuclidean;
+        ec.enabled = (thr >= 1e-10 && thr <= 1e10) ? 1 : 0; // false for NaN
+        ec.tbLo = ec.tbHi = 0.0f;
+        if (ec.enabled) {
+            const double u = 5.9604644775390625e-08;
+            auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; };
+            auto down = [](double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; };
+            if (pl.mode == PS_ADAPTIVE_ERROR) {
+                ec.tbLo = down(thr * (1.0 - 7.0 * u));
+                ec.tbHi = up(thr * (1.0 + 7.0 * u));
+            } else {
+                const double Tb = std::sqrt((double)sq_bound_f32(thr));
+                ec.tbLo = down(Tb * (1.0 - 6.0 * u));
+                ec.tbHi = up(Tb * (1.0 + 6.0 * u));
+            }
         }
     }
     pl.pa.fx = k[0]; pl.pa.fy = k[4]; pl.pa.cx = k[2]; pl.pa.cy = k[5];
@@ -407,9 +431,17 @@ int ensure_split(PsContext *ctx, int P, int cap)
     return PS_OK;
 }
 
+// The Euclidean fast scoring kernel reads its own pair-interleaved record, kept in the block the reprojection kernels use
+// for theirs (recF): kernel 2 writes one or the other.
+bool with_euclid_fast(const PsContext *ctx, int mode)
+{
+    return ctx->scoreFast != 0 && (mode == PS_EUCLIDEAN_ERROR || mode == PS_ADAPTIVE_ERROR);
+}
+
 RecPtrs rec_ptrs(PsContext *ctx, int cap, int mode)
 {
     RecPtrs r;
+    r.G = with_euclid_fast(ctx, mode) ? (float *)ctx->recF.p : nullptr;
     r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
     r.E = (float4 *)ctx->recE.p;
     r.F = (float2 *)ctx->recF.p;
@@ -471,8 +503,24 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     const int msplit = pl.msplit; // counts were cleared by kernel 2 when the range is split (prepare_score)
     dim3 grid((unsigned)hb * (unsigned)msplit * (unsigned)P);
     tick(ctx, slot0, false);
+    unsigned long long *dbgE = nullptr;
+    if (ctx->scoreStats && with_euclid_fast(ctx, pl.mode)) {
+        PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
+        PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        dbgE = (unsigned long long *)ctx->dbgCnt.p;
+    }
+#define PS_LAUNCH_EUCLID(MODE)                                                                                         \
+    hipLaunchKernelGGL(ps_ransac_score_euclid<MODE>, grid, dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p,  \
+                       (const float4 *)ctx->recB.p, (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,       \
+                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.ec, pl.H, cap, pl.minRun, msplit,                 \
+                       (int32_t *)ctx->counts.p, dbgE)
     switch (pl.mode) {
-    case PS_EUCLIDEAN_ERROR: launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit); break;
+    case PS_EUCLIDEAN_ERROR:
+        if (with_euclid_fast(ctx, pl.mode))
+            PS_LAUNCH_EUCLID(PS_EUCLIDEAN_ERROR);
+        else
+            launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit);
+        break;
     case PS_REPROJECTION_ERROR:
         if (ctx->scoreFast == 2) {
             unsigned long long *dbg = nullptr;
@@ -511,9 +559,15 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
         launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
-    case PS_ADAPTIVE_ERROR: launch_score<PS_ADAPTIVE_ERROR>(ctx, grid, pl, cap, msplit); break;
+    case PS_ADAPTIVE_ERROR:
+        if (with_euclid_fast(ctx, pl.mode))
+            PS_LAUNCH_EUCLID(PS_ADAPTIVE_ERROR);
+        else
+            launch_score<PS_ADAPTIVE_ERROR>(ctx, grid, pl, cap, msplit);
+        break;
     default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
     }
+#undef PS_LAUNCH_EUCLID
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     SelectArgs sa = pl.sa;
@@ -531,14 +585,16 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     return PS_OK;
 }
 
-int ensure_records(PsContext *ctx, size_t n)
+int ensure_records(PsContext *ctx, size_t P, size_t cap)
 {
+    const size_t n = P * cap;
     PS_ENSURE(ctx->recA, n * 16);
     PS_ENSURE(ctx->recB, n * 16);
     PS_ENSURE(ctx->recC, n * 16);
     PS_ENSURE(ctx->recD, n * 16);
     PS_ENSURE(ctx->recE, n * 16);
-    PS_ENSURE(ctx->recF, n * 40);
+    // 40 B per match (reprojection kernels) or up to 64 B per match pair (Euclidean kernel, ps_score_euclid.h)
+    PS_ENSURE(ctx->recF, n * 40 > P * ((cap + 1) / 2) * 64 ? n * 40 : P * ((cap + 1) / 2) * 64);
     return PS_OK;
 }
 
@@ -551,7 +607,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     PS_ENSURE(ctx->mvalid, (size_t)P * sizeof(int32_t));
     PS_ENSURE(ctx->cmax, (size_t)P * sizeof(float2));
     if (withRecords) {
-        int rc = ensure_records(ctx, (size_t)P * cap);
+        int rc = ensure_records(ctx, (size_t)P, (size_t)cap);
         if (rc != PS_OK) return rc;
         if (with_split(ctx, pa.mode)) {
             rc = ensure_split(ctx, P, cap);
@@ -940,7 +996,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->sStats, sizeof(PsRansacStats));
     PS_ENSURE(ctx->mvalid, sizeof(int32_t));
     PS_ENSURE(ctx->cmax, sizeof(float2));
-    rc = ensure_records(ctx, (size_t)cap);
+    rc = ensure_records(ctx, 1, (size_t)cap);
     if (rc) return rc;
     if (with_split(ctx, pl.pa.mode)) {
         rc = ensure_split(ctx, 1, cap);
@@ -1495,7 +1551,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 1) | (ctx->scoreStats << 3);
+    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4); // disjoint bit fields
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);

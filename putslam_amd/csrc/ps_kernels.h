@@ -183,6 +183,9 @@ struct RecPtrs {
                 // the SGPR pairs its packed instructions take (one s_load_dwordx8 + one dwordx2, no repacking; 8 B less
                 // scalar-cache footprint per match than prev + cur + offsets):
                 // (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew) (cy - vOld, cy - vNew)
+    float *G;   // the Euclidean fast scoring kernel's pair-interleaved record (ps_score_euclid.h), [P][ceil(cap/2)][12 or 16]:
+                // match 2k in the even floats, match 2k+1 in the odd ones; null unless that kernel will run (it then
+                // replaces E and F, which only the reprojection kernels read)
     uint4 *H;   // f16 match operands of the matrix-core scoring kernel, [P][6 kinds][capH][2 K-blocks] (ps_score_mfma.h)
     int2 *S;    // per pair: (eP, kappa), the power-of-two scales those operands were written with
     int capH;   // cap rounded up to whole 32-match tiles
@@ -275,6 +278,22 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
     r.B[slot] = make_float4(cx_, cy_, cz_, 1.0f);
     r.C[slot] = make_float4(ou, ov, nu, nv);
     r.D[slot] = make_int4(srcIdx, q, t, 0);
+    if (r.G != nullptr) {
+        // Euclidean metrics: the pair-interleaved operands of ps_ransac_score_euclid; errorVersion 4 normalises the match
+        // by its own depth (the adaptive threshold thr * prev.z becomes the constant thr, ps_score_euclid.h)
+        const bool adaptive = a.mode == PS_ADAPTIVE_ERROR;
+        const int rf = adaptive ? 16 : 12;
+        float *g = r.G + ((size_t)p * (size_t)((a.cap + 1) >> 1) + (size_t)(v >> 1)) * rf + (v & 1);
+        if (adaptive) {
+            const float w = 1.0f / pz;
+            g[0] = cx_ * w; g[2] = cy_ * w; g[4] = cz_ * w; g[6] = w;
+            g[8] = px * w; g[10] = py * w; g[12] = pz * w; g[14] = 0.0f;
+        } else {
+            g[0] = cx_; g[2] = cy_; g[4] = cz_;
+            g[6] = px; g[8] = py; g[10] = pz;
+        }
+        return 0.0f;
+    }
     // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
@@ -287,6 +306,17 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
     // (a NaN offset reports an infinite bound: the decision-exact kernels then leave the pair to the value-exact code)
     const bool num = e.x == e.x && e.y == e.y && e.z == e.z && e.w == e.w;
     return num ? fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))) : INFINITY;
+}
+
+// An odd number of depth-valid matches leaves the second half of the last pair record unwritten: it repeats the first
+// (finite, inside the pair's bounds; the scoring kernel does not count it).  Called by one thread after the records of
+// the pair are visible to it.
+PS_D void finish_pair_records(const PrepArgs &a, const RecPtrs &r, int p, int M)
+{
+    if (r.G == nullptr || !(M & 1)) return;
+    const int rf = a.mode == PS_ADAPTIVE_ERROR ? 16 : 12;
+    float *g = r.G + ((size_t)p * (size_t)((a.cap + 1) >> 1) + (size_t)(M >> 1)) * rf;
+    for (int i = 0; i < rf; i += 2) g[i + 1] = g[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -366,6 +396,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         float u = block_max<BLOCK>(um, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
         write_split_operands<BLOCK>(a, rec, p, vbase, c, u); // (block_max ends with a barrier: the records are visible)
+        if (threadIdx.x == 0) finish_pair_records(a, rec, p, vbase);
         if (a.zeroCounts)
             for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroH + i] = 0;
     }
@@ -411,6 +442,7 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
     if (threadIdx.x == 0) {
         mvalid[0] = vbase;
         cmaxOut[0] = make_float2(c, u);
+        finish_pair_records(a, rec, 0, vbase);
     }
     write_split_operands<kBlock>(a, rec, 0, vbase, c, u);
     if (a.zeroCounts)

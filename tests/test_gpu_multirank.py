@@ -12,7 +12,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--frames", "14", "--kpts", "700", "--hyp", "768", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+ARGS = ["--frames", "14", "--kpts", "700", "--hyp", "768", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+        "--repeats", "2", "--no-other-modes"]
+TINY = ["--kpts", "300", "--hyp", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--repeats", "1",
+        "--no-other-modes", "--streams", "1"]
 
 
 def _free_port():
@@ -47,6 +50,8 @@ def test_bench_two_ranks_on_one_gpu_equal_two_single_rank_runs(tmp_path, streams
     import json
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["pairs_per_step"] == 26 and j["value"] > 0
+    assert j["config"]["world_size"] == 2 and j["config"]["backend"] == "gloo"     # the line shows what the ranks ran on
+    assert j["repeats"] == 2 and j["value_min"] <= j["value"] <= j["value_max"]
     got = np.load(multi)
     assert got.shape == (2, 13, 18)
     for r in range(2):
@@ -59,3 +64,73 @@ def test_bench_two_ranks_on_one_gpu_equal_two_single_rank_runs(tmp_path, streams
         assert one.shape == (1, 13, 18)
         assert got[r].tobytes() == one[0].tobytes(), f"rank {r}: gathered records differ from the single-rank run"
     assert got[0].tobytes() != got[1].tobytes()      # the two ranks worked on different sequences
+
+
+def _launch_ranks(world, extra, dump):
+    bench = os.path.join(ROOT, "bench.py")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = _env(RANK=r, LOCAL_RANK=r, WORLD_SIZE=world, MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   PUTSLAM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=0)
+        cmd = [sys.executable, bench, "--gpus", str(world), "--dump-records", str(dump)] + extra
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    import json
+    return json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """World size 8 (BASELINE configs[3]'s shape: one sequence per rank, gather of 72 B per pair to rank 0), tiny sizes,
+    eight processes sharing the one GPU over gloo: every rank's block arrives on rank 0 and equals that rank's own
+    single-process run."""
+    extra = ["--frames", "5"] + TINY
+    multi = tmp_path / "multi8.npy"
+    j = _launch_ranks(8, extra, multi)
+    assert j["n_gpus"] == 8 and j["config"]["world_size"] == 8 and j["config"]["pairs_per_step"] == 32
+    assert j["scaling"] == "weak"
+    got = np.load(multi)
+    assert got.shape == (8, 4, 18)
+    assert len({got[r].tobytes() for r in range(8)}) == 8                  # eight different sequences
+    bench = os.path.join(ROOT, "bench.py")
+    for r in (0, 3, 7):
+        single = tmp_path / f"s{r}.npy"
+        p = subprocess.run([sys.executable, bench, "--gpus", "1", "--as-rank", str(r), "--dump-records", str(single)] + extra,
+                           env=_env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert got[r].tobytes() == np.load(single)[0].tobytes(), f"rank {r}"
+
+
+def test_bench_one_sequence_sharded_eight_ways_equals_unsharded(tmp_path):
+    """--shard sequence: ONE sequence split over eight ranks with a one-frame halo (sharding.shard_sequence); the pair
+    records rank 0 gathers, put back in order, are byte-identical to the unsharded single-rank run (pair p keeps its
+    hypothesis stream seed + p wherever it runs)."""
+    from putslam_amd import sharding
+    frames = 20
+    extra = ["--frames", str(frames), "--shard", "sequence"] + TINY
+    multi = tmp_path / "shard8.npy"
+    j = _launch_ranks(8, extra, multi)
+    assert j["scaling"] == "strong" and j["config"]["pairs_per_step"] == frames - 1 and j["config"]["shard"] == "sequence"
+    got = np.load(multi)                                              # (8, largest shard, 18), short shards zero-padded
+    assert got.shape == (8, 3, 18)
+    bench = os.path.join(ROOT, "bench.py")
+    single = tmp_path / "unsharded.npy"
+    p = subprocess.run([sys.executable, bench, "--gpus", "1", "--dump-records", str(single), "--frames", str(frames)] + TINY,
+                       env=_env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    want = np.load(single)[0]
+    assert want.shape == (frames - 1, 18)
+    back = []
+    for r in range(8):
+        sh = sharding.shard_sequence(frames, 8, r)
+        n = sh["pair_hi"] - sh["pair_lo"]
+        back.append(got[r][:n])
+        assert not got[r][n:].any()                                   # padding only
+    back = np.concatenate(back)
+    assert back.tobytes() == want.tobytes()
+    # and the trajectory rank 0 would compose from them (PUTSLAM.cpp:735-740) is the unsharded one
+    inc = back[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
+    assert sharding.compose_trajectory(inc).tobytes() == \
+        sharding.compose_trajectory(want[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)).tobytes()

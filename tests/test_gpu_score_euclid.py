@@ -1,0 +1,221 @@
+"""Kernel 3 pairs for the Euclidean metrics (errorVersion 0 = EUCLIDEAN_ERROR, the metric every shipped reference
+config runs, and 4 = ADAPTIVE_ERROR): the decision-exact packed kernel (ps_ransac_score_euclid, default) and the
+value-exact kernel (ps_ransac_score<0/4>) must give the oracle's inlier count for EVERY hypothesis
+(reference src/TransformEst/RANSAC.cpp:251-281), over thresholds 1e-4 ... 10 m, noise levels, odd / tiny match counts,
+depths at the depth-filter limits and degenerate data."""
+import numpy as np
+import pytest
+
+from putslam_amd import api, synth
+from putslam_amd._abi import (ADAPTIVE_ERROR, DMATCH_DTYPE, EST_FIXED, EST_RANSAC, EUCLIDEAN_ERROR, TUM_FR1_K,
+                              default_ransac_params, make_config)
+
+pytestmark = pytest.mark.gpu
+
+MODES = [EUCLIDEAN_ERROR, ADAPTIVE_ERROR]
+
+
+@pytest.fixture(scope="module")
+def fctx():
+    c = api.Context(0)
+    c.set_option("score", 1)
+    c.set_option("score_stats", 1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ectx():
+    c = api.Context(0)
+    c.set_option("score", 0)
+    yield c
+    c.close()
+
+
+def _counts(fctx, ectx, oracle, prm, cfg, K, prev, cur, m, expect_fast=True):
+    g = fctx.debug_ransac_counts(prm, cfg, K, prev, cur, m)
+    parked, evals = fctx.score_stats()
+    e = ectx.debug_ransac_counts(prm, cfg, K, prev, cur, m)
+    c, M = oracle.hypothesis_counts(prm, cfg, K, prev, cur, m)
+    assert np.array_equal(e, c), "value-exact kernel differs from the oracle"
+    assert np.array_equal(g, c), "decision-exact Euclidean kernel differs from the oracle"
+    assert parked <= evals
+    if expect_fast and M >= 3:
+        assert evals >= cfg.numHypotheses * M, "the fast path did not run"
+    return parked, evals, M
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("thr", [1e-4, 1e-3, 0.01, 0.04, 0.040000001, 0.3, 2.0, 10.0])
+def test_euclid_thresholds(fctx, ectx, oracle, mode, thr):
+    a, b = synth.make_pair(900, config=2, index=5000 + int(thr * 1000))
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    prm.inlierThresholdEuclidean = thr
+    cfg, _ = make_config(EST_FIXED, 3000, seed=17)
+    parked, evals, M = _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    assert M > 100
+    if thr == 0.04:
+        # the band is a few 1e-6 m wide; a marked evaluation has its whole 64-match block recounted, and the statistic
+        # counts those recounted evaluations
+        assert parked < 0.05 * evals, (parked, evals)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("noise,frac", [(1e-5, 0.9), (0.004, 0.7), (0.02, 0.25), (0.05, 0.1)])
+def test_euclid_noise(fctx, ectx, oracle, mode, noise, frac):
+    a, b = synth.make_pair(1000, config=2, index=5200, inlier_frac=frac, noise=noise)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=31)
+    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n", [3, 4, 5, 16, 17, 63, 64, 65, 127, 257])
+def test_euclid_odd_and_tiny_match_counts(fctx, ectx, oracle, mode, n):
+    """Odd counts exercise the half-filled last pair record, tiny ones the split of the match range on pairs."""
+    rng = np.random.default_rng(700 + n)
+    prev = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 3]).astype(np.float32)
+    R, t = synth.random_motion(rng)
+    cur = ((prev.astype(np.float64) - t) @ R + rng.normal(0, 0.01, (n, 3))).astype(np.float32)
+    cur[:, 2] = np.clip(cur[:, 2], 0.11, 5.9)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    prm = default_ransac_params(mode)
+    prm.minimalNumberOfMatches = 3
+    cfg, _ = make_config(EST_FIXED, 700, seed=n)
+    for msplit in (0, 1, 3, 32):
+        fctx.set_option("msplit", msplit)
+        ectx.set_option("msplit", msplit)
+        _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m)
+    fctx.set_option("msplit", 0)
+    ectx.set_option("msplit", 0)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_euclid_depth_filter_limits_and_degenerate_geometry(fctx, ectx, oracle, mode):
+    """Previous-frame depths exactly at 0.1 / 6 (the adaptive threshold's extremes, RANSAC.cpp:65-74,270-271),
+    coincident points (invalid 3-point models), huge lateral offsets."""
+    rng = np.random.default_rng(99)
+    n = 401
+    prev = np.zeros((n, 3), np.float32)
+    prev[:, 2] = rng.choice(np.float32([0.1, 0.1000001, 0.5, 3.0, 6.0, 5.999999]), n)
+    prev[:, 0] = (rng.standard_normal(n) * rng.choice([1e-6, 0.01, 1.0, 50.0], n)).astype(np.float32)
+    prev[:, 1] = (rng.standard_normal(n) * rng.choice([1e-6, 0.01, 1.0, 50.0], n)).astype(np.float32)
+    prev[::17] = prev[1]
+    R, t = synth.random_motion(rng, 10.0, 0.3)
+    cur = ((prev.astype(np.float64) - t) @ R + rng.normal(0, 0.003, (n, 3))).astype(np.float32)
+    cur[:, 2] = np.clip(cur[:, 2], 0.1, 6.0)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    m["trainIdx"][::5] = rng.permutation(n)[: len(m["trainIdx"][::5])]
+    for thr in (0.004, 0.04, 1.0):
+        prm = default_ransac_params(mode)
+        prm.inlierThresholdEuclidean = thr
+        cfg, _ = make_config(EST_FIXED, 4096, seed=3)
+        _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 1e4])
+def test_euclid_coordinate_scale(fctx, ectx, oracle, mode, scale):
+    """Scene scale x threshold scale: the band follows S (relative), not metres.  Depths are kept inside the filter."""
+    rng = np.random.default_rng(12)
+    n = 500
+    prev = (rng.uniform(-1, 1, (n, 3)) * [scale, scale, 1] + [0, 0, 3]).astype(np.float32)
+    R, t = synth.random_motion(rng, 3.0, 0.02)
+    cur = ((prev.astype(np.float64) - t) @ R + rng.normal(0, 0.002, (n, 3))).astype(np.float32)
+    cur[:, 2] = np.clip(cur[:, 2], 0.1, 6.0)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(EST_FIXED, 2048, seed=5)
+    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("thr", [0.0, -1.0, float("nan"), 1e-12, 1e12, float("inf")])
+def test_euclid_thresholds_outside_the_band_derivation(fctx, ectx, oracle, mode, thr):
+    """Thresholds the bounds were not derived for run the value-exact loop inside the same kernel."""
+    a, b = synth.make_pair(300, config=2, index=5300)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(mode)
+    prm.inlierThresholdEuclidean = thr
+    cfg, _ = make_config(EST_FIXED, 512, seed=2)
+    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m, expect_fast=False)
+
+
+def test_euclid_non_finite_and_huge_coordinates(fctx, ectx, oracle):
+    """x / y may be infinite or huge after the depth filter (only z and NaN are checked, RANSAC.cpp:65-74)."""
+    rng = np.random.default_rng(5)
+    n = 200
+    prev = (rng.uniform(-1, 1, (n, 3)) + [0, 0, 3]).astype(np.float32)
+    cur = prev + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = np.arange(n)
+    cfg, _ = make_config(EST_FIXED, 1024, seed=8)
+    for bad in (np.inf, 1e30, 3e16):
+        p2, c2 = prev.copy(), cur.copy()
+        p2[7, 0] = bad
+        c2[11, 1] = -bad
+        for mode in MODES:
+            prm = default_ransac_params(mode)
+            _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, p2, c2, m, expect_fast=False)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_euclid_full_results(fctx, ectx, oracle, mode):
+    """Whole RANSAC call (selection, refit, final mask, pose, stats) through both kernels vs the oracle."""
+    for idx in range(4):
+        a, b = synth.make_pair(1200, config=2, index=5400 + idx, inlier_frac=0.5, noise=0.006)
+        m = oracle.match_hamming256(a["desc"], b["desc"])
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(EST_RANSAC, 1157, seed=idx)
+        c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+        for ctx in (fctx, ectx):
+            g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+            assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+            assert g["stats"]["bestHypothesis"] == c["stats"]["bestHypothesis"]
+            assert g["stats"]["bestInlierCount"] == c["stats"]["bestInlierCount"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_euclid_batch_on_a_full_chip(oracle, mode):
+    """Fast and value-exact kernels over a batch that fills the chip (several work-groups per CU), and one pair of it
+    against the oracle at the automatic split."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(33, 1999, config=3, index=2)          # odd keypoint count
+    prm = default_ransac_params(mode)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=42)
+    outs = {}
+    for score in (1, 0, 1):
+        c = api.Context(0)
+        c.set_option("score", score)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        c.close()
+        if "ref" not in outs:
+            outs["ref"] = g
+            continue
+        r = outs["ref"]
+        assert g["pose"].tobytes() == r["pose"].tobytes(), "score=%d" % score
+        assert np.array_equal(g["inlierMask"], r["inlierMask"]), "score=%d" % score
+        for k in ("bestHypothesis", "bestInlierCount", "numInliers", "numMatchesValid"):
+            assert np.array_equal(g["stats"][k], r["stats"][k]), (score, k)
+    p = 11
+    cfgp, _ = make_config(EST_FIXED, 4096, seed=42 + p)
+    c = api.Context(0)
+    m = c.match_hamming256(seq["desc"][p], seq["desc"][p + 1])
+    want, _ = oracle.hypothesis_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], m)
+    got = c.debug_ransac_counts(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], m)
+    assert np.array_equal(got, want)
+    ref = oracle.ransac_rigid3d(prm, cfgp, TUM_FR1_K, seq["pts"][p], seq["pts"][p + 1], m)
+    assert outs["ref"]["pose"][p].reshape(4, 4).T.tobytes() == ref["pose"].tobytes()
+    c.close()

@@ -81,6 +81,48 @@ def test_matcher_vs_numpy_bruteforce(oracle):
 
 
 # ------------------------------------------------------------------ schedules (A6, A11)
+def test_simd_matcher_equals_scalar(oracle):
+    """The timed baseline's SIMD popcount sweep (what OpenCV's vectorised normHamming amounts to) and the scalar popcnt
+    loop are the same function: ragged sizes, ties, duplicates.  On a host without AVX2 both runs take the scalar path."""
+    rng = np.random.default_rng(77)
+    try:
+        for nq, nt in [(1, 1), (3, 7), (64, 65), (257, 130), (1000, 999)]:
+            q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+            k = min(nq, nt) // 2
+            t[:k] = q[:k] ^ (rng.random((k, 32)) < 0.04).astype(np.uint8)     # near-duplicates -> ties and real matches
+            if nq > 10:
+                q[5] = q[6]                                                     # exact duplicates: lowest index wins
+            oracle.set_matcher_simd(True)
+            a = oracle.match_hamming256(q, t)
+            oracle.set_matcher_simd(False)
+            b = oracle.match_hamming256(q, t)
+            assert a.tobytes() == b.tobytes()
+        assert oracle.matcher_simd_kind() in ("scalar", "avx2-lut", "avx512-vpopcnt")
+    finally:
+        oracle.set_matcher_simd(True)
+
+
+def test_eval_errors_agree_with_is_inlier(oracle):
+    """The error values returned for the band-edge tests are the ones po_is_inlier compares: a threshold just above an
+    error accepts the match, the error itself (strict '<') does not."""
+    from putslam_amd._abi import TUM_FR1_K
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        ang = rng.uniform(-0.2, 0.2)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+        T[:3, 3] = rng.uniform(-0.1, 0.1, 3)
+        cp = (rng.uniform(-1, 1, 3) + [0, 0, 3]).astype(np.float32)
+        pp = (T[:3, :3] @ cp + T[:3, 3] + rng.normal(0, 0.01, 3)).astype(np.float32)
+        e = oracle.eval_errors(T, TUM_FR1_K, pp, cp)
+        assert oracle.is_inlier(0, T, TUM_FR1_K, pp, cp, np.nextafter(e[0], np.inf), 1.0)
+        assert not oracle.is_inlier(0, T, TUM_FR1_K, pp, cp, e[0], 1.0)
+        big = max(e[1], e[2])
+        assert oracle.is_inlier(1, T, TUM_FR1_K, pp, cp, 1.0, np.nextafter(big, np.inf))
+        assert not oracle.is_inlier(1, T, TUM_FR1_K, pp, cp, 1.0, big)
+
+
 def test_ransac_iteration_table(oracle):
     table = {0.15: 1157, 0.2: 487, 0.25: 248, 0.3: 142, 0.4: 59, 0.5: 29, 0.6: 16, 0.7: 9, 0.8: 5, 0.9: 2}
     for r, it in table.items():
