@@ -542,22 +542,33 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             // more work-groups than fit at once (256 CUs x 6): the build for big launches (ps_score_fast.h)
-#define PS_LAUNCH_FAST(BIG)                                                                                            \
-    hipLaunchKernelGGL((ps_ransac_score_fast<PS_REPROJECTION_ERROR, BIG>), grid, dim3(kBlock), 0, ctx->stream,         \
+#define PS_LAUNCH_FAST(MODE, BIG)                                                                                      \
+    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG>), grid, dim3(kBlock), 0, ctx->stream,                          \
                        (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,          \
                        (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,       \
-                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, pl.minRun, msplit,                 \
+                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.H, cap, pl.minRun, msplit,          \
                        (int32_t *)ctx->counts.p, dbg)
             if (grid.x > 1536u)
-                PS_LAUNCH_FAST(true);
+                PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, true);
             else
-                PS_LAUNCH_FAST(false);
-#undef PS_LAUNCH_FAST
+                PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, false);
         } else
             launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
     case PS_EUCLIDEAN_AND_REPROJECTION_ERROR:
-        launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
+        if (ctx->scoreFast != 0) {
+            unsigned long long *dbg = nullptr;
+            if (ctx->scoreStats) {
+                PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
+                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+                dbg = (unsigned long long *)ctx->dbgCnt.p;
+            }
+            if (grid.x > 1280u)
+                PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, true);
+            else
+                PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, false);
+        } else
+            launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
     case PS_ADAPTIVE_ERROR:
         if (with_euclid_fast(ctx, pl.mode))
@@ -568,6 +579,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
     }
 #undef PS_LAUNCH_EUCLID
+#undef PS_LAUNCH_FAST
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     SelectArgs sa = pl.sa;

@@ -60,12 +60,6 @@
 
 namespace psdev {
 
-struct EuclidConsts {
-    float tbLo;  // errorVersion 0: sqrt(B) (1 - 6u) rounded down; errorVersion 4: thr (1 - 7u) rounded down
-    float tbHi;  // ... (1 + 6u) / (1 + 7u) rounded up
-    int enabled; // threshold inside the range the bounds were derived for
-};
-
 constexpr int kEuclidRecFloats0 = 12; // per match PAIR: (c_x c_x')(c_y c_y')(c_z c_z')(p_x p_x')(p_y p_y')(p_z p_z')
 constexpr int kEuclidRecFloats4 = 16; // (c'_x ..)(c'_y ..)(c'_z ..)(w w')(p'_x ..)(p'_y ..)(p'_z ..)(pad)
 

@@ -62,6 +62,14 @@ struct FastConsts {
     int enabled;  // thresholds and camera constants inside the range the bounds were derived for
 };
 
+// Limits of the decision-exact Euclidean test (derivation: ps_score_euclid.h), used by ps_ransac_score_euclid<0/4> and by
+// the Euclidean term of ps_ransac_score_fast<2>.
+struct EuclidConsts {
+    float tbLo;  // errorVersion 0 / 2: sqrt(B) (1 - 6u) rounded down; errorVersion 4: thr (1 - 7u) rounded down
+    float tbHi;  // ... (1 + 6u) / (1 + 7u) rounded up
+    int enabled; // threshold inside the range the bounds were derived for
+};
+
 constexpr int kQueueCap = 256; // parked evaluations per wave (drained by the wave itself when full)
 constexpr float kEpsU = 5.9604644775390625e-08f; // 2^-24
 
@@ -122,15 +130,23 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 // scalar-cache footprint of the records every wave streams; 1.77 -> 1.70 -> 1.68 ms per 499 pairs).  Small launches are bound
 // by the latency of ONE prologue and of cold record loads: 6 waves (80 VGPRs, no spills) and the three 16-byte records,
 // whose loads go out side by side (single pair: 31 against 36 us).
+// MODE = EUCLIDEAN_AND_REPROJECTION_ERROR (RANSAC.cpp:377-436: both reprojection errors AND the Euclidean residual below their
+// thresholds) adds the Euclidean term of ps_score_euclid.h to every evaluation: the unfolded current -> previous transform as
+// three FMA chains (plain instructions: only one direction has a Euclidean test), the squared residual against the same
+// per-lane limits lo / hi; "inlier" needs both certain, one certain "outlier" suffices, anything else is parked and decided by
+// inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel; five
+// waves per SIMD (the second model costs 12 registers).
 template <int MODE, bool BIG>
-__global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
+__global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
     const float2 *__restrict__ pairBound,
-    ModelArgs ma, ScoreConsts k, FastConsts fc, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
-    unsigned long long *__restrict__ dbg)
+    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, int H, int cap, int minRun, int msplit,
+    int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
 {
-    static_assert(MODE == PS_REPROJECTION_ERROR, "the fast path covers the reprojection metric");
+    static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
+                  "the metrics with a reprojection test");
+    constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
     __shared__ float s_mdl[12][kBlock];
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
     model_norms(inv, rho, tau);
     const float S = (rho * cmax + tau) * 1.001f;
     // (comparisons are false for NaN: a non-finite model, cmax or umax sends the wavefront to the value-exact loop)
-    const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f;
+    const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f &&
+                          (!EUCLID || (ec.enabled != 0 && cmax <= 1.0e15f));
     int cnt = 0;
 
     if (!wave_all(boundsOk)) {
@@ -191,6 +208,8 @@ __global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
         // every launch: 40 dwords per lane, 349 MB of writes per 499 pairs, profiles/r02d).
         FastModel F;
         float cL, G2;
+        float U[3][4];          // EUCLID: the unfolded model (R | t), current point -> previous frame
+        float loE = 0.0f, hiE = 0.0f; // EUCLID: per-lane limits of the squared residual (ps_score_euclid.h)
         // uniform part of the band: E = lambda S, |e_z - Z~| <= 8 u S, G = (sqrt2 lambda + 8 u T') S = g S
         const float lam = 1.05f * kEpsU * (14.0f * fc.fmaxK + 11.0f * umax + 4.0f * fc.cmaxK);
         const float g = 1.4143f * lam + 8.0f * kEpsU * fc.thrUp;
@@ -213,6 +232,21 @@ __global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
             const float G = ((rho2 * cmax + tau2) * 1.001f) * g;
             cL = (2.0f * fc.thrUp * G) * (1.00001f * up4);   // 2 T' G, rounded up
             G2 = (G * G) * 1.0001f;
+            if (EUCLID) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) U[i][j] = md.R[i][j];
+                    U[i][3] = md.t[i];
+                }
+                float rhoE = 0.0f, tauE = 0.0f;
+                model_norms(md, rhoE, tauE);
+                const float aE = ((rhoE * cmax + tauE) * 1.001f) * (12.7f * kEpsU);
+                const float xl = ec.tbLo - aE;
+                loE = xl > 0.0f ? (xl * xl) * (1.0f - 8.0f * kEpsU) : -1.0f;
+                const float yh = ec.tbHi + aE * (1.0f + 4.0f * kEpsU);
+                hiE = (yh * yh) * (1.0f + 8.0f * kEpsU);
+            }
         };
         rebuild();
         int qn = 0;                      // parked evaluations of this wave (wave-uniform)
@@ -243,13 +277,16 @@ __global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
         for (int m = m0; m < m1; ++m) {
             v2f_t Z, ss;
+            float cxm, cym, czm, pxm, pym, pzm; // the match's current and previous point (wave-uniform)
             if (BIG) {
                 const float2 *__restrict__ e = pf + 5 * m;
                 const float2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
                 ss = fast_sq2(F, v2f_t{e0.x, e0.y}, v2f_t{e1.x, e1.y}, v2f_t{e2.x, e2.y}, v2f_t{e3.x, e3.y}, v2f_t{e4.x, e4.y}, Z);
+                cxm = e0.x; cym = e1.x; czm = e2.x; pxm = e0.y; pym = e1.y; pzm = e2.y;
             } else {
                 const float4 A = pa[m], B = pb[m], E = pe[m];
                 ss = fast_sq2(F, v2f_t{B.x, A.x}, v2f_t{B.y, A.y}, v2f_t{B.z, A.z}, v2f_t{E.x, E.y}, v2f_t{E.z, E.w}, Z);
+                cxm = B.x; cym = B.y; czm = B.z; pxm = A.x; pym = A.y; pzm = A.z;
             }
             // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
             // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
@@ -264,10 +301,18 @@ __global__ __launch_bounds__(kBlock, BIG ? 7 : 6) void ps_ransac_score_fast(
             const v2f_t hi = pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, q, band);
             // (scalar copies: comparisons on vector-element expressions; any NaN makes all four comparisons false)
             const float se = ss.x, sn = ss.y, loe = lo.x, lon = lo.y, hie = hi.x, hin = hi.y;
-            const unsigned long long mIn =
+            unsigned long long mIn =
                 __builtin_amdgcn_ballot_w64(se < loe) & __builtin_amdgcn_ballot_w64(sn < lon);
-            const unsigned long long mOut =
+            unsigned long long mOut =
                 __builtin_amdgcn_ballot_w64(se > hie) | __builtin_amdgcn_ballot_w64(sn > hin);
+            if (EUCLID) {
+                const float d0 = __builtin_fmaf(U[0][0], cxm, __builtin_fmaf(U[0][1], cym, __builtin_fmaf(U[0][2], czm, U[0][3]))) - pxm;
+                const float d1 = __builtin_fmaf(U[1][0], cxm, __builtin_fmaf(U[1][1], cym, __builtin_fmaf(U[1][2], czm, U[1][3]))) - pym;
+                const float d2 = __builtin_fmaf(U[2][0], cxm, __builtin_fmaf(U[2][1], cym, __builtin_fmaf(U[2][2], czm, U[2][3]))) - pzm;
+                const float sE = __builtin_fmaf(d0, d0, __builtin_fmaf(d1, d1, d2 * d2));
+                mIn &= __builtin_amdgcn_ballot_w64(sE < loE);
+                mOut |= __builtin_amdgcn_ballot_w64(sE > hiE);
+            }
             add_mask(cnt, mIn);
             const unsigned long long mU = execAll & ~(mIn | mOut);
             if (mU != 0ull) {

@@ -1,18 +1,18 @@
-"""Kernel 3 pairs for the Euclidean metrics (errorVersion 0 = EUCLIDEAN_ERROR, the metric every shipped reference
-config runs, and 4 = ADAPTIVE_ERROR): the decision-exact packed kernel (ps_ransac_score_euclid, default) and the
-value-exact kernel (ps_ransac_score<0/4>) must give the oracle's inlier count for EVERY hypothesis
-(reference src/TransformEst/RANSAC.cpp:251-281), over thresholds 1e-4 ... 10 m, noise levels, odd / tiny match counts,
-depths at the depth-filter limits and degenerate data."""
+"""Kernel 3 pairs for the metrics with a Euclidean test (errorVersion 0 = EUCLIDEAN_ERROR, the metric every shipped
+reference config runs, 4 = ADAPTIVE_ERROR, 2 = EUCLIDEAN_AND_REPROJECTION_ERROR): the decision-exact kernels
+(ps_ransac_score_euclid<0/4>, ps_ransac_score_fast<2>; default) and the value-exact kernel (ps_ransac_score<0/2/4>) must
+give the oracle's inlier count for EVERY hypothesis (reference src/TransformEst/RANSAC.cpp:251-281,377-436), over
+thresholds 1e-4 ... 10 m, noise levels, odd / tiny match counts, depths at the depth-filter limits and degenerate data."""
 import numpy as np
 import pytest
 
 from putslam_amd import api, synth
-from putslam_amd._abi import (ADAPTIVE_ERROR, DMATCH_DTYPE, EST_FIXED, EST_RANSAC, EUCLIDEAN_ERROR, TUM_FR1_K,
-                              default_ransac_params, make_config)
+from putslam_amd._abi import (ADAPTIVE_ERROR, DMATCH_DTYPE, EST_FIXED, EST_RANSAC, EUCLIDEAN_AND_REPROJECTION_ERROR,
+                              EUCLIDEAN_ERROR, TUM_FR1_K, default_ransac_params, make_config)
 
 pytestmark = pytest.mark.gpu
 
-MODES = [EUCLIDEAN_ERROR, ADAPTIVE_ERROR]
+MODES = [EUCLIDEAN_ERROR, ADAPTIVE_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR]
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +59,20 @@ def test_euclid_thresholds(fctx, ectx, oracle, mode, thr):
         # the band is a few 1e-6 m wide; a marked evaluation has its whole 64-match block recounted, and the statistic
         # counts those recounted evaluations
         assert parked < 0.05 * evals, (parked, evals)
+
+
+@pytest.mark.parametrize("thrR", [0.05, 0.5, 2.0, 7.3, 40.0, 900.0])
+@pytest.mark.parametrize("thrE", [0.004, 0.04, 0.5])
+def test_both_metrics_threshold_grid(fctx, ectx, oracle, thrE, thrR):
+    """errorVersion 2: the Euclidean and the two reprojection tests decide together (RANSAC.cpp:377-436); whichever of
+    the two thresholds binds, every hypothesis's count equals the oracle's."""
+    a, b = synth.make_pair(800, config=2, index=5100 + int(thrR * 10))
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    prm = default_ransac_params(EUCLIDEAN_AND_REPROJECTION_ERROR)
+    prm.inlierThresholdEuclidean = thrE
+    prm.inlierThresholdReprojection = thrR
+    cfg, _ = make_config(EST_FIXED, 2048, seed=19)
+    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
 
 
 @pytest.mark.parametrize("mode", MODES)
