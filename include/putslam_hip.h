@@ -119,12 +119,22 @@ int ps_context_synchronize(PsContext *ctx);
  *              (default: the matrix-core form, one launch more, from about five 2000-keypoint pairs per call on)
  *              (environment: PUTSLAM_HIP_MATCHER=mfma|valu|auto, read at context creation); "matcher_used" (read only)
  *              tells which of the two the last matching call ran.
- *   "score":   1 = decision-exact fast scoring kernel for errorVersion 1 (ps_ransac_score_fast: cheap evaluation with a
- *              proven error band, in-band evaluations re-done by the value-exact code; default), 2 = the same scheme
- *              with the two rigid transforms and the image-offset products on the matrix cores in split f16
- *              (ps_ransac_score_mfma, v_mfma_f32_32x32x16_f16; 5 % faster on its own, relies on a measured MFMA accumulation bound),
- *              0 = value-exact ps_ransac_score<1> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
- *              Counts are identical.
+ *   "score":   1 = decision-exact fast scoring kernels (cheap evaluation with a proven error band, in-band evaluations
+ *              re-done by the value-exact code; default): ps_ransac_score_euclid for errorVersion 0 / 4 (the metric every
+ *              shipped reference config runs), ps_ransac_score_fast for errorVersion 1 / 2;
+ *              2 = EXPERIMENTAL, errorVersion 1 only: the same scheme with the two rigid transforms and the image-offset
+ *              products on the matrix cores in split f16 (ps_ransac_score_mfma, v_mfma_f32_32x32x16_f16); its error band
+ *              rests on an MFMA accumulation bound that is measured on the device (tests/test_gpu_mfma_accuracy.py), not
+ *              documented by the ISA, and on source-operand fences described in ps_score_mfma.h; other error versions
+ *              run the "1" kernels;
+ *              0 = value-exact ps_ransac_score<M> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
+ *              Per-hypothesis counts are identical between 0 and 1 by proof + tests, between 0 and 2 by tests.
+ *   "prune":   1 (default) = large batches score the first 256 hypotheses of every pair completely, then abandon every
+ *              later hypothesis as soon as it cannot become a record of the sequential selection any more (count so far +
+ *              matches left <= best count of the earlier ones, RANSAC.cpp:438-455) and never start hypotheses beyond
+ *              the adaptive trip limit (RANSAC.cpp:450-453); all outputs are unchanged, only the scratch counts of
+ *              abandoned hypotheses are lower bounds.  0 = every hypothesis is scored completely
+ *              (PUTSLAM_HIP_PRUNE=0|1).  The diagnostic ps_debug_ransac_counts always scores completely.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
  *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).
@@ -286,6 +296,10 @@ int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, u
 /* After a scoring launch with option "score_stats" = 1: evaluations the fast kernel parked for the value-exact
  * code, and (hypothesis, match) evaluations it made in all (lanes of partially filled wavefronts included). */
 int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations);
+/* All eight counters of the last scoring launch: [0] parked, [1] evaluations of a complete sweep, [2] 64-match
+ * wave-blocks actually computed, [3] wave-blocks of a complete sweep ([2] / [3] = the share of the sweep the pruned
+ * launch still did), [4] lane re-packings; [5..7] reserved (0). */
+int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
 size_t ps_abi_sizeof_dmatch(void);
 size_t ps_abi_sizeof_params(void);

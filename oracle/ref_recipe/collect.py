@@ -7,8 +7,9 @@ import struct
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-REF = os.path.join(ROOT, "oracle", "_ref")
-GOLD = os.path.join(ROOT, "tests", "golden")
+# PUTSLAM_REF_DIR / PUTSLAM_GOLD_DIR: used by tests/test_ref_recipe_plumbing.py (temporary directories)
+REF = os.environ.get("PUTSLAM_REF_DIR") or os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.environ.get("PUTSLAM_GOLD_DIR") or os.path.join(ROOT, "tests", "golden")
 
 
 def _r(f, fmt):

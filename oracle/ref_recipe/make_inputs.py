@@ -11,14 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from putslam_amd import synth  # noqa: E402
 
-OUT = os.path.join(ROOT, "oracle", "_ref", "inputs")
+# PUTSLAM_REF_DIR / PUTSLAM_REF_N: used by tests/test_ref_recipe_plumbing.py (a temporary directory, fewer samples)
+OUT = os.path.join(os.environ.get("PUTSLAM_REF_DIR") or os.path.join(ROOT, "oracle", "_ref"), "inputs")
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261003)
     # eigen core: N 3-point samples (src, dst), NK k-point sets, N 4x4 rigid matrices to invert, N 3x3 matrices
-    n = 20000
+    n = int(os.environ.get("PUTSLAM_REF_N", "20000"))
     src = (rng.uniform(-2.5, 2.5, (n, 3, 3)) + [0, 0, 3]).astype(np.float32)
     dst = (src + rng.normal(0, 0.01, src.shape) + rng.uniform(-0.2, 0.2, (n, 1, 3))).astype(np.float32)
     dst[::7] = rng.uniform(-3, 3, dst[::7].shape).astype(np.float32)

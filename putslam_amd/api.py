@@ -69,6 +69,13 @@ class Context:
         self._chk(self._L.ps_debug_score_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def score_stats_ex(self):
+        """All eight counters of the last scoring launch (ps_debug_score_stats_ex): parked, evaluations, wave-blocks
+        computed, wave-blocks of a complete sweep, re-packings, reserved x 3."""
+        out = (C.c_uint64 * 8)()
+        self._chk(self._L.ps_debug_score_stats_ex(self._h, out))
+        return [int(v) for v in out]
+
     def get_option(self, name):
         v = self._L.ps_context_get_option(self._h, name.encode())
         if v < 0:

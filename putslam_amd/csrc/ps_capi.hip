@@ -72,6 +72,9 @@ struct PsContext {
     // 0 = value-exact ps_ransac_score<1>
     int scoreFast = 1;
     int scoreStats = 0;
+    // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
+    // abandon later hypotheses that cannot become records (default), 0 = every hypothesis is scored completely
+    int prune = 1;
 };
 
 namespace {
@@ -306,6 +309,7 @@ struct Plan {
     SelectArgs sa{};
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
+    bool prune = false; // two launches: hypotheses [0, kPrefix) completely (msplit applies to it), the rest pruned
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -478,10 +482,16 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     const int H = pl.H;
     PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
     const int hb = (H + kBlock - 1) / kBlock;
-    pl.msplit = pick_split((long long)P * hb, 32, 64, cap);
+    // pruned scoring: worth its second launch when the hypotheses beyond the prefix fill the chip by themselves
+    const bool prunable = with_euclid_fast(ctx, pl.mode) ||
+                          (pl.mode == PS_REPROJECTION_ERROR && ctx->scoreFast == 1) ||
+                          (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR && ctx->scoreFast != 0);
+    pl.prune = ctx->prune != 0 && prunable && H > kPrefix && (long long)P * (hb - 1) >= 256;
+    pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
     pl.pa.zeroCounts = pl.msplit > 1 ? (int32_t *)ctx->counts.p : nullptr;
-    pl.pa.zeroH = H;
+    pl.pa.zeroH = pl.prune ? kPrefix : H;
+    pl.pa.zeroStride = H;
     pl.ma.models = nullptr;
     const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
     if (P <= kWidePairs && mbytes <= ((size_t)64 << 20)) {
@@ -509,11 +519,22 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
         dbgE = (unsigned long long *)ctx->dbgCnt.p;
     }
-#define PS_LAUNCH_EUCLID(MODE)                                                                                         \
-    hipLaunchKernelGGL(ps_ransac_score_euclid<MODE>, grid, dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p,  \
-                       (const float4 *)ctx->recB.p, (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,       \
-                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.ec, pl.H, cap, pl.minRun, msplit,                 \
+    // (PRUNE launches: hypotheses [kPrefix, H) after a launch that scored [0, kPrefix) completely; ps_score_euclid.h)
+#define PS_LAUNCH_EUCLID_RANGE(MODE, PRUNE, HBASE, HCOUNT, MSPLIT)                                                     \
+    hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, PRUNE>),                                                          \
+                       dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
+                       dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
+                       (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,       \
+                       pl.ma, pl.sc, pl.ec, pl.sa, (HBASE), (HCOUNT), pl.H, cap, pl.minRun, (MSPLIT),                  \
                        (int32_t *)ctx->counts.p, dbgE)
+#define PS_LAUNCH_EUCLID(MODE)                                                                                         \
+    do {                                                                                                               \
+        if (pl.prune) {                                                                                                \
+            PS_LAUNCH_EUCLID_RANGE(MODE, false, 0, kPrefix, msplit);                                                   \
+            PS_LAUNCH_EUCLID_RANGE(MODE, true, kPrefix, pl.H - kPrefix, 1);                                            \
+        } else                                                                                                         \
+            PS_LAUNCH_EUCLID_RANGE(MODE, false, 0, pl.H, msplit);                                                      \
+    } while (0)
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR:
         if (with_euclid_fast(ctx, pl.mode))
@@ -542,16 +563,28 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             // more work-groups than fit at once (256 CUs x 6): the build for big launches (ps_score_fast.h)
-#define PS_LAUNCH_FAST(MODE, BIG)                                                                                      \
-    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG>), grid, dim3(kBlock), 0, ctx->stream,                          \
-                       (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,          \
-                       (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,       \
-                       (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.H, cap, pl.minRun, msplit,          \
-                       (int32_t *)ctx->counts.p, dbg)
-            if (grid.x > 1536u)
-                PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, true);
-            else
-                PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, false);
+#define PS_LAUNCH_FAST_RANGE(MODE, BIG, PRUNE, HBASE, HCOUNT, MSPLIT)                                                  \
+    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, PRUNE>),                                                       \
+                       dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
+                       dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
+                       (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p,          \
+                       (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.sa, \
+                       (HBASE), (HCOUNT), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbg)
+    // more work-groups than fit at once: the build for big launches (ps_score_fast.h); pruned: prefix, then the rest
+#define PS_LAUNCH_FAST(MODE, BIGLIMIT)                                                                                 \
+    do {                                                                                                               \
+        if (pl.prune) {                                                                                                \
+            if ((unsigned)msplit * (unsigned)P > (BIGLIMIT))                                                           \
+                PS_LAUNCH_FAST_RANGE(MODE, true, false, 0, kPrefix, msplit);                                           \
+            else                                                                                                       \
+                PS_LAUNCH_FAST_RANGE(MODE, false, false, 0, kPrefix, msplit);                                          \
+            PS_LAUNCH_FAST_RANGE(MODE, true, true, kPrefix, pl.H - kPrefix, 1);                                        \
+        } else if (grid.x > (BIGLIMIT))                                                                                \
+            PS_LAUNCH_FAST_RANGE(MODE, true, false, 0, pl.H, msplit);                                                  \
+        else                                                                                                           \
+            PS_LAUNCH_FAST_RANGE(MODE, false, false, 0, pl.H, msplit);                                                 \
+    } while (0)
+            PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, 1536u);
         } else
             launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
@@ -563,10 +596,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
-            if (grid.x > 1280u)
-                PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, true);
-            else
-                PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, false);
+            PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, 1280u);
         } else
             launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
@@ -579,7 +609,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
     }
 #undef PS_LAUNCH_EUCLID
+#undef PS_LAUNCH_EUCLID_RANGE
 #undef PS_LAUNCH_FAST
+#undef PS_LAUNCH_FAST_RANGE
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     SelectArgs sa = pl.sa;
@@ -750,6 +782,7 @@ int ps_context_create(int device, PsContext **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
     if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
+    if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER"))
         ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
@@ -816,6 +849,11 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->scoreStats = value;
         return PS_OK;
     }
+    if (strcmp(name, "prune") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "prune: 0 or 1");
+        ctx->prune = value;
+        return PS_OK;
+    }
     if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
         if (value < 0 || value > 1024) return fail(ctx, PS_ERR_BAD_ARG, "split: 0..1024");
         (name[0] == 'q' ? ctx->forceQsplit : ctx->forceMsplit) = value;
@@ -831,6 +869,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
     if (strcmp(name, "score") == 0) return ctx->scoreFast;
     if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
+    if (strcmp(name, "prune") == 0) return ctx->prune;
     if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
     if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
     return PS_ERR_BAD_ARG;
@@ -1128,6 +1167,23 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
     PS_HIP(hipStreamSynchronize(ctx->stream));
     *parked = h[0];
     *evaluations = h[1];
+    return PS_OK;
+}
+
+// Diagnostic: all eight counters of the last scoring launch (option "score_stats"): [0] evaluations handed to the
+// value-exact code, [1] evaluations of a complete sweep, [2] 64-match wave-blocks computed, [3] wave-blocks of a complete
+// sweep, [4] lane re-packings of the pruned launch; the rest reserved.
+int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out8) return PS_ERR_BAD_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!ctx->dbgCnt.p) return PS_OK;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i) out8[i] = h[i];
     return PS_OK;
 }
 
@@ -1563,7 +1619,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4); // disjoint bit fields
+    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5); // disjoint bit fields
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);

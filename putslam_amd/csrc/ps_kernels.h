@@ -168,8 +168,9 @@ struct PrepArgs {
     double thrE;            // inlierThresholdEuclidean
     int mode;               // RANSAC::ERROR_VERSION
     int cap;
-    int32_t *zeroCounts;    // optional: counts[P][zeroH] to clear for kernel 3's split-range atomics (saves a memset launch)
-    int zeroH;
+    int32_t *zeroCounts;    // optional: the first zeroH counts of every pair (row stride zeroStride) to clear for kernel 3's
+    int zeroH;              // split-range atomics (saves a memset launch)
+    int zeroStride;
 };
 
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         write_split_operands<BLOCK>(a, rec, p, vbase, c, u); // (block_max ends with a barrier: the records are visible)
         if (threadIdx.x == 0) finish_pair_records(a, rec, p, vbase);
         if (a.zeroCounts)
-            for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroH + i] = 0;
+            for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroStride + i] = 0;
     }
     if (threadIdx.x == 0) {
         numMatches[p] = base;

@@ -125,6 +125,50 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
     return pk_fma(Au, Au, Bv * Bv);
 }
 
+
+// ---- pruned scoring, shared by ps_ransac_score_fast<.., PRUNE = true> and ps_ransac_score_euclid<.., true>
+// (description: ps_score_euclid.h, "Pruned scoring") ----
+constexpr int kPrefix = kBlock;   // hypotheses scored completely by launch A
+constexpr int kPruneEvery = 128;  // matches between two checks
+
+// Replay of the sequential selection over counts[0 .. n) by one wavefront (the rule of ps_select_refit part (1)):
+// best = the best count among the consumed ones, limit = the trip limit afterwards (a.H for the fixed schedule).
+PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const SelectArgs &a, int M, int &best, int &limit)
+{
+    const int lane = threadIdx.x & 63;
+    if (a.estimator == PS_EST_FIXED) {
+        int b = 0;
+        for (int i = lane; i < n; i += 64) b = max(b, cnts[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b = max(b, __shfl_xor(b, o, 64));
+        best = b;
+        limit = a.H;
+        return;
+    }
+    int pos = 0;
+    best = 0;
+    limit = a.iter0;
+    for (;;) {
+        const int lim = limit < n ? limit : n;
+        unsigned found = 0xFFFFFFFFu;
+        for (int i = pos + lane; i < lim; i += 64)
+            if (cnts[i] > best) {
+                found = (unsigned)i;
+                break;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)found, o, 64);
+            found = other < found ? other : found;
+        }
+        if (found == 0xFFFFFFFFu) break;
+        best = cnts[found];
+        pos = (int)found + 1;
+        limit = a.estimator == PS_EST_USAC ? usac_limit(a, (unsigned)best, (unsigned)M)
+                                           : ransac_limit(a, (float)best / (float)M); // ratio as RANSAC.cpp:280
+    }
+}
+
 // Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
 // a few prologue values spilled) and the packed 40-byte match record (RecPtrs::F: the loop is sensitive to the
 // scalar-cache footprint of the records every wave streams; 1.77 -> 1.70 -> 1.68 ms per 499 pairs).  Small launches are bound
@@ -136,29 +180,58 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 // per-lane limits lo / hi; "inlier" needs both certain, one certain "outlier" suffices, anything else is parked and decided by
 // inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel; five
 // waves per SIMD (the second model costs 12 registers).
-template <int MODE, bool BIG>
+// PRUNE: launch B of the pruned scoring (hypotheses [hBase, hBase + hCount) after a launch that scored [0, kPrefix)
+// completely); this launch and the plain one share every line of the evaluation.
+template <int MODE, bool BIG, bool PRUNE = false>
 __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
     const float2 *__restrict__ pairBound,
-    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, int H, int cap, int minRun, int msplit,
-    int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
+    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, SelectArgs sa, int hBase, int hCount, int H, int cap,
+    int minRun, int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
 {
+    // This launch scores hypotheses [hBase, hBase + hCount) of every pair; counts[] has H entries per pair.
     static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
                   "the metrics with a reprojection test");
     constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
     __shared__ float s_mdl[12][kBlock];
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
+    __shared__ int s_pref[2];
+    __shared__ int s_alive[kBlock / 64];
+    __shared__ uint32_t s_list[kBlock];
+    __shared__ int s_slot[kBlock]; // PRUNE: hypothesis slot scored by each thread (changes when lanes are re-packed)
 
-    const unsigned hb = (unsigned)((H + kBlock - 1) / kBlock);
+    const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int h = (int)bx * kBlock + tid;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: says so to the compiler)
+    const int hFirst = hBase + (int)bx * kBlock; // hypothesis of this work-group's slot 0
+    int hEnd = hBase + hCount;
+    int best0 = 0;
+    if (PRUNE) { // replay of the selection over the prefix: best count so far, trip limit (msplit == 1 in this form)
+        if (wv == 0) {
+            int b, l;
+            wave_replay_prefix(counts + (size_t)p * H, hBase < H ? hBase : H, sa, M, b, l);
+            if (lane == 0) {
+                s_pref[0] = b;
+                s_pref[1] = l;
+            }
+        }
+        __syncthreads();
+        // (LDS loads count as divergent for the compiler: readfirstlane keeps the work-group-uniform values in SGPRs and
+        // the branches on them scalar)
+        best0 = __builtin_amdgcn_readfirstlane(s_pref[0]);
+        if (best0 > 0) hEnd = min(hEnd, __builtin_amdgcn_readfirstlane(s_pref[1])); // (without a record the first one may still raise the limit)
+        if (hFirst >= hEnd) return; // never consumed by the selection
+    }
+    int slot = tid;
+    const int h = hFirst + tid;
+    int32_t *__restrict__ cout = counts + (size_t)p * H;
     const size_t rbase = (size_t)p * cap;
     const int m0 = (int)(((long long)M * by) / msplit);
     const int m1 = (int)(((long long)M * (by + 1)) / msplit);
@@ -166,8 +239,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     Rigid mdl, inv;
     set_identity(mdl);
     bool valid = false;
-    if (h < H) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-    if (ma.models && by == 0 && h < H) store_model(ma, (size_t)p * H + h, mdl);
+    if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+    if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
     inverse_rigid_general(mdl, inv);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -176,6 +249,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         s_mdl[9 + i][tid] = mdl.t[i];
     }
     s_cnt[tid] = 0;
+    if (PRUNE) s_slot[tid] = tid;
 
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
@@ -193,8 +267,10 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f &&
                           (!EUCLID || (ec.enabled != 0 && cmax <= 1.0e15f));
     int cnt = 0;
+    // PRUNE: one decision for the work-group (its wavefronts meet at barriers)
+    const bool fastOk = PRUNE ? (__syncthreads_and(boundsOk ? 1 : 0) != 0) : wave_all(boundsOk);
 
-    if (!wave_all(boundsOk)) {
+    if (!fastOk) {
         for (int m = m0; m < m1; ++m) {
             const float4 A = pa[m], B = pb[m], C = pc[m];
             score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
@@ -219,8 +295,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
-                md.t[i] = s_mdl[9 + i][tid];
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][slot];
+                md.t[i] = s_mdl[9 + i][slot];
             }
             // md: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
             // iv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
@@ -258,12 +334,13 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             for (int e = lane; e < qn; e += 64) {
                 const uint32_t ent = s_q[wv][e];
                 const int t = wv * 64 + (int)(ent & 63u), m = (int)(ent >> 6);
+                const int ts = PRUNE ? s_slot[t] : t; // the hypothesis that thread was scoring
                 Rigid md, iv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][t];
-                    md.t[i] = s_mdl[9 + i][t];
+                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][ts];
+                    md.t[i] = s_mdl[9 + i][ts];
                 }
                 inverse_rigid_general(md, iv);
                 const float4 A = pa[m], B = pb[m], C = pc[m];
@@ -274,8 +351,25 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             qn = 0;
         };
 
-        const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
-        for (int m = m0; m < m1; ++m) {
+        unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
+        bool active = h < hEnd;       // PRUNE: this lane still scores a live hypothesis
+        if (PRUNE) {
+            if (active && !valid) {   // an invalid sample scores 0 (RANSAC.cpp:107)
+                cout[h] = 0;
+                active = false;
+            }
+            execAll = __builtin_amdgcn_ballot_w64(active); // only live lanes park evaluations
+        }
+        int liveWaves = kBlock / 64;  // PRUNE: wavefronts that still hold live hypotheses (work-group uniform)
+        unsigned dbgSteps = 0;
+        // PRUNE: the match range in segments of kPruneEvery with a checkpoint between them; the hot loop inside a segment is
+        // the plain one, and everything it keeps in registers per hypothesis is rebuilt after a checkpoint (as after a
+        // drain), so none of it is live across the checkpoint's code
+        const int segLen = PRUNE ? kPruneEvery : (m1 > m0 ? m1 - m0 : 1);
+        for (int seg = m0; seg < m1; seg += segLen) {
+        const int send = seg + segLen < m1 ? seg + segLen : m1;
+        dbgSteps += (unsigned)(send - seg);
+        for (int m = seg; m < send; ++m) {
             v2f_t Z, ss;
             float cxm, cym, czm, pxm, pym, pzm; // the match's current and previous point (wave-uniform)
             if (BIG) {
@@ -326,19 +420,82 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
                 qn += n;
             }
         }
+            // ---- PRUNE checkpoint: abandon what cannot become a record any more, re-pack the rest
+            if (PRUNE && send < m1) {
+                const int left = m1 - send;
+                // count so far: decided evaluations + drained parked ones; the qn evaluations still parked by this wave
+                // bound what this lane may still gain from them
+                const int sofar = cnt + s_cnt[tid];
+                if (active && sofar + qn + left <= best0) {
+                    cout[hFirst + slot] = sofar; // (<= best0: never selected, never a record)
+                    active = false;
+                }
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+                execAll = am;
+                if (lane == 0) s_alive[wv] = __popcll(am);
+                __syncthreads();
+                int total = 0, before = 0;
+#pragma unroll
+                for (int i = 0; i < kBlock / 64; ++i) {
+                    const int n = i < liveWaves ? s_alive[i] : 0; // (wavefronts beyond liveWaves have ended)
+                    if (i < wv) before += n;
+                    total += n;
+                }
+                total = __builtin_amdgcn_readfirstlane(total);
+                before = __builtin_amdgcn_readfirstlane(before);
+                if (total == 0) break; // (work-group uniform)
+                const int need = (total + 63) >> 6;
+                if (need < liveWaves) {
+                    drain();                      // parked evaluations refer to threads: settle them before lanes move
+                    cnt += s_cnt[tid];
+                    s_cnt[tid] = 0;
+                    if (active) s_list[before + __popcll(am & ((1ull << lane) - 1ull))] = ((uint32_t)cnt << 8) | (uint32_t)slot;
+                    __syncthreads();
+                    active = tid < total;
+                    if (active) {
+                        const uint32_t e = s_list[tid];
+                        slot = (int)(e & 255u);
+                        cnt = (int)(e >> 8);
+                        s_slot[tid] = slot;
+                    }
+                    execAll = __builtin_amdgcn_ballot_w64(active);
+                    liveWaves = need;
+                    if (wv >= need) {
+                        // no live hypothesis left in this wavefront: it ends here and frees its registers (S_BARRIER waits
+                        // only for the wavefronts of the group that have not terminated)
+                        if (lane == 0) s_alive[wv] = 0;
+                        if (dbg != nullptr && lane == 0) {
+                            atomicAdd(&dbg[0], parked);
+                            atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
+                            atomicAdd(&dbg[2], (unsigned long long)dbgSteps);
+                            atomicAdd(&dbg[3], (unsigned long long)(m1 - m0));
+                        }
+                        return;
+                    }
+                }
+                __syncthreads(); // s_alive / s_list are reused at the next checkpoint
+                rebuild();
+            }
+        }
         drain();
         cnt += s_cnt[tid];
         if (dbg != nullptr && lane == 0) {
             atomicAdd(&dbg[0], parked);
             atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
+            atomicAdd(&dbg[2], (unsigned long long)dbgSteps); // wave-steps computed / of a complete sweep
+            atomicAdd(&dbg[3], (unsigned long long)(m1 - m0));
+        }
+        if (PRUNE) {
+            if (active) cout[hFirst + slot] = cnt; // (abandoned and invalid hypotheses stored theirs already)
+            return;
         }
     }
-    if (h < H) {
+    if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)
-            counts[(size_t)p * H + h] = cnt;
+            cout[h] = cnt;
         else if (cnt)
-            atomicAdd(&counts[(size_t)p * H + h], cnt);
+            atomicAdd(&cout[h], cnt);
     }
 }
 

@@ -4,6 +4,7 @@ error modes, estimators, thresholds, seeds).  tests/test_gpu_fuzz_slice.py colle
 `-m gpu`; longer soaks are run by hand on the GPU box:
 
     python tests/fuzz_gpu.py --iters 3000 --seed 1
+    python tests/fuzz_gpu.py --iters 100000 --procs 8 --modes 0,2,4 --counts     (round 3: the new scoring kernels)
 """
 import argparse
 import os
@@ -20,8 +21,9 @@ from putslam_amd import api, synth  # noqa: E402
 from putslam_amd._abi import EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config  # noqa: E402
 
 
-def run(iters, seed, max_kpts=1500, ctx=None, verbose=True):
-    """Returns the number of configurations in which the HIP path and the oracle disagree."""
+def run(iters, seed, max_kpts=1500, ctx=None, verbose=True, modes=(0, 1, 2, 4, 3), counts=False):
+    """Returns the number of configurations in which the HIP path and the oracle disagree.  counts=True also compares
+    the inlier count of EVERY hypothesis (ps_debug_ransac_counts vs po_hypothesis_counts), not only the call's outputs."""
     rng = np.random.default_rng(seed)
     ctx = ctx or api.Context(0)
     t0 = time.time()
@@ -31,7 +33,7 @@ def run(iters, seed, max_kpts=1500, ctx=None, verbose=True):
         frac = float(rng.uniform(0.05, 0.95))
         noise = float(10 ** rng.uniform(-4, -1.3))
         pa, pb = synth.make_pair(n, config=7, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)
-        mode = int(rng.choice([0, 1, 2, 4, 3]))
+        mode = int(rng.choice(list(modes)))
         est, H = [(EST_RANSAC, 1157), (EST_USAC, int(rng.integers(50, 3000))), (EST_FIXED, int(rng.integers(1, 3000)))][
             int(rng.integers(0, 3))]
         prm = default_ransac_params(mode, lc=bool(rng.integers(0, 2)))
@@ -50,6 +52,10 @@ def run(iters, seed, max_kpts=1500, ctx=None, verbose=True):
         for f in c["stats"].dtype.names:
             x, y = g["stats"][f], c["stats"][f]
             ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+        if counts:
+            cg = ctx.debug_ransac_counts(prm, cfg, K, pa["pts"], pb["pts"], mc)
+            cc, _ = po.hypothesis_counts(prm, cfg, K, pa["pts"], pb["pts"], mc)
+            ok &= np.array_equal(cg, cc[: len(cg)])
         if not ok:
             bad += 1
             print("MISMATCH", dict(it=it, n=n, frac=frac, noise=noise, mode=mode, est=est, H=H), g["stats"], c["stats"], flush=True)
@@ -63,8 +69,27 @@ def main():
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-kpts", type=int, default=1500)
+    ap.add_argument("--modes", default="0,1,2,4,3", help="RANSAC::ERROR_VERSION values to draw from")
+    ap.add_argument("--counts", action="store_true", help="also compare every hypothesis's inlier count")
+    ap.add_argument("--procs", type=int, default=1, help="worker processes (seeds seed, seed+1, ...), iterations split evenly")
     a = ap.parse_args()
-    bad = run(a.iters, a.seed, a.max_kpts)
+    modes = tuple(int(x) for x in a.modes.split(","))
+    if a.procs > 1:
+        import subprocess
+        per = (a.iters + a.procs - 1) // a.procs
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--iters", str(per), "--seed", str(a.seed + i),
+                                "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else []),
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(a.procs)]
+        rc = 0
+        for i, p in enumerate(ps):
+            out, _ = p.communicate()
+            tail = [l for l in out.splitlines() if l.startswith("fuzz done") or l.startswith("MISMATCH")]
+            print(f"[worker {i}, seed {a.seed + i}] " + " | ".join(tail[-3:]), flush=True)
+            rc |= p.returncode
+        print(f"fuzz done: {per * a.procs} iterations over {a.procs} workers, modes {a.modes}, "
+              f"{'no mismatches' if rc == 0 else 'MISMATCHES'}")
+        return rc
+    bad = run(a.iters, a.seed, a.max_kpts, modes=modes, counts=a.counts)
     print(f"fuzz done: {a.iters} iterations, {bad} mismatches")
     return 1 if bad else 0
 

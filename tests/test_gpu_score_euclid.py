@@ -148,7 +148,9 @@ def test_euclid_coordinate_scale(fctx, ectx, oracle, mode, scale):
     m["trainIdx"] = np.arange(n)
     prm = default_ransac_params(mode)
     cfg, _ = make_config(EST_FIXED, 2048, seed=5)
-    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m)
+    # (errorVersion 2 at 1e4 m: the image offsets exceed the reprojection kernel's 1e7 bound -> its value-exact loop)
+    fast = not (mode == EUCLIDEAN_AND_REPROJECTION_ERROR and scale >= 1e4)
+    _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m, expect_fast=fast)
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -1,0 +1,115 @@
+"""Plumbing check of oracle/ref_recipe (the staged pin of the oracle to a real Eigen / OpenCV / PUTSLAM build).
+
+THIS PINS NOTHING.  The recipe's harnesses cannot be built here (no Eigen, no OpenCV); what can be checked is that a
+maintainer's run will be consumed correctly: make_inputs.py -> the harnesses' binary output format -> collect.py ->
+tests/test_golden_ref.py.  Here the harness outputs are written BY THE ORACLE ITSELF in the documented formats
+(eigen_core_harness.cpp, kabsch_harness.cpp, bfmatcher_harness.cpp, ransac_harness.cpp), collected into a temporary
+golden directory, and test_golden_ref's checks are pointed at it: they must load every field and pass (they compare the
+oracle with itself), so a failure after a real run means a real difference, not a format slip."""
+import importlib
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECIPE = os.path.join(ROOT, "oracle", "ref_recipe")
+
+
+def _colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T).T).tobytes()
+
+
+def test_recipe_roundtrip_through_collect_and_golden_checks(oracle, tmp_path, monkeypatch):
+    from putslam_amd._abi import DMATCH_DTYPE, EST_RANSAC, TUM_FR1_K, default_ransac_params, make_config
+    ref = tmp_path / "_ref"
+    gold = tmp_path / "golden"
+    gold.mkdir()
+    env = dict(os.environ, PUTSLAM_REF_DIR=str(ref), PUTSLAM_GOLD_DIR=str(gold), PUTSLAM_REF_N="300")
+    subprocess.check_call([sys.executable, os.path.join(RECIPE, "make_inputs.py")], env=env, stdout=subprocess.DEVNULL)
+    inp = ref / "inputs"
+
+    # ---- eigen_core.out as eigen_core_harness.cpp writes it
+    with open(inp / "eigen_core.bin", "rb") as f:
+        n, nk, z = struct.unpack("<3i", f.read(12))
+        src = np.frombuffer(f.read(n * 36), np.float32).reshape(n, 3, 3)
+        dst = np.frombuffer(f.read(n * 36), np.float32).reshape(n, 3, 3)
+        mats = np.frombuffer(f.read(n * 36), np.float32).reshape(n, 3, 3)
+        sets = []
+        for _ in range(nk):
+            (k,) = struct.unpack("<i", f.read(4))
+            sets.append((np.frombuffer(f.read(k * 12), np.float32).reshape(k, 3),
+                         np.frombuffer(f.read(k * 12), np.float32).reshape(k, 3)))
+    with open(ref / "eigen_core.out", "wb") as o:
+        o.write(struct.pack("<3i", n, nk, z))
+        for i in range(n):
+            T, ok = oracle.umeyama_f32(src[i], dst[i])
+            if not ok:
+                T = np.full((4, 4), np.nan, np.float32)          # the reference's invalid model: NaN at (0, 0)
+            Ti = oracle.inverse4_f32(T)
+            e = (T[:3, :3] @ src[i][0] + T[:3, 3]).astype(np.float32)
+            o.write(_colmajor16(T)); o.write(_colmajor16(Ti)); o.write(e.tobytes())
+        for i in range(n):
+            U, S, V = oracle.jacobi_svd3(mats[i])
+            o.write(np.ascontiguousarray(U, np.float32).tobytes()); o.write(np.asarray(S, np.float32).tobytes())
+            o.write(np.ascontiguousarray(V, np.float32).tobytes())
+        for s_, d_ in sets:
+            T, ok = oracle.umeyama_f32(s_, d_)
+            o.write(struct.pack("<i", len(s_))); o.write(_colmajor16(T))
+
+    # ---- kabsch.out as kabsch_harness.cpp writes it
+    with open(inp / "kabsch.bin", "rb") as f, open(ref / "kabsch.out", "wb") as o:
+        (cases,) = struct.unpack("<i", f.read(4))
+        o.write(struct.pack("<i", cases))
+        for _ in range(cases):
+            (m,) = struct.unpack("<i", f.read(4))
+            A = np.frombuffer(f.read(m * 24), np.float64).reshape(3, m).T
+            B = np.frombuffer(f.read(m * 24), np.float64).reshape(3, m).T
+            T = oracle.kabsch_f64(A, B)
+            o.write(struct.pack("<i", m)); o.write(np.ascontiguousarray(np.asarray(T, np.float64).T).tobytes())
+
+    # ---- bfmatcher.out / ransac.out as the two OpenCV harnesses write them
+    pairs = []
+    with open(inp / "pairs.bin", "rb") as f:
+        (cases,) = struct.unpack("<i", f.read(4))
+        for _ in range(cases):
+            (nk_,) = struct.unpack("<i", f.read(4))
+            pairs.append((nk_, np.frombuffer(f.read(nk_ * 32), np.uint8).reshape(nk_, 32),
+                          np.frombuffer(f.read(nk_ * 32), np.uint8).reshape(nk_, 32),
+                          np.frombuffer(f.read(nk_ * 12), np.float32).reshape(nk_, 3),
+                          np.frombuffer(f.read(nk_ * 12), np.float32).reshape(nk_, 3)))
+    with open(ref / "bfmatcher.out", "wb") as o, open(ref / "ransac.out", "wb") as r:
+        o.write(struct.pack("<i", len(pairs)))
+        r.write(struct.pack("<i", len(pairs)))
+        for c, (nk_, d0, d1, p0, p1) in enumerate(pairs):
+            m = oracle.match_hamming256(d0, d1)
+            o.write(struct.pack("<i", len(m))); o.write(np.ascontiguousarray(m, DMATCH_DTYPE).tobytes())
+            for mode in range(2):
+                prm = default_ransac_params(mode)
+                cfg, _ = make_config(EST_RANSAC, 487, seed=1000 + 10 * c + mode)
+                res = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, p0, p1, m)
+                nit = int(res["stats"]["iterationsRun"])
+                M = int(res["stats"]["numMatchesValid"])
+                used = np.array([oracle.sample_triplet(cfg, h, M) for h in range(nit)], np.int32).reshape(-1, 3) if M >= 3 \
+                    else np.zeros((0, 3), np.int32)
+                inl = m[res["mask"].astype(bool)]
+                r.write(struct.pack("<5i", nk_, mode, len(m), len(inl), len(used)))
+                r.write(_colmajor16(res["pose"]))
+                r.write(np.stack([inl["queryIdx"], inl["trainIdx"]], 1).astype(np.int32).tobytes())
+                r.write(used.tobytes())
+
+    subprocess.check_call([sys.executable, os.path.join(RECIPE, "collect.py")], env=env, stdout=subprocess.DEVNULL)
+    assert sorted(os.listdir(gold)) == ["ref_bfmatcher.npz", "ref_eigen_core.npz", "ref_kabsch.npz", "ref_ransac.npz"]
+
+    # ---- the real consumers, pointed at the temporary golden directory
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    tgr = importlib.import_module("test_golden_ref")
+    monkeypatch.setattr(tgr, "GOLD", str(gold))
+    tgr.test_ref_eigen_core(oracle)
+    tgr.test_ref_kabsch(oracle)
+    tgr.test_ref_bfmatcher(oracle)
+    tgr.test_ref_ransac(oracle)
+    # nothing was written into the repository's own golden directory
+    assert not [f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.startswith("ref_")]
