@@ -129,10 +129,11 @@ int ps_context_synchronize(PsContext *ctx);
  *              run the "1" kernels;
  *              0 = value-exact ps_ransac_score<M> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
  *              Per-hypothesis counts are identical between 0 and 1 by proof + tests, between 0 and 2 by tests.
- *   "prune":   1 (default) = large batches score the first 256 hypotheses of every pair completely, then abandon every
- *              later hypothesis as soon as it cannot become a record of the sequential selection any more (count so far +
- *              matches left <= best count of the earlier ones, RANSAC.cpp:438-455) and never start hypotheses beyond
- *              the adaptive trip limit (RANSAC.cpp:450-453); all outputs are unchanged, only the scratch counts of
+ *   "prune":   1 (default) = staged scoring of large batches: the first 256 hypotheses of every pair are scored
+ *              completely, the later ones in three stages over growing match ranges; between the stages every
+ *              hypothesis that cannot become a record of the sequential selection any more (count so far + matches left
+ *              <= best count of the earlier ones, RANSAC.cpp:438-455) is abandoned, and hypotheses beyond the adaptive
+ *              trip limit (RANSAC.cpp:450-453) are never started; all outputs are unchanged, only the scratch counts of
  *              abandoned hypotheses are lower bounds.  0 = every hypothesis is scored completely
  *              (PUTSLAM_HIP_PRUNE=0|1).  The diagnostic ps_debug_ransac_counts always scores completely.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
@@ -296,9 +297,8 @@ int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, u
 /* After a scoring launch with option "score_stats" = 1: evaluations the fast kernel parked for the value-exact
  * code, and (hypothesis, match) evaluations it made in all (lanes of partially filled wavefronts included). */
 int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations);
-/* All eight counters of the last scoring launch: [0] parked, [1] evaluations of a complete sweep, [2] 64-match
- * wave-blocks actually computed, [3] wave-blocks of a complete sweep ([2] / [3] = the share of the sweep the pruned
- * launch still did), [4] lane re-packings; [5..7] reserved (0). */
+/* All eight counters of the last scoring step: [0] parked, [1] evaluations made (with the staged scoring: what is left of
+ * the complete sweep of H hypotheses x M matches); [2..7] reserved (0). */
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
 size_t ps_abi_sizeof_dmatch(void);

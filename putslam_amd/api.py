@@ -70,8 +70,7 @@ class Context:
         return int(a.value), int(b.value)
 
     def score_stats_ex(self):
-        """All eight counters of the last scoring launch (ps_debug_score_stats_ex): parked, evaluations, wave-blocks
-        computed, wave-blocks of a complete sweep, re-packings, reserved x 3."""
+        """All eight counters of the last scoring step (ps_debug_score_stats_ex): parked, evaluations made, reserved x 6."""
         out = (C.c_uint64 * 8)()
         self._chk(self._L.ps_debug_score_stats_ex(self._h, out))
         return [int(v) for v in out]

@@ -43,7 +43,9 @@ struct PsContext {
     char arch[64] = {0};
     // scratch arena (device)
     Buf keys, recA, recB, recC, recD, recE, recF, recH, recS, counts, mvalid, cmax, idxList, raw;
-    Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches only)
+    Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
+                // of the staged scoring (large batches)
+    Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
@@ -309,7 +311,7 @@ struct Plan {
     SelectArgs sa{};
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
-    bool prune = false; // two launches: hypotheses [0, kPrefix) completely (msplit applies to it), the rest pruned
+    bool prune = false; // staged scoring: hypotheses [0, kPrefix) completely (msplit applies to it), the rest in pruned stages
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -486,17 +488,26 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     const bool prunable = with_euclid_fast(ctx, pl.mode) ||
                           (pl.mode == PS_REPROJECTION_ERROR && ctx->scoreFast == 1) ||
                           (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR && ctx->scoreFast != 0);
-    pl.prune = ctx->prune != 0 && prunable && H > kPrefix && (long long)P * (hb - 1) >= 256;
+    // (the later stages read the models back from HBM, 48 B per hypothesis: ps_score_fast.h)
+    const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
+    pl.prune = ctx->prune != 0 && prunable && H > kPrefix && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
     pl.pa.zeroCounts = pl.msplit > 1 ? (int32_t *)ctx->counts.p : nullptr;
     pl.pa.zeroH = pl.prune ? kPrefix : H;
     pl.pa.zeroStride = H;
     pl.ma.models = nullptr;
-    const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
-    if (P <= kWidePairs && mbytes <= ((size_t)64 << 20)) {
+    if ((P <= kWidePairs && mbytes <= ((size_t)64 << 20)) || pl.prune) {
         PS_ENSURE(ctx->models, mbytes);
         pl.ma.models = (float *)ctx->models.p;
+    }
+    pl.pa.zeroSurvA = pl.pa.zeroSurvB = nullptr;
+    if (pl.prune) {
+        PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
+        PS_ENSURE(ctx->survB, (size_t)P * H * sizeof(int32_t));
+        PS_ENSURE(ctx->survN, (size_t)2 * P * sizeof(int32_t));
+        pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
+        pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
     }
     return PS_OK;
 }
@@ -519,21 +530,33 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
         dbgE = (unsigned long long *)ctx->dbgCnt.p;
     }
-    // (PRUNE launches: hypotheses [kPrefix, H) after a launch that scored [0, kPrefix) completely; ps_score_euclid.h)
-#define PS_LAUNCH_EUCLID_RANGE(MODE, PRUNE, HBASE, HCOUNT, MSPLIT)                                                     \
-    hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, PRUNE>),                                                          \
+    // Staged scoring (ps_score_fast.h): stage 0 = the prefix completely, stages 1 .. 3 = the rest with hypotheses abandoned
+    // between the launches.  stage_args(i) describes launch i.
+    auto stage_args = [&](int stage) {
+        StageArgs st{};
+        st.stage = stage;
+        st.hBase = stage == 0 ? 0 : kPrefix;
+        st.hCount = stage == 0 ? kPrefix : pl.H - kPrefix;
+        int32_t *nA = (int32_t *)ctx->survN.p, *nB = nA + P;
+        if (stage == 1) { st.listOut = (int32_t *)ctx->survA.p; st.countOut = nA; }
+        if (stage == 2) { st.listIn = (const int32_t *)ctx->survA.p; st.countIn = nA; st.listOut = (int32_t *)ctx->survB.p; st.countOut = nB; }
+        if (stage == 3) { st.listIn = (const int32_t *)ctx->survB.p; st.countIn = nB; }
+        return st;
+    };
+    const StageArgs stNone{};
+#define PS_LAUNCH_EUCLID_ONE(MODE, STAGED, ST, HCOUNT, MSPLIT)                                                         \
+    hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, STAGED>),                                                         \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
                        (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,       \
-                       pl.ma, pl.sc, pl.ec, pl.sa, (HBASE), (HCOUNT), pl.H, cap, pl.minRun, (MSPLIT),                  \
-                       (int32_t *)ctx->counts.p, dbgE)
+                       pl.ma, pl.sc, pl.ec, pl.sa, (ST), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbgE)
 #define PS_LAUNCH_EUCLID(MODE)                                                                                         \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
-            PS_LAUNCH_EUCLID_RANGE(MODE, false, 0, kPrefix, msplit);                                                   \
-            PS_LAUNCH_EUCLID_RANGE(MODE, true, kPrefix, pl.H - kPrefix, 1);                                            \
+            PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(0), kPrefix, msplit);                                          \
+            for (int sg = 1; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(sg), pl.H - kPrefix, 1); \
         } else                                                                                                         \
-            PS_LAUNCH_EUCLID_RANGE(MODE, false, 0, pl.H, msplit);                                                      \
+            PS_LAUNCH_EUCLID_ONE(MODE, false, stNone, pl.H, msplit);                                                   \
     } while (0)
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR:
@@ -563,26 +586,27 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             // more work-groups than fit at once (256 CUs x 6): the build for big launches (ps_score_fast.h)
-#define PS_LAUNCH_FAST_RANGE(MODE, BIG, PRUNE, HBASE, HCOUNT, MSPLIT)                                                  \
-    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, PRUNE>),                                                       \
+#define PS_LAUNCH_FAST_ONE(MODE, BIG, STAGED, ST, HCOUNT, MSPLIT)                                                      \
+    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, STAGED>),                                                      \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
                        (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p,          \
                        (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.sa, \
-                       (HBASE), (HCOUNT), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbg)
-    // more work-groups than fit at once: the build for big launches (ps_score_fast.h); pruned: prefix, then the rest
+                       (ST), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbg)
+    // more work-groups than fit at once: the build for big launches (ps_score_fast.h); staged: prefix, then the stages
 #define PS_LAUNCH_FAST(MODE, BIGLIMIT)                                                                                 \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
             if ((unsigned)msplit * (unsigned)P > (BIGLIMIT))                                                           \
-                PS_LAUNCH_FAST_RANGE(MODE, true, false, 0, kPrefix, msplit);                                           \
+                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(0), kPrefix, msplit);                                  \
             else                                                                                                       \
-                PS_LAUNCH_FAST_RANGE(MODE, false, false, 0, kPrefix, msplit);                                          \
-            PS_LAUNCH_FAST_RANGE(MODE, true, true, kPrefix, pl.H - kPrefix, 1);                                        \
+                PS_LAUNCH_FAST_ONE(MODE, false, true, stage_args(0), kPrefix, msplit);                                 \
+            for (int sg = 1; sg <= kStages; ++sg)                                                                      \
+                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(sg), pl.H - kPrefix, 1);                               \
         } else if (grid.x > (BIGLIMIT))                                                                                \
-            PS_LAUNCH_FAST_RANGE(MODE, true, false, 0, pl.H, msplit);                                                  \
+            PS_LAUNCH_FAST_ONE(MODE, true, false, stNone, pl.H, msplit);                                               \
         else                                                                                                           \
-            PS_LAUNCH_FAST_RANGE(MODE, false, false, 0, pl.H, msplit);                                                 \
+            PS_LAUNCH_FAST_ONE(MODE, false, false, stNone, pl.H, msplit);                                              \
     } while (0)
             PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, 1536u);
         } else
@@ -609,9 +633,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
     }
 #undef PS_LAUNCH_EUCLID
-#undef PS_LAUNCH_EUCLID_RANGE
+#undef PS_LAUNCH_EUCLID_ONE
 #undef PS_LAUNCH_FAST
-#undef PS_LAUNCH_FAST_RANGE
+#undef PS_LAUNCH_FAST_ONE
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     SelectArgs sa = pl.sa;
@@ -803,7 +827,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -1170,9 +1194,9 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
     return PS_OK;
 }
 
-// Diagnostic: all eight counters of the last scoring launch (option "score_stats"): [0] evaluations handed to the
-// value-exact code, [1] evaluations of a complete sweep, [2] 64-match wave-blocks computed, [3] wave-blocks of a complete
-// sweep, [4] lane re-packings of the pruned launch; the rest reserved.
+// Diagnostic: all eight counters of the last scoring step (option "score_stats"): [0] evaluations handed to the
+// value-exact code, [1] (hypothesis, match) evaluations made (lanes of partially filled wavefronts included; with the
+// staged scoring this is what is left of the complete sweep); the rest reserved.
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8)
 {
     int rc = bind(ctx);

@@ -171,6 +171,7 @@ struct PrepArgs {
     int32_t *zeroCounts;    // optional: the first zeroH counts of every pair (row stride zeroStride) to clear for kernel 3's
     int zeroH;              // split-range atomics (saves a memset launch)
     int zeroStride;
+    int32_t *zeroSurvA, *zeroSurvB; // optional: per-pair survivor counters of the staged scoring to clear (ps_score_fast.h)
 };
 
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
@@ -404,6 +405,10 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
     if (threadIdx.x == 0) {
         numMatches[p] = base;
         if (WITH_RECORDS) mvalid[p] = vbase;
+        if (WITH_RECORDS && a.zeroSurvA) {
+            a.zeroSurvA[p] = 0;
+            a.zeroSurvB[p] = 0;
+        }
     }
 }
 

@@ -82,89 +82,71 @@ template <int MODE> PS_D EuclidRec<MODE> load_euclid_rec(const float2 *__restric
     return r;
 }
 
-// ------------------------------------------------------------------------------------------
-// Pruned scoring (PRUNE = true): hypotheses that provably cannot matter are abandoned.
-//
-// The selection of kernel 4 consumes the counts sequentially: hypothesis i matters only if its count is a RECORD,
-// count_i > max_{j<i} count_j (strict '>' first-best, RANSAC.cpp:438-455; the arg-max of the fixed schedule takes the
-// lowest index among equals, the same rule), and only while i is below the adaptive trip limit, which never grows
-// (RANSAC.cpp:450-453, USAC.h:944-971).  So the step is scored in two launches:
-//   launch A (PRUNE = false)  the first kPrefix = 256 hypotheses of every pair, completely;
-//   launch B (PRUNE = true)   the hypotheses from kPrefix on.  Every work-group first replays the selection over the
-//       prefix (wave_replay_prefix: the same record walk as ps_select_refit) and gets  B0 = the best count so far and
-//       L0 = the trip limit after the prefix (valid as a bound once the prefix holds a record: from record to record
-//       the limit only shrinks).  Hypotheses >= L0 are never consumed: their work-groups return at once
-//       (with the reference's own <= 487-iteration schedule that is nearly every pair: the limit after 256 hypotheses is
-//       typically 2 ... 30).  A hypothesis below L0 is abandoned as soon as  count so far + matches left <= B0 : it can
-//       no longer become a record; its partial count (<= B0, hence never selected, never a record) is what it stores.
-//   Lanes are re-packed: every two 64-match blocks the work-group counts its live hypotheses and, when they fit into
-//   fewer wavefronts, compacts them (slot + count through LDS, the model re-read from the LDS copy), so that whole
-//   wavefronts retire.  With 75 ... 90 % inliers a bad sample is abandoned after 10 ... 25 % of the matches and a good one
-//   that is not better than the prefix's best after 50 ... 70 %.
-// Outputs of kernel 4 are unchanged bit for bit (tests/test_gpu_prune.py: pruned vs unpruned vs oracle); what changes is
-// the meaning of counts[] for abandoned hypotheses (a lower bound <= B0 instead of the count), which is why the
-// diagnostic ps_debug_ransac_counts and small batches run unpruned.
-// ------------------------------------------------------------------------------------------
-template <int MODE, bool PRUNE>
+// STAGED: a launch of the staged scoring (ps_score_fast.h, "Staged scoring"); the plain form scores every hypothesis of
+// [0, H) completely.
+template <int MODE, bool STAGED = false>
 __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_euclid(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
     const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
-    EuclidConsts ec, SelectArgs sa, int hBase, int hCount, int H, int cap, int minRun, int msplit,
-    int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
+    EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
+    unsigned long long *__restrict__ dbg)
 {
-    // This launch scores hypotheses [hBase, hBase + hCount) of every pair; counts[] has H entries per pair.
     static_assert(MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR, "the Euclidean metrics");
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? kEuclidRecFloats4 : kEuclidRecFloats0;
     __shared__ float s_mdl[12][kBlock];
     __shared__ int s_pref[2];
-    __shared__ int s_alive[kBlock / 64];
-    __shared__ uint32_t s_list[kBlock];
 
+    // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
+    const int hCount = STAGED ? st.hCount : H;
     const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: says so to the compiler)
-    const int hFirst = hBase + (int)bx * kBlock; // hypothesis of this work-group's slot 0
-    int hEnd = hBase + hCount;                   // hypotheses of this launch end here ...
-    int best0 = 0;
-    if (PRUNE) { // ... or at the trip limit the prefix leaves (msplit == 1 in this form)
-        if (wv == 0) {
-            int b, l;
-            wave_replay_prefix(counts + (size_t)p * H, hBase < H ? hBase : H, sa, M, b, l);
-            if (lane == 0) {
-                s_pref[0] = b;
-                s_pref[1] = l;
-            }
-        }
-        __syncthreads();
-        // (LDS loads count as divergent for the compiler: readfirstlane keeps the work-group-uniform values in SGPRs and
-        // the branches on them scalar)
-        best0 = __builtin_amdgcn_readfirstlane(s_pref[0]);
-        // the limit only shrinks from record to record, but the FIRST record may raise it above its initial value
-        // (RANSAC.cpp:30 starts from computeRANSACIteration(0.20); a first ratio below 0.2 gives more): without a record
-        // in the prefix nothing can be cut
-        if (best0 > 0) hEnd = min(hEnd, __builtin_amdgcn_readfirstlane(s_pref[1]));
-        if (hFirst >= hEnd) return; // never consumed by the selection
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t rbase = (size_t)p * cap;
+    int32_t *__restrict__ cout = counts + (size_t)p * H;
+    int h = (STAGED ? st.hBase : 0) + (int)bx * kBlock + tid;
+    int hEnd = STAGED ? st.hBase + st.hCount : H; // this lane scores hypothesis h if h < hEnd
     // the match range is split on match PAIRS (the packed loop takes two matches per step)
     const int npair = (M + 1) >> 1;
-    const int m0 = 2 * (int)(((long long)npair * by) / msplit);
+    int m0 = 2 * (int)(((long long)npair * by) / msplit);
     int m1 = 2 * (int)(((long long)npair * (by + 1)) / msplit);
     m1 = m1 < M ? m1 : M;
+    int best0 = 0, cnt0 = 0;
+    const bool pruned = STAGED && st.stage >= 1;
+    if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
+        int hLimit;
+        stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);
+        stage_range(st.stage, M, best0, m0, m1);
+        if (m0 >= m1) return; // an earlier stage finished the pair's matches
+        if (st.stage == 1) {
+            hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
+            if (st.hBase + (int)bx * kBlock >= hEnd) return;
+        } else {
+            const int n = st.countIn[p];
+            const int i = (int)bx * kBlock + tid;
+            if ((int)bx * kBlock >= n) return;
+            hEnd = 0x7FFFFFFF;
+            h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
+            if (i < n) cnt0 = cout[h]; // count so far
+        }
+    }
 
-    int slot = tid; // which of the work-group's 256 hypotheses this lane is scoring (changes when lanes are re-packed)
-    const int h = hFirst + tid;
     Rigid mdl, inv;
     set_identity(mdl);
     set_identity(inv);
     bool valid = false;
-    if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-    if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
+    if (pruned && st.stage >= 2) {
+        if (h < hEnd) {
+            load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
+            valid = true;
+        }
+    } else {
+        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -176,7 +158,6 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     const float4 *__restrict__ pb = recB + rbase;
     const float2 *__restrict__ pg = recG + (size_t)p * ((size_t)((cap + 1) >> 1) * (RF / 2));
     const float cmax = pairBound[p].x;
-    int32_t *__restrict__ cout = counts + (size_t)p * H;
 
     float rho = 0.0f, tau = 0.0f;
     model_norms(mdl, rho, tau);
@@ -184,71 +165,34 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     // (comparisons are false for NaN: a non-finite model or cmax sends the wavefront to the value-exact loop)
     const bool boundsOk = ec.enabled != 0 && S >= 1.0e-20f && S <= 1.0e15f && cmax <= 1.0e15f;
     int cnt = 0;
-    // PRUNE: one decision for the work-group (its wavefronts meet at barriers)
-    const bool fastOk = PRUNE ? (__syncthreads_and(boundsOk ? 1 : 0) != 0) : wave_all(boundsOk);
 
-    if (!fastOk) {
+    if (!wave_all(boundsOk)) {
         for (int m = m0; m < m1; ++m) {
             const float4 A = pa[m], B = pb[m];
             score_accumulate<MODE, false>(mdl, inv, k, A, B, A, cnt);
         }
-        if (h < hEnd) {
-            if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
-            if (msplit == 1)
-                cout[h] = cnt;
-            else if (cnt)
-                atomicAdd(&cout[h], cnt);
-        }
-        return;
-    }
-
-    // ---- per-lane registers of the hot loop, (re)built from a model: the limits lo / hi of the squared residual (see
-    // the header: a = 12.5 u S for errorVersion 0, 10.001 * 17.5 u (S + cmax) for errorVersion 4, both with 1 % slack
-    // for their own float roundings), the indicator's c and K, and the model splat over both halves
-    v2f_t negc, kk, r00, r01, r02, t0, r10, r11, r12, t1, r20, r21, r22, t2;
-    auto build = [&](const Rigid &md) {
-        float rh = 0.0f, ta = 0.0f;
-        model_norms(md, rh, ta);
-        const float Sl = (rh * cmax + ta) * 1.001f;
-        const float a = MODE == PS_ADAPTIVE_ERROR ? (Sl + cmax) * (177.0f * kEpsU) : Sl * (12.7f * kEpsU);
+    } else {
+        // per-lane limits (see the header): a = 12.5 u S (errorVersion 0) or 10.001 * 17.5 u (S + cmax) (errorVersion 4),
+        // both with 1 % slack for their own float roundings
+        const float a = MODE == PS_ADAPTIVE_ERROR ? (S + cmax) * (177.0f * kEpsU) : S * (12.7f * kEpsU);
         const float x = ec.tbLo - a;
         const float lo = x > 0.0f ? (x * x) * (1.0f - 8.0f * kEpsU) : -1.0f;
         const float y = ec.tbHi + a * (1.0f + 4.0f * kEpsU);
         const float hi = (y * y) * (1.0f + 8.0f * kEpsU);
-        // indicator  ind = clamp01(K - c s~):  exactly 0 only for s~ >= hi, exactly 1 only for s~ <= lo
+        // indicator  ind = clamp01(K - c s~):  exactly 0 for s~ >= hi, exactly 1 for s~ <= lo, fractional in between
+        // (see "decision without compares" in the header); c, K rounded to the safe sides
         const float den = __builtin_fmaf(hi, 4.76837158203125e-07f /* 2^-21 */, hi) - lo;
         const float cInd = 0.98f / den;
         const float kInd = (cInd * hi) * (1.0f + 2.384185791015625e-07f /* 2^-22 */);
-        negc = splat(-cInd);
-        kk = splat(kInd);
-        r00 = splat(md.R[0][0]); r01 = splat(md.R[0][1]); r02 = splat(md.R[0][2]); t0 = splat(md.t[0]);
-        r10 = splat(md.R[1][0]); r11 = splat(md.R[1][1]); r12 = splat(md.R[1][2]); t1 = splat(md.t[1]);
-        r20 = splat(md.R[2][0]); r21 = splat(md.R[2][1]); r22 = splat(md.R[2][2]); t2 = splat(md.t[2]);
-    };
-    auto model_of_slot = [&](int sl, Rigid &md) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][sl];
-            md.t[i] = s_mdl[9 + i][sl];
-        }
-    };
-    build(mdl);
-    unsigned long long parked = 0;
-    unsigned dbgBlocks = 0, dbgRepack = 0; // (statistics: 64-match blocks this wave computed, re-packings)
-    const int m1e = m1 & ~1;              // whole pairs; an odd last match is scored by the value-exact code below
-    const int tailMatches = m1 - m1e;     // 0 or 1
-    bool active = h < hEnd;               // PRUNE: this lane still scores a live hypothesis
-    if (PRUNE && active && !valid) {      // an invalid sample scores 0 (RANSAC.cpp:107): nothing to do for it
-        cout[h] = 0;
-        active = false;
-    }
-    int liveWaves = kBlock / 64;          // PRUNE: wavefronts that still hold live hypotheses (work-group uniform)
+        const v2f_t negc = splat(-cInd), kk = splat(kInd);
+        const v2f_t r00 = splat(mdl.R[0][0]), r01 = splat(mdl.R[0][1]), r02 = splat(mdl.R[0][2]), t0 = splat(mdl.t[0]);
+        const v2f_t r10 = splat(mdl.R[1][0]), r11 = splat(mdl.R[1][1]), r12 = splat(mdl.R[1][2]), t1 = splat(mdl.t[1]);
+        const v2f_t r20 = splat(mdl.R[2][0]), r21 = splat(mdl.R[2][1]), r22 = splat(mdl.R[2][2]), t2 = splat(mdl.t[2]);
+        unsigned long long parked = 0;
+        const int m1e = m1 & ~1; // whole pairs; an odd last match is scored by the value-exact code below
 
-    for (int blk = m0; blk < m1e; blk += kEuclidBlock) {
-        const int bend = blk + kEuclidBlock < m1e ? blk + kEuclidBlock : m1e;
-        if (!PRUNE || wv < liveWaves) {
-            ++dbgBlocks;
+        for (int blk = m0; blk < m1e; blk += kEuclidBlock) {
+            const int bend = blk + kEuclidBlock < m1e ? blk + kEuclidBlock : m1e;
             v2f_t acc = {0.0f, 0.0f}; // inliers of this block (even / odd matches)
             uint32_t frac = 0u;       // != 0 as soon as one indicator of the block was neither 0 nor 1
             const float2 *__restrict__ g = pg + (size_t)(blk >> 1) * (RF / 2);
@@ -287,15 +231,20 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             if (m < bend) step(load_euclid_rec<MODE>(g));
             // block epilogue: lanes whose indicators were all 0 / 1 take the sum; the others are recounted value-exactly,
             // the wave's 64 lanes taking the block's (at most) 64 matches of one such hypothesis at a time
-            const bool clean = frac == 0u || (PRUNE && !active);
+            const bool clean = frac == 0u;
             if (clean) cnt += (int)(acc.x + acc.y);
             unsigned long long todo = __builtin_amdgcn_ballot_w64(!clean);
             while (todo != 0ull) {
                 const int l = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const int t = PRUNE ? __builtin_amdgcn_readlane(slot, l) : wv * 64 + l;
+                const int t = wv * 64 + l;
                 Rigid md;
-                model_of_slot(t, md);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][t];
+                    md.t[i] = s_mdl[9 + i][t];
+                }
                 const int mm = blk + lane;
                 bool in = false;
                 if (mm < bend) {
@@ -307,74 +256,24 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
                 parked += (unsigned long long)(bend - blk);
             }
         }
-        // ---- PRUNE checkpoint every second block: abandon what cannot become a record any more, re-pack the rest
-        if (PRUNE && (((blk - m0) / kEuclidBlock) & 1) == 1 && bend < m1e) {
-            const int left = (m1e - bend) + tailMatches;
-            if (active && cnt + left <= best0) { // count_i <= best of the earlier hypotheses whatever the rest brings
-                cout[hFirst + slot] = cnt;
-                active = false;
-            }
-            const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
-            if (lane == 0) s_alive[wv] = __popcll(am);
-            __syncthreads();
-            int total = 0, before = 0;
-#pragma unroll
-            for (int i = 0; i < kBlock / 64; ++i) {
-                const int n = i < liveWaves ? s_alive[i] : 0; // (wavefronts beyond liveWaves have ended)
-                if (i < wv) before += n;
-                total += n;
-            }
-            total = __builtin_amdgcn_readfirstlane(total);
-            before = __builtin_amdgcn_readfirstlane(before);
-            if (total == 0) break; // (work-group uniform)
-            const int need = (total + 63) >> 6;
-            if (need < liveWaves) {
-                if (active) s_list[before + __popcll(am & ((1ull << lane) - 1ull))] = ((uint32_t)cnt << 8) | (uint32_t)slot;
-                __syncthreads();
-                active = tid < total;
-                if (active) {
-                    const uint32_t e = s_list[tid];
-                    slot = (int)(e & 255u);
-                    cnt = (int)(e >> 8);
-                    Rigid md;
-                    model_of_slot(slot, md);
-                    build(md);
-                }
-                liveWaves = need;
-                ++dbgRepack;
-                if (wv >= need) {
-                    // this wavefront holds no live hypothesis any more: it ends here and frees its registers for other
-                    // work-groups (S_BARRIER waits only for the wavefronts of the group that have not terminated)
-                    if (lane == 0) s_alive[wv] = 0;
-                    if (dbg != nullptr && lane == 0) {
-                        atomicAdd(&dbg[0], parked);
-                        atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
-                        atomicAdd(&dbg[2], (unsigned long long)dbgBlocks);
-                        atomicAdd(&dbg[3], (unsigned long long)((m1e - m0 + kEuclidBlock - 1) / kEuclidBlock));
-                    }
-                    return;
-                }
-            }
-            __syncthreads(); // s_alive / s_list are reused at the next checkpoint
+        if (m1e < m1) { // odd last match of the range
+            const float4 A = pa[m1e], B = pb[m1e];
+            score_accumulate<MODE, false>(mdl, inv, k, A, B, A, cnt);
+        }
+        if (dbg != nullptr && lane == 0) {
+            atomicAdd(&dbg[0], parked);
+            atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
         }
     }
-    if (m1e < m1 && (!PRUNE || active)) { // odd last match of the range
-        Rigid md;
-        model_of_slot(slot, md);
-        const float4 A = pa[m1e], B = pb[m1e];
-        score_accumulate<MODE, false>(md, md, k, A, B, A, cnt);
+    if (pruned) {
+        const bool mine = h < hEnd;
+        const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
+        if (mine) cout[h] = total;
+        // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
+        if (st.stage < kStages && m1 < M) stage_append(mine && valid && total + (M - m1) > best0, h, st.listOut, st.countOut, p, H);
+        return;
     }
-    if (dbg != nullptr && lane == 0) {
-        atomicAdd(&dbg[0], parked);
-        atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
-        // wave-blocks computed / wave-blocks of an unpruned sweep / re-packings (ps_debug_score_stats_ex)
-        atomicAdd(&dbg[2], (unsigned long long)dbgBlocks);
-        atomicAdd(&dbg[3], (unsigned long long)((m1e - m0 + kEuclidBlock - 1) / kEuclidBlock));
-        if (wv == 0) atomicAdd(&dbg[4], (unsigned long long)dbgRepack);
-    }
-    if (PRUNE) {
-        if (active) cout[hFirst + slot] = cnt; // (invalid samples were stored as 0 above)
-    } else if (h < hEnd) {
+    if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)
             cout[h] = cnt;

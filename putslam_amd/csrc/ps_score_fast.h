@@ -126,10 +126,44 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 }
 
 
-// ---- pruned scoring, shared by ps_ransac_score_fast<.., PRUNE = true> and ps_ransac_score_euclid<.., true>
-// (description: ps_score_euclid.h, "Pruned scoring") ----
-constexpr int kPrefix = kBlock;   // hypotheses scored completely by launch A
-constexpr int kPruneEvery = 128;  // matches between two checks
+// ------------------------------------------------------------------------------------------
+// Staged scoring: hypotheses that provably cannot matter are abandoned between launches.
+//
+// The selection of kernel 4 consumes the counts sequentially: hypothesis i matters only if its count is a RECORD,
+// count_i > max_{j<i} count_j (strict '>' first-best, RANSAC.cpp:438-455; the arg-max of the fixed schedule takes the
+// lowest index among equals, the same rule), and only while i is below the adaptive trip limit, which from record to
+// record only shrinks (RANSAC.cpp:450-453, USAC.h:944-971).  So a large batch is scored in stages:
+//   stage 0   the first kPrefix = 256 hypotheses of every pair, all matches (the plain launch);
+//   stage 1   every later hypothesis below the trip limit L0 the prefix leaves, matches [0, c1);
+//   stage 2   the SURVIVORS of stage 1, matches [c1, c2);        stage 3   the survivors of stage 2, matches [c2, M).
+// Every work-group of stages 1-3 first replays the selection over the prefix (wave_replay_prefix: the record walk of
+// ps_select_refit) and gets B0 = the best count so far and L0.  After its match range a hypothesis survives if
+// count so far + matches left > B0; otherwise it can no longer become a record and keeps its partial count
+// (<= B0: never selected, never a record).  Survivors are appended (one atomic per wavefront) to the next stage's
+// per-pair list, which the next launch reads back densely: 256 live hypotheses per work-group again, full wavefronts,
+// no barrier and no re-packing inside the hot loops -- they are the plain loops.  The models travel through HBM
+// (ma.models, 48 B per hypothesis), the partial counts through counts[].
+//   c1 = about 1.15 (M - B0) + 32 matches: where a hypothesis without inliers has run out of chances (with 75 % inliers
+//   a bad sample is abandoned after a quarter of the matches); c2 halves the rest.  With the reference's own <= 487-iteration
+//   schedule L0 is typically 2 ... 30, far below the prefix: stages 1-3 return at once.
+// An in-kernel form (checkpoints + re-packing of live lanes through LDS inside one launch) was built first and kept
+// the wave-steps it saved (29 %) from showing up as time: barriers, rebuilds and 300 bytes of scratch per lane made the
+// loop 20 % slower before anything was abandoned (profiles/r03c/README.md).
+// Outputs of kernel 4 are unchanged bit for bit (tests/test_gpu_prune.py: staged vs complete vs oracle); what changes is
+// the meaning of counts[] for abandoned hypotheses (a lower bound <= B0 instead of the count), which is why the
+// diagnostic ps_debug_ransac_counts and small batches score completely.
+// ------------------------------------------------------------------------------------------
+constexpr int kPrefix = kBlock; // hypotheses scored completely by stage 0
+constexpr int kStages = 3;      // pruned stages after the prefix
+
+struct StageArgs {
+    int stage;                 // 0 = plain launch over [hBase, hBase + hCount), all matches; 1 .. kStages = pruned stages
+    int hBase, hCount;         // stage 0 / 1: the hypothesis range of this launch
+    const int32_t *listIn;     // stage >= 2: survivors of the previous stage, [P][H] hypothesis indices ...
+    const int32_t *countIn;    //             ... and how many per pair
+    int32_t *listOut;          // stage < kStages: where this stage's survivors go
+    int32_t *countOut;
+};
 
 // Replay of the sequential selection over counts[0 .. n) by one wavefront (the rule of ps_select_refit part (1)):
 // best = the best count among the consumed ones, limit = the trip limit afterwards (a.H for the fixed schedule).
@@ -169,6 +203,58 @@ PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const Sele
     }
 }
 
+// Match range [lo, hi) of pruned stage `stage` (1 .. kStages) for a pair with M matches whose prefix reached best0.
+PS_D void stage_range(int stage, int M, int best0, int &lo, int &hi)
+{
+    int c1 = M, c2 = M;
+    if (best0 > 0) {
+        const int miss = M - best0; // a hypothesis is out once it has missed this many matches
+        c1 = (miss + miss / 7 + 32 + 63) & ~63;
+        if (c1 >= M - M / 8) c1 = M; // nothing worth a second launch
+        if (c1 < M) {
+            c2 = (c1 + (M - c1) / 2 + 63) & ~63;
+            if (c2 >= M - M / 16) c2 = M;
+        }
+    }
+    const int cut[kStages + 1] = {0, c1, c2, M};
+    lo = cut[stage - 1];
+    hi = cut[stage];
+}
+
+// What every work-group of a pruned stage needs before it starts: the prefix's best count and trip limit (work-group
+// uniform, in SGPRs) -- wave 0 replays, the others wait.
+PS_D void stage_prefix(const int32_t *__restrict__ cnts, int nPrefix, const SelectArgs &sa, int M, int *s_pref, int &best0,
+                       int &hLimit)
+{
+    if ((threadIdx.x >> 6) == 0) {
+        int b, l;
+        wave_replay_prefix(cnts, nPrefix, sa, M, b, l);
+        if ((threadIdx.x & 63) == 0) {
+            s_pref[0] = b;
+            s_pref[1] = l;
+        }
+    }
+    __syncthreads();
+    // (LDS loads count as divergent for the compiler: readfirstlane keeps the values in SGPRs and the branches scalar)
+    best0 = __builtin_amdgcn_readfirstlane(s_pref[0]);
+    // the limit only shrinks from record to record, but the FIRST record may raise it above its initial value
+    // (RANSAC.cpp:30 starts from computeRANSACIteration(0.20); a first ratio below 0.2 gives more): without a record in
+    // the prefix nothing can be cut
+    hLimit = best0 > 0 ? __builtin_amdgcn_readfirstlane(s_pref[1]) : sa.H;
+}
+
+// Appends the hypotheses of the lanes with `alive` to the next stage's list of pair p (one atomic per wavefront).
+PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t *__restrict__ countOut, int p, int H)
+{
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
+    if (am == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(am)) base = atomicAdd(&countOut[p], __popcll(am));
+    base = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
+    if (alive) listOut[(size_t)p * H + base + __popcll(am & ((1ull << lane) - 1ull))] = h;
+}
+
 // Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
 // a few prologue values spilled) and the packed 40-byte match record (RecPtrs::F: the loop is sensitive to the
 // scalar-cache footprint of the records every wave streams; 1.77 -> 1.70 -> 1.68 ms per 499 pairs).  Small launches are bound
@@ -180,17 +266,15 @@ PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const Sele
 // per-lane limits lo / hi; "inlier" needs both certain, one certain "outlier" suffices, anything else is parked and decided by
 // inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel; five
 // waves per SIMD (the second model costs 12 registers).
-// PRUNE: launch B of the pruned scoring (hypotheses [hBase, hBase + hCount) after a launch that scored [0, kPrefix)
-// completely); this launch and the plain one share every line of the evaluation.
-template <int MODE, bool BIG, bool PRUNE = false>
+// STAGED: a launch of the staged scoring (stage 0 included); the plain form scores every hypothesis of [0, H) completely.
+template <int MODE, bool BIG, bool STAGED = false>
 __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
     const float2 *__restrict__ pairBound,
-    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, SelectArgs sa, int hBase, int hCount, int H, int cap,
-    int minRun, int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
+    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun,
+    int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
 {
-    // This launch scores hypotheses [hBase, hBase + hCount) of every pair; counts[] has H entries per pair.
     static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
                   "the metrics with a reprojection test");
     constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
@@ -198,49 +282,54 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
     __shared__ int s_pref[2];
-    __shared__ int s_alive[kBlock / 64];
-    __shared__ uint32_t s_list[kBlock];
-    __shared__ int s_slot[kBlock]; // PRUNE: hypothesis slot scored by each thread (changes when lanes are re-packed)
 
+    // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
+    const int hCount = STAGED ? st.hCount : H;
     const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform: says so to the compiler)
-    const int hFirst = hBase + (int)bx * kBlock; // hypothesis of this work-group's slot 0
-    int hEnd = hBase + hCount;
-    int best0 = 0;
-    if (PRUNE) { // replay of the selection over the prefix: best count so far, trip limit (msplit == 1 in this form)
-        if (wv == 0) {
-            int b, l;
-            wave_replay_prefix(counts + (size_t)p * H, hBase < H ? hBase : H, sa, M, b, l);
-            if (lane == 0) {
-                s_pref[0] = b;
-                s_pref[1] = l;
-            }
-        }
-        __syncthreads();
-        // (LDS loads count as divergent for the compiler: readfirstlane keeps the work-group-uniform values in SGPRs and
-        // the branches on them scalar)
-        best0 = __builtin_amdgcn_readfirstlane(s_pref[0]);
-        if (best0 > 0) hEnd = min(hEnd, __builtin_amdgcn_readfirstlane(s_pref[1])); // (without a record the first one may still raise the limit)
-        if (hFirst >= hEnd) return; // never consumed by the selection
-    }
-    int slot = tid;
-    const int h = hFirst + tid;
-    int32_t *__restrict__ cout = counts + (size_t)p * H;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t rbase = (size_t)p * cap;
-    const int m0 = (int)(((long long)M * by) / msplit);
-    const int m1 = (int)(((long long)M * (by + 1)) / msplit);
+    int32_t *__restrict__ cout = counts + (size_t)p * H;
+    int h = (STAGED ? st.hBase : 0) + (int)bx * kBlock + tid;
+    int hEnd = STAGED ? st.hBase + st.hCount : H; // this lane scores hypothesis h if h < hEnd
+    int m0 = (int)(((long long)M * by) / msplit);
+    int m1 = (int)(((long long)M * (by + 1)) / msplit);
+    int best0 = 0, cnt0 = 0;
+    const bool pruned = STAGED && st.stage >= 1;
+    if (pruned) { // (msplit == 1 in these stages)
+        int hLimit;
+        stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);
+        stage_range(st.stage, M, best0, m0, m1);
+        if (m0 >= m1) return; // an earlier stage finished the pair's matches
+        if (st.stage == 1) {
+            hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
+        } else {
+            const int n = st.countIn[p];
+            const int i = (int)bx * kBlock + tid;
+            hEnd = 0x7FFFFFFF;
+            h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
+            if ((int)bx * kBlock >= n) return;
+            if (i < n) cnt0 = cout[h]; // count so far
+        }
+        if (st.stage == 1 && st.hBase + (int)bx * kBlock >= hEnd) return;
+    }
 
     Rigid mdl, inv;
     set_identity(mdl);
     bool valid = false;
-    if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-    if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
+    if (pruned && st.stage >= 2) {
+        if (h < hEnd) {
+            load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
+            valid = true;
+        }
+    } else {
+        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
+    }
     inverse_rigid_general(mdl, inv);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -249,7 +338,6 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         s_mdl[9 + i][tid] = mdl.t[i];
     }
     s_cnt[tid] = 0;
-    if (PRUNE) s_slot[tid] = tid;
 
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
@@ -267,10 +355,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f &&
                           (!EUCLID || (ec.enabled != 0 && cmax <= 1.0e15f));
     int cnt = 0;
-    // PRUNE: one decision for the work-group (its wavefronts meet at barriers)
-    const bool fastOk = PRUNE ? (__syncthreads_and(boundsOk ? 1 : 0) != 0) : wave_all(boundsOk);
 
-    if (!fastOk) {
+    if (!wave_all(boundsOk)) {
         for (int m = m0; m < m1; ++m) {
             const float4 A = pa[m], B = pb[m], C = pc[m];
             score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
@@ -295,8 +381,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][slot];
-                md.t[i] = s_mdl[9 + i][slot];
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
+                md.t[i] = s_mdl[9 + i][tid];
             }
             // md: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
             // iv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
@@ -334,13 +420,12 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             for (int e = lane; e < qn; e += 64) {
                 const uint32_t ent = s_q[wv][e];
                 const int t = wv * 64 + (int)(ent & 63u), m = (int)(ent >> 6);
-                const int ts = PRUNE ? s_slot[t] : t; // the hypothesis that thread was scoring
                 Rigid md, iv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][ts];
-                    md.t[i] = s_mdl[9 + i][ts];
+                    for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][t];
+                    md.t[i] = s_mdl[9 + i][t];
                 }
                 inverse_rigid_general(md, iv);
                 const float4 A = pa[m], B = pb[m], C = pc[m];
@@ -351,25 +436,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             qn = 0;
         };
 
-        unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
-        bool active = h < hEnd;       // PRUNE: this lane still scores a live hypothesis
-        if (PRUNE) {
-            if (active && !valid) {   // an invalid sample scores 0 (RANSAC.cpp:107)
-                cout[h] = 0;
-                active = false;
-            }
-            execAll = __builtin_amdgcn_ballot_w64(active); // only live lanes park evaluations
-        }
-        int liveWaves = kBlock / 64;  // PRUNE: wavefronts that still hold live hypotheses (work-group uniform)
-        unsigned dbgSteps = 0;
-        // PRUNE: the match range in segments of kPruneEvery with a checkpoint between them; the hot loop inside a segment is
-        // the plain one, and everything it keeps in registers per hypothesis is rebuilt after a checkpoint (as after a
-        // drain), so none of it is live across the checkpoint's code
-        const int segLen = PRUNE ? kPruneEvery : (m1 > m0 ? m1 - m0 : 1);
-        for (int seg = m0; seg < m1; seg += segLen) {
-        const int send = seg + segLen < m1 ? seg + segLen : m1;
-        dbgSteps += (unsigned)(send - seg);
-        for (int m = seg; m < send; ++m) {
+        const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
+        for (int m = m0; m < m1; ++m) {
             v2f_t Z, ss;
             float cxm, cym, czm, pxm, pym, pzm; // the match's current and previous point (wave-uniform)
             if (BIG) {
@@ -420,75 +488,20 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
                 qn += n;
             }
         }
-            // ---- PRUNE checkpoint: abandon what cannot become a record any more, re-pack the rest
-            if (PRUNE && send < m1) {
-                const int left = m1 - send;
-                // count so far: decided evaluations + drained parked ones; the qn evaluations still parked by this wave
-                // bound what this lane may still gain from them
-                const int sofar = cnt + s_cnt[tid];
-                if (active && sofar + qn + left <= best0) {
-                    cout[hFirst + slot] = sofar; // (<= best0: never selected, never a record)
-                    active = false;
-                }
-                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
-                execAll = am;
-                if (lane == 0) s_alive[wv] = __popcll(am);
-                __syncthreads();
-                int total = 0, before = 0;
-#pragma unroll
-                for (int i = 0; i < kBlock / 64; ++i) {
-                    const int n = i < liveWaves ? s_alive[i] : 0; // (wavefronts beyond liveWaves have ended)
-                    if (i < wv) before += n;
-                    total += n;
-                }
-                total = __builtin_amdgcn_readfirstlane(total);
-                before = __builtin_amdgcn_readfirstlane(before);
-                if (total == 0) break; // (work-group uniform)
-                const int need = (total + 63) >> 6;
-                if (need < liveWaves) {
-                    drain();                      // parked evaluations refer to threads: settle them before lanes move
-                    cnt += s_cnt[tid];
-                    s_cnt[tid] = 0;
-                    if (active) s_list[before + __popcll(am & ((1ull << lane) - 1ull))] = ((uint32_t)cnt << 8) | (uint32_t)slot;
-                    __syncthreads();
-                    active = tid < total;
-                    if (active) {
-                        const uint32_t e = s_list[tid];
-                        slot = (int)(e & 255u);
-                        cnt = (int)(e >> 8);
-                        s_slot[tid] = slot;
-                    }
-                    execAll = __builtin_amdgcn_ballot_w64(active);
-                    liveWaves = need;
-                    if (wv >= need) {
-                        // no live hypothesis left in this wavefront: it ends here and frees its registers (S_BARRIER waits
-                        // only for the wavefronts of the group that have not terminated)
-                        if (lane == 0) s_alive[wv] = 0;
-                        if (dbg != nullptr && lane == 0) {
-                            atomicAdd(&dbg[0], parked);
-                            atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
-                            atomicAdd(&dbg[2], (unsigned long long)dbgSteps);
-                            atomicAdd(&dbg[3], (unsigned long long)(m1 - m0));
-                        }
-                        return;
-                    }
-                }
-                __syncthreads(); // s_alive / s_list are reused at the next checkpoint
-                rebuild();
-            }
-        }
         drain();
         cnt += s_cnt[tid];
         if (dbg != nullptr && lane == 0) {
             atomicAdd(&dbg[0], parked);
             atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
-            atomicAdd(&dbg[2], (unsigned long long)dbgSteps); // wave-steps computed / of a complete sweep
-            atomicAdd(&dbg[3], (unsigned long long)(m1 - m0));
         }
-        if (PRUNE) {
-            if (active) cout[hFirst + slot] = cnt; // (abandoned and invalid hypotheses stored theirs already)
-            return;
-        }
+    }
+    if (pruned) {
+        const bool mine = h < hEnd;
+        const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
+        if (mine) cout[h] = total;
+        // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
+        if (st.stage < kStages && m1 < M) stage_append(mine && valid && total + (M - m1) > best0, h, st.listOut, st.countOut, p, H);
+        return;
     }
     if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
