@@ -28,7 +28,8 @@ After the timed regions (never part of `value`) rank 0 of a single-GPU run adds 
   * a single-chain leg -- the same step as ONE launch chain on one stream, HIP events around every kernel: the
     kernels' own durations.  `kernel_ms`, `roofline`, `kernel_bounds`, `single_chain` come from it (the timed region's
     per-launch figures, measured while three chains share the CUs, are kept as `timed_region_kernel_ms`);
-  * one pass with the fast scoring kernel's statistics on (`score_parked_frac`);
+  * one pass with the fast scoring kernel's statistics on (`score_parked_frac`; `score_evals_frac` = share of the
+    complete hypotheses x matches sweep the staged scoring still evaluates, 1.0 without it);
   * `other_modes`: the same sequence as ONE launch chain in the regimes every shipped reference config runs --
     errorVersion 0 with H = 4096 fixed, and errorVersion 0 with the reference's own adaptive <= 487-iteration schedule
     (RANSAC.cpp:30,450-453) -- `ms_per_step`, `pairs_per_s` and the kernels' own durations;
@@ -259,6 +260,8 @@ def main():
     # `roofline` is computed from this leg; profiles/ holds the rocprofv3 kernel trace of `--streams 1`.
     solo = {}
     parked_frac = None
+    evals_made = 0
+    evals_frac = None
     if world == 1:
         c0 = ctxs[0]
         solo_steps = max(3, min(8, args.steps))
@@ -285,7 +288,13 @@ def main():
             pk, ev = c0.score_stats()
             c0.set_option("score_stats", 0)
             parked_frac = pk / ev if ev else None
+            evals_made = ev
     res = pb.download()
+    if evals_made:
+        # staged scoring: evaluations made / evaluations of the complete H x M sweep (whole wavefronts, like the counter)
+        mv = res["stats"]["numMatchesValid"].astype(np.int64)
+        complete = int(mv[mv >= max(3, prm.minimalNumberOfMatches)].sum()) * ((args.hyp + 255) // 256) * 256
+        evals_frac = evals_made / complete if complete else None
     # ---- the regimes the reference's shipped configs run (errorVersion 0: resources/putslammatcherOpenCVParameters.xml:30-31
     # and all configs/*), same sequence, ONE launch chain, HIP events around every kernel; results go to a second output
     # block so that `res` above stays the timed workload's
@@ -442,6 +451,8 @@ def main():
                               "kernel_ms_sum": sum(solo.values())} if solo else None),
             "timed_region_kernel_ms": kern,
             "score_parked_frac": parked_frac,
+            "score_evals_frac": evals_frac,
+            "staged_scoring": bool(ctx.get_option("prune")),
             "other_modes": other_modes,
             "streams_note": (None if S == 1 else
                              f"value / ms_per_step: {S} sub-batch chains on {S} HIP streams (join={args.join}); "

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     m1 = m1 < M ? m1 : M;
     int best0 = 0, cnt0 = 0;
     const bool pruned = STAGED && st.stage >= 1;
+    if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
         stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     int m1 = (int)(((long long)M * (by + 1)) / msplit);
     int best0 = 0, cnt0 = 0;
     const bool pruned = STAGED && st.stage >= 1;
+    if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);
