@@ -137,6 +137,8 @@ int ps_context_synchronize(PsContext *ctx);
  *              abandoned hypotheses are lower bounds.  0 = every hypothesis is scored completely
  *              (PUTSLAM_HIP_PRUNE=0|1).  The diagnostic ps_debug_ransac_counts always scores completely.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
+ *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
+ *              are passed a null pointer and record nothing.
  *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
  *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).
  * ps_context_get_option returns the value or a negative PsStatus. */
@@ -300,6 +302,10 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
 /* All eight counters of the last scoring step: [0] parked, [1] evaluations made (with the staged scoring: what is left of
  * the complete sweep of H hypotheses x M matches); [2..7] reserved (0). */
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
+/* Latency study (option "stamps" = 1): the shader-clock stamps (s_memtime) work-group 0 of kernels 2 and 4 of the last call
+ * wrote into a private buffer: out16[0..3] = ps_crosscheck_prep (start, best[q] built, matches compacted + records written,
+ * end), out16[4..9] = ps_select_refit (start, selection replayed, winner's inlier pass, refit, re-selection, end). */
+int ps_debug_stamps(PsContext *ctx, uint64_t *out16);
 /* sizeof() of the PODs as compiled into the library (layout check for foreign-language bindings). */
 size_t ps_abi_sizeof_dmatch(void);
 size_t ps_abi_sizeof_params(void);

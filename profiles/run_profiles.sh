@@ -11,7 +11,7 @@ set -u
 TAG=${1:-r02}
 # 20 warm-up steps: the chip needs ~10 launches of this step to reach its steady clock (r02g/kernel_launch_ms.json),
 # and rocprofv3's --stats average runs over every launch of the process
-ARGS=${2:-"--streams 1 --steps 20 --warmup 20 --no-cpu-baseline"}
+ARGS=${2:-"--streams 1 --steps 20 --warmup 20 --repeats 1 --no-other-modes --no-cpu-baseline"}
 # bench.py sets this with os.environ.setdefault, but under rocprofv3 the profiler's preloaded library may initialise the
 # HIP runtime before Python runs: export it here so that profiled and un-profiled runs use the same queue count
 export GPU_MAX_HW_QUEUES=8

@@ -27,6 +27,14 @@ def main():
             if line.startswith("{"):
                 with open(os.path.join(dst, "bench_under_rocprof.json"), "w") as f:
                     f.write(line)
+    def short_name(k):
+        short = k.split("psdev::")[1].split("<")[0].split("(")[0]
+        # bench.py's name of the timing slot: all builds / stages of the scoring kernel are one step of the path
+        return {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_euclid": "ps_ransac_score",
+                "ps_ransac_score_mfma": "ps_ransac_score"}.get(short, short)
+
+    # A kernel may be launched several times per step (the staged scoring: prefix + three stages): every figure below
+    # is PER STEP = sum over the step's launches; steps = dispatches of the once-per-step kernel ps_crosscheck_prep.
     kern = {}
     for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         path = os.path.join(src, name, "bench_counter_collection.csv")
@@ -37,16 +45,17 @@ def main():
             k = r["Kernel_Name"]
             if "psdev::" not in k or r["Counter_Name"] != ctr:
                 continue
-            short = k.split("psdev::")[1].split("<")[0].split("(")[0]
-            short = {"ps_ransac_score_fast": "ps_ransac_score"}.get(short, short)   # bench.py's name of the timing slot
-            agg[short].append(float(r["Counter_Value"]))
+            agg[short_name(k)].append(float(r["Counter_Value"]))
+        steps = max(len(agg.get("ps_crosscheck_prep", [])), 1)
         for k, v in agg.items():
-            kern.setdefault(k, {})[ctr + "_KB_per_launch"] = sum(v) / len(v)
+            kern.setdefault(k, {})[ctr + "_KB_per_launch"] = sum(v) / steps      # (per step; key name kept for bench.py)
             kern[k]["launches"] = len(v)
+            kern[k]["launches_per_step"] = len(v) / steps
     summary = {
         "command": "profiles/run_profiles.sh " + tag + "  (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE: "
                    "three separate passes of the same bench.py command)",
-        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+        "note": "FETCH_SIZE / WRITE_SIZE are KB per STEP of the path (sum over the step's launches of the kernel: the staged "
+                "scoring launches its kernel four times per step). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
                 "counts 128-B requests at 64 B, i.e. reports half of the bytes read -> doubled before use. Calibrated on "
                 "this access pattern in round 1 (scalar s_load_dwordx4/x16 + 16-byte vector loads: the VALU matcher read every "
                 "descriptor row of the 500-frame sequence, 32.0 MB unique, and reported FETCH_SIZE = 16.4 MB = 32.7 MB after "
@@ -55,44 +64,60 @@ def main():
         "kernels": kern}
     with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    # SQ / MFMA counters (averages per dispatch)
+    # SQ / MFMA counters (sums per step, by full kernel name)
     sq = os.path.join(src, "sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        nstep = 0
         for r in csv.DictReader(open(sq)):
             k = r["Kernel_Name"]
             if "psdev::" in k:
                 agg[k.split("psdev::")[1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            if k.startswith("ps_crosscheck_prep"):
+                nstep = max(nstep, max(len(v) for v in cs.values()))
+        nstep = max(nstep, 1)
         with open(os.path.join(dst, "sq_counters.json"), "w") as f:
-            json.dump({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}, f, indent=1)
-    # per-launch durations from the kernel trace, in launch order (the --stats average mixes warm-up launches, the timed
-    # region and bench.py's single-chain leg; with the default profile command --streams 1 --steps 5 --warmup 2 the
-    # launches are: 2 warm-up, 5 timed, 1 leg warm-up, 5 leg (these are what `kernel_ms` averages), 1 statistics pass)
+            json.dump({k: dict({c: sum(v) / nstep for c, v in cs.items()}, launches_per_step=max(len(v) for v in cs.values()) / nstep)
+                       for k, cs in agg.items()}, f, indent=1)
+    # per-step durations from the kernel trace, in launch order (the --stats average mixes warm-up launches, the timed
+    # region and bench.py's single-chain leg).  Launch order of bench.py --streams 1 --repeats 1 --no-other-modes:
+    # W warm-up steps, K timed, 1 leg warm-up, L = max(3, min(8, K)) leg steps (what `kernel_ms` averages), 1 statistics pass
     tr = os.path.join(src, "trace", "bench_kernel_trace.csv")
     if os.path.exists(tr):
-        per = collections.defaultdict(list)
+        launches = collections.defaultdict(list)
         for r in csv.DictReader(open(tr)):
             k = r["Kernel_Name"]
             if "psdev::" in k:
-                per[k.split("psdev::")[1].split("(")[0]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+                launches[short_name(k)].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        step_starts = sorted(t for t, _ in launches.get("ps_crosscheck_prep", []))
         out = {}
-        # launch order of bench.py --streams 1: W warm-up, K timed, 1 leg warm-up, L = max(3, min(8, K)) leg launches
-        # (what `kernel_ms` averages), 1 statistics pass
         K = W = None
         try:
             line = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())
             K, W = int(line["steps"]), int(line["warmup"])
         except Exception:
             pass
-        for k, v in per.items():
+        import bisect
+        for k, v in launches.items():
             v.sort()
-            ms = [round(x[1], 4) for x in v]
+            per_step = [0.0] * len(step_starts)
+            # a launch belongs to the step whose cross-check kernel started last before it (kernel 1 runs before
+            # kernel 2 of its own step: it is attributed through the NEXT cross-check start)
+            for t, ms in v:
+                i = bisect.bisect_right(step_starts, t) - 1
+                if k in ("ps_expand_query_fp4", "ps_hamming_mfma", "ps_hamming_nn"):
+                    i += 1
+                if 0 <= i < len(per_step):
+                    per_step[i] += ms
+            ms_list = [round(x, 4) for x in per_step]
             leg = None
             if K is not None:
                 L = max(3, min(8, K))
-                if len(ms) == W + K + 1 + L + 1:
-                    leg = sum(ms[-(L + 1):-1]) / L
-            out[k] = {"launch_ms": ms, "all_launches_mean_ms": sum(ms) / len(ms), "single_chain_leg_mean_ms": leg}
+                if len(ms_list) == W + K + 1 + L + 1:
+                    leg = sum(ms_list[-(L + 1):-1]) / L
+            out[k] = {"step_ms": ms_list, "launches_per_step": len(v) / max(len(step_starts), 1),
+                      "all_steps_mean_ms": sum(ms_list) / max(len(ms_list), 1), "single_chain_leg_mean_ms": leg}
         with open(os.path.join(dst, "kernel_launch_ms.json"), "w") as f:
             json.dump(out, f, indent=1)
     for extra in ("bench_default.json",):

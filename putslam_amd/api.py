@@ -75,6 +75,12 @@ class Context:
         self._chk(self._L.ps_debug_score_stats_ex(self._h, out))
         return [int(v) for v in out]
 
+    def stamps(self):
+        """Shader-clock stamps of kernels 2 and 4 of the last call (needs set_option("stamps", 1)); ps_debug_stamps."""
+        out = (C.c_uint64 * 16)()
+        self._chk(self._L.ps_debug_stamps(self._h, out))
+        return [int(v) for v in out]
+
     def get_option(self, name):
         v = self._L.ps_context_get_option(self._h, name.encode())
         if v < 0:

@@ -77,6 +77,8 @@ struct PsContext {
     // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
     // abandon later hypotheses that cannot become records (default), 0 = every hypothesis is scored completely
     int prune = 1;
+    int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
+    Buf stamps;
 };
 
 namespace {
@@ -647,7 +649,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                        (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
                        (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
                        dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
-                       dMask, dStats);
+                       dMask, dStats, ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -727,7 +729,8 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
 #define PS_LAUNCH_PREP(REC, BLK)                                                                                       \
     hipLaunchKernelGGL((ps_crosscheck_prep<REC, BLK>), dim3((unsigned)P), dim3(BLK), lds, ctx->stream, fs.pts, fs.nkpts, \
                        dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, rp,                           \
-                       (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p)
+                       (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p,                                                \
+                       ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr)
     RecPtrs rp{};
     if (withRecords) {
         rp = rec_ptrs(ctx, cap, pa.mode);
@@ -827,7 +830,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -878,6 +881,17 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->prune = value;
         return PS_OK;
     }
+    if (strcmp(name, "stamps") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "stamps: 0 or 1");
+        if (value) {
+            int rc = bind(ctx);
+            if (rc) return rc;
+            PS_ENSURE(ctx->stamps, 16 * sizeof(unsigned long long));
+            PS_HIP(hipMemsetAsync(ctx->stamps.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        }
+        ctx->stampsOn = value;
+        return PS_OK;
+    }
     if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
         if (value < 0 || value > 1024) return fail(ctx, PS_ERR_BAD_ARG, "split: 0..1024");
         (name[0] == 'q' ? ctx->forceQsplit : ctx->forceMsplit) = value;
@@ -894,6 +908,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "score") == 0) return ctx->scoreFast;
     if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
     if (strcmp(name, "prune") == 0) return ctx->prune;
+    if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
     if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
     if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
     return PS_ERR_BAD_ARG;
@@ -1208,6 +1223,23 @@ int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8)
     PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 8; ++i) out8[i] = h[i];
+    return PS_OK;
+}
+
+// Diagnostic: the shader-clock stamps kernels 2 and 4 of the LAST call wrote (option "stamps"): out16[0..3] = kernel 2
+// (start, best[q] built, matches compacted + records, end), out16[4..9] = kernel 4 (start, selection, inlier pass,
+// refit, re-selection, end), of work-group 0.  Differences are shader-clock ticks (s_memtime).
+int ps_debug_stamps(PsContext *ctx, uint64_t *out16)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out16) return PS_ERR_BAD_ARG;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (!ctx->stamps.p) return PS_OK;
+    unsigned long long h[16];
+    PS_HIP(hipMemcpyAsync(h, ctx->stamps.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 16; ++i) out16[i] = h[i];
     return PS_OK;
 }
 
@@ -1643,7 +1675,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5); // disjoint bit fields
+    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6); // disjoint bit fields
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);

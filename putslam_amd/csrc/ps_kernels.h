@@ -36,6 +36,14 @@ PS_D unsigned xcd_remap(unsigned L, unsigned total)
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
 }
 
+// Phase stamps of the latency study (option "stamps", ps_debug_stamps): thread 0 of work-group 0 writes the shader clock
+// (s_memtime) at the phase boundaries of kernels 2 and 4 into a private buffer -- never into outputs.  stamps == nullptr in
+// every ordinary launch (one scalar compare per boundary).
+PS_D void phase_stamp(unsigned long long *stamps, int i)
+{
+    if (stamps != nullptr && threadIdx.x == 0 && blockIdx.x == 0) stamps[i] = __builtin_readcyclecounter();
+}
+
 // v_bcnt_u32_b32: popcount(x) + acc in one VALU op (the compiler emits bcnt + add otherwise).
 PS_D uint32_t bcnt_acc(uint32_t x, uint32_t acc)
 {
@@ -147,6 +155,30 @@ template <int BLOCK = kBlock> PS_D int block_scan_flag(bool flag, int &total, in
     }
     __syncthreads();
     return off + pre;
+}
+
+// Two ordered compactions with one pair of barriers: exclusive prefixes of flagA and flagB over the work-group
+// (flagB implies nothing about flagA); the wave sums travel packed (A in the low 16 bits, B in the high ones).
+template <int BLOCK = kBlock>
+PS_D void block_scan_flags2(bool flagA, bool flagB, int &posA, int &totalA, int &posB, int &totalB, int *wsum)
+{
+    const unsigned long long ba = __ballot(flagA), bb = __ballot(flagB);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) wsum[w] = __popcll(ba) | (__popcll(bb) << 16);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) {
+        const int sv = wsum[i];
+        if (i < w) off += sv;
+        tot += sv;
+    }
+    __syncthreads();
+    posA = (off & 0xFFFF) + __popcll(ba & below);
+    posB = (off >> 16) + __popcll(bb & below);
+    totalA = tot & 0xFFFF;
+    totalB = tot >> 16;
 }
 
 // workgroup-wide maximum of a non-negative float (4 waves)
@@ -334,9 +366,11 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
                                                              const uint32_t *__restrict__ keys, PrepArgs a,
                                                              PsDMatch *__restrict__ matches,
                                                              int32_t *__restrict__ numMatches, RecPtrs rec,
-                                                             int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut)
+                                                             int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut,
+                                                             unsigned long long *__restrict__ stamps)
 {
     extern __shared__ __align__(16) uint32_t s_best[];
+    phase_stamp(stamps, 0);
     __shared__ int s_wsum[BLOCK / 64];
     __shared__ float s_red[BLOCK / 64];
     float cm = 0.0f; // largest |coordinate| among this pair's depth-valid matches
@@ -357,6 +391,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         }
     }
     __syncthreads();
+    phase_stamp(stamps, 1); // best[q] built
     const float *pp = pts + (size_t)fq * cap * 3;
     const float *cp = pts + (size_t)ft * cap * 3;
     int base = 0, vbase = 0;
@@ -364,9 +399,17 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         const int q = q0 + threadIdx.x;
         uint32_t key = (q < nq) ? s_best[q] : kNoKey;
         const bool has = key != kNoKey;
-        int total;
-        int pos = block_scan_flag<BLOCK>(has, total, s_wsum);
         const int t = (int)(key & 0xFFFFu);
+        float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
+        bool ok = false;
+        if (WITH_RECORDS && has) {
+            px = pp[3 * q]; py = pp[3 * q + 1]; pz = pp[3 * q + 2];
+            cx_ = cp[3 * t]; cy_ = cp[3 * t + 1]; cz_ = cp[3 * t + 2];
+            ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
+        }
+        // both ordered compactions (cross-check survivors; depth-valid ones among them) with one pair of barriers
+        int pos, total, vpos, vtotal;
+        block_scan_flags2<BLOCK>(has, ok, pos, total, vpos, vtotal, s_wsum);
         if (has) {
             PsDMatch m;
             m.queryIdx = q;
@@ -376,15 +419,6 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             matches[(size_t)p * cap + base + pos] = m;
         }
         if (WITH_RECORDS) {
-            float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
-            bool ok = false;
-            if (has) {
-                px = pp[3 * q]; py = pp[3 * q + 1]; pz = pp[3 * q + 2];
-                cx_ = cp[3 * t]; cy_ = cp[3 * t + 1]; cz_ = cp[3 * t + 2];
-                ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
-            }
-            int vtotal;
-            int vpos = block_scan_flag<BLOCK>(ok, vtotal, s_wsum);
             if (ok) {
                 um = fmaxf(um, write_records(a, rec, p, vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_));
                 cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
@@ -393,6 +427,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         }
         base += total;
     }
+    phase_stamp(stamps, 2); // matches compacted, records written
     if (WITH_RECORDS) {
         float c = block_max<BLOCK>(cm, s_red);
         float u = block_max<BLOCK>(um, s_red);
@@ -410,6 +445,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             a.zeroSurvB[p] = 0;
         }
     }
+    phase_stamp(stamps, 3); // bounds, split operands, counters cleared
 }
 
 // Depth filter + records for a caller-supplied match list (stand-alone RANSAC entry point).
@@ -906,8 +942,10 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
                                                           ModelArgs ma, ScoreConsts k, SelectArgs a,
                                                           int32_t *__restrict__ idxList, float *__restrict__ poseOut,
                                                           uint8_t *__restrict__ maskOut,
-                                                          PsRansacStats *__restrict__ statsOut)
+                                                          PsRansacStats *__restrict__ statsOut,
+                                                          unsigned long long *__restrict__ stamps)
 {
+    phase_stamp(stamps, 4);
     extern __shared__ __align__(16) uint32_t s_bits[]; // two bitmaps over train indices: 2 * ceil(trainRange/32) words
     __shared__ int s_wsum[BLOCK / 64];
     __shared__ unsigned long long s_red[BLOCK / 64];
@@ -996,6 +1034,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         trips = s_sel[2];
     }
 
+    phase_stamp(stamps, 5); // (1) selection replayed
     // ---- (2) inliers of the selected hypothesis ----
     Rigid mdl, inv;
     set_identity(mdl);
@@ -1040,13 +1079,34 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         __syncthreads(); // list / staged points visible to the whole workgroup
     }
 
+    phase_stamp(stamps, 6); // (2) winner's model, inlier pass, ordered compaction
     const float ratioF = run ? (float)bestCount / (float)M : 0.0f;
     const double ratioD = (double)ratioF;
     bool accepted = run && !(ratioD < a.minRatio);
     int nfinal = 0;
 
+    // pointInlierRatio (RANSAC.h:56-66) needs the unique trainIdx among ALL input matches and among the final inliers.
+    // The first does not depend on the refit: the other wavefronts build it while wave 0 runs the refit's serial
+    // Umeyama + Jacobi-SVD chain (14 of this kernel's 35 us for a single pair, profiles/r03e/latency_stamps.json).
+    for (int i = tid; i < 2 * words; i += BLOCK) s_bits[i] = 0u;
+    if (tid == 0) s_uniq[0] = s_uniq[1] = 0;
+    __syncthreads();
+    const PsDMatch *mm = matches + (size_t)p * matchStride;
+    int ua = 0, ui = 0;
+    auto all_matches_pass = [&](int first, int stride) {
+        for (int i = first; i < nIn; i += stride) {
+            const int t = mm[i].trainIdx;
+            if (t >= 0 && t < a.trainRange) {
+                const uint32_t bit = 1u << (t & 31);
+                const uint32_t old = atomicOr(&s_bits[t >> 5], bit);
+                ua += (old & bit) ? 0 : 1;
+            }
+        }
+    };
+
     if (run && a.estimator != PS_EST_USAC) {
         // ---- (3) refit on the best inliers (wave 0), re-selection with the Euclid/adaptive rule ----
+        if (wv != 0) all_matches_pass(tid - 64, BLOCK - 64);
         if (wv == 0) {
             Rigid ref;
             wave_umeyama(kin,
@@ -1066,6 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             if (lane == 0) s_model = ref;
         }
         __syncthreads();
+        phase_stamp(stamps, 7); // (3a) refit: wave-level Umeyama + Jacobi SVD
         mdl = s_model;
         for (int j0 = 0; j0 < kin; j0 += BLOCK) {
             const int j = j0 + tid;
@@ -1087,23 +1148,19 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         // when the ratio gate replaces the pose by identity (USAC_wrapper.cpp:139-141).
         for (int j = tid; j < kin; j += BLOCK) mask[recD[rbase + list[j]].x] = 1;
         nfinal = kin;
-    }
+        all_matches_pass(tid, BLOCK);
+    } else
+        all_matches_pass(tid, BLOCK);
     __syncthreads();
 
-    // ---- (4) pointInlierRatio: unique trainIdx among final inliers / among all input matches ----
-    for (int i = tid; i < 2 * words; i += BLOCK) s_bits[i] = 0u;
-    if (tid == 0) s_uniq[0] = s_uniq[1] = 0;
-    __syncthreads();
-    const PsDMatch *mm = matches + (size_t)p * matchStride;
-    int ua = 0, ui = 0;
+    phase_stamp(stamps, 8); // (3b) Euclidean re-selection, mask
+    // ---- (4) pointInlierRatio: unique trainIdx among the final inliers ----
     for (int i = tid; i < nIn; i += BLOCK) {
-        int t = mm[i].trainIdx;
-        if (t >= 0 && t < a.trainRange) {
-            uint32_t bit = 1u << (t & 31);
-            uint32_t old = atomicOr(&s_bits[t >> 5], bit);
-            ua += (old & bit) ? 0 : 1;
-            if (mask[i]) {
-                old = atomicOr(&s_bits[words + (t >> 5)], bit);
+        if (mask[i]) {
+            const int t = mm[i].trainIdx;
+            if (t >= 0 && t < a.trainRange) {
+                const uint32_t bit = 1u << (t & 31);
+                const uint32_t old = atomicOr(&s_bits[words + (t >> 5)], bit);
                 ui += (old & bit) ? 0 : 1;
             }
         }
@@ -1128,6 +1185,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         st.pointInlierRatio = (double)s_uniq[1] / (double)s_uniq[0];
         statsOut[p] = st;
     }
+    phase_stamp(stamps, 9); // (4) pointInlierRatio, pose and statistics stored
 }
 
 // ------------------------------------------------------------------------------------------

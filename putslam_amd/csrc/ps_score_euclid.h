@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
         }
     } else {
         if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-        if (ma.models && by == 0 && h < hEnd) store_model(ma, (size_t)p * H + h, mdl);
+        // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
+        if (ma.models && by == 0 && h < hEnd && !pruned) store_model(ma, (size_t)p * H + h, mdl);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -271,7 +272,18 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
-        if (st.stage < kStages && m1 < M) stage_append(mine && valid && total + (M - m1) > best0, h, st.listOut, st.countOut, p, H);
+        const bool alive = mine && valid && total + (M - m1) > best0;
+        if (st.stage == 1 && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
+            Rigid md;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
+                md.t[i] = s_mdl[9 + i][tid];
+            }
+            store_model(ma, (size_t)p * H + h, md);
+        }
+        if (st.stage < kStages && m1 < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
         return;
     }
     if (h < hEnd) {
