@@ -13,6 +13,10 @@ $(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSR
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I$(CSRC)/dropin $< -o $@ -Lputslam_amd -lputslam_hip '-Wl,-rpath,$$ORIGIN'
 
+# A/B build of kernel 1 with the query tiles staged through LDS (profiles/scripts/r02h_matcher_direct.sh)
+putslam_amd/libputslam_hip_lds.so: $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DPS_MFMA_DIRECT=0 -shared $(CSRC)/ps_capi.hip -o $@
+
 oracle:
 	$(MAKE) -C oracle
 

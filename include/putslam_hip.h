@@ -109,8 +109,10 @@ void ps_context_destroy(PsContext *ctx);
 /* Use an externally owned hipStream_t (e.g. the caller's current stream); NULL restores the private stream, which
  * is created hipStreamNonBlocking: it is NOT ordered with the legacy default stream, so a caller working on the
  * default stream hands over an explicit stream (forked from / joined to the default one) or synchronises.
- * The scratch arena belongs to the context: when the stream changes, the new stream is made to wait (event) for
- * the work already queued on the previous one, so consecutive calls on different streams never overlap on it.
+ * The scratch arena belongs to the context: when the stream changes, the new stream is made to wait for the event
+ * recorded at the end of the last asynchronous call (ps_vo_pairs_device), so consecutive calls on different streams
+ * never overlap on it.  The previous stream itself is not touched by ps_context_set_stream: its owner may destroy it once
+ * the calls submitted to it have been synchronised or a later stream has been selected.
  * One context still serves one caller thread at a time; concurrent chains use one context each. */
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);

@@ -38,7 +38,8 @@ struct PsContext {
     int device = 0;
     hipStream_t own = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t handoff = nullptr; // orders a newly selected stream behind the work queued on the previous one
+    hipEvent_t handoff = nullptr; // recorded behind every asynchronous call: a newly selected stream waits for it
+    bool handoffPending = false;
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
@@ -69,6 +70,9 @@ struct PsContext {
     // not earn back
     int matcher = 2;
     int matcherUsed = 1; // what the last matching call ran (1 MFMA, 0 VALU)
+    // matrix-core matcher: 1 = the work-group expands its query tiles itself through LDS (default), 0 = round 2's form
+    // with the FP4 image of the query frames written to HBM by a launch of its own (option "matcher_fused")
+    int matcherFused = 1;
     // errorVersion 1: 1 = decision-exact VALU kernel (ps_score_fast.h, default), 2 = decision-exact scoring with the
     // transforms on the matrix cores (ps_score_mfma.h: correct, measured 8 % slower, profiles/r02f),
     // 0 = value-exact ps_ransac_score<1>
@@ -695,9 +699,21 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         constexpr int TT = PS_MFMA_TT;
         const int tpf = (cap + kTileRows - 1) / kTileRows;
         const int groups = (tpf + kWavesPerWG * TT - 1) / (kWavesPerWG * TT);
-        PS_ENSURE(ctx->xq, (size_t)P * tpf * kTileU4 * sizeof(uint4));
         int qsplit = pick_split((long long)P * groups, tpf, 1, tpf);
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
+        if (ctx->matcherFused) {
+            // fused expansion: every work-group of a query split expands its own share of the query tiles, so a split only
+            // pays when the groups do not fill the chip by themselves; the keys are then cleared by a memset
+            if (ctx->forceQsplit <= 0 && (long long)P * groups >= 1024) qsplit = 1;
+            if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+            tick(ctx, 5, false);
+            hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
+                               ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                               (uint32_t *)ctx->keys.p);
+            tick(ctx, 5, true);
+            PS_HIP(hipGetLastError());
+        } else {
+        PS_ENSURE(ctx->xq, (size_t)P * tpf * kTileU4 * sizeof(uint4));
         int xchunks = tpf < 8 ? tpf : 8;
         if ((long long)P * xchunks < 1024) xchunks = tpf < 64 ? tpf : 64;
         tick(ctx, 4, false);
@@ -711,6 +727,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
                            (const uint4 *)ctx->xq.p, (uint32_t *)ctx->keys.p);
         tick(ctx, 5, true);
         PS_HIP(hipGetLastError());
+        }
     } else {
         constexpr int TPL = 2;
         const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
@@ -810,6 +827,7 @@ int ps_context_create(int device, PsContext **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
+    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER_FUSED")) ctx->matcherFused = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER"))
         ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
@@ -850,10 +868,10 @@ int ps_context_set_stream(PsContext *ctx, void *s)
     int rc = bind(ctx);
     if (rc) return rc;
     // The scratch arena and the stop tables belong to the context, not to a stream: work queued on the new stream
-    // must not start before the work already queued on the old one has finished with them.
-    if (!ctx->handoff) PS_HIP(hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming));
-    PS_HIP(hipEventRecord(ctx->handoff, ctx->stream));
-    PS_HIP(hipStreamWaitEvent(next, ctx->handoff, 0));
+    // must not start before the work already queued on the old one has finished with them.  The event was recorded
+    // at the end of the last asynchronous call, on the stream that call ran on: the previous stream is not touched
+    // here, so it may already have been destroyed by its owner.
+    if (ctx->handoff && ctx->handoffPending) PS_HIP(hipStreamWaitEvent(next, ctx->handoff, 0));
     ctx->stream = next;
     return PS_OK;
 }
@@ -864,6 +882,11 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
     if (strcmp(name, "matcher") == 0) {
         if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)");
         ctx->matcher = value;
+        return PS_OK;
+    }
+    if (strcmp(name, "matcher_fused") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "matcher_fused: 0 or 1");
+        ctx->matcherFused = value;
         return PS_OK;
     }
     if (strcmp(name, "score") == 0) {
@@ -905,6 +928,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (!ctx || !name) return PS_ERR_BAD_ARG;
     if (strcmp(name, "matcher") == 0) return ctx->matcher;
     if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
+    if (strcmp(name, "matcher_fused") == 0) return ctx->matcherFused;
     if (strcmp(name, "score") == 0) return ctx->scoreFast;
     if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
     if (strcmp(name, "prune") == 0) return ctx->prune;
@@ -1482,8 +1506,13 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     if (rc) return rc;
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
-    return run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask,
-                            out->stats, 2);
+    rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);
+    if (rc) return rc;
+    // this call returns with its work still queued: mark where it ends, for a later ps_context_set_stream
+    if (!ctx->handoff) PS_HIP(hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming));
+    PS_HIP(hipEventRecord(ctx->handoff, ctx->stream));
+    ctx->handoffPending = true;
+    return PS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1675,7 +1704,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6); // disjoint bit fields
+    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6) | (ctx->matcherFused << 7); // disjoint bit fields
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);

@@ -257,4 +257,128 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused form (default since round 3): no FP4 image in HBM and no expansion launch.  The work-group expands the query
+// tiles itself, kFuseChunk tiles at a time, into a double-buffered LDS image in the same fragment-major layout
+// (thread o of the group writes piece o of every tile of the chunk: one descriptor dword -> 32 nibbles -> one
+// ds_write_b128), and all four waves read their A operands from it (four ds_read_b128 per tile, conflict-free).  One barrier
+// per chunk -- the first LDS form of this kernel had one per tile and lost 14 % to it (profiles/r02h); the expansion of
+// chunk c + 1 is issued before the MFMAs of chunk c, so its vector work sits in their shadow.  Every work-group of a
+// pair expands the whole query range it sweeps (28 vector instructions per tile and wave): the four groups of a
+// 2000-row frame repeat each other's expansion, which costs about what the separate launch did (0.036 ms per 499 pairs)
+// and removes 0.29 GB of traffic per step and one launch.
+// ------------------------------------------------------------------------------------------
+constexpr int kFuseChunk = 4; // query tiles per chunk: 2 x 4 x 4 KiB = 32 KiB of LDS per work-group
+
+template <int TT>
+__global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(const uint32_t *__restrict__ desc,
+                                                                const int32_t *__restrict__ nkpts,
+                                                                const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                                int groups, int qsplit, uint32_t *__restrict__ keys)
+{
+    __shared__ uint4 s_a[2][kFuseChunk][kTileU4];
+    const unsigned perPair = (unsigned)(groups * qsplit);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = (int)(L / perPair);
+    const int inner = (int)(L - (unsigned)p * perPair);
+    const int g = inner / qsplit, qs = inner - g * qsplit;
+    const int fq = pairs[2 * p], ft = pairs[2 * p + 1]; // query = previous frame, train = current
+    const int nq = nkpts[fq], nt = nkpts[ft];
+    if (g * (kWavesPerWG * TT * kTileRows) >= nt) return; // whole work-group beyond the train rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile0 = (g * kWavesPerWG + wave) * TT;
+    const int nqTiles = (nq + kTileRows - 1) / kTileRows;
+    const int T0 = (int)(((long long)nqTiles * qs) / qsplit), T1 = (int)(((long long)nqTiles * (qs + 1)) / qsplit);
+
+    // B operands: this wave's train tiles, expanded in registers (rows beyond nt repeat the last row; never stored)
+    const uint32_t *__restrict__ t32 = desc + (size_t)ft * cap * 8;
+    v4i_t B[TT][4];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        int t = (tile0 + i) * kTileRows + r;
+        t = t < nt ? t : nt - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) B[i][s] = fp4_from_dword(t32[(size_t)t * 8 + 2 * s + h]);
+    }
+    v16f_t C;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)(kMfmaBias - 4096 - tile_row(reg, h));
+    int best[TT], bestT[TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        best[i] = 0; // below every valid entry (their patterns are >= 0x4B000000)
+        bestT[i] = 0;
+    }
+
+    // expansion role of this thread: piece o = s * 64 + h * 32 + r of a tile = dword 2 s + h of row r
+    const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
+    const int es = tid >> 6, eh = (tid >> 5) & 1, er = tid & 31;
+    auto expand_chunk = [&](int buf, int Tc) {
+#pragma unroll
+        for (int j = 0; j < kFuseChunk; ++j) {
+            const int T = Tc + j;
+            if (T < T1) {
+                const int row = T * kTileRows + er;
+                v4i_t e = {0, 0, 0, 0}; // rows beyond the frame: 0.0 in FP4 (masked by the accumulator start anyway)
+                if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * es + eh]);
+                s_a[buf][j][tid] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+            }
+        }
+    };
+    if (T0 < T1) expand_chunk(0, T0);
+    __syncthreads();
+    int c = 0;
+    for (int Tc = T0; Tc < T1; Tc += kFuseChunk, ++c) {
+        if (Tc + kFuseChunk < T1) expand_chunk((c + 1) & 1, Tc + kFuseChunk);
+#pragma unroll 1
+        for (int j = 0; j < kFuseChunk; ++j) {
+            const int T = Tc + j;
+            if (T >= T1) break;
+            v4i_t A[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint4 a = s_a[c & 1][j][s * 64 + lane];
+                A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
+            }
+            v16f_t Cin = C;
+            if (T * kTileRows + kTileRows > nq) { // last, partial query tile: rows beyond nq can never win
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    if (T * kTileRows + tile_row(reg, h) >= nq) Cin[reg] = kMfmaNoRow;
+            }
+#pragma unroll
+            for (int i = 0; i < TT; ++i) {
+                v16f_t acc = mfma_fp4(A[0], B[i][0], Cin);
+                acc = mfma_fp4(A[1], B[i][1], acc);
+                acc = mfma_fp4(A[2], B[i][2], acc);
+                acc = mfma_fp4(A[3], B[i][3], acc);
+                const int m = max16(acc);
+                if (m > (best[i] | 31)) { // strictly smaller distance only: the earlier (lower) query tile keeps a tie
+                    best[i] = m;
+                    bestT[i] = T;
+                }
+            }
+        }
+        __syncthreads(); // chunk c + 1 is complete, chunk c may be overwritten
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int t = (tile0 + i) * kTileRows + r;
+        uint32_t key = kNoKey;
+        if (best[i] > 0) {
+            const int v = kMfmaBias - (best[i] & 0x7FFFFF); // 32 * hamming + row of the tile
+            key = ((uint32_t)(v >> 5) << 16) | (uint32_t)(bestT[i] * kTileRows + (v & 31));
+        }
+        const uint32_t other = (uint32_t)__shfl_xor((int)key, 32, 64); // the other half's 16 rows of every tile
+        key = other < key ? other : key;
+        if (h == 0 && t < nt) {
+            if (qsplit == 1)
+                keys[(size_t)p * cap + t] = key;
+            else
+                atomicMin(&keys[(size_t)p * cap + t], key);
+        }
+    }
+}
+
 } // namespace psdev

@@ -394,3 +394,32 @@ def test_maximum_keypoints_batch_with_coresident_workgroups(ctx, oracle):
         c = oracle.match_hamming256(desc[p], desc[p + 1])
         k = int(outs[0]["numMatches"][p])
         assert k == len(c) and outs[0]["matches"][p, :k].tobytes() == c.tobytes(), p
+
+
+def test_stream_graph_key_separates_kernel_variants(oracle):
+    """The streaming call replays a captured hipGraph while its key (parameters, kernel variants, arena) is unchanged.
+    Changing a kernel-variant option after warm-up must change the key: the next push is enqueued afresh with the newly
+    selected kernels ("matcher_used" is written when a push is ENQUEUED, not when a graph is replayed -- with the key's
+    variant fields overlapping, as in round 2, it kept reporting the old kernel), and poses stay the oracle's."""
+    from putslam_amd import api
+    c = api.Context(0)
+    c.set_option("matcher", 1)
+    seq = synth.make_sequence(9, 700, config=3, index=55)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    st = api.VoStream(c, 700)
+    poses = []
+    for f in range(9):
+        if f == 5:
+            c.set_option("matcher", 0)          # after the graphs of both slots were captured and replayed
+            c.set_option("score", 0)
+        cfg, _ = make_config(EST_RANSAC, 487, seed=900 + f)
+        r = st.push(prm, cfg, TUM_FR1_K, seq["desc"][f], seq["pts"][f])
+        if f in (4, 8):
+            assert c.get_option("matcher_used") == (1 if f == 4 else 0), f
+        if f > 0:
+            poses.append(r["pose"])
+            m = oracle.match_hamming256(seq["desc"][f - 1], seq["desc"][f])
+            want = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, seq["pts"][f - 1], seq["pts"][f], m)
+            assert r["pose"].tobytes() == want["pose"].tobytes(), f
+    st.close()
+    c.close()

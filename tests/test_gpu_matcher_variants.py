@@ -1,5 +1,6 @@
-"""Kernel 1 twins: the FP4 matrix-core sweep (ps_hamming_mfma, default) and the integer VALU sweep
-(ps_hamming_nn) must both reproduce the oracle's BFMatcher(NORM_HAMMING, crossCheck=true) list bit for bit
+"""Kernel 1 triplets: the FP4 matrix-core sweep with the query tiles expanded by the work-group itself
+(ps_hamming_mfma_fused, default), the same sweep reading an FP4 image written by a launch of its own (ps_hamming_mfma,
+round 2's form) and the integer VALU sweep (ps_hamming_nn) must all reproduce the oracle's BFMatcher(NORM_HAMMING, crossCheck=true) list bit for bit
 (reference src/Matcher/matcherOpenCV.cpp:100-105,198-206)."""
 import numpy as np
 import pytest
@@ -8,14 +9,15 @@ from putslam_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [("mfma", 1), ("valu", 0)]
+VARIANTS = [("mfma-fused", 1, 1), ("mfma-image", 1, 0), ("valu", 0, 0)]
 
 
 @pytest.fixture(scope="module", params=VARIANTS, ids=[v[0] for v in VARIANTS])
 def vctx(request):
     c = api.Context(0)
     c.set_option("matcher", request.param[1])
-    assert c.get_option("matcher") == request.param[1]
+    c.set_option("matcher_fused", request.param[2])
+    assert c.get_option("matcher") == request.param[1] and c.get_option("matcher_fused") == request.param[2]
     yield c
     c.close()
 
@@ -92,23 +94,25 @@ def test_variants_agree_on_a_batch(oracle):
     prm = default_ransac_params(REPROJECTION_ERROR)
     cfg, _ = make_config(EST_RANSAC, 487, seed=4242)
     outs = []
-    for kind in (1, 0):
+    for kind, fused in ((1, 1), (0, 0), (1, 0)):
         c = api.Context(0)
         c.set_option("matcher", kind)
+        c.set_option("matcher_fused", fused)
         fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
         pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
         run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb, use_torch_stream=False)
         c.synchronize()
         outs.append(pb.download())
         c.close()
-    a, b = outs
-    assert np.array_equal(a["numMatches"], b["numMatches"])
-    for p in range(len(seq["pairs"])):
-        n = int(a["numMatches"][p])
-        assert a["matches"][p][:n].tobytes() == b["matches"][p][:n].tobytes()
-        assert np.array_equal(a["inlierMask"][p][:n], b["inlierMask"][p][:n])
-    assert a["pose"].tobytes() == b["pose"].tobytes()
-    assert a["stats"].tobytes() == b["stats"].tobytes()
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["numMatches"], b["numMatches"])
+        for p in range(len(seq["pairs"])):
+            n = int(a["numMatches"][p])
+            assert a["matches"][p][:n].tobytes() == b["matches"][p][:n].tobytes()
+            assert np.array_equal(a["inlierMask"][p][:n], b["inlierMask"][p][:n])
+        assert a["pose"].tobytes() == b["pose"].tobytes()
+        assert a["stats"].tobytes() == b["stats"].tobytes()
     for p in (0, 3, 7):
         f0, f1 = seq["pairs"][p]
         n0, n1 = int(seq["nkpts"][f0]), int(seq["nkpts"][f1])
