@@ -352,6 +352,7 @@ def main():
                                                               int(s["numMatchesValid"]), Hs) for s in stats]))
         kern = {k: (v[0] / max(v[1], 1)) for k, v in totals.items()}   # timed region: average launch duration, ms
         matcher = "mfma" if ctx.get_option("matcher_used") == 1 else "valu"   # what this workload's calls ran
+        matcher_fused = bool(ctx.get_option("matcher_fused")) and matcher == "mfma"
         score = ({1: "fast", 2: "mfma"}.get(ctx.get_option("score"), "exact") if args.error_version == 1 else
                  ("fast" if (args.error_version in (0, 4) and ctx.get_option("score") >= 1) else "exact"))
 
@@ -429,7 +430,7 @@ def main():
                 "world_size": (dist.get_world_size() if world > 1 else 1),
                 "backend": (dist.get_backend() if world > 1 else None), "shard": args.shard,
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "join": args.join,
-                "matcher_kernel": matcher, "score_kernel": score,
+                "matcher_kernel": matcher + ("-fused" if matcher_fused else ""), "score_kernel": score,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
                 "mean_inliers": float(stats["numInliers"].mean()),
