@@ -106,6 +106,15 @@ PS_D v16f_t mfma_fp4(const v4i_t &a, const v4i_t &b, const v16f_t &c)
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);
 }
 
+// The same instruction in its block-scaled form with the uniform scales 2^9 (A side) and 2^0 (B side): E8M0 bytes 136 and
+// 127 in every byte of the scale operands, so that the result does not depend on which byte a lane's block takes.
+PS_D v16f_t mfma_fp4s(const v4i_t &a, const v4i_t &b, const v16f_t &c)
+{
+    const v8i_t a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+    const v8i_t b8 = __builtin_shufflevector(b, b, 0, 1, 2, 3, -1, -1, -1, -1);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, (int)0x88888888u, 0, (int)0x7F7F7F7Fu);
+}
+
 PS_D int fbits(float f) { return __builtin_bit_cast(int, f); }
 PS_D int imax3(int a, int b, int c) { return max(max(a, b), c); }
 // maximum of the 16 accumulator entries as integer bit patterns (valid entries are >= +0.0f)
@@ -268,6 +277,18 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
 // 2000-row frame repeat each other's expansion, which costs about what the separate launch did (0.036 ms per 499 pairs)
 // and removes 0.29 GB of traffic per step and one launch.
 // ------------------------------------------------------------------------------------------
+// PS_MFMA_SCALED: block-scaled MFMA + add/max epilogue (10 instead of 13 vector instructions per 32 x 32 tile);
+// PS_MFMA_LUT: the 8 bits -> 8 nibbles expansion through a 256-entry table in LDS (2 vector instructions + one LDS read per
+// byte instead of 7).  On gfx950 MFMA and vector instructions of a SIMD do not overlap -- not across waves and, as the
+// software-pipelined epilogue tried here showed (profiles/r03h: 0.232 ms either way), not inside one wave either -- so this
+// kernel's time is its 512 matrix cycles PLUS its ~90 vector instructions per query tile and wave, and only removing
+// vector instructions shortens it.
+#ifndef PS_MFMA_SCALED
+#define PS_MFMA_SCALED 1
+#endif
+#ifndef PS_MFMA_LUT
+#define PS_MFMA_LUT 1
+#endif
 constexpr int kFuseChunk = 4; // query tiles per chunk: 2 x 4 x 4 KiB = 32 KiB of LDS per work-group
 
 template <int TT>
@@ -277,6 +298,10 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
                                                                 int groups, int qsplit, uint32_t *__restrict__ keys)
 {
     __shared__ uint4 s_a[2][kFuseChunk][kTileU4];
+#if PS_MFMA_LUT
+    __shared__ uint32_t s_lut[256]; // byte -> its 8 FP4 nibbles
+    s_lut[threadIdx.x] = fp4_from_byte(threadIdx.x);
+#endif
     const unsigned perPair = (unsigned)(groups * qsplit);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int p = (int)(L / perPair);
@@ -303,7 +328,11 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     }
     v16f_t C;
 #pragma unroll
+#if PS_MFMA_SCALED
+    for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)((1 << 21) + 31 - tile_row(reg, h));
+#else
     for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)(kMfmaBias - 4096 - tile_row(reg, h));
+#endif
     int best[TT], bestT[TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
@@ -314,62 +343,108 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     // expansion role of this thread: piece o = s * 64 + h * 32 + r of a tile = dword 2 s + h of row r
     const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
     const int es = tid >> 6, eh = (tid >> 5) & 1, er = tid & 31;
+    // The last query tile of a frame may be partial (rows beyond nq must never win: their accumulators start from -1e30).
+    // It is taken out of the main loop: left inside, the compiler turns the rare masking into 16 compares + 16 selects for
+    // EVERY tile (50 of the 126 vector instructions per tile this kernel had, profiles/r03h).
+    const int lastT = (nq & (kTileRows - 1)) ? nqTiles - 1 : -1;
+    const bool hasPartial = lastT >= T0 && lastT < T1;
+    const int Tm = hasPartial ? lastT : T1; // main loop: whole tiles [T0, Tm)
+    auto expand_tile = [&](uint4 *dst, int T) {
+        const int row = T * kTileRows + er;
+        v4i_t e = {0, 0, 0, 0}; // rows beyond the frame: 0.0 in FP4 (masked by the accumulator start anyway)
+#if PS_MFMA_LUT
+        if (row < nq) {
+            const uint32_t w = q32[(size_t)row * 8 + 2 * es + eh];
+            e.x = (int)s_lut[w & 0xFFu];
+            e.y = (int)s_lut[(w >> 8) & 0xFFu];
+            e.z = (int)s_lut[(w >> 16) & 0xFFu];
+            e.w = (int)s_lut[w >> 24];
+        }
+#else
+        if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * es + eh]);
+#endif
+        dst[tid] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+    };
     auto expand_chunk = [&](int buf, int Tc) {
 #pragma unroll
-        for (int j = 0; j < kFuseChunk; ++j) {
-            const int T = Tc + j;
-            if (T < T1) {
-                const int row = T * kTileRows + er;
-                v4i_t e = {0, 0, 0, 0}; // rows beyond the frame: 0.0 in FP4 (masked by the accumulator start anyway)
-                if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * es + eh]);
-                s_a[buf][j][tid] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+        for (int j = 0; j < kFuseChunk; ++j)
+            if (Tc + j < Tm) expand_tile(s_a[buf][j], Tc + j);
+    };
+    // one query tile against this wave's TT train tiles
+    auto tile_body = [&](int T, const uint4 *__restrict__ tile, const v16f_t &Cin) {
+        v4i_t A[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 a = tile[s * 64 + lane];
+            A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
+        }
+#if PS_MFMA_SCALED
+        // block-scaled MFMA: every product carries 2^9, the accumulator's mantissa is 2^14 (256 - hamming) + (31 - row);
+        // adding the tile's 16352 - 32 T turns it into 2^14 (256 - hamming) + (16383 - query row), whose maximum over rows
+        // AND tiles is the nearest query, lowest index first: 8 v_max3 + add + max per 32 x 32 tile
+        const int cT = 16352 - 32 * T;
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            v16f_t acc = mfma_fp4s(A[0], B[i][0], Cin);
+            acc = mfma_fp4s(A[1], B[i][1], acc);
+            acc = mfma_fp4s(A[2], B[i][2], acc);
+            acc = mfma_fp4s(A[3], B[i][3], acc);
+            best[i] = max(best[i], max16(acc) + cT);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            v16f_t acc = mfma_fp4(A[0], B[i][0], Cin);
+            acc = mfma_fp4(A[1], B[i][1], acc);
+            acc = mfma_fp4(A[2], B[i][2], acc);
+            acc = mfma_fp4(A[3], B[i][3], acc);
+            const int m = max16(acc);
+            if (m > (best[i] | 31)) { // strictly smaller distance only: the earlier (lower) query tile keeps a tie
+                best[i] = m;
+                bestT[i] = T;
             }
         }
+#endif
     };
-    if (T0 < T1) expand_chunk(0, T0);
+#if PS_MFMA_LUT
+    __syncthreads(); // the table is complete
+#endif
+    if (T0 < Tm) expand_chunk(0, T0);
     __syncthreads();
     int c = 0;
-    for (int Tc = T0; Tc < T1; Tc += kFuseChunk, ++c) {
-        if (Tc + kFuseChunk < T1) expand_chunk((c + 1) & 1, Tc + kFuseChunk);
+    for (int Tc = T0; Tc < Tm; Tc += kFuseChunk, ++c) {
+        if (Tc + kFuseChunk < Tm) expand_chunk((c + 1) & 1, Tc + kFuseChunk);
 #pragma unroll 1
         for (int j = 0; j < kFuseChunk; ++j) {
-            const int T = Tc + j;
-            if (T >= T1) break;
-            v4i_t A[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint4 a = s_a[c & 1][j][s * 64 + lane];
-                A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
-            }
-            v16f_t Cin = C;
-            if (T * kTileRows + kTileRows > nq) { // last, partial query tile: rows beyond nq can never win
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    if (T * kTileRows + tile_row(reg, h) >= nq) Cin[reg] = kMfmaNoRow;
-            }
-#pragma unroll
-            for (int i = 0; i < TT; ++i) {
-                v16f_t acc = mfma_fp4(A[0], B[i][0], Cin);
-                acc = mfma_fp4(A[1], B[i][1], acc);
-                acc = mfma_fp4(A[2], B[i][2], acc);
-                acc = mfma_fp4(A[3], B[i][3], acc);
-                const int m = max16(acc);
-                if (m > (best[i] | 31)) { // strictly smaller distance only: the earlier (lower) query tile keeps a tie
-                    best[i] = m;
-                    bestT[i] = T;
-                }
-            }
+            if (Tc + j >= Tm) break;
+            tile_body(Tc + j, s_a[c & 1][j], C);
         }
         __syncthreads(); // chunk c + 1 is complete, chunk c may be overwritten
+    }
+    if (hasPartial) { // (work-group uniform)
+        expand_tile(s_a[0][0], lastT);
+        __syncthreads();
+        v16f_t Cin = C;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if (lastT * kTileRows + tile_row(reg, h) >= nq) Cin[reg] = kMfmaNoRow;
+        tile_body(lastT, s_a[0][0], Cin);
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
         const int t = (tile0 + i) * kTileRows + r;
         uint32_t key = kNoKey;
+#if PS_MFMA_SCALED
+        if (best[i] > 0) {
+            const int d = best[i] & 0x7FFFFF; // 2^14 (256 - hamming) + (16383 - query row)
+            key = ((uint32_t)(256 - (d >> 14)) << 16) | (uint32_t)(16383 - (d & 0x3FFF));
+        }
+#else
         if (best[i] > 0) {
             const int v = kMfmaBias - (best[i] & 0x7FFFFF); // 32 * hamming + row of the tile
             key = ((uint32_t)(v >> 5) << 16) | (uint32_t)(bestT[i] * kTileRows + (v & 31));
         }
+#endif
         const uint32_t other = (uint32_t)__shfl_xor((int)key, 32, 64); // the other half's 16 rows of every tile
         key = other < key ? other : key;
         if (h == 0 && t < nt) {
