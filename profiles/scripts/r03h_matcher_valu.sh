@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/r03h}
 mkdir -p $out
 for rep in 1 2; do
-for v in "" _tt2 _tt3 _plain; do
+for v in "" _tt6 _tt8; do
   lib=$PWD/putslam_amd/libputslam_hip$v.so
   [ -f $lib ] || continue
   PUTSLAM_HIP_LIB=$lib python3 bench.py --streams 1 --steps 10 --warmup 5 --repeats 3 --error-version 0 --estimator ransac --hyp 487 --no-cpu-baseline --no-other-modes > $out/E0_ransac487${v}_$rep.json 2>> $out/err.txt
