@@ -401,7 +401,8 @@ def main():
                 sq = json.load(open(os.path.join(ROOT, os.path.dirname(t[key]["_source"]), "sq_counters.json")))
                 for kname, c in sq.items():
                     short = kname.split("<")[0]
-                    short = {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_mfma": "ps_ransac_score"}.get(short, short)
+                    short = {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_mfma": "ps_ransac_score",
+                             "ps_ransac_score_euclid": "ps_ransac_score", "ps_hamming_mfma_fused": "ps_hamming_mfma"}.get(short, short)
                     if short in bounds_solo and c.get("GRBM_GUI_ACTIVE"):
                         cyc = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0      # kernel cycles x SIMDs (8 XCDs report separately)
                         bounds_solo[short]["pipe_busy_pmc"] = {
