@@ -317,7 +317,8 @@ struct Plan {
     SelectArgs sa{};
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
-    bool prune = false; // staged scoring: hypotheses [0, kPrefix) completely (msplit applies to it), the rest in pruned stages
+    bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
+    int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -496,11 +497,12 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
                           (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR && ctx->scoreFast != 0);
     // (the later stages read the models back from HBM, 48 B per hypothesis: ps_score_fast.h)
     const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
-    pl.prune = ctx->prune != 0 && prunable && H > kPrefix && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
+    pl.prefix = pl.sa.estimator == PS_EST_FIXED ? kPrefixFixed : kPrefixAdaptive;
+    pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
     pl.pa.zeroCounts = pl.msplit > 1 ? (int32_t *)ctx->counts.p : nullptr;
-    pl.pa.zeroH = pl.prune ? kPrefix : H;
+    pl.pa.zeroH = pl.prune ? pl.prefix : H;
     pl.pa.zeroStride = H;
     pl.ma.models = nullptr;
     if ((P <= kWidePairs && mbytes <= ((size_t)64 << 20)) || pl.prune) {
@@ -541,8 +543,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
-        st.hBase = stage == 0 ? 0 : kPrefix;
-        st.hCount = stage == 0 ? kPrefix : pl.H - kPrefix;
+        st.hBase = stage == 0 ? 0 : pl.prefix;
+        st.hCount = stage == 0 ? pl.prefix : pl.H - pl.prefix;
         int32_t *nA = (int32_t *)ctx->survN.p, *nB = nA + P;
         if (stage == 1) { st.listOut = (int32_t *)ctx->survA.p; st.countOut = nA; }
         if (stage == 2) { st.listIn = (const int32_t *)ctx->survA.p; st.countIn = nA; st.listOut = (int32_t *)ctx->survB.p; st.countOut = nB; }
@@ -559,8 +561,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
 #define PS_LAUNCH_EUCLID(MODE)                                                                                         \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
-            PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(0), kPrefix, msplit);                                          \
-            for (int sg = 1; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(sg), pl.H - kPrefix, 1); \
+            PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(0), pl.prefix, msplit);                                          \
+            for (int sg = 1; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(sg), pl.H - pl.prefix, 1); \
         } else                                                                                                         \
             PS_LAUNCH_EUCLID_ONE(MODE, false, stNone, pl.H, msplit);                                                   \
     } while (0)
@@ -604,11 +606,11 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
             if ((unsigned)msplit * (unsigned)P > (BIGLIMIT))                                                           \
-                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(0), kPrefix, msplit);                                  \
+                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(0), pl.prefix, msplit);                                  \
             else                                                                                                       \
-                PS_LAUNCH_FAST_ONE(MODE, false, true, stage_args(0), kPrefix, msplit);                                 \
+                PS_LAUNCH_FAST_ONE(MODE, false, true, stage_args(0), pl.prefix, msplit);                                 \
             for (int sg = 1; sg <= kStages; ++sg)                                                                      \
-                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(sg), pl.H - kPrefix, 1);                               \
+                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(sg), pl.H - pl.prefix, 1);                               \
         } else if (grid.x > (BIGLIMIT))                                                                                \
             PS_LAUNCH_FAST_ONE(MODE, true, false, stNone, pl.H, msplit);                                               \
         else                                                                                                           \

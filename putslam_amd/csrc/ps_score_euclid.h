@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
-        stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);
+        stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st.stage, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (st.stage == 1) {
@@ -134,6 +134,8 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             if (i < n) cnt0 = cout[h]; // count so far
         }
     }
+
+    if (STAGED && hFirstOfWave(h, lane) >= hEnd) return; // a wavefront without a hypothesis of its own (ps_score_fast.h)
 
     Rigid mdl, inv;
     set_identity(mdl);

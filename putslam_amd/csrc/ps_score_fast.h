@@ -133,7 +133,8 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 // count_i > max_{j<i} count_j (strict '>' first-best, RANSAC.cpp:438-455; the arg-max of the fixed schedule takes the
 // lowest index among equals, the same rule), and only while i is below the adaptive trip limit, which from record to
 // record only shrinks (RANSAC.cpp:450-453, USAC.h:944-971).  So a large batch is scored in stages:
-//   stage 0   the first kPrefix = 256 hypotheses of every pair, all matches (the plain launch);
+//   stage 0   the first 256 hypotheses of every pair (64 for the adaptive schedules, whose limit after a few dozen
+//             hypotheses is usually below that already), all matches (the plain launch);
 //   stage 1   every later hypothesis below the trip limit L0 the prefix leaves, matches [0, c1);
 //   stage 2   the SURVIVORS of stage 1, matches [c1, c2);        stage 3   the survivors of stage 2, matches [c2, M).
 // Every work-group of stages 1-3 first replays the selection over the prefix (wave_replay_prefix: the record walk of
@@ -153,7 +154,8 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 // the meaning of counts[] for abandoned hypotheses (a lower bound <= B0 instead of the count), which is why the
 // diagnostic ps_debug_ransac_counts and small batches score completely.
 // ------------------------------------------------------------------------------------------
-constexpr int kPrefix = kBlock; // hypotheses scored completely by stage 0
+constexpr int kPrefixFixed = kBlock; // hypotheses scored completely by stage 0: fixed schedule (arg-max over all H) ...
+constexpr int kPrefixAdaptive = 64;  // ... and RANSAC / USAC schedules (the reference consumes 3 of 487 on good data)
 constexpr int kStages = 3;      // pruned stages after the prefix
 
 struct StageArgs {
@@ -220,6 +222,10 @@ PS_D void stage_range(int stage, int M, int best0, int &lo, int &hi)
     lo = cut[stage - 1];
     hi = cut[stage];
 }
+
+// hypothesis of lane 0 of the calling lane's wavefront (h is consecutive over the lanes, or 0x7FFFFFFF for an idle lane
+// of a survivor list: the wave's first lane then tells whether the whole wave is idle)
+PS_D int hFirstOfWave(int h, int lane) { return __builtin_amdgcn_readfirstlane(h); }
 
 // What every work-group of a pruned stage needs before it starts: the prefix's best count and trip limit (work-group
 // uniform, in SGPRs) -- wave 0 replays, the others wait.
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
-        stage_prefix(cout, kPrefix, sa, M, s_pref, best0, hLimit);
+        stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st.stage, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (st.stage == 1) {
@@ -318,6 +324,10 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         }
         if (st.stage == 1 && st.hBase + (int)bx * kBlock >= hEnd) return;
     }
+
+    // (STAGED: a wavefront without a hypothesis of its own has nothing to do -- the 64-hypothesis prefix of the adaptive
+    // schedules fills one of the four; no barrier follows in any of the launch forms)
+    if (STAGED && hFirstOfWave(h, lane) >= hEnd) return;
 
     Rigid mdl, inv;
     set_identity(mdl);
