@@ -551,9 +551,10 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage == 3) { st.listIn = (const int32_t *)ctx->survB.p; st.countIn = nB; }
         return st;
     };
-    const StageArgs stNone{};
-#define PS_LAUNCH_EUCLID_ONE(MODE, STAGED, ST, HCOUNT, MSPLIT)                                                         \
-    hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, STAGED>),                                                         \
+    StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
+    stAll.hCount = pl.H;
+#define PS_LAUNCH_EUCLID_ONE(MODE, KIND, ST, HCOUNT, MSPLIT)                                                           \
+    hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, KIND>),                                                           \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
                        (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,       \
@@ -561,10 +562,11 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
 #define PS_LAUNCH_EUCLID(MODE)                                                                                         \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
-            PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(0), pl.prefix, msplit);                                          \
-            for (int sg = 1; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, true, stage_args(sg), pl.H - pl.prefix, 1); \
+            PS_LAUNCH_EUCLID_ONE(MODE, 0, stage_args(0), pl.prefix, msplit);                                           \
+            PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
+            for (int sg = 2; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), pl.H - pl.prefix, 1);  \
         } else                                                                                                         \
-            PS_LAUNCH_EUCLID_ONE(MODE, false, stNone, pl.H, msplit);                                                   \
+            PS_LAUNCH_EUCLID_ONE(MODE, 0, stAll, pl.H, msplit);                                                        \
     } while (0)
     switch (pl.mode) {
     case PS_EUCLIDEAN_ERROR:
@@ -594,8 +596,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
             // more work-groups than fit at once (256 CUs x 6): the build for big launches (ps_score_fast.h)
-#define PS_LAUNCH_FAST_ONE(MODE, BIG, STAGED, ST, HCOUNT, MSPLIT)                                                      \
-    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, STAGED>),                                                      \
+#define PS_LAUNCH_FAST_ONE(MODE, BIG, KIND, ST, HCOUNT, MSPLIT)                                                        \
+    hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, KIND>),                                                        \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
                        (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p,          \
@@ -606,15 +608,16 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
             if ((unsigned)msplit * (unsigned)P > (BIGLIMIT))                                                           \
-                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(0), pl.prefix, msplit);                                  \
+                PS_LAUNCH_FAST_ONE(MODE, true, 0, stage_args(0), pl.prefix, msplit);                                   \
             else                                                                                                       \
-                PS_LAUNCH_FAST_ONE(MODE, false, true, stage_args(0), pl.prefix, msplit);                                 \
-            for (int sg = 1; sg <= kStages; ++sg)                                                                      \
-                PS_LAUNCH_FAST_ONE(MODE, true, true, stage_args(sg), pl.H - pl.prefix, 1);                               \
+                PS_LAUNCH_FAST_ONE(MODE, false, 0, stage_args(0), pl.prefix, msplit);                                  \
+            PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
+            for (int sg = 2; sg <= kStages; ++sg)                                                                      \
+                PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), pl.H - pl.prefix, 1);                                \
         } else if (grid.x > (BIGLIMIT))                                                                                \
-            PS_LAUNCH_FAST_ONE(MODE, true, false, stNone, pl.H, msplit);                                               \
+            PS_LAUNCH_FAST_ONE(MODE, true, 0, stAll, pl.H, msplit);                                                    \
         else                                                                                                           \
-            PS_LAUNCH_FAST_ONE(MODE, false, false, stNone, pl.H, msplit);                                              \
+            PS_LAUNCH_FAST_ONE(MODE, false, 0, stAll, pl.H, msplit);                                                   \
     } while (0)
             PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, 1536u);
         } else

@@ -82,9 +82,9 @@ template <int MODE> PS_D EuclidRec<MODE> load_euclid_rec(const float2 *__restric
     return r;
 }
 
-// STAGED: a launch of the staged scoring (ps_score_fast.h, "Staged scoring"); the plain form scores every hypothesis of
-// [0, H) completely.
-template <int MODE, bool STAGED = false>
+// KIND (ps_score_fast.h): 0 = the hypotheses [hBase, hBase + hCount) completely (plain launch, stage 0), 1 = stage 1,
+// 2 = stages 2+ of the staged scoring.
+template <int MODE, int KIND = 0>
 __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_euclid(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
     const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
@@ -93,36 +93,38 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
 {
     static_assert(MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR, "the Euclidean metrics");
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? kEuclidRecFloats4 : kEuclidRecFloats0;
-    __shared__ float s_mdl[12][kBlock];
+    __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
     __shared__ int s_pref[2];
 
     // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
-    const int hCount = STAGED ? st.hCount : H;
+    const int hCount = st.hCount;
     const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: keep it and what hangs on it scalar)
     const size_t rbase = (size_t)p * cap;
     int32_t *__restrict__ cout = counts + (size_t)p * H;
-    int h = (STAGED ? st.hBase : 0) + (int)bx * kBlock + tid;
-    int hEnd = STAGED ? st.hBase + st.hCount : H; // this lane scores hypothesis h if h < hEnd
+    int h = st.hBase + (int)bx * kBlock + tid;
+    int hEnd = st.hBase + st.hCount; // this lane scores hypothesis h if h < hEnd
     // the match range is split on match PAIRS (the packed loop takes two matches per step)
     const int npair = (M + 1) >> 1;
     int m0 = 2 * (int)(((long long)npair * by) / msplit);
     int m1 = 2 * (int)(((long long)npair * (by + 1)) / msplit);
     m1 = m1 < M ? m1 : M;
-    int best0 = 0, cnt0 = 0;
-    const bool pruned = STAGED && st.stage >= 1;
-    if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
+    int best0 = 0;
+    constexpr bool LIST = KIND == 2; // stage >= 2: hypotheses from the survivor list, models from HBM
+    constexpr bool pruned = KIND >= 1;
+    if (LIST && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st.stage, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
-        if (st.stage == 1) {
+        if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
             if (st.hBase + (int)bx * kBlock >= hEnd) return;
         } else {
@@ -131,25 +133,34 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             if ((int)bx * kBlock >= n) return;
             hEnd = 0x7FFFFFFF;
             h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
-            if (i < n) cnt0 = cout[h]; // count so far
         }
     }
 
-    if (STAGED && hFirstOfWave(h, lane) >= hEnd) return; // a wavefront without a hypothesis of its own (ps_score_fast.h)
+    if (hFirstOfWave(h, lane) >= hEnd) return; // a wavefront without a hypothesis of its own (ps_score_fast.h)
 
     Rigid mdl, inv;
     set_identity(mdl);
     set_identity(inv);
     bool valid = false;
-    if (pruned && st.stage >= 2) {
+    if (LIST) {
         if (h < hEnd) {
             load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
             valid = true;
         }
     } else {
-        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        // (s_mdl is free until the model exists: stage 1 lets the means and the SVD's left factor wait there)
+        if (h < hEnd) {
+            if (KIND == 1)
+                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl,
+                                  LdsPark(&s_mdl[0][tid], kBlock));
+            else
+                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        }
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
-        if (ma.models && by == 0 && h < hEnd && !pruned) store_model(ma, (size_t)p * H + h, mdl);
+        if (ma.models && by == 0 && !pruned) {
+            const int hs = stage_hypothesis_again(false, st, (int)bx, tid, p, H); // (ps_score_fast.h)
+            if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -269,25 +280,30 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
         }
     }
+    int tidE = tid; // (a fresh copy for the epilogue's LDS addresses: kept alive across the loops they went to scratch memory)
+    asm volatile("" : "+v"(tidE));
     if (pruned) {
+        h = stage_hypothesis_again(LIST, st, (int)bx, tid, p, H);
         const bool mine = h < hEnd;
+        const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
         const bool alive = mine && valid && total + (M - m1) > best0;
-        if (st.stage == 1 && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
+        if (!LIST && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
-                md.t[i] = s_mdl[9 + i][tid];
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tidE];
+                md.t[i] = s_mdl[9 + i][tidE];
             }
             store_model(ma, (size_t)p * H + h, md);
         }
         if (st.stage < kStages && m1 < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
         return;
     }
+    h = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
     if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)

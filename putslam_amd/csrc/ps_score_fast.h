@@ -159,7 +159,8 @@ constexpr int kPrefixAdaptive = 64;  // ... and RANSAC / USAC schedules (the ref
 constexpr int kStages = 3;      // pruned stages after the prefix
 
 struct StageArgs {
-    int stage;                 // 0 = plain launch over [hBase, hBase + hCount), all matches; 1 .. kStages = pruned stages
+    int stage;                 // 0 = the hypotheses [hBase, hBase + hCount) completely (the plain launch: [0, H)); 1 .. kStages
+                               // = pruned stages
     int hBase, hCount;         // stage 0 / 1: the hypothesis range of this launch
     const int32_t *listIn;     // stage >= 2: survivors of the previous stage, [P][H] hypothesis indices ...
     const int32_t *countIn;    //             ... and how many per pair
@@ -218,9 +219,9 @@ PS_D void stage_range(int stage, int M, int best0, int &lo, int &hi)
             if (c2 >= M - M / 16) c2 = M;
         }
     }
-    const int cut[kStages + 1] = {0, c1, c2, M};
-    lo = cut[stage - 1];
-    hi = cut[stage];
+    static_assert(kStages == 3, "three pruned stages");
+    lo = stage == 1 ? 0 : (stage == 2 ? c1 : c2); // (selects, not an indexed array: that would live in scratch memory)
+    hi = stage == 1 ? c1 : (stage == 2 ? c2 : M);
 }
 
 // hypothesis of lane 0 of the calling lane's wavefront (h is consecutive over the lanes, or 0x7FFFFFFF for an idle lane
@@ -258,7 +259,19 @@ PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t
     int base = 0;
     if (lane == __builtin_ctzll(am)) base = atomicAdd(&countOut[p], __popcll(am));
     base = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
-    if (alive) listOut[(size_t)p * H + base + __popcll(am & ((1ull << lane) - 1ull))] = h;
+    if (alive) listOut[(size_t)p * H + base + lanes_below(am)] = h;
+}
+
+// The hypothesis of a lane, derived AGAIN at the end of a staged launch from values that cost no vector register in between
+// (the scalar work-group offset passes through an empty asm, so that the compiler cannot keep the first derivation -- or
+// the 64-bit addresses built on it -- alive across the loops: at seven waves per SIMD it kept them in scratch memory).
+PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int bx, int tid, int p, int H)
+{
+    int base = (int)bx * kBlock;
+    asm volatile("" : "+s"(base));
+    if (!list) return st.hBase + base + tid;
+    const int i = base + tid;
+    return i < st.countIn[p] ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF;
 }
 
 // Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
@@ -272,8 +285,15 @@ PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t
 // per-lane limits lo / hi; "inlier" needs both certain, one certain "outlier" suffices, anything else is parked and decided by
 // inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel; five
 // waves per SIMD (the second model costs 12 registers).
-// STAGED: a launch of the staged scoring (stage 0 included); the plain form scores every hypothesis of [0, H) completely.
-template <int MODE, bool BIG, bool STAGED = false>
+// KIND: what the launch scores (StageArgs).  0 = the hypotheses [hBase, hBase + hCount) completely -- the plain launch over
+// [0, H) and stage 0 of the staged scoring; 1 = stage 1 (generates its models, first match range); 2 = stages 2+ (models and
+// hypothesis list read back).  Builds of their own because the sample -> Umeyama -> SVD prologue is what the register
+// budget of seven waves cannot hold: left to the register allocator 12 ... 19 values per lane went to scratch memory, i.e.
+// through HBM (0.4 GB per 499 pairs in all, profiles/r03i).  Kind 1 -- almost all prologues of a large batch -- keeps the
+// SVD's left factor and the means in LDS meanwhile (LdsPark), kind 2 has no SVD, kind 0 is small or latency-bound (a single
+// pair, the 64-hypothesis prefix: 0.065 against 0.079 ms per 499 pairs with the LDS form) and keeps the register form;
+// the epilogues derive the hypothesis index again instead of keeping it.
+template <int MODE, bool BIG, int KIND = 0>
 __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
@@ -284,35 +304,37 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
                   "the metrics with a reprojection test");
     constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
-    __shared__ float s_mdl[12][kBlock];
+    __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
     __shared__ int s_pref[2];
 
     // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
-    const int hCount = STAGED ? st.hCount : H;
+    const int hCount = st.hCount;
     const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: keep it and what hangs on it scalar)
     const size_t rbase = (size_t)p * cap;
     int32_t *__restrict__ cout = counts + (size_t)p * H;
-    int h = (STAGED ? st.hBase : 0) + (int)bx * kBlock + tid;
-    int hEnd = STAGED ? st.hBase + st.hCount : H; // this lane scores hypothesis h if h < hEnd
+    int h = st.hBase + (int)bx * kBlock + tid;
+    int hEnd = st.hBase + st.hCount; // this lane scores hypothesis h if h < hEnd
     int m0 = (int)(((long long)M * by) / msplit);
     int m1 = (int)(((long long)M * (by + 1)) / msplit);
-    int best0 = 0, cnt0 = 0;
-    const bool pruned = STAGED && st.stage >= 1;
-    if (pruned && st.stage >= 2 && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
+    int best0 = 0;
+    constexpr bool LIST = KIND == 2; // stage >= 2: hypotheses from the survivor list, models from HBM
+    constexpr bool pruned = KIND >= 1;
+    if (LIST && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st.stage, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
-        if (st.stage == 1) {
+        if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
         } else {
             const int n = st.countIn[p];
@@ -320,29 +342,37 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             hEnd = 0x7FFFFFFF;
             h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
             if ((int)bx * kBlock >= n) return;
-            if (i < n) cnt0 = cout[h]; // count so far
         }
-        if (st.stage == 1 && st.hBase + (int)bx * kBlock >= hEnd) return;
+        if (!LIST && st.hBase + (int)bx * kBlock >= hEnd) return;
     }
 
-    // (STAGED: a wavefront without a hypothesis of its own has nothing to do -- the 64-hypothesis prefix of the adaptive
+    // (a wavefront without a hypothesis of its own has nothing to do -- the 64-hypothesis prefix of the adaptive
     // schedules fills one of the four; no barrier follows in any of the launch forms)
-    if (STAGED && hFirstOfWave(h, lane) >= hEnd) return;
+    if (hFirstOfWave(h, lane) >= hEnd) return;
 
-    Rigid mdl, inv;
+    Rigid mdl;
     set_identity(mdl);
     bool valid = false;
-    if (pruned && st.stage >= 2) {
+    if (LIST) {
         if (h < hEnd) {
             load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
             valid = true;
         }
     } else {
-        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        // (s_mdl is free until the model exists: stage 1 lets the means and the SVD's left factor wait there)
+        if (h < hEnd) {
+            if (KIND == 1)
+                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl,
+                                  LdsPark(&s_mdl[0][tid], kBlock));
+            else
+                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
+        }
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
-        if (ma.models && by == 0 && h < hEnd && !pruned) store_model(ma, (size_t)p * H + h, mdl);
+        if (ma.models && by == 0 && !pruned) {
+            const int hs = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
+            if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+        }
     }
-    inverse_rigid_general(mdl, inv);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -359,29 +389,16 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     const float2 pbnd = pairBound[p];
     const float cmax = pbnd.x, umax = pbnd.y;
 
-    float rho = 0.0f, tau = 0.0f;
-    model_norms(mdl, rho, tau);
-    model_norms(inv, rho, tau);
-    const float S = (rho * cmax + tau) * 1.001f;
-    // (comparisons are false for NaN: a non-finite model, cmax or umax sends the wavefront to the value-exact loop)
-    const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f &&
-                          (!EUCLID || (ec.enabled != 0 && cmax <= 1.0e15f));
+    // The model leaves the registers here: everything below reads it back from LDS.
+    // Everything the hot loop keeps in registers per hypothesis -- the folded models and the band coefficients -- is
+    // (re)built by rebuild() from the model parked in LDS: once before the loop and again after every in-loop drain, so that
+    // none of it has to stay alive across the drain's register-hungry code (kept alive it was spilled to scratch on
+    // every launch: 40 dwords per lane, 349 MB of writes per 499 pairs, profiles/r02d).  The size S the bounds hang on
+    // comes out of the same pass (one general inverse per hypothesis, not two).
     int cnt = 0;
-
-    if (!wave_all(boundsOk)) {
-        for (int m = m0; m < m1; ++m) {
-            const float4 A = pa[m], B = pb[m], C = pc[m];
-            score_accumulate<MODE, false>(mdl, inv, k, A, B, C, cnt);
-        }
-    } else {
-        // mdl: current point -> previous image (estimatedOldPosition, RANSAC.cpp:346);
-        // inv: previous point -> current image (estimatedNewPosition, RANSAC.cpp:348)
-        // Everything the hot loop keeps in registers per hypothesis -- the folded models and the band coefficients -- is
-        // (re)built here from the model parked in LDS: once before the loop and again after every in-loop drain, so that
-        // none of it has to stay alive across the drain's register-hungry code (kept alive it was spilled to scratch on
-        // every launch: 40 dwords per lane, 349 MB of writes per 499 pairs, profiles/r02d).
+    {
         FastModel F;
-        float cL, G2;
+        float cL, G2, S;
         float U[3][4];          // EUCLID: the unfolded model (R | t), current point -> previous frame
         float loE = 0.0f, hiE = 0.0f; // EUCLID: per-lane limits of the squared residual (ps_score_euclid.h)
         // uniform part of the band: E = lambda S, |e_z - Z~| <= 8 u S, G = (sqrt2 lambda + 8 u T') S = g S
@@ -403,7 +420,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             float rho2 = 0.0f, tau2 = 0.0f;
             model_norms(md, rho2, tau2);
             model_norms(iv, rho2, tau2);
-            const float G = ((rho2 * cmax + tau2) * 1.001f) * g;
+            S = (rho2 * cmax + tau2) * 1.001f;
+            const float G = S * g;
             cL = (2.0f * fc.thrUp * G) * (1.00001f * up4);   // 2 T' G, rounded up
             G2 = (G * G) * 1.0001f;
             if (EUCLID) {
@@ -423,6 +441,23 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             }
         };
         rebuild();
+        // (comparisons are false for NaN: a non-finite model, cmax or umax sends the wavefront to the value-exact loop)
+        const bool boundsOk = fc.enabled != 0 && S * fc.fmaxK <= kDivHi && S >= 1.0e-20f && umax <= 1.0e7f &&
+                              (!EUCLID || (ec.enabled != 0 && cmax <= 1.0e15f));
+        if (!wave_all(boundsOk)) {
+            Rigid md, iv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
+                md.t[i] = s_mdl[9 + i][tid];
+            }
+            inverse_rigid_general(md, iv);
+            for (int m = m0; m < m1; ++m) {
+                const float4 A = pa[m], B = pb[m], C = pc[m];
+                score_accumulate<MODE, false>(md, iv, k, A, B, C, cnt);
+            }
+        } else {
         int qn = 0;                      // parked evaluations of this wave (wave-uniform)
         unsigned long long parked = 0;
 
@@ -495,8 +530,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
                     drain();
                     rebuild();
                 }
-                if ((mU >> lane) & 1ull)
-                    s_q[wv][qn + __popcll(mU & ((1ull << lane) - 1ull))] = ((uint32_t)m << 6) | (uint32_t)lane;
+                if (lane_in(mU)) s_q[wv][qn + lanes_below(mU)] = ((uint32_t)m << 6) | (uint32_t)lane;
                 qn += n;
             }
         }
@@ -506,26 +540,32 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             atomicAdd(&dbg[0], parked);
             atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
         }
+        }
     }
+    int tidE = tid; // (a fresh copy for the epilogue's LDS addresses: kept alive across the loops they went to scratch memory)
+    asm volatile("" : "+v"(tidE));
     if (pruned) {
+        h = stage_hypothesis_again(LIST, st, (int)bx, tid, p, H);
         const bool mine = h < hEnd;
+        const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
         const bool alive = mine && valid && total + (M - m1) > best0;
-        if (st.stage == 1 && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
+        if (!LIST && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tid];
-                md.t[i] = s_mdl[9 + i][tid];
+                for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tidE];
+                md.t[i] = s_mdl[9 + i][tidE];
             }
             store_model(ma, (size_t)p * H + h, md);
         }
         if (st.stage < kStages && m1 < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
         return;
     }
+    h = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
     if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)
