@@ -5,6 +5,7 @@ error modes, estimators, thresholds, seeds).  tests/test_gpu_fuzz_slice.py colle
 
     python tests/fuzz_gpu.py --iters 3000 --seed 1
     python tests/fuzz_gpu.py --iters 100000 --procs 8 --modes 0,2,4 --counts     (round 3: the new scoring kernels)
+    python tests/fuzz_gpu.py --batch --iters 400 --procs 4                       (staged scoring: random batches)
 """
 import argparse
 import os
@@ -68,6 +69,77 @@ def run(iters, seed, max_kpts=1500, ctx=None, verbose=True, modes=(0, 1, 2, 4, 3
     return bad
 
 
+STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
+               "accepted", "bestInlierRatio", "pointInlierRatio")
+
+
+def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
+    """Random BATCHES large enough for the staged scoring (ps_score_fast.h): the staged run (option prune = 1) against the
+    complete one (prune = 0: the launch form the single-pair soak above checks against the oracle) on every pair and every
+    output field, and against the oracle on a few pairs of each batch.  Returns the number of batches with a difference."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    bad = 0
+    ctxs = {}
+    for pr in (1, 0):
+        ctxs[pr] = api.Context(0)
+        ctxs[pr].set_option("prune", pr)
+    for it in range(iters):
+        mode = int(rng.choice(list(modes)))
+        est, H = [(EST_RANSAC, int(rng.choice([487, 1157, 2000]))), (EST_USAC, int(rng.integers(300, 5000))),
+                  (EST_FIXED, int(rng.integers(257, 6000)))][int(rng.integers(0, 3))]
+        hb = (H + 255) // 256
+        kpts = int(rng.integers(40, 900))
+        frames = int(max(6, min(400, 300 // max(hb - 1, 1) + int(rng.integers(2, 60)))))  # P (hb - 1) >= 256 most of the time
+        frac = float(rng.uniform(0.05, 0.95))
+        noise = float(10 ** rng.uniform(-4, -1.5))
+        seq = synth.make_sequence(frames, kpts, config=3, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)
+        if rng.random() < 0.3:  # ragged keypoint counts, a few nearly empty frames
+            for f in rng.integers(0, frames, max(1, frames // 8)):
+                seq["nkpts"][f] = int(rng.integers(0, kpts))
+        if rng.random() < 0.2:  # quantised points: groups of bit-identical models and counts (ties)
+            seq["pts"] = (np.round(seq["pts"] * 64) / 64).astype(np.float32)
+        prm = default_ransac_params(mode, lc=bool(rng.integers(0, 2)))
+        prm.inlierThresholdEuclidean = float(10 ** rng.uniform(-2.5, -0.7))
+        prm.inlierThresholdReprojection = float(10 ** rng.uniform(-0.5, 1.2))
+        prm.minimalInlierRatioThreshold = float(rng.choice([0.02, 0.05, 0.1, 0.2, 0.3]))
+        base = int(rng.integers(0, 2 ** 40))
+        cfg, _ = make_config(est, H, seed=base)
+        outs = {}
+        for pr in (1, 0):
+            fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+            pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+            run_pairs(ctxs[pr], prm, cfg, TUM_FR1_K, fs, pb)
+            outs[pr] = pb.download()
+        a, b = outs[1], outs[0]
+        P = len(seq["pairs"])
+        ok = a["pose"].tobytes() == b["pose"].tobytes() and np.array_equal(a["numMatches"], b["numMatches"])
+        for p in range(P):
+            n = int(a["numMatches"][p])
+            ok &= np.array_equal(a["inlierMask"][p, :n], b["inlierMask"][p, :n])
+            for f in STAT_FIELDS:
+                x, y = a["stats"][p][f], b["stats"][p][f]
+                ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+        for p in rng.integers(0, P, oracle_pairs):
+            cfgp, _ = make_config(est, H, seed=base + int(p))
+            c = po.vo_pairs(prm, cfgp, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][p:p + 1], threads=1)
+            n = int(c["numMatches"][0])
+            ok &= n == int(a["numMatches"][p]) and np.array_equal(a["inlierMask"][p, :n], c["inlierMask"][0, :n])
+            ok &= a["pose"][p].tobytes() == c["pose"][0].tobytes()
+            for f in STAT_FIELDS:
+                x, y = a["stats"][p][f], c["stats"][0][f]
+                ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+        if not ok:
+            bad += 1
+            print("MISMATCH", dict(it=it, mode=mode, est=est, H=H, frames=frames, kpts=kpts, frac=frac, noise=noise, seed=base), flush=True)
+        if verbose and (it + 1) % 20 == 0:
+            print(f"{it + 1} batches, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    for c in ctxs.values():
+        c.close()
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=1000)
@@ -76,13 +148,15 @@ def main():
     ap.add_argument("--modes", default="0,1,2,4,3", help="RANSAC::ERROR_VERSION values to draw from")
     ap.add_argument("--counts", action="store_true", help="also compare every hypothesis's inlier count")
     ap.add_argument("--procs", type=int, default=1, help="worker processes (seeds seed, seed+1, ...), iterations split evenly")
+    ap.add_argument("--batch", action="store_true", help="random batches: staged scoring vs complete scoring vs oracle")
     a = ap.parse_args()
     modes = tuple(int(x) for x in a.modes.split(","))
     if a.procs > 1:
         import subprocess
         per = (a.iters + a.procs - 1) // a.procs
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--iters", str(per), "--seed", str(a.seed + i),
-                                "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else []),
+                                "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else [])
+                               + (["--batch"] if a.batch else []),
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(a.procs)]
         rc = 0
         for i, p in enumerate(ps):
@@ -93,7 +167,10 @@ def main():
         print(f"fuzz done: {per * a.procs} iterations over {a.procs} workers, modes {a.modes}, "
               f"{'no mismatches' if rc == 0 else 'MISMATCHES'}")
         return rc
-    bad = run(a.iters, a.seed, a.max_kpts, modes=modes, counts=a.counts)
+    if a.batch:
+        bad = run_batch(a.iters, a.seed, modes=tuple(m for m in modes if m != 3))
+    else:
+        bad = run(a.iters, a.seed, a.max_kpts, modes=modes, counts=a.counts)
     print(f"fuzz done: {a.iters} iterations, {bad} mismatches")
     return 1 if bad else 0
 

@@ -14,3 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def test_fuzz_slice(ctx, oracle, seed):
     import fuzz_gpu
     assert fuzz_gpu.run(150, seed, max_kpts=1200, ctx=ctx, verbose=False) == 0
+
+
+def test_fuzz_batch_slice(oracle):
+    """Random batches through the staged scoring: staged == complete on every pair, == oracle on sampled pairs."""
+    import fuzz_gpu
+    assert fuzz_gpu.run_batch(12, 77, verbose=False) == 0
