@@ -138,6 +138,12 @@ int ps_context_synchronize(PsContext *ctx);
  *              trip limit (RANSAC.cpp:450-453) are never started; all outputs are unchanged, only the scratch counts of
  *              abandoned hypotheses are lower bounds.  0 = every hypothesis is scored completely
  *              (PUTSLAM_HIP_PRUNE=0|1).  The diagnostic ps_debug_ransac_counts always scores completely.
+ *   "reorder": the stages after the first sweep a copy of the pair's match record in which the matches the best hypotheses
+ *              so far reject come first (written by a launch of its own between the stages): whatever is not better than
+ *              those hypotheses rejects nearly all of them too and is abandoned a few matches later.  Counts are sums over
+ *              all matches, so the order changes no output.  1 = always, 0 = original match order, 2 (default) = with the
+ *              fixed schedule only (under the adaptive ones the trip limit usually ends the scoring before the stages
+ *              start and the launch would buy nothing)  (PUTSLAM_HIP_REORDER=0|1|2).
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.

@@ -47,6 +47,7 @@ struct PsContext {
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
                 // of the staged scoring (large batches)
     Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
+    Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
     Buf tabR, tabU;
@@ -81,6 +82,12 @@ struct PsContext {
     // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
     // abandon later hypotheses that cannot become records (default), 0 = every hypothesis is scored completely
     int prune = 1;
+    // staged scoring: stages 1+ sweep the matches in the order ps_stage_reorder writes (those the prefix's best hypotheses
+    // reject first: hypotheses end sooner, ps_score_fast.h).  1 = always, 0 = never (original order), 2 (default) = for the
+    // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
+    // extra launch (6 us per call) buys nothing (option "reorder")
+    int reorder = 2;
+    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 4; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
 };
@@ -317,6 +324,7 @@ struct Plan {
     SelectArgs sa{};
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
+    bool reorder = false; // staged scoring: stages 1+ sweep the reordered hot record (ps_stage_reorder)
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
 };
@@ -514,6 +522,12 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
         PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
         PS_ENSURE(ctx->survB, (size_t)P * H * sizeof(int32_t));
         PS_ENSURE(ctx->survN, (size_t)2 * P * sizeof(int32_t));
+        pl.reorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
+        if (pl.reorder) {
+            const size_t n = (size_t)P * cap;
+            PS_ENSURE(ctx->recF2, n * 40 > (size_t)P * ((cap + 1) / 2) * 64 ? n * 40 : (size_t)P * ((cap + 1) / 2) * 64);
+            PS_ENSURE(ctx->permBuf, n * sizeof(int32_t));
+        }
         pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
         pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
     }
@@ -549,20 +563,36 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage == 1) { st.listOut = (int32_t *)ctx->survA.p; st.countOut = nA; }
         if (stage == 2) { st.listIn = (const int32_t *)ctx->survA.p; st.countIn = nA; st.listOut = (int32_t *)ctx->survB.p; st.countOut = nB; }
         if (stage == 3) { st.listIn = (const int32_t *)ctx->survB.p; st.countIn = nB; }
+        if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
+        st.margin = ctx->reorderMargin;
+        st.c2div = ctx->reorderC2div;
         return st;
     };
+    // the hot record of stages 1+: reordered between stage 0 and stage 1 (ps_stage_reorder) unless the option is off
+    const float2 *hotF = (const float2 *)(pl.reorder ? ctx->recF2.p : ctx->recF.p);
+#define PS_LAUNCH_REORDER(MODE)                                                                                        \
+    do {                                                                                                               \
+        if (pl.reorder)                                                                                                \
+            hipLaunchKernelGGL(ps_stage_reorder<MODE>, dim3((unsigned)P), dim3(kBlock), 0, ctx->stream,                \
+                               (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,  \
+                               (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, pl.ma, pl.sc, pl.sa,       \
+                               pl.prefix, ctx->reorderTop, pl.H, cap, pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p, \
+                               (int32_t *)ctx->permBuf.p);                                                             \
+    } while (0)
     StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
     stAll.hCount = pl.H;
 #define PS_LAUNCH_EUCLID_ONE(MODE, KIND, ST, HCOUNT, MSPLIT)                                                           \
     hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, KIND>),                                                           \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
-                       (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p,       \
+                       (KIND) >= 1 ? hotF : (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p,               \
+                       (const float2 *)ctx->cmax.p,                                                                    \
                        pl.ma, pl.sc, pl.ec, pl.sa, (ST), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbgE)
 #define PS_LAUNCH_EUCLID(MODE)                                                                                         \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stage_args(0), pl.prefix, msplit);                                           \
+            PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
             for (int sg = 2; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), pl.H - pl.prefix, 1);  \
         } else                                                                                                         \
@@ -600,7 +630,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, KIND>),                                                        \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
-                       (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p, (const float2 *)ctx->recF.p,          \
+                       (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p,                                       \
+                       (KIND) >= 1 ? hotF : (const float2 *)ctx->recF.p,                                               \
                        (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.sa, \
                        (ST), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbg)
     // more work-groups than fit at once: the build for big launches (ps_score_fast.h); staged: prefix, then the stages
@@ -611,6 +642,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_LAUNCH_FAST_ONE(MODE, true, 0, stage_args(0), pl.prefix, msplit);                                   \
             else                                                                                                       \
                 PS_LAUNCH_FAST_ONE(MODE, false, 0, stage_args(0), pl.prefix, msplit);                                  \
+            PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
             for (int sg = 2; sg <= kStages; ++sg)                                                                      \
                 PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), pl.H - pl.prefix, 1);                                \
@@ -643,6 +675,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         break;
     default: launch_score<PS_MAHALANOBIS_ERROR>(ctx, grid, pl, cap, msplit); break;
     }
+#undef PS_LAUNCH_REORDER
 #undef PS_LAUNCH_EUCLID
 #undef PS_LAUNCH_EUCLID_ONE
 #undef PS_LAUNCH_FAST
@@ -832,6 +865,10 @@ int ps_context_create(int device, PsContext **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
+    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER")) ctx->reorder = std::min(std::max(std::atoi(v), 0), 2);
+    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_TOP")) ctx->reorderTop = std::min(std::max(std::atoi(v), 1), kReorderTopMax);
+    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_MARGIN")) ctx->reorderMargin = std::min(std::max(std::atoi(v), 1), 4096);
+    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_C2DIV")) ctx->reorderC2div = std::min(std::max(std::atoi(v), 1), 64);
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER_FUSED")) ctx->matcherFused = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER"))
         ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
@@ -853,7 +890,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -909,6 +946,11 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->prune = value;
         return PS_OK;
     }
+    if (strcmp(name, "reorder") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "reorder: 0, 1 or 2");
+        ctx->reorder = value;
+        return PS_OK;
+    }
     if (strcmp(name, "stamps") == 0) {
         if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "stamps: 0 or 1");
         if (value) {
@@ -937,6 +979,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "score") == 0) return ctx->scoreFast;
     if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
     if (strcmp(name, "prune") == 0) return ctx->prune;
+    if (strcmp(name, "reorder") == 0) return ctx->reorder;
     if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
     if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
     if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
@@ -1709,7 +1752,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6) | (ctx->matcherFused << 7); // disjoint bit fields
+    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6) | (ctx->matcherFused << 7) | (ctx->reorder << 8); // disjoint bit fields
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
-        stage_range(st.stage, M, best0, m0, m1);
+        stage_range(st, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
@@ -173,6 +173,9 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     const float4 *__restrict__ pb = recB + rbase;
     const float2 *__restrict__ pg = recG + (size_t)p * ((size_t)((cap + 1) >> 1) * (RF / 2));
     const float cmax = pairBound[p].x;
+    // position of the hot record -> match of the original record arrays (stages after ps_stage_reorder; the cold paths)
+    const int32_t *__restrict__ pperm = (pruned && st.perm != nullptr) ? st.perm + rbase : nullptr;
+    auto orig = [&](int m) { return pperm != nullptr ? pperm[m] : m; };
 
     float rho = 0.0f, tau = 0.0f;
     model_norms(mdl, rho, tau);
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
 
     if (!wave_all(boundsOk)) {
         for (int m = m0; m < m1; ++m) {
-            const float4 A = pa[m], B = pb[m];
+            const int mo = orig(m);
+            const float4 A = pa[mo], B = pb[mo];
             score_accumulate<MODE, false>(mdl, inv, k, A, B, A, cnt);
         }
     } else {
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
                 const int mm = blk + lane;
                 bool in = false;
                 if (mm < bend) {
-                    const float4 A = pa[mm], B = pb[mm];
+                    const int mo = orig(mm);
+                    const float4 A = pa[mo], B = pb[mo];
                     in = inlier_test<MODE>(md, md, k, A, B, A);
                 }
                 const int c = __popcll(__builtin_amdgcn_ballot_w64(in));
@@ -272,7 +277,8 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             }
         }
         if (m1e < m1) { // odd last match of the range
-            const float4 A = pa[m1e], B = pb[m1e];
+            const int mo = orig(m1e);
+            const float4 A = pa[mo], B = pb[mo];
             score_accumulate<MODE, false>(mdl, inv, k, A, B, A, cnt);
         }
         if (dbg != nullptr && lane == 0) {

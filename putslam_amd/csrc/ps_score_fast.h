@@ -157,6 +157,9 @@ PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, 
 constexpr int kPrefixFixed = kBlock; // hypotheses scored completely by stage 0: fixed schedule (arg-max over all H) ...
 constexpr int kPrefixAdaptive = 64;  // ... and RANSAC / USAC schedules (the reference consumes 3 of 487 on good data)
 constexpr int kStages = 3;      // pruned stages after the prefix
+constexpr int kReorderTopMax = 16; // ps_stage_reorder: at most this many of the prefix's best hypotheses vote on the order
+constexpr int kReorderMargin = 16; // reordered sweep: stage 1 ends this many matches (rounded up to 64) after the point where
+                                   // a hypothesis that rejects all the leading matches is out
 
 struct StageArgs {
     int stage;                 // 0 = the hypotheses [hBase, hBase + hCount) completely (the plain launch: [0, H)); 1 .. kStages
@@ -166,19 +169,27 @@ struct StageArgs {
     const int32_t *countIn;    //             ... and how many per pair
     int32_t *listOut;          // stage < kStages: where this stage's survivors go
     int32_t *countOut;
+    const int32_t *perm;       // stage >= 1 after ps_stage_reorder: [P][cap], match of the ORIGINAL record arrays at each position
+                               // of the reordered hot record (null: the hot record is in the original order)
+    int margin, c2div;         // reordered sweep: where stages 1 and 2 end (stage_range)
 };
 
 // Replay of the sequential selection over counts[0 .. n) by one wavefront (the rule of ps_select_refit part (1)):
 // best = the best count among the consumed ones, limit = the trip limit afterwards (a.H for the fixed schedule).
-PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const SelectArgs &a, int M, int &best, int &limit)
+// bestIdx = the hypothesis that holds `best` (the first of equals), -1 without a record.
+PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const SelectArgs &a, int M, int &best, int &limit,
+                             int &bestIdx)
 {
     const int lane = threadIdx.x & 63;
+    bestIdx = -1;
     if (a.estimator == PS_EST_FIXED) {
+        // (count, lowest index first) as one key: counts are <= PS_MAX_KPTS < 2^15, prefixes <= 2^16 hypotheses
         int b = 0;
-        for (int i = lane; i < n; i += 64) b = max(b, cnts[i]);
+        for (int i = lane; i < n; i += 64) b = max(b, (cnts[i] << 16) | (0xFFFF - i));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) b = max(b, __shfl_xor(b, o, 64));
-        best = b;
+        best = b >> 16;
+        if (best > 0) bestIdx = 0xFFFF - (b & 0xFFFF);
         limit = a.H;
         return;
     }
@@ -200,6 +211,7 @@ PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const Sele
         }
         if (found == 0xFFFFFFFFu) break;
         best = cnts[found];
+        bestIdx = (int)found;
         pos = (int)found + 1;
         limit = a.estimator == PS_EST_USAC ? usac_limit(a, (unsigned)best, (unsigned)M)
                                            : ransac_limit(a, (float)best / (float)M); // ratio as RANSAC.cpp:280
@@ -207,16 +219,29 @@ PS_D void wave_replay_prefix(const int32_t *__restrict__ cnts, int n, const Sele
 }
 
 // Match range [lo, hi) of pruned stage `stage` (1 .. kStages) for a pair with M matches whose prefix reached best0.
-PS_D void stage_range(int stage, int M, int best0, int &lo, int &hi)
+// reordered: the stages sweep the record ps_stage_reorder wrote -- the matches the prefix's best hypothesis rejects first.
+// Every hypothesis that is not better than that one rejects (almost all of) them too and is out a few matches later.
+PS_D void stage_range(const StageArgs &st, int M, int best0, int &lo, int &hi)
 {
+    const int stage = st.stage;
+    const bool reordered = st.perm != nullptr;
     int c1 = M, c2 = M;
     if (best0 > 0) {
         const int miss = M - best0; // a hypothesis is out once it has missed this many matches
-        c1 = (miss + miss / 7 + 32 + 63) & ~63;
-        if (c1 >= M - M / 8) c1 = M; // nothing worth a second launch
-        if (c1 < M) {
-            c2 = (c1 + (M - c1) / 2 + 63) & ~63;
-            if (c2 >= M - M / 16) c2 = M;
+        if (reordered) {
+            c1 = (miss + st.margin + 63) & ~63;
+            if (c1 >= M - M / 8) c1 = M;
+            if (c1 < M) {
+                c2 = (c1 + (M - c1) / st.c2div + 63) & ~63;
+                if (c2 >= M - M / 16) c2 = M;
+            }
+        } else {
+            c1 = (miss + miss / 7 + 32 + 63) & ~63;
+            if (c1 >= M - M / 8) c1 = M; // nothing worth a second launch
+            if (c1 < M) {
+                c2 = (c1 + (M - c1) / 2 + 63) & ~63;
+                if (c2 >= M - M / 16) c2 = M;
+            }
         }
     }
     static_assert(kStages == 3, "three pruned stages");
@@ -234,8 +259,8 @@ PS_D void stage_prefix(const int32_t *__restrict__ cnts, int nPrefix, const Sele
                        int &hLimit)
 {
     if ((threadIdx.x >> 6) == 0) {
-        int b, l;
-        wave_replay_prefix(cnts, nPrefix, sa, M, b, l);
+        int b, l, bi;
+        wave_replay_prefix(cnts, nPrefix, sa, M, b, l, bi);
         if ((threadIdx.x & 63) == 0) {
             s_pref[0] = b;
             s_pref[1] = l;
@@ -332,7 +357,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
-        stage_range(st.stage, M, best0, m0, m1);
+        stage_range(st, M, best0, m0, m1);
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
@@ -386,6 +411,9 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     const float4 *__restrict__ pc = recC + rbase;
     const float4 *__restrict__ pe = recE + rbase;
     const float2 *__restrict__ pf = recF + rbase * 5;
+    // position of the hot record -> match of the original record arrays (stages after ps_stage_reorder; the cold paths)
+    const int32_t *__restrict__ pperm = (pruned && st.perm != nullptr) ? st.perm + rbase : nullptr;
+    auto orig = [&](int m) { return pperm != nullptr ? pperm[m] : m; };
     const float2 pbnd = pairBound[p];
     const float cmax = pbnd.x, umax = pbnd.y;
 
@@ -454,7 +482,8 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             }
             inverse_rigid_general(md, iv);
             for (int m = m0; m < m1; ++m) {
-                const float4 A = pa[m], B = pb[m], C = pc[m];
+                const int mo = orig(m);
+                const float4 A = pa[mo], B = pb[mo], C = pc[mo];
                 score_accumulate<MODE, false>(md, iv, k, A, B, C, cnt);
             }
         } else {
@@ -466,7 +495,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (int e = lane; e < qn; e += 64) {
                 const uint32_t ent = s_q[wv][e];
-                const int t = wv * 64 + (int)(ent & 63u), m = (int)(ent >> 6);
+                const int t = wv * 64 + (int)(ent & 63u), m = orig((int)(ent >> 6));
                 Rigid md, iv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -572,6 +601,149 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             cout[h] = cnt;
         else if (cnt)
             atomicAdd(&cout[h], cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Between stage 0 and stage 1: the hot record of every pair in the order that ends hypotheses soonest.
+//
+// A hypothesis is out once it has missed M - B0 matches.  The prefix's best hypothesis misses exactly that many; nearly
+// every other hypothesis misses THOSE matches too (they are the wrong correspondences) and then a few more.  In the original
+// order the wrong correspondences are spread over the whole list, and a hypothesis that ends up five inliers short of B0 is
+// only out at the very end; with the matches the prefix's best hypothesis rejects moved to the front, it is out at its first
+// miss among the remaining ones.  Any order is valid -- a count is a sum over all matches and the bound "count so far +
+// matches left <= B0" holds for every subset -- so this changes no output, only where hypotheses stop.
+// One hypothesis's verdict is a noisy guide (it rejects marginal matches others accept, which leaves those others slack):
+// the nTopMax best hypotheses of the prefix VOTE, and the matches are ordered by how many of them reject each (a stable
+// counting sort: all-reject first -- the wrong correspondences --, then the marginal ones, the solid ones last).
+// One work-group per pair: replay the prefix, pick the voters, read their models (parked by stage 0), test every match
+// value-exactly against each, sort, and write
+//   F2 / G2  the hot record of the stage kernels (RecPtrs::F or ::G layout),   perm  position -> original match
+// (the cold paths -- value-exact recounts, the sampler of gen_model -- keep using the original arrays through perm).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restrict__ recA, const float4 *__restrict__ recB,
+                                                           const float4 *__restrict__ recC, const float2 *__restrict__ recF,
+                                                           const int32_t *__restrict__ mvalid, ModelArgs ma, ScoreConsts k,
+                                                           SelectArgs sa, int prefix, int nTopMax, int H, int cap, int minRun,
+                                                           const int32_t *__restrict__ counts, float2 *__restrict__ recF2,
+                                                           int32_t *__restrict__ perm)
+{
+    constexpr bool EUCLID_REC = MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR; // hot record = RecPtrs::G
+    constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? 16 : 12;
+    constexpr int kMaxChunks = PS_MAX_KPTS / kBlock;
+    __shared__ int s_top[kReorderTopMax + 1];                              // [0] = how many, then the hypotheses
+    __shared__ uint8_t s_rej[PS_MAX_KPTS];                                 // per match: how many of them reject it
+    __shared__ int s_tab[(kReorderTopMax + 1) * kMaxChunks * (kBlock / 64)]; // bucket-major counts -> start positions
+    const int p = blockIdx.x;
+    const int M = mvalid[p];
+    if (M < minRun) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t rbase = (size_t)p * cap;
+    const int32_t *__restrict__ cnts = counts + (size_t)p * H;
+    if (wv == 0) {
+        // the limit the prefix leaves: with every later hypothesis beyond it the stages return at once and read nothing
+        int b, l, bi;
+        wave_replay_prefix(cnts, prefix, sa, M, b, l, bi);
+        int n = 0;
+        const bool idle = b > 0 && l <= prefix; // (without a record nothing can be cut: the stages sweep everything)
+        if (b > 0 && !idle) {
+            // the nTopMax best counts of the prefix (first of equals first): (count, 0xFFFF - index) keys, lane i holds
+            // hypotheses i, i + 64, ...
+            int key[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;
+                key[j] = (i < prefix && cnts[i] > 0) ? ((cnts[i] << 16) | (0xFFFF - i)) : 0;
+            }
+            for (; n < nTopMax; ++n) {
+                int m = max(max(key[0], key[1]), max(key[2], key[3]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+                if (m == 0) break;
+                if (lane == 0) s_top[1 + n] = 0xFFFF - (m & 0xFFFF);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (key[j] == m) key[j] = 0;
+            }
+        }
+        if (lane == 0) s_top[0] = idle ? -1 : n; // (no record: no votes, one bucket, the original order)
+    }
+    for (int m = tid; m < M; m += kBlock) s_rej[m] = 0;
+    __syncthreads();
+    const int nTop = s_top[0];
+    if (nTop < 0) return; // nothing beyond the prefix will be scored
+    const float4 *__restrict__ pa = recA + rbase;
+    const float4 *__restrict__ pb = recB + rbase;
+    const float4 *__restrict__ pc = recC + rbase;
+    for (int t = 0; t < nTop; ++t) {
+        Rigid mdl, inv;
+        load_model(ma, (size_t)p * H + s_top[1 + t], mdl); // parked by stage 0
+        inverse_rigid_general(mdl, inv);
+        for (int m = tid; m < M; m += kBlock)
+            if (!inlier_test<MODE>(mdl, inv, k, pa[m], pb[m], pc[m])) s_rej[m] += 1; // (the thread's own matches)
+    }
+    // Stable counting sort by "rejected by how many" (descending): bucket d = nTop - rejections.  Counts per (bucket,
+    // chunk of 256 matches, wave) -> exclusive prefix in that order -> position = start + lanes below in the same bucket.
+    const int nChunks = (M + kBlock - 1) / kBlock;
+    for (int c = 0; c < nChunks; ++c) {
+        const int m = c * kBlock + tid;
+        const int d = m < M ? nTop - (int)s_rej[m] : -1;
+        for (int b = 0; b <= nTop; ++b) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(d == b);
+            if (lane == 0) s_tab[(b * nChunks + c) * (kBlock / 64) + wv] = __popcll(bal);
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int n = (nTop + 1) * nChunks * (kBlock / 64);
+        int carry = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            const int v = e < n ? s_tab[e] : 0;
+            int inc = v; // inclusive scan over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += u;
+            }
+            if (e < n) s_tab[e] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+    }
+    __syncthreads();
+    const float *__restrict__ gIn = reinterpret_cast<const float *>(recF) + (size_t)p * ((size_t)((cap + 1) >> 1) * RF);
+    float *__restrict__ gOut = reinterpret_cast<float *>(recF2) + (size_t)p * ((size_t)((cap + 1) >> 1) * RF);
+    for (int c = 0; c < nChunks; ++c) {
+        const int m = c * kBlock + tid;
+        const int d = m < M ? nTop - (int)s_rej[m] : -1;
+        int pos = 0;
+        for (int b = 0; b <= nTop; ++b) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(d == b);
+            if (d == b) pos = s_tab[(b * nChunks + c) * (kBlock / 64) + wv] + lanes_below(bal);
+        }
+        if (m < M) {
+            perm[rbase + pos] = m;
+            if (EUCLID_REC) {
+                const float *src = gIn + (size_t)(m >> 1) * RF + (m & 1);
+                float *dst = gOut + (size_t)(pos >> 1) * RF + (pos & 1);
+#pragma unroll
+                for (int i = 0; i < RF; i += 2) dst[i] = src[i];
+            } else {
+                const float2 *src = recF + 5 * (rbase + m);
+                float2 *dst = recF2 + 5 * (rbase + pos);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) dst[i] = src[i];
+            }
+        }
+    }
+    if (EUCLID_REC && (M & 1)) { // the unwritten second half of the last pair record repeats the first (finish_pair_records)
+        __syncthreads();
+        if (tid == 0) {
+            float *g = gOut + (size_t)(M >> 1) * RF;
+            for (int i = 0; i < RF; i += 2) g[i + 1] = g[i];
+        }
     }
 }
 

@@ -74,17 +74,19 @@ STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierC
 
 
 def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
-    """Random BATCHES large enough for the staged scoring (ps_score_fast.h): the staged run (option prune = 1) against the
-    complete one (prune = 0: the launch form the single-pair soak above checks against the oracle) on every pair and every
-    output field, and against the oracle on a few pairs of each batch.  Returns the number of batches with a difference."""
+    """Random BATCHES large enough for the staged scoring (ps_score_fast.h): the staged run with the reordered match record
+    (options prune = 1, reorder = 1) against the staged run in the original order (reorder = 0) and the complete one
+    (prune = 0: the launch form the single-pair soak above checks against the oracle) on every pair and every output
+    field, and against the oracle on a few pairs of each batch.  Returns the number of batches with a difference."""
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     rng = np.random.default_rng(seed)
     t0 = time.time()
     bad = 0
     ctxs = {}
-    for pr in (1, 0):
+    for pr in (1, 2, 0):   # 1: staged, reordered match record; 2: staged, original order; 0: complete
         ctxs[pr] = api.Context(0)
-        ctxs[pr].set_option("prune", pr)
+        ctxs[pr].set_option("prune", 1 if pr else 0)
+        ctxs[pr].set_option("reorder", 1 if pr == 1 else 0)
     for it in range(iters):
         mode = int(rng.choice(list(modes)))
         est, H = [(EST_RANSAC, int(rng.choice([487, 1157, 2000]))), (EST_USAC, int(rng.integers(300, 5000))),
@@ -107,20 +109,22 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
         base = int(rng.integers(0, 2 ** 40))
         cfg, _ = make_config(est, H, seed=base)
         outs = {}
-        for pr in (1, 0):
+        for pr in (1, 2, 0):
             fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
             pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
             run_pairs(ctxs[pr], prm, cfg, TUM_FR1_K, fs, pb)
             outs[pr] = pb.download()
-        a, b = outs[1], outs[0]
+        a = outs[1]
         P = len(seq["pairs"])
-        ok = a["pose"].tobytes() == b["pose"].tobytes() and np.array_equal(a["numMatches"], b["numMatches"])
-        for p in range(P):
-            n = int(a["numMatches"][p])
-            ok &= np.array_equal(a["inlierMask"][p, :n], b["inlierMask"][p, :n])
-            for f in STAT_FIELDS:
-                x, y = a["stats"][p][f], b["stats"][p][f]
-                ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+        ok = True
+        for b in (outs[2], outs[0]):
+            ok &= a["pose"].tobytes() == b["pose"].tobytes() and np.array_equal(a["numMatches"], b["numMatches"])
+            for p in range(P):
+                n = int(a["numMatches"][p])
+                ok &= np.array_equal(a["inlierMask"][p, :n], b["inlierMask"][p, :n])
+                for f in STAT_FIELDS:
+                    x, y = a["stats"][p][f], b["stats"][p][f]
+                    ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
         for p in rng.integers(0, P, oracle_pairs):
             cfgp, _ = make_config(est, H, seed=base + int(p))
             c = po.vo_pairs(prm, cfgp, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][p:p + 1], threads=1)

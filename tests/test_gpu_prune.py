@@ -2,7 +2,9 @@
 sequential selection (RANSAC.cpp:438-455: strict '>' first-best; adaptive trip limit :450-453, USAC.h:944-971) are
 abandoned early and hypotheses beyond the trip limit are never scored.  Every OUTPUT of the path -- selected hypothesis,
 its count, iterations run, inlier mask, pose bytes, ratios -- must equal both the unpruned run's and the oracle's, for all
-three schedules, good and bad data, and batches large enough for the pruned launch to be used."""
+three schedules, good and bad data, and batches large enough for the pruned launch to be used -- with the stages sweeping
+the matches in the reordered record (ps_stage_reorder: what the prefix's best hypotheses reject first) and in the original
+order."""
 import numpy as np
 import pytest
 
@@ -16,10 +18,12 @@ STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierC
                "accepted", "bestInlierRatio", "pointInlierRatio")
 
 
-def _run(seq, prm, cfg, prune):
+def _run(seq, prm, cfg, prune, reorder=1):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     c = api.Context(0)
     c.set_option("prune", prune)
+    c.set_option("reorder", reorder)   # 1 = also under the adaptive schedules (the default reorders the fixed one only)
+    assert c.get_option("reorder") == reorder
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
     run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
@@ -63,6 +67,7 @@ def test_pruned_equals_unpruned_equals_oracle(oracle, mode, est, H, frames, kpts
     pruned = _run(seq, prm, cfg, 1)
     full = _run(seq, prm, cfg, 0)
     _same(pruned, full, P)
+    _same(_run(seq, prm, cfg, 1, reorder=0), full, P)   # the stages in the original match order
     # the oracle on a sample of the pairs (the whole batch for the small cases)
     idx = np.arange(P) if P <= 40 else np.unique(np.linspace(0, P - 1, 24).astype(int))
     # pair p of the batch uses seed + p: the oracle is run per sampled pair with that pair's seed
@@ -96,3 +101,4 @@ def test_prune_ties_and_late_records(oracle):
             pruned = _run(seq, prm, cfg, 1)
             full = _run(seq, prm, cfg, 0)
             _same(pruned, full, P)
+            _same(_run(seq, prm, cfg, 1, reorder=0), full, P)
