@@ -1,6 +1,6 @@
 # Convenience targets; __graft_entry__.build() does the same from Python.
 HIPCC ?= /opt/rocm/bin/hipcc
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize -mllvm -disable-vector-combine
 CSRC := putslam_amd/csrc
 LIB := putslam_amd/libputslam_hip.so
 DROPIN := putslam_amd/libputslam_dropin.so

@@ -310,6 +310,9 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
 /* All eight counters of the last scoring step: [0] parked, [1] evaluations made (with the staged scoring: what is left of
  * the complete sweep of H hypotheses x M matches); [2..7] reserved (0). */
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
+/* Staged scoring: hypotheses of every pair that survived stage 1 (out[0..P)) and stage 2 (out[P..2P)) of the last call
+ * that was scored in stages (the last P pairs' counters; zeros if none was). */
+int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out);
 /* Latency study (option "stamps" = 1): the shader-clock stamps (s_memtime) work-group 0 of kernels 2 and 4 of the last call
  * wrote into a private buffer: out16[0..3] = ps_crosscheck_prep (start, best[q] built, matches compacted + records written,
  * end), out16[4..9] = ps_select_refit (start, selection replayed, winner's inlier pass, refit, re-selection, end). */

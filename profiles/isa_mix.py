@@ -67,7 +67,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                               "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
+                               "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
                               stderr=subprocess.DEVNULL)
         s = open(asm).read()
     out = {"cost_source": "profiles/microbench/valu_rates_mi355x.txt (cycles per wave64 instruction per SIMD @ 2.4 GHz)"}

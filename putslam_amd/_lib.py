@@ -22,7 +22,7 @@ EXPORTED = [
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
-    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stamps",
+    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stamps",
     "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
     "ps_abi_sizeof_frameset", "ps_abi_sizeof_results",
 ]
@@ -41,7 +41,7 @@ def _try_build():
     if not (os.path.exists(hipcc) and os.path.exists(src)):
         return
     import subprocess
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", src, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-shared", src, "-o", LIB_PATH]
     try:
         subprocess.check_call(cmd)
     except (OSError, subprocess.CalledProcessError):
@@ -78,6 +78,7 @@ def load():
     L.ps_context_get_option.argtypes = [vp, C.c_char_p]
     L.ps_debug_score_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ps_debug_score_stats_ex.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ps_debug_stage_survivors.argtypes = [vp, i32, vp]
     L.ps_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ps_last_error.argtypes = [vp]
     L.ps_last_error.restype = C.c_char_p

@@ -75,6 +75,12 @@ class Context:
         self._chk(self._L.ps_debug_score_stats_ex(self._h, out))
         return [int(v) for v in out]
 
+    def stage_survivors(self, P):
+        """(2, P) hypotheses of every pair that survived stages 1 and 2 of the last staged scoring step."""
+        out = np.zeros((2, int(P)), np.int32)
+        self._chk(self._L.ps_debug_stage_survivors(self._h, int(P), out.ctypes.data))
+        return out
+
     def stamps(self):
         """Shader-clock stamps of kernels 2 and 4 of the last call (needs set_option("stamps", 1)); ps_debug_stamps."""
         out = (C.c_uint64 * 16)()

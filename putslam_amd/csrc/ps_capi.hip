@@ -87,6 +87,9 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
+    int listRsplit3 = 8; // PUTSLAM_HIP_LISTR3
+    int listGroups2 = 8, listGroups3 = 2; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
+    int forcePrefix = 0; // PUTSLAM_HIP_PREFIX: hypotheses stage 0 scores completely under the fixed schedule (64 .. 256)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 4; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
@@ -506,6 +509,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     // (the later stages read the models back from HBM, 48 B per hypothesis: ps_score_fast.h)
     const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
     pl.prefix = pl.sa.estimator == PS_EST_FIXED ? kPrefixFixed : kPrefixAdaptive;
+    if (ctx->forcePrefix > 0 && pl.sa.estimator == PS_EST_FIXED) pl.prefix = ctx->forcePrefix; // (tuning knob)
     pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
@@ -554,11 +558,21 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     }
     // Staged scoring (ps_score_fast.h): stage 0 = the prefix completely, stages 1 .. 3 = the rest with hypotheses abandoned
     // between the launches.  stage_args(i) describes launch i.
+    // stages 2+: work-groups per pair (they loop over longer lists; after the reordered stage 1 few hypotheses are left)
+    auto list_groups = [&](int stage) {
+        const int all = (pl.H - pl.prefix + kBlock - 1) / kBlock;
+        const int want = pl.reorder ? (stage == 2 ? ctx->listGroups2 : ctx->listGroups3) : all;
+        return want < all ? want : all;
+    };
+    // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
+    // swept by one wavefront per SIMD pays the full latency of every record load, 0.25 us per match)
+    auto list_rsplit = [&](int stage) { return (pl.reorder && stage == kStages) ? ctx->listRsplit3 : 1; };
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
         st.hBase = stage == 0 ? 0 : pl.prefix;
         st.hCount = stage == 0 ? pl.prefix : pl.H - pl.prefix;
+        if (stage >= 2) st.hCount = list_groups(stage) * kBlock; // work-groups per pair that sweep the survivor list
         int32_t *nA = (int32_t *)ctx->survN.p, *nB = nA + P;
         if (stage == 1) { st.listOut = (int32_t *)ctx->survA.p; st.countOut = nA; }
         if (stage == 2) { st.listIn = (const int32_t *)ctx->survA.p; st.countIn = nA; st.listOut = (int32_t *)ctx->survB.p; st.countOut = nB; }
@@ -594,7 +608,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stage_args(0), pl.prefix, msplit);                                           \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
-            for (int sg = 2; sg <= kStages; ++sg) PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), pl.H - pl.prefix, 1);  \
+            for (int sg = 2; sg <= kStages; ++sg)                                                                      \
+                PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));              \
         } else                                                                                                         \
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stAll, pl.H, msplit);                                                        \
     } while (0)
@@ -645,7 +660,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
             for (int sg = 2; sg <= kStages; ++sg)                                                                      \
-                PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), pl.H - pl.prefix, 1);                                \
+                PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));          \
         } else if (grid.x > (BIGLIMIT))                                                                                \
             PS_LAUNCH_FAST_ONE(MODE, true, 0, stAll, pl.H, msplit);                                                    \
         else                                                                                                           \
@@ -866,6 +881,10 @@ int ps_context_create(int device, PsContext **out)
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER")) ctx->reorder = std::min(std::max(std::atoi(v), 0), 2);
+    if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
+    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);
+    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG3")) ctx->listGroups3 = std::min(std::max(std::atoi(v), 1), 64);
+    if (const char *v = std::getenv("PUTSLAM_HIP_PREFIX")) ctx->forcePrefix = std::min(std::max(std::atoi(v) & ~63, 64), 256);
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_TOP")) ctx->reorderTop = std::min(std::max(std::atoi(v), 1), kReorderTopMax);
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_MARGIN")) ctx->reorderMargin = std::min(std::max(std::atoi(v), 1), 4096);
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_C2DIV")) ctx->reorderC2div = std::min(std::max(std::atoi(v), 1), 64);
@@ -1295,6 +1314,20 @@ int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8)
     PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 8; ++i) out8[i] = h[i];
+    return PS_OK;
+}
+
+// Diagnostic: how many hypotheses of every pair survived stages 1 and 2 of the LAST staged scoring step (zeros if that
+// call was not staged); out = [2][P].
+int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out || P <= 0) return PS_ERR_BAD_ARG;
+    memset(out, 0, (size_t)2 * P * sizeof(int32_t));
+    if (!ctx->survN.p || ctx->survN.cap < (size_t)2 * P * sizeof(int32_t)) return PS_OK;
+    PS_HIP(hipMemcpyAsync(out, ctx->survN.p, (size_t)2 * P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
     return PS_OK;
 }
 

@@ -303,47 +303,39 @@ PS_HD bool umeyama3(const float (&src)[3][3], const float (&dst)[3][3], Rigid &M
 
 // Eigen Matrix4f::inverse(), generic cofactor path, for T = [R t; 0 0 0 1]
 // (RANSAC.cpp:337-338,386-387).  m is the full 4x4 accessed as m(r,c).
-struct Mat4 {
-    float v[4][4]; // v[r][c]
-};
-PS_HD float det3_helper(const Mat4 &m, int i1, int i2, int i3, int j1, int j2, int j3)
+// (Elements through a compile-time accessor and the cofactors as twelve named scalars: with float[4][4] temporaries the
+// compiler turned rows into 4-vectors and, to take them apart again, wrote one to scratch memory -- 20 bytes per lane that
+// made every launch of the scoring kernels a launch with a scratch allocation.)
+template <int R, int C> PS_HD float mat4_at(const Rigid &M)
 {
-    return m.v[i1][j1] * (m.v[i2][j2] * m.v[i3][j3] - m.v[i2][j3] * m.v[i3][j2]);
+    if (R < 3 && C < 3) return M.R[R < 3 ? R : 0][C < 3 ? C : 0];
+    if (R < 3) return M.t[R < 3 ? R : 0];
+    return C == 3 ? 1.0f : 0.0f;
 }
-template <int I, int J> PS_HD float cofactor4(const Mat4 &m)
+template <int I1, int I2, int I3, int J1, int J2, int J3> PS_HD float det3_helper(const Rigid &m)
+{
+    return mat4_at<I1, J1>(m) * (mat4_at<I2, J2>(m) * mat4_at<I3, J3>(m) - mat4_at<I2, J3>(m) * mat4_at<I3, J2>(m));
+}
+template <int I, int J> PS_HD float cofactor4(const Rigid &m)
 {
     constexpr int i1 = (I + 1) % 4, i2 = (I + 2) % 4, i3 = (I + 3) % 4;
     constexpr int j1 = (J + 1) % 4, j2 = (J + 2) % 4, j3 = (J + 3) % 4;
-    return (det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3)) +
-           det3_helper(m, i3, i1, i2, j1, j2, j3);
+    return (det3_helper<i1, i2, i3, j1, j2, j3>(m) + det3_helper<i2, i3, i1, j1, j2, j3>(m)) +
+           det3_helper<i3, i1, i2, j1, j2, j3>(m);
 }
+// result(j,i) = (-1)^(i+j) * cofactor(i,j)
+template <int I, int J> PS_HD float adj4(const Rigid &m) { return ((I + J) & 1) ? -cofactor4<I, J>(m) : cofactor4<I, J>(m); }
 PS_HD void inverse_rigid_general(const Rigid &M, Rigid &Inv)
 {
-    Mat4 m;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) m.v[i][j] = M.R[i][j];
-        m.v[i][3] = M.t[i];
-        m.v[3][i] = 0.0f;
-    }
-    m.v[3][3] = 1.0f;
-    // result(j,i) = (-1)^(i+j) * cofactor(i,j)
-    float r[4][4];
-#define PS_COF(I, J) r[J][I] = (((I) + (J)) & 1) ? -cofactor4<I, J>(m) : cofactor4<I, J>(m)
-    PS_COF(0, 0); PS_COF(0, 1); PS_COF(0, 2); PS_COF(0, 3);
-    PS_COF(1, 0); PS_COF(1, 1); PS_COF(1, 2); PS_COF(1, 3);
-    PS_COF(2, 0); PS_COF(2, 1); PS_COF(2, 2); PS_COF(2, 3);
-    PS_COF(3, 0); PS_COF(3, 1); PS_COF(3, 2); PS_COF(3, 3);
-#undef PS_COF
-    float p0 = m.v[0][0] * r[0][0], p1 = m.v[1][0] * r[0][1], p2 = m.v[2][0] * r[0][2], p3 = m.v[3][0] * r[0][3];
-    float det = (p0 + p1) + (p2 + p3);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Inv.R[i][j] = r[i][j] / det;
-        Inv.t[i] = r[i][3] / det;
-    }
+    // rows 0 .. 2 of the adjugate (row 3 of the inverse is never used), r_ji = adj4<i, j>
+    const float r00 = adj4<0, 0>(M), r01 = adj4<1, 0>(M), r02 = adj4<2, 0>(M), r03 = adj4<3, 0>(M);
+    const float r10 = adj4<0, 1>(M), r11 = adj4<1, 1>(M), r12 = adj4<2, 1>(M), r13 = adj4<3, 1>(M);
+    const float r20 = adj4<0, 2>(M), r21 = adj4<1, 2>(M), r22 = adj4<2, 2>(M), r23 = adj4<3, 2>(M);
+    const float p0 = mat4_at<0, 0>(M) * r00, p1 = mat4_at<1, 0>(M) * r01, p2 = mat4_at<2, 0>(M) * r02, p3 = 0.0f * r03;
+    const float det = (p0 + p1) + (p2 + p3);
+    Inv.R[0][0] = r00 / det; Inv.R[0][1] = r01 / det; Inv.R[0][2] = r02 / det; Inv.t[0] = r03 / det;
+    Inv.R[1][0] = r10 / det; Inv.R[1][1] = r11 / det; Inv.R[1][2] = r12 / det; Inv.t[1] = r13 / det;
+    Inv.R[2][0] = r20 / det; Inv.R[2][1] = r21 / det; Inv.R[2][2] = r22 / det; Inv.t[2] = r23 / det;
 }
 
 // R*p + t with Eigen 3.3 fixed-size evaluation order a0 + (a1 + a2) (RANSAC.cpp:266,346-348).

@@ -84,27 +84,25 @@ template <int MODE> PS_D EuclidRec<MODE> load_euclid_rec(const float2 *__restric
 
 // KIND (ps_score_fast.h): 0 = the hypotheses [hBase, hBase + hCount) completely (plain launch, stage 0), 1 = stage 1,
 // 2 = stages 2+ of the staged scoring.
-template <int MODE, int KIND = 0>
-__global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_euclid(
-    const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
-    const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
-    EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
-    unsigned long long *__restrict__ dbg)
+// One pass of a work-group (ps_score_fast.h, score_fast_pass): 256 hypotheses, or one pass over the survivor list.
+template <int MODE, int KIND>
+PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
+                            const float2 *__restrict__ pairBound, const ModelArgs &ma, const ScoreConsts &k,
+                            const EuclidConsts &ec, const SelectArgs &sa, const StageArgs &st, int H, int cap, int msplit,
+                            int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg, const unsigned bx,
+                            const unsigned by, const int p, const int M)
 {
-    static_assert(MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR, "the Euclidean metrics");
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? kEuclidRecFloats4 : kEuclidRecFloats0;
     __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
+    __shared__ int s_tot[kBlock]; // kind 2, split match range: the counts of the range's parts meet here
     __shared__ int s_pref[2];
 
-    // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
-    const int hCount = st.hCount;
-    const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
-    const int p = (int)(L / (hb * (unsigned)msplit));
-    const int M = mvalid[p];
-    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    // (kind 2 calls this in a loop: without the empty asm the compiler computes everything that hangs on the thread index --
+    // a dozen LDS row addresses -- once before the loop and, short of registers, keeps it in scratch memory, the inlier
+    // counter of the hot loop with it)
+    if (KIND == 2) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: keep it and what hangs on it scalar)
     const size_t rbase = (size_t)p * cap;
     int32_t *__restrict__ cout = counts + (size_t)p * H;
@@ -118,25 +116,43 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     int best0 = 0;
     constexpr bool LIST = KIND == 2; // stage >= 2: hypotheses from the survivor list, models from HBM
     constexpr bool pruned = KIND >= 1;
-    if (LIST && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
+    int cover = kBlock, slot = tid, part = 0; // kind 2: hypotheses per pass, the lane's place, its part of the match range
+    int mStageEnd = m1;
+    if (LIST) s_tot[tid] = 0;
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st, M, best0, m0, m1);
+        mStageEnd = m1;
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
             if (st.hBase + (int)bx * kBlock >= hEnd) return;
         } else {
+            if (msplit > 1) { // the LAST stage may split its range over work-groups too: their counts meet in counts[]
+                const int blen = (((m1 - m0 + msplit - 1) / msplit) + 63) & ~63;
+                m0 += (int)by * blen;
+                m1 = m1 < m0 + blen ? m1 : m0 + blen;
+                if (m0 >= m1) return;
+            }
             const int n = st.countIn[p];
-            const int i = (int)bx * kBlock + tid;
-            if ((int)bx * kBlock >= n) return;
+            cover = list_cover(n);
+            part = __builtin_amdgcn_readfirstlane(tid / cover);
+            slot = tid - part * cover;
+            const int i = (int)bx * cover + slot;
             hEnd = 0x7FFFFFFF;
             h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
+            // this wavefront's part of the stage's match range (whole blocks of 64 matches; a part may be empty)
+            const int parts = kBlock / cover;
+            const int plen = ((m1 - m0 + parts * 64 - 1) / (parts * 64)) * 64;
+            m0 += part * plen;
+            m1 = m1 < m0 + plen ? m1 : m0 + plen;
+            m1 = m1 < m0 ? m0 : m1; // (an empty part: nothing to sweep, no odd last match either)
         }
     }
 
-    if (hFirstOfWave(h, lane) >= hEnd) return; // a wavefront without a hypothesis of its own (ps_score_fast.h)
+    // a wavefront without a hypothesis of its own (ps_score_fast.h; not in a pass with a split match range: barrier to come)
+    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return;
 
     Rigid mdl, inv;
     set_identity(mdl);
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
         }
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
-            const int hs = stage_hypothesis_again(false, st, (int)bx, tid, p, H); // (ps_score_fast.h)
+            const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H); // (ps_score_fast.h)
             if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
         }
     }
@@ -288,15 +304,24 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
     }
     int tidE = tid; // (a fresh copy for the epilogue's LDS addresses: kept alive across the loops they went to scratch memory)
     asm volatile("" : "+v"(tidE));
+    if (LIST && cover < kBlock) { // (work-group uniform) the parts of the match range add up
+        if (part > 0 && h < hEnd) atomicAdd(&s_tot[slot], cnt);
+        __syncthreads();
+        if (part == 0) cnt += s_tot[slot];
+    }
     if (pruned) {
-        h = stage_hypothesis_again(LIST, st, (int)bx, tid, p, H);
-        const bool mine = h < hEnd;
+        h = stage_hypothesis_again(LIST, st, (int)bx * cover, slot, p, H);
+        const bool mine = h < hEnd && part == 0;
+        if (LIST && msplit > 1) { // (last stage, range split over work-groups: nothing survives it, the counts add up)
+            if (mine && valid && cnt) atomicAdd(&cout[h], cnt);
+            return;
+        }
         const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
-        const bool alive = mine && valid && total + (M - m1) > best0;
-        if (!LIST && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
+        const bool alive = mine && valid && total + (M - mStageEnd) > best0;
+        if (!LIST && ma.models && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -306,10 +331,10 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
             }
             store_model(ma, (size_t)p * H + h, md);
         }
-        if (st.stage < kStages && m1 < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
+        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
         return;
     }
-    h = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
+    h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
     if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)
@@ -317,6 +342,34 @@ __global__ __launch_bounds__(kBlock, PS_EUCLID_WAVES) void ps_ransac_score_eucli
         else if (cnt)
             atomicAdd(&cout[h], cnt);
     }
+}
+
+// (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast)
+template <int MODE, int KIND = 0>
+__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : PS_EUCLID_WAVES) void ps_ransac_score_euclid(
+    const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
+    const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
+    EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
+    unsigned long long *__restrict__ dbg)
+{
+    static_assert(MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR, "the Euclidean metrics");
+    // hypotheses of this launch: [hBase, hBase + hCount) (plain launch: [0, H); stages 0 / 1), or a survivor list swept by
+    // hCount / 256 work-groups per pair (stages 2+)
+    const unsigned hb = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
+    const int p = (int)(L / (hb * (unsigned)msplit));
+    const int M = mvalid[p];
+    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
+    if (KIND == 2) {
+        const int n = st.countIn[p];
+        const int cover = list_cover(n);
+        for (unsigned b = bx; (int)b * cover < n; b += hb) {
+            if (b != bx) __syncthreads(); // (the pass before is done with the work-group's LDS)
+            score_euclid_pass<MODE, KIND>(recA, recB, recG, pairBound, ma, k, ec, sa, st, H, cap, msplit, counts, dbg, b, by, p, M);
+        }
+    } else
+        score_euclid_pass<MODE, KIND>(recA, recB, recG, pairBound, ma, k, ec, sa, st, H, cap, msplit, counts, dbg, bx, by, p, M);
 }
 
 } // namespace psdev

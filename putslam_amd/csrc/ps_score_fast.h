@@ -77,20 +77,25 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 // Both folded models of one hypothesis, packed across the two directions for v_pk_fma_f32:
 // .x = current point -> previous image (model), .y = previous point -> current image (inverse model).
+// (twelve named pairs, not arrays of pairs: the compiler merged array neighbours into 4-vectors and took them apart again
+// through scratch memory)
 struct FastModel {
-    v2f_t r0[3], t0; // fx * row 0, fx * t_0
-    v2f_t r1[3], t1; // fy * row 1, fy * t_1
-    v2f_t r2[3], t2; // row 2, t_2
+    v2f_t r00, r01, r02, t0; // fx * row 0, fx * t_0
+    v2f_t r10, r11, r12, t1; // fy * row 1, fy * t_1
+    v2f_t r20, r21, r22, t2; // row 2, t_2
 };
 
 PS_D void make_fast(const Rigid &m, const Rigid &inv, float fx, float fy, FastModel &f)
 {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        f.r0[j] = v2f_t{fx * m.R[0][j], fx * inv.R[0][j]};
-        f.r1[j] = v2f_t{fy * m.R[1][j], fy * inv.R[1][j]};
-        f.r2[j] = v2f_t{m.R[2][j], inv.R[2][j]};
-    }
+    f.r00 = v2f_t{fx * m.R[0][0], fx * inv.R[0][0]};
+    f.r01 = v2f_t{fx * m.R[0][1], fx * inv.R[0][1]};
+    f.r02 = v2f_t{fx * m.R[0][2], fx * inv.R[0][2]};
+    f.r10 = v2f_t{fy * m.R[1][0], fy * inv.R[1][0]};
+    f.r11 = v2f_t{fy * m.R[1][1], fy * inv.R[1][1]};
+    f.r12 = v2f_t{fy * m.R[1][2], fy * inv.R[1][2]};
+    f.r20 = v2f_t{m.R[2][0], inv.R[2][0]};
+    f.r21 = v2f_t{m.R[2][1], inv.R[2][1]};
+    f.r22 = v2f_t{m.R[2][2], inv.R[2][2]};
     f.t0 = v2f_t{fx * m.t[0], fx * inv.t[0]};
     f.t1 = v2f_t{fy * m.t[1], fy * inv.t[1]};
     f.t2 = v2f_t{m.t[2], inv.t[2]};
@@ -116,9 +121,9 @@ PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(
 // Z~ of the two projected depths.
 PS_D v2f_t fast_sq2(const FastModel &f, v2f_t px, v2f_t py, v2f_t pz, v2f_t kx, v2f_t ky, v2f_t &Zout)
 {
-    const v2f_t X = pk_fma(f.r0[0], px, pk_fma(f.r0[1], py, pk_fma(f.r0[2], pz, f.t0)));
-    const v2f_t Y = pk_fma(f.r1[0], px, pk_fma(f.r1[1], py, pk_fma(f.r1[2], pz, f.t1)));
-    const v2f_t Z = pk_fma(f.r2[0], px, pk_fma(f.r2[1], py, pk_fma(f.r2[2], pz, f.t2)));
+    const v2f_t X = pk_fma(f.r00, px, pk_fma(f.r01, py, pk_fma(f.r02, pz, f.t0)));
+    const v2f_t Y = pk_fma(f.r10, px, pk_fma(f.r11, py, pk_fma(f.r12, pz, f.t1)));
+    const v2f_t Z = pk_fma(f.r20, px, pk_fma(f.r21, py, pk_fma(f.r22, pz, f.t2)));
     const v2f_t Au = pk_fma(kx, Z, X);
     const v2f_t Bv = pk_fma(ky, Z, Y);
     Zout = Z;
@@ -290,14 +295,23 @@ PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t
 // The hypothesis of a lane, derived AGAIN at the end of a staged launch from values that cost no vector register in between
 // (the scalar work-group offset passes through an empty asm, so that the compiler cannot keep the first derivation -- or
 // the 64-bit addresses built on it -- alive across the loops: at seven waves per SIMD it kept them in scratch memory).
-PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int bx, int tid, int p, int H)
+// base = first hypothesis (or list entry) of the work-group's pass, slot = the lane's place in it.
+PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int base, int slot, int p, int H)
 {
-    int base = (int)bx * kBlock;
     asm volatile("" : "+s"(base));
-    if (!list) return st.hBase + base + tid;
-    const int i = base + tid;
+    if (!list) return st.hBase + base + slot;
+    const int i = base + slot;
     return i < st.countIn[p] ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF;
 }
+
+// Stages 2+: hypotheses one pass of a work-group takes from the survivor list.  After the reordered stage 1 the lists are
+// short and the ranges left are long: a pair with at most 64 (128) survivors is swept by ONE work-group whose four
+// wavefronts each take a quarter (two halves) of the match range for the same hypotheses and add their counts up in LDS --
+// a single wavefront alone on its SIMD waits out every record load (stage 3 of the bench step: 21 survivors per pair, 157 us
+// that way, profiles/r03k).  Longer lists: 256 hypotheses per pass as before.  The launches carry a few work-groups per
+// pair (StageArgs::hCount / 256) that loop over the list: thousands of work-groups that find nothing to do still cost
+// their launch (30 ... 50 us per empty stage of 7485 work-groups).
+PS_D int list_cover(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : kBlock); }
 
 // Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
 // a few prologue values spilled) and the packed 40-byte match record (RecPtrs::F: the loop is sensitive to the
@@ -318,31 +332,28 @@ PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int bx, int tid,
 // SVD's left factor and the means in LDS meanwhile (LdsPark), kind 2 has no SVD, kind 0 is small or latency-bound (a single
 // pair, the 64-hypothesis prefix: 0.065 against 0.079 ms per 499 pairs with the LDS form) and keeps the register form;
 // the epilogues derive the hypothesis index again instead of keeping it.
-template <int MODE, bool BIG, int KIND = 0>
-__global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
-    const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
-    const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
-    const float2 *__restrict__ pairBound,
-    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun,
-    int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
+// One pass of a work-group: the hypotheses [hBase + bx * 256, + 256) (kinds 0 / 1) or one pass over the survivor list (kind 2).
+template <int MODE, bool BIG, int KIND>
+PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
+                          const float4 *__restrict__ recE, const float2 *__restrict__ recF,
+                          const float2 *__restrict__ pairBound, const ModelArgs &ma, const ScoreConsts &k,
+                          const FastConsts &fc, const EuclidConsts &ec, const SelectArgs &sa, const StageArgs &st, int H, int cap,
+                          int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg, const unsigned bx,
+                          const unsigned by, const int p, const int M)
 {
-    static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
-                  "the metrics with a reprojection test");
     constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
     __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
+    __shared__ int s_tot[kBlock]; // kind 2, split match range: the counts of the range's parts meet here
     __shared__ int s_pref[2];
 
-    // hypotheses of this launch: [0, H) (plain), [hBase, hBase + hCount) (stages 0 / 1) or a survivor list (stages 2+)
-    const int hCount = st.hCount;
-    const unsigned hb = (unsigned)((hCount + kBlock - 1) / kBlock);
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
-    const int p = (int)(L / (hb * (unsigned)msplit));
-    const int M = mvalid[p];
-    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    // (kind 2 calls this in a loop: without the empty asm the compiler computes everything that hangs on the thread index --
+    // a dozen LDS row addresses -- once before the loop and, short of registers, keeps it in scratch memory, the inlier
+    // counter of the hot loop with it)
+    if (KIND == 2) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform by construction: keep it and what hangs on it scalar)
     const size_t rbase = (size_t)p * cap;
     int32_t *__restrict__ cout = counts + (size_t)p * H;
@@ -353,27 +364,44 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     int best0 = 0;
     constexpr bool LIST = KIND == 2; // stage >= 2: hypotheses from the survivor list, models from HBM
     constexpr bool pruned = KIND >= 1;
-    if (LIST && (int)bx * kBlock >= st.countIn[p]) return; // no survivors left for this work-group
+    int cover = kBlock, slot = tid, part = 0; // kind 2: hypotheses per pass, the lane's place, its part of the match range
+    int mStageEnd = m1;
+    if (LIST) s_tot[tid] = 0;
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
         stage_range(st, M, best0, m0, m1);
+        mStageEnd = m1;
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
         } else {
+            if (msplit > 1) { // the LAST stage may split its range over work-groups too: their counts meet in counts[]
+                const int blen = (((m1 - m0 + msplit - 1) / msplit) + 63) & ~63;
+                m0 += (int)by * blen;
+                m1 = m1 < m0 + blen ? m1 : m0 + blen;
+                if (m0 >= m1) return;
+            }
             const int n = st.countIn[p];
-            const int i = (int)bx * kBlock + tid;
+            cover = list_cover(n);
+            part = __builtin_amdgcn_readfirstlane(tid / cover);
+            slot = tid - part * cover;
+            const int i = (int)bx * cover + slot;
             hEnd = 0x7FFFFFFF;
             h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
-            if ((int)bx * kBlock >= n) return;
+            // this wavefront's part of the stage's match range (whole blocks of 64 matches; a part may be empty)
+            const int parts = kBlock / cover;
+            const int plen = ((m1 - m0 + parts * 64 - 1) / (parts * 64)) * 64;
+            m0 += part * plen;
+            m1 = m1 < m0 + plen ? m1 : m0 + plen;
+            m1 = m1 < m0 ? m0 : m1; // (an empty part: nothing to sweep, no odd last match either)
         }
         if (!LIST && st.hBase + (int)bx * kBlock >= hEnd) return;
     }
 
     // (a wavefront without a hypothesis of its own has nothing to do -- the 64-hypothesis prefix of the adaptive
-    // schedules fills one of the four; no barrier follows in any of the launch forms)
-    if (hFirstOfWave(h, lane) >= hEnd) return;
+    // schedules fills one of the four; a pass with a split match range has no such wavefront, and a barrier to come)
+    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return;
 
     Rigid mdl;
     set_identity(mdl);
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         }
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
-            const int hs = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
+            const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
             if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
         }
     }
@@ -513,19 +541,37 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         };
 
         const unsigned long long execAll = __builtin_amdgcn_ballot_w64(true);
-        for (int m = m0; m < m1; ++m) {
-            v2f_t Z, ss;
-            float cxm, cym, czm, pxm, pym, pzm; // the match's current and previous point (wave-uniform)
+        // one match: its record as the five operand pairs (cur.x, prev.x) (cur.y, prev.y) (cur.z, prev.z) (cx - uOld, cx - uNew)
+        // (cy - vOld, cy - vNew)
+        // (held as five 64-bit scalars = the aligned register pairs the packed instructions take)
+        struct Rec {
+            unsigned long long q[5];
+        };
+        auto pair64 = [](float lo, float hi) {
+            return (unsigned long long)__builtin_bit_cast(uint32_t, lo) | ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
+        };
+        auto load_rec = [&](int m) {
+            Rec r;
             if (BIG) {
-                const float2 *__restrict__ e = pf + 5 * m;
-                const float2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
-                ss = fast_sq2(F, v2f_t{e0.x, e0.y}, v2f_t{e1.x, e1.y}, v2f_t{e2.x, e2.y}, v2f_t{e3.x, e3.y}, v2f_t{e4.x, e4.y}, Z);
-                cxm = e0.x; cym = e1.x; czm = e2.x; pxm = e0.y; pym = e1.y; pzm = e2.y;
+                const unsigned long long *__restrict__ e = reinterpret_cast<const unsigned long long *>(pf + 5 * m);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) r.q[i] = e[i];
             } else {
                 const float4 A = pa[m], B = pb[m], E = pe[m];
-                ss = fast_sq2(F, v2f_t{B.x, A.x}, v2f_t{B.y, A.y}, v2f_t{B.z, A.z}, v2f_t{E.x, E.y}, v2f_t{E.z, E.w}, Z);
-                cxm = B.x; cym = B.y; czm = B.z; pxm = A.x; pym = A.y; pzm = A.z;
+                r.q[0] = pair64(B.x, A.x); r.q[1] = pair64(B.y, A.y); r.q[2] = pair64(B.z, A.z);
+                r.q[3] = pair64(E.x, E.y); r.q[4] = pair64(E.z, E.w);
             }
+            return r;
+        };
+        // decides one match for the 64 hypotheses of the wavefront: counts the certain inliers, returns the undecided lanes
+        auto eval = [&](const Rec &r) -> unsigned long long {
+            v2f_t Z;
+            const v2f_t e0 = __builtin_bit_cast(v2f_t, r.q[0]), e1 = __builtin_bit_cast(v2f_t, r.q[1]),
+                        e2 = __builtin_bit_cast(v2f_t, r.q[2]), e3 = __builtin_bit_cast(v2f_t, r.q[3]),
+                        e4 = __builtin_bit_cast(v2f_t, r.q[4]);
+            const v2f_t ss = fast_sq2(F, e0, e1, e2, e3, e4, Z);
+            // the match's current and previous point (wave-uniform)
+            const float cxm = e0.x, cym = e1.x, czm = e2.x, pxm = e0.y, pym = e1.y, pzm = e2.y;
             // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
             // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
             const v2f_t q = Z * Z;
@@ -552,15 +598,33 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
                 mOut |= __builtin_amdgcn_ballot_w64(sE > hiE);
             }
             add_mask(cnt, mIn);
-            const unsigned long long mU = execAll & ~(mIn | mOut);
-            if (mU != 0ull) {
-                const int n = __popcll(mU);
-                if (qn + n > kQueueCap) {
-                    drain();
-                    rebuild();
+            return execAll & ~(mIn | mOut);
+        };
+        // Two matches per trip, both records requested before the first is used: a wavefront that is alone on its SIMD (the
+        // stages with few hypotheses, a single pair) otherwise waits out one scalar load per match.  The undecided lanes of
+        // both are parked afterwards, in ONE copy of the parking code (it holds the drain).
+        for (int m = m0; m < m1; m += 2) {
+            const bool two = m + 1 < m1; // (wave-uniform)
+            Rec ra = load_rec(m), rb = load_rec(two ? m + 1 : m);
+            // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
+            asm volatile("" : "+s"(ra.q[0]), "+s"(ra.q[1]), "+s"(ra.q[2]), "+s"(ra.q[3]), "+s"(ra.q[4]), "+s"(rb.q[0]), "+s"(rb.q[1]),
+                         "+s"(rb.q[2]), "+s"(rb.q[3]), "+s"(rb.q[4]));
+            const unsigned long long ua = eval(ra);
+            unsigned long long ub = 0ull;
+            if (two) ub = eval(rb);
+            if ((ua | ub) != 0ull) {
+#pragma nounroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned long long mU = j ? ub : ua;
+                    if (mU == 0ull) continue;
+                    const int n = __popcll(mU);
+                    if (qn + n > kQueueCap) {
+                        drain();
+                        rebuild();
+                    }
+                    if (lane_in(mU)) s_q[wv][qn + lanes_below(mU)] = ((uint32_t)(m + j) << 6) | (uint32_t)lane;
+                    qn += n;
                 }
-                if (lane_in(mU)) s_q[wv][qn + lanes_below(mU)] = ((uint32_t)m << 6) | (uint32_t)lane;
-                qn += n;
             }
         }
         drain();
@@ -573,15 +637,24 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
     }
     int tidE = tid; // (a fresh copy for the epilogue's LDS addresses: kept alive across the loops they went to scratch memory)
     asm volatile("" : "+v"(tidE));
+    if (LIST && cover < kBlock) { // (work-group uniform) the parts of the match range add up
+        if (part > 0 && h < hEnd) atomicAdd(&s_tot[slot], cnt);
+        __syncthreads();
+        if (part == 0) cnt += s_tot[slot];
+    }
     if (pruned) {
-        h = stage_hypothesis_again(LIST, st, (int)bx, tid, p, H);
-        const bool mine = h < hEnd;
+        h = stage_hypothesis_again(LIST, st, (int)bx * cover, slot, p, H);
+        const bool mine = h < hEnd && part == 0;
+        if (LIST && msplit > 1) { // (last stage, range split over work-groups: nothing survives it, the counts add up)
+            if (mine && valid && cnt) atomicAdd(&cout[h], cnt);
+            return;
+        }
         const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
-        const bool alive = mine && valid && total + (M - m1) > best0;
-        if (!LIST && ma.models && (alive || (mine && m1 >= M))) { // survivors (or: this stage was the whole sweep)
+        const bool alive = mine && valid && total + (M - mStageEnd) > best0;
+        if (!LIST && ma.models && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -591,10 +664,10 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
             }
             store_model(ma, (size_t)p * H + h, md);
         }
-        if (st.stage < kStages && m1 < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
+        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
         return;
     }
-    h = stage_hypothesis_again(false, st, (int)bx, tid, p, H);
+    h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
     if (h < hEnd) {
         if (!valid) cnt = 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
         if (msplit == 1)
@@ -602,6 +675,39 @@ __global__ __launch_bounds__(kBlock, MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR
         else if (cnt)
             atomicAdd(&cout[h], cnt);
     }
+}
+
+// (kind 2 sweeps short lists with few wavefronts: five per SIMD are plenty, and its loop over the list needs the registers --
+// at seven the kernel arguments it keeps across the passes went to scratch memory and the inlier counter with them)
+template <int MODE, bool BIG, int KIND = 0>
+__global__ __launch_bounds__(kBlock, (MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || KIND == 2) ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
+    const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
+    const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
+    const float2 *__restrict__ pairBound,
+    ModelArgs ma, ScoreConsts k, FastConsts fc, EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun,
+    int msplit, int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg)
+{
+    static_assert(MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR,
+                  "the metrics with a reprojection test");
+    // hypotheses of this launch: [hBase, hBase + hCount) (plain launch: [0, H); stages 0 / 1), or a survivor list swept by
+    // hCount / 256 work-groups per pair (stages 2+)
+    const unsigned hb = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
+    const int p = (int)(L / (hb * (unsigned)msplit));
+    const int M = mvalid[p];
+    if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
+    if (KIND == 2) {
+        const int n = st.countIn[p];
+        const int cover = list_cover(n);
+        for (unsigned b = bx; (int)b * cover < n; b += hb) {
+            if (b != bx) __syncthreads(); // (the pass before is done with the work-group's LDS)
+            score_fast_pass<MODE, BIG, KIND>(recA, recB, recC, recE, recF, pairBound, ma, k, fc, ec, sa, st, H, cap, msplit, counts,
+                                             dbg, b, by, p, M);
+        }
+    } else
+        score_fast_pass<MODE, BIG, KIND>(recA, recB, recC, recE, recF, pairBound, ma, k, fc, ec, sa, st, H, cap, msplit, counts, dbg,
+                                         bx, by, p, M);
 }
 
 // ------------------------------------------------------------------------------------------
