@@ -69,19 +69,7 @@ template <typename T> PS_HD void make_jacobi(T x, T y, T z, T &c, T &s)
 // rows == cols (no QR preconditioner step): used by Eigen::umeyama (reference
 // src/TransformEst/RANSAC.cpp:225) and by src/TransformEst/kabschEst.cpp:47.
 // A, U, V are row-major [3][3]; S descending.  Sweeps are capped at PS_SVD_MAX_SWEEPS.
-// Where the left factor U lives while the sweeps run.  RegU: in registers.  A kernel short of registers passes a type
-// that keeps it in LDS (kernel 3: LdsPark::LdsU in ps_kernels.h): U is only rotated (two columns read and written per step),
-// never an operand of the decisions, and nine registers less is what the seven-wave builds of kernel 3 are short of.
-// RegU is an empty tag: the matrix is the caller's plain array (a struct holding it turned into one nine-register tuple
-// that, short of registers, went to scratch memory as a whole).
-struct RegU {
-    template <typename T> PS_HD T get(const T (&U)[3][3], int i, int j) const { return U[i][j]; }
-    template <typename T> PS_HD void set(T (&U)[3][3], int i, int j, T v) const { U[i][j] = v; }
-    template <typename T> PS_HD void finish(T (&)[3][3]) const {}
-};
-
-template <typename T, typename UAcc = RegU>
-PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3], UAcc ua = UAcc())
+template <typename T> PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3])
 {
     T W[3][3];
     // cwiseAbs().maxCoeff(): the visitor starts from (0,0) and walks column by column keeping
@@ -100,8 +88,7 @@ PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3]
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             W[i][j] = A[i][j] / scale;
-            V[i][j] = (i == j) ? T(1) : T(0);
-            ua.set(U, i, j, (i == j) ? T(1) : T(0));
+            U[i][j] = V[i][j] = (i == j) ? T(1) : T(0);
         }
     const T precision = T(2) * Lim<T>::eps();
     const T considerAsZero = Lim<T>::min_normal();
@@ -147,12 +134,7 @@ PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3]
 #pragma unroll
                     for (int i = 0; i < 3; ++i) rot_pair(W[p][i], W[q][i], cl, sl);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        T up = ua.get(U, i, p), uq = ua.get(U, i, q);
-                        rot_pair(up, uq, cl, sl);
-                        ua.set(U, i, p, up);
-                        ua.set(U, i, q, uq);
-                    }
+                    for (int i = 0; i < 3; ++i) rot_pair(U[i][p], U[i][q], cl, sl);
                 }
                 if (!(cr == T(1) && nsr == T(0))) {
 #pragma unroll
@@ -172,7 +154,7 @@ PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3]
         S[i] = ps_abs(a);
         if (a < T(0)) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) ua.set(U, r, i, -ua.get(U, r, i));
+            for (int r = 0; r < 3; ++r) U[r][i] = -U[r][i];
         }
     }
 #pragma unroll
@@ -204,13 +186,12 @@ PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T (&S)[3], T (&V)[3][3]
                     S[j] = tmp;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        tmp = ua.get(U, r, i); ua.set(U, r, i, ua.get(U, r, j)); ua.set(U, r, j, tmp);
+                        tmp = U[r][i]; U[r][i] = U[r][j]; U[r][j] = tmp;
                         tmp = V[r][i]; V[r][i] = V[r][j]; V[r][j] = tmp;
                     }
                 }
         }
     }
-    ua.finish(U);
 }
 
 PS_HD float det3(const float (&M)[3][3])
@@ -225,34 +206,12 @@ struct Rigid {
     float t[3];
 };
 
-// Where the six mean coordinates wait while the SVD runs.  NoPark: in registers.  A kernel whose register budget the SVD
-// exhausts passes a type that moves them to LDS and back (kernel 3: LdsPark in ps_kernels.h) -- left to the register
-// allocator they went to scratch memory, i.e. through HBM, for every hypothesis.
-struct NoPark {
-    PS_HD void put(int, float) const {}
-    PS_HD float get(int, float v) const { return v; }
-    PS_HD RegU umat() const { return RegU(); }
-};
-
 // Tail of Eigen::umeyama(src, dst, false) once means and sigma are known:
 // SVD, reflection fix by sign(det U * det V), R = U*S*V^T, t = dst_mean - R*src_mean (column by column).
-template <typename Park = NoPark>
-PS_HD bool umeyama_finish(const float (&sigma)[3][3], const float (&sm_)[3], const float (&dm_)[3], Rigid &M,
-                          const Park &park = Park())
+PS_HD bool umeyama_finish(const float (&sigma)[3][3], const float (&sm)[3], const float (&dm)[3], Rigid &M)
 {
     float U[3][3], V[3][3], S[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        park.put(i, sm_[i]);
-        park.put(3 + i, dm_[i]);
-    }
-    jacobi_svd3<float>(sigma, U, S, V, park.umat());
-    float sm[3], dm[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        sm[i] = park.get(i, sm_[i]);
-        dm[i] = park.get(3 + i, dm_[i]);
-    }
+    jacobi_svd3<float>(sigma, U, S, V);
     float s2 = (det3(U) * det3(V) < 0.0f) ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -276,8 +235,7 @@ PS_HD void set_identity(Rigid &M)
 
 // 3-point minimal fit (RANSAC.cpp:100 -> :207-244).  Sums follow the canonical order used for any k
 // (64 strided partials + stride-1,2,4.. tree), which for three points is ((a+b)+c)+0.
-template <typename Park = NoPark>
-PS_HD bool umeyama3(const float (&src)[3][3], const float (&dst)[3][3], Rigid &M, const Park &park = Park())
+PS_HD bool umeyama3(const float (&src)[3][3], const float (&dst)[3][3], Rigid &M)
 {
     const float one_over_n = 1.0f / 3.0f;
     float sm[3], dm[3];
@@ -296,7 +254,7 @@ PS_HD bool umeyama3(const float (&src)[3][3], const float (&dst)[3][3], Rigid &M
             float p2 = (dst[2][r] - dm[r]) * (src[2][c] - sm[c]);
             sigma[r][c] = one_over_n * (((p0 + p1) + p2) + 0.0f);
         }
-    bool ok = umeyama_finish(sigma, sm, dm, M, park);
+    bool ok = umeyama_finish(sigma, sm, dm, M);
     if (!ok) set_identity(M);
     return ok;
 }

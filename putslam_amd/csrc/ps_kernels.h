@@ -522,36 +522,8 @@ PS_D void load_model(const ModelArgs &ma, size_t slot, Rigid &m)
 }
 PS_D uint64_t base_seed(const ModelArgs &ma) { return ma.seedDev ? *ma.seedDev : ma.seed; }
 
-// Parking place in LDS for values that have to outlive a register-hungry stretch: slot i of the calling thread in a
-// [slots][work-group size] float array.  Volatile accesses: the value really leaves the register file.
-typedef __attribute__((address_space(3))) volatile float lds_vfloat_t;
-struct LdsPark {
-    lds_vfloat_t *base; // &array[0][threadIdx.x]
-    int stride;         // work-group size
-    PS_D LdsPark(float *b, int s) : base((lds_vfloat_t *)b), stride(s) {}
-    PS_D void put(int i, float v) const { base[i * stride] = v; }
-    PS_D float get(int i, float) const { return base[i * stride]; }
-    // slots 6 .. 14: the SVD's left factor (ps_device_math.h, jacobi_svd3)
-    struct LdsU {
-        lds_vfloat_t *base;
-        int stride;
-        PS_D float get(const float (&)[3][3], int i, int j) const { return base[(6 + 3 * i + j) * stride]; }
-        PS_D void set(float (&)[3][3], int i, int j, float v) const { base[(6 + 3 * i + j) * stride] = v; }
-        PS_D void finish(float (&U)[3][3]) const
-        {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) U[i][j] = base[(6 + 3 * i + j) * stride];
-        }
-    };
-    PS_D LdsU umat() const { return LdsU{base, stride}; }
-};
-constexpr int kParkSlots = 15; // floats per thread an LdsPark needs
-
-template <typename Park = NoPark>
 PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ recB, size_t rbase, uint32_t M,
-                    const ModelArgs &ma, uint64_t pairSeed, uint32_t h, Rigid &mdl, const Park &park = Park())
+                    const ModelArgs &ma, uint64_t pairSeed, uint32_t h, Rigid &mdl)
 {
     uint32_t idx[3];
     sample_triplet(pairSeed, ma.raw, h, M, idx);
@@ -563,7 +535,7 @@ PS_D bool gen_model(const float4 *__restrict__ recA, const float4 *__restrict__ 
         dst[j][0] = A.x; dst[j][1] = A.y; dst[j][2] = A.z;
         src[j][0] = B.x; src[j][1] = B.y; src[j][2] = B.z;
     }
-    return umeyama3(src, dst, mdl, park);
+    return umeyama3(src, dst, mdl);
 }
 
 struct ScoreConsts {

@@ -93,7 +93,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
                             const unsigned by, const int p, const int M)
 {
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? kEuclidRecFloats4 : kEuclidRecFloats0;
-    __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
+    __shared__ float s_mdl[12][kBlock];
     __shared__ int s_tot[kBlock]; // kind 2, split match range: the counts of the range's parts meet here
     __shared__ int s_pref[2];
 
@@ -164,14 +164,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
             valid = true;
         }
     } else {
-        // (s_mdl is free until the model exists: stage 1 lets the means and the SVD's left factor wait there)
-        if (h < hEnd) {
-            if (KIND == 1)
-                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl,
-                                  LdsPark(&s_mdl[0][tid], kBlock));
-            else
-                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-        }
+        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H); // (ps_score_fast.h)
@@ -346,7 +339,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
 
 // (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast)
 template <int MODE, int KIND = 0>
-__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : PS_EUCLID_WAVES) void ps_ransac_score_euclid(
+__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_euclid(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
     const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
     EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,

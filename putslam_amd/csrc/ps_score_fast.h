@@ -313,25 +313,22 @@ PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int base, int sl
 // their launch (30 ... 50 us per empty stage of 7485 work-groups).
 PS_D int list_cover(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : kBlock); }
 
-// Two builds.  BIG (launches that fill the chip several times over): register budget cut for 7 waves per SIMD (72 VGPRs,
-// a few prologue values spilled) and the packed 40-byte match record (RecPtrs::F: the loop is sensitive to the
-// scalar-cache footprint of the records every wave streams; 1.77 -> 1.70 -> 1.68 ms per 499 pairs).  Small launches are bound
-// by the latency of ONE prologue and of cold record loads: 6 waves (80 VGPRs, no spills) and the three 16-byte records,
-// whose loads go out side by side (single pair: 31 against 36 us).
+// Two record forms.  BIG (launches that fill the chip several times over): the packed 40-byte match record (RecPtrs::F: the
+// loop is sensitive to the scalar-cache footprint of the records every wave streams).  Small launches are bound by the
+// latency of ONE prologue and of cold record loads: the three 16-byte records, whose loads go out side by side.
 // MODE = EUCLIDEAN_AND_REPROJECTION_ERROR (RANSAC.cpp:377-436: both reprojection errors AND the Euclidean residual below their
 // thresholds) adds the Euclidean term of ps_score_euclid.h to every evaluation: the unfolded current -> previous transform as
 // three FMA chains (plain instructions: only one direction has a Euclidean test), the squared residual against the same
 // per-lane limits lo / hi; "inlier" needs both certain, one certain "outlier" suffices, anything else is parked and decided by
-// inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel; five
-// waves per SIMD (the second model costs 12 registers).
+// inlier_test<2>().  40 vector instructions per evaluation instead of 61 + the Euclidean part of the value-exact kernel.
 // KIND: what the launch scores (StageArgs).  0 = the hypotheses [hBase, hBase + hCount) completely -- the plain launch over
 // [0, H) and stage 0 of the staged scoring; 1 = stage 1 (generates its models, first match range); 2 = stages 2+ (models and
-// hypothesis list read back).  Builds of their own because the sample -> Umeyama -> SVD prologue is what the register
-// budget of seven waves cannot hold: left to the register allocator 12 ... 19 values per lane went to scratch memory, i.e.
-// through HBM (0.4 GB per 499 pairs in all, profiles/r03i).  Kind 1 -- almost all prologues of a large batch -- keeps the
-// SVD's left factor and the means in LDS meanwhile (LdsPark), kind 2 has no SVD, kind 0 is small or latency-bound (a single
-// pair, the 64-hypothesis prefix: 0.065 against 0.079 ms per 499 pairs with the LDS form) and keeps the register form;
-// the epilogues derive the hypothesis index again instead of keeping it.
+// hypothesis list read back, a loop over the list).
+// Registers: the library is built with the SLP vectoriser and VectorCombine off (Makefile).  With them the scalar prologue
+// (sample -> Umeyama -> SVD -> general inverse) was turned into packed instructions whose aligned register pairs and
+// shuffles cost 20 registers: 72 VGPRs + 12 ... 19 values per lane in scratch memory at seven waves per SIMD (0.4 GB of HBM
+// traffic per 499 pairs, profiles/r03i) against 56 VGPRs, no scratch memory and eight waves without (profiles/r03l).  The
+// epilogues still derive the hypothesis index again instead of keeping it across the loops.
 // One pass of a work-group: the hypotheses [hBase + bx * 256, + 256) (kinds 0 / 1) or one pass over the survivor list (kind 2).
 template <int MODE, bool BIG, int KIND>
 PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
@@ -342,7 +339,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                           const unsigned by, const int p, const int M)
 {
     constexpr bool EUCLID = MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
-    __shared__ float s_mdl[kParkSlots][kBlock]; // rows 0 .. 11: the model; all rows: parking place of the prologue
+    __shared__ float s_mdl[12][kBlock];
     __shared__ uint32_t s_q[kBlock / 64][kQueueCap];
     __shared__ int s_cnt[kBlock];
     __shared__ int s_tot[kBlock]; // kind 2, split match range: the counts of the range's parts meet here
@@ -412,14 +409,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             valid = true;
         }
     } else {
-        // (s_mdl is free until the model exists: stage 1 lets the means and the SVD's left factor wait there)
-        if (h < hEnd) {
-            if (KIND == 1)
-                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl,
-                                  LdsPark(&s_mdl[0][tid], kBlock));
-            else
-                valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-        }
+        if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
@@ -677,10 +667,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     }
 }
 
-// (kind 2 sweeps short lists with few wavefronts: five per SIMD are plenty, and its loop over the list needs the registers --
-// at seven the kernel arguments it keeps across the passes went to scratch memory and the inlier counter with them)
+// (kind 2 sweeps short lists with few wavefronts: five per SIMD are plenty, and its loop over the list keeps the kernel
+// arguments alive across the passes -- at seven or eight they went to scratch memory and the inlier counter with them)
 template <int MODE, bool BIG, int KIND = 0>
-__global__ __launch_bounds__(kBlock, (MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || KIND == 2) ? 5 : (BIG ? 7 : 6)) void ps_ransac_score_fast(
+__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
     const float2 *__restrict__ pairBound,
