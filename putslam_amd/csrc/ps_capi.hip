@@ -47,6 +47,7 @@ struct PsContext {
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
                 // of the staged scoring (large batches)
     Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
+    Buf prefInfo;            // staged scoring: per pair (best count, trip limit) of the prefix, written by ps_stage_reorder
     Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
@@ -87,10 +88,10 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
-    int listRsplit3 = 8; // PUTSLAM_HIP_LISTR3
-    int listGroups2 = 8, listGroups3 = 2; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
+    int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
+    int listGroups2 = 64, listGroups3 = 1; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
     int forcePrefix = 0; // PUTSLAM_HIP_PREFIX: hypotheses stage 0 scores completely under the fixed schedule (64 .. 256)
-    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 4; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
+    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
 };
@@ -531,6 +532,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
             const size_t n = (size_t)P * cap;
             PS_ENSURE(ctx->recF2, n * 40 > (size_t)P * ((cap + 1) / 2) * 64 ? n * 40 : (size_t)P * ((cap + 1) / 2) * 64);
             PS_ENSURE(ctx->permBuf, n * sizeof(int32_t));
+            PS_ENSURE(ctx->prefInfo, (size_t)2 * P * sizeof(int32_t));
         }
         pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
         pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
@@ -578,6 +580,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage == 2) { st.listIn = (const int32_t *)ctx->survA.p; st.countIn = nA; st.listOut = (int32_t *)ctx->survB.p; st.countOut = nB; }
         if (stage == 3) { st.listIn = (const int32_t *)ctx->survB.p; st.countIn = nB; }
         if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
+        if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
         st.margin = ctx->reorderMargin;
         st.c2div = ctx->reorderC2div;
         return st;
@@ -591,7 +594,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                                (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,  \
                                (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, pl.ma, pl.sc, pl.sa,       \
                                pl.prefix, ctx->reorderTop, pl.H, cap, pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p, \
-                               (int32_t *)ctx->permBuf.p);                                                             \
+                               (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p);                                 \
     } while (0)
     StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
     stAll.hCount = pl.H;
@@ -909,7 +912,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};

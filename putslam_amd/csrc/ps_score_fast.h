@@ -177,6 +177,8 @@ struct StageArgs {
     const int32_t *perm;       // stage >= 1 after ps_stage_reorder: [P][cap], match of the ORIGINAL record arrays at each position
                                // of the reordered hot record (null: the hot record is in the original order)
     int margin, c2div;         // reordered sweep: where stages 1 and 2 end (stage_range)
+    const int32_t *prefInfo;   // after ps_stage_reorder: [P][2] = (best count, trip limit) the prefix leaves (null: every
+                               // work-group of the stages replays the prefix itself)
 };
 
 // Replay of the sequential selection over counts[0 .. n) by one wavefront (the rule of ps_select_refit part (1)):
@@ -237,7 +239,8 @@ PS_D void stage_range(const StageArgs &st, int M, int best0, int &lo, int &hi)
             c1 = (miss + st.margin + 63) & ~63;
             if (c1 >= M - M / 8) c1 = M;
             if (c1 < M) {
-                c2 = (c1 + (M - c1) / st.c2div + 63) & ~63;
+                const int step = ((M - c1) / st.c2div + 63) & ~63;
+                c2 = c1 + (step > 0 ? step : 64); // (never an empty stage 2: it hands the survivors on)
                 if (c2 >= M - M / 16) c2 = M;
             }
         } else {
@@ -261,8 +264,13 @@ PS_D int hFirstOfWave(int h, int lane) { return __builtin_amdgcn_readfirstlane(h
 // What every work-group of a pruned stage needs before it starts: the prefix's best count and trip limit (work-group
 // uniform, in SGPRs) -- wave 0 replays, the others wait.
 PS_D void stage_prefix(const int32_t *__restrict__ cnts, int nPrefix, const SelectArgs &sa, int M, int *s_pref, int &best0,
-                       int &hLimit)
+                       int &hLimit, const int32_t *__restrict__ prefInfo = nullptr)
 {
+    if (prefInfo != nullptr) { // replayed once per pair by ps_stage_reorder (scalar loads, no barrier)
+        best0 = prefInfo[0];
+        hLimit = best0 > 0 ? prefInfo[1] : sa.H;
+        return;
+    }
     if ((threadIdx.x >> 6) == 0) {
         int b, l, bi;
         wave_replay_prefix(cnts, nPrefix, sa, M, b, l, bi);
@@ -366,7 +374,8 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     if (LIST) s_tot[tid] = 0;
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
-        stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit); // (stage >= 1: hBase = size of the prefix)
+        stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)
+                     st.prefInfo != nullptr ? st.prefInfo + 2 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
         mStageEnd = m1;
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
@@ -723,13 +732,14 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                                                            const int32_t *__restrict__ mvalid, ModelArgs ma, ScoreConsts k,
                                                            SelectArgs sa, int prefix, int nTopMax, int H, int cap, int minRun,
                                                            const int32_t *__restrict__ counts, float2 *__restrict__ recF2,
-                                                           int32_t *__restrict__ perm)
+                                                           int32_t *__restrict__ perm, int32_t *__restrict__ prefInfo)
 {
     constexpr bool EUCLID_REC = MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR; // hot record = RecPtrs::G
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? 16 : 12;
     constexpr int kMaxChunks = PS_MAX_KPTS / kBlock;
     __shared__ int s_top[kReorderTopMax + 1];                              // [0] = how many, then the hypotheses
     __shared__ uint8_t s_rej[PS_MAX_KPTS];                                 // per match: how many of them reject it
+    __shared__ float s_vote[kReorderTopMax][24];                           // the voters' models and their inverses
     __shared__ int s_tab[(kReorderTopMax + 1) * kMaxChunks * (kBlock / 64)]; // bucket-major counts -> start positions
     const int p = blockIdx.x;
     const int M = mvalid[p];
@@ -742,6 +752,10 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         // the limit the prefix leaves: with every later hypothesis beyond it the stages return at once and read nothing
         int b, l, bi;
         wave_replay_prefix(cnts, prefix, sa, M, b, l, bi);
+        if (lane == 0) { // what every work-group of the stages needs (stage_prefix)
+            prefInfo[2 * p] = b;
+            prefInfo[2 * p + 1] = l;
+        }
         int n = 0;
         const bool idle = b > 0 && l <= prefix; // (without a record nothing can be cut: the stages sweep everything)
         if (b > 0 && !idle) {
@@ -766,19 +780,47 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         }
         if (lane == 0) s_top[0] = idle ? -1 : n; // (no record: no votes, one bucket, the original order)
     }
-    for (int m = tid; m < M; m += kBlock) s_rej[m] = 0;
     __syncthreads();
     const int nTop = s_top[0];
     if (nTop < 0) return; // nothing beyond the prefix will be scored
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float4 *__restrict__ pc = recC + rbase;
-    for (int t = 0; t < nTop; ++t) {
+    // the voters' models and inverses, one thread each, side by side (one global round trip instead of one per voter)
+    if (tid < nTop) {
         Rigid mdl, inv;
-        load_model(ma, (size_t)p * H + s_top[1 + t], mdl); // parked by stage 0
+        load_model(ma, (size_t)p * H + s_top[1 + tid], mdl); // parked by stage 0
         inverse_rigid_general(mdl, inv);
-        for (int m = tid; m < M; m += kBlock)
-            if (!inlier_test<MODE>(mdl, inv, k, pa[m], pb[m], pc[m])) s_rej[m] += 1; // (the thread's own matches)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                s_vote[tid][3 * i + j] = mdl.R[i][j];
+                s_vote[tid][12 + 3 * i + j] = inv.R[i][j];
+            }
+            s_vote[tid][9 + i] = mdl.t[i];
+            s_vote[tid][21 + i] = inv.t[i];
+        }
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += kBlock) { // (the thread's own matches)
+        const float4 A = pa[m], B = pb[m], C = pc[m];
+        int rej = 0;
+        for (int t = 0; t < nTop; ++t) {
+            Rigid mdl, inv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    mdl.R[i][j] = s_vote[t][3 * i + j];
+                    inv.R[i][j] = s_vote[t][12 + 3 * i + j];
+                }
+                mdl.t[i] = s_vote[t][9 + i];
+                inv.t[i] = s_vote[t][21 + i];
+            }
+            rej += inlier_test<MODE>(mdl, inv, k, A, B, C) ? 0 : 1;
+        }
+        s_rej[m] = (uint8_t)rej;
     }
     // Stable counting sort by "rejected by how many" (descending): bucket d = nTop - rejections.  Counts per (bucket,
     // chunk of 256 matches, wave) -> exclusive prefix in that order -> position = start + lanes below in the same bucket.

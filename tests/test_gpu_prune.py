@@ -55,6 +55,11 @@ CASES = [  # (errorVersion, estimator, H, frames, kpts, inlier_frac, noise)
     (REPROJECTION_ERROR, EST_RANSAC, 1157, 90, 400, 0.12, 0.03),
     (REPROJECTION_ERROR, EST_USAC, 3000, 40, 500, 0.30, 0.01),
     (EUCLIDEAN_AND_REPROJECTION_ERROR, EST_FIXED, 2048, 40, 500, 0.60, 0.005),
+    # few matches: the stage cuts (multiples of 64) come close to each other and to M -- no stage may be left empty while
+    # a later one still expects its survivors (round 3: stage 2 was, with M - c1 < 16)
+    (REPROJECTION_ERROR, EST_FIXED, 1161, 132, 270, 0.94, 0.0014),
+    (EUCLIDEAN_ERROR, EST_FIXED, 1500, 120, 150, 0.80, 0.002),
+    (ADAPTIVE_ERROR, EST_FIXED, 1161, 140, 90, 0.90, 0.001),
 ]
 
 
