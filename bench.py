@@ -367,9 +367,12 @@ def main():
                                           "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": ach / MFMA_FP4_PEAK_TFLOPS}
             vk = {"ps_hamming_nn": (VALU_PER_UNIT["ps_hamming_nn"], args.kpts * float(args.kpts) * pairs_per_launch / 64.0),
+                  # evaluations the scoring step really made (staged scoring: a fraction of the complete H x M sweep; the
+                  # counter of the statistics pass), not the sweep it stands for
                   "ps_ransac_score": (VALU_PER_UNIT["ps_ransac_score_%s<%d>" % (score, args.error_version)]
                                       if ("ps_ransac_score_%s<%d>" % (score, args.error_version)) in VALU_PER_UNIT else None,
-                                      Hs * m_valid * pairs_per_launch / 64.0)}
+                                      (evals_made / 64.0 * pairs_per_launch / P) if evals_made
+                                      else Hs * m_valid * pairs_per_launch / 64.0)}
             for name, (per_unit, wave_units) in vk.items():
                 if name in kms and per_unit:
                     ach = wave_units * per_unit * 64.0 / (kms[name] * 1e-3) / 1e12
@@ -381,6 +384,12 @@ def main():
                         out[name]["lane_ops_per_unit"] = per_unit + pk
                         out[name]["achieved_lane_ops"] = ach * (per_unit + pk) / per_unit
                         out[name]["frac_lane_ops"] = out[name]["achieved_lane_ops"] / VALU_PEAK_TOPS
+                    if name == "ps_ransac_score" and evals_made:
+                        out[name]["note"] = ("instructions of the evaluation loops only (evaluations really made x instructions "
+                                             "per evaluation); the per-hypothesis prologue (sample -> Umeyama -> SVD, ~4200 "
+                                             "vector instructions per wavefront of 64 hypotheses) and the reorder launch are "
+                                             "inside the time but not in the count")
+                        out[name]["complete_sweep_equivalent"] = Hs * m_valid * pairs_per_launch * per_unit / (kms[name] * 1e-3) / 1e12
             return out
 
         rk = solo if solo else kern                      # kernels' own durations when the single-chain leg ran
@@ -402,6 +411,7 @@ def main():
                 for kname, c in sq.items():
                     short = kname.split("<")[0]
                     short = {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_mfma": "ps_ransac_score",
+                             "ps_stage_reorder": "ps_ransac_score",
                              "ps_ransac_score_euclid": "ps_ransac_score", "ps_hamming_mfma_fused": "ps_hamming_mfma"}.get(short, short)
                     if short in bounds_solo and c.get("GRBM_GUI_ACTIVE"):
                         cyc = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0      # kernel cycles x SIMDs (8 XCDs report separately)

@@ -31,6 +31,7 @@ def main():
         short = k.split("psdev::")[1].split("<")[0].split("(")[0]
         # bench.py's name of the timing slot: all builds / stages of the scoring kernel are one step of the path
         return {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_euclid": "ps_ransac_score",
+                "ps_stage_reorder": "ps_ransac_score",   # (the scoring step's own launch between stage 0 and stage 1)
                 "ps_ransac_score_mfma": "ps_ransac_score"}.get(short, short)
 
     # A kernel may be launched several times per step (the staged scoring: prefix + three stages): every figure below
