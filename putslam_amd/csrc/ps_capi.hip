@@ -498,6 +498,9 @@ void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit
 
 // Decisions of the scoring stage that the preceding kernels need to know: how the match range is split (kernel 2 then
 // clears the counts, instead of a memset launch) and whether kernel 3 parks its models for kernel 4.
+// launches of the reprojection kernels with more work-groups than this use the packed match record (ps_score_fast.h, BIG)
+unsigned big_limit(int mode) { return mode == PS_REPROJECTION_ERROR ? 1536u : 1280u; }
+
 int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
 {
     const int H = pl.H;
@@ -523,6 +526,17 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
         pl.ma.models = (float *)ctx->models.p;
     }
     pl.pa.zeroSurvA = pl.pa.zeroSurvB = nullptr;
+    {
+        // which record form of the reprojection kernels the launches of this call read (kernel 2 writes only those:
+        // 16 + 40 bytes per match otherwise): the packed form F for launches that fill the chip and every stage after
+        // the prefix, the three-record form (A, B, E) for small ones -- the same decisions as in run_ransac_stage
+        const bool fastRep = (pl.mode == PS_REPROJECTION_ERROR && ctx->scoreFast == 1) ||
+                             (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR && ctx->scoreFast != 0);
+        const unsigned bigLimit = big_limit(pl.mode);
+        const bool firstBig = (unsigned)pl.msplit * (unsigned)P * (pl.prune ? 1u : (unsigned)hb) > bigLimit;
+        pl.pa.skipF = !(fastRep && (pl.prune || firstBig));
+        pl.pa.skipE = !(fastRep && !firstBig) && !with_split(ctx, pl.mode); // (the matrix-core scoring's operands are built from E)
+    }
     if (pl.prune) {
         PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
         PS_ENSURE(ctx->survB, (size_t)P * H * sizeof(int32_t));
@@ -669,7 +683,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         else                                                                                                           \
             PS_LAUNCH_FAST_ONE(MODE, false, 0, stAll, pl.H, msplit);                                                   \
     } while (0)
-            PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, 1536u);
+            PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, big_limit(PS_REPROJECTION_ERROR));
         } else
             launch_score<PS_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;
@@ -681,7 +695,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 dbg = (unsigned long long *)ctx->dbgCnt.p;
             }
-            PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, 1280u);
+            PS_LAUNCH_FAST(PS_EUCLIDEAN_AND_REPROJECTION_ERROR, big_limit(PS_EUCLIDEAN_AND_REPROJECTION_ERROR));
         } else
             launch_score<PS_EUCLIDEAN_AND_REPROJECTION_ERROR>(ctx, grid, pl, cap, msplit);
         break;

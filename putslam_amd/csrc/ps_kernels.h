@@ -204,6 +204,7 @@ struct PrepArgs {
     int zeroH;              // split-range atomics (saves a memset launch)
     int zeroStride;
     int32_t *zeroSurvA, *zeroSurvB; // optional: per-pair survivor counters of the staged scoring to clear (ps_score_fast.h)
+    int skipE, skipF;       // the reprojection kernels' record forms no launch of this call will read (RecPtrs::E / ::F)
 };
 
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
@@ -331,8 +332,8 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
     // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
-    r.E[slot] = e;
-    {
+    if (!a.skipE) r.E[slot] = e;
+    if (!a.skipF) {
         float2 *f = r.F + 5 * slot;
         f[0] = make_float2(cx_, px); f[1] = make_float2(cy_, py); f[2] = make_float2(cz_, pz);
         f[3] = make_float2(e.x, e.y); f[4] = make_float2(e.z, e.w);
