@@ -47,6 +47,7 @@ struct PsContext {
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
                 // of the staged scoring (large batches)
     Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
+    Buf frontRec;            // staged scoring: the pre-test operands of the all-reject front, [P][cap / 2][10] floats
     Buf prefInfo;            // staged scoring: per pair (best count, trip limit) of the prefix, written by ps_stage_reorder
     Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
@@ -88,6 +89,7 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
+    int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
     int listGroups2 = 64, listGroups3 = 1; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
     int forcePrefix = 0; // PUTSLAM_HIP_PREFIX: hypotheses stage 0 scores completely under the fixed schedule (64 .. 256)
@@ -546,7 +548,8 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
             const size_t n = (size_t)P * cap;
             PS_ENSURE(ctx->recF2, n * 40 > (size_t)P * ((cap + 1) / 2) * 64 ? n * 40 : (size_t)P * ((cap + 1) / 2) * 64);
             PS_ENSURE(ctx->permBuf, n * sizeof(int32_t));
-            PS_ENSURE(ctx->prefInfo, (size_t)2 * P * sizeof(int32_t));
+            PS_ENSURE(ctx->prefInfo, (size_t)4 * P * sizeof(int32_t));
+            PS_ENSURE(ctx->frontRec, (size_t)P * ((cap + 1) / 2) * 10 * sizeof(float));
         }
         pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
         pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
@@ -583,6 +586,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
     // swept by one wavefront per SIMD pays the full latency of every record load, 0.25 us per match)
     auto list_rsplit = [&](int stage) { return (pl.reorder && stage == kStages) ? ctx->listRsplit3 : 1; };
+    // stage 1's one-direction pre-test on the all-reject front: errorVersion 2 only (ps_score_fast.h)
+    const bool usePretest = pl.reorder && ctx->pretest != 0 && pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
@@ -595,6 +600,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage == 3) { st.listIn = (const int32_t *)ctx->survB.p; st.countIn = nB; }
         if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
         if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
+        if (stage == 1 && usePretest) st.frontRec = (const float2 *)ctx->frontRec.p;
         st.margin = ctx->reorderMargin;
         st.c2div = ctx->reorderC2div;
         return st;
@@ -608,7 +614,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                                (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,  \
                                (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, pl.ma, pl.sc, pl.sa,       \
                                pl.prefix, ctx->reorderTop, pl.H, cap, pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p, \
-                               (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p);                                 \
+                               (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p,                            \
+                               usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr);                            \
     } while (0)
     StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
     stAll.hCount = pl.H;
@@ -662,7 +669,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     hipLaunchKernelGGL((ps_ransac_score_fast<MODE, BIG, KIND>),                                                        \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
                        dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p,         \
-                       (const float4 *)ctx->recC.p, (const float4 *)ctx->recE.p,                                       \
+                       (const float4 *)ctx->recC.p,                                                                    \
+                       ((KIND) == 1 && (ST).frontRec != nullptr) ? (const float4 *)(ST).frontRec : (const float4 *)ctx->recE.p, \
                        (KIND) >= 1 ? hotF : (const float2 *)ctx->recF.p,                                               \
                        (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.ec, pl.sa, \
                        (ST), pl.H, cap, pl.minRun, (MSPLIT), (int32_t *)ctx->counts.p, dbg)
@@ -898,6 +906,7 @@ int ps_context_create(int device, PsContext **out)
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER")) ctx->reorder = std::min(std::max(std::atoi(v), 0), 2);
+    if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG3")) ctx->listGroups3 = std::min(std::max(std::atoi(v), 1), 64);
@@ -926,7 +935,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};

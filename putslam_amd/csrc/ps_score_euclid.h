@@ -122,7 +122,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     if (pruned) { // (msplit == 1 in these stages; the cuts are multiples of 64)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)
-                     st.prefInfo != nullptr ? st.prefInfo + 2 * p : nullptr);
+                     st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
         mStageEnd = m1;
         if (m0 >= m1) return; // an earlier stage finished the pair's matches

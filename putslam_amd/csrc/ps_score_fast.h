@@ -176,9 +176,13 @@ struct StageArgs {
     int32_t *countOut;
     const int32_t *perm;       // stage >= 1 after ps_stage_reorder: [P][cap], match of the ORIGINAL record arrays at each position
                                // of the reordered hot record (null: the hot record is in the original order)
+    const float2 *frontRec;    // after ps_stage_reorder (reprojection metrics): [P][cap / 2][5] the matches ALL voters reject, two
+                               // per record: (cur.x) (cur.y) (cur.z) (cx - uOld) (cy - vOld) of matches 2k | 2k + 1 -- the
+                               // operands of the one-direction pre-test of stage 1 (null: no pre-test)
     int margin, c2div;         // reordered sweep: where stages 1 and 2 end (stage_range)
-    const int32_t *prefInfo;   // after ps_stage_reorder: [P][2] = (best count, trip limit) the prefix leaves (null: every
-                               // work-group of the stages replays the prefix itself)
+    const int32_t *prefInfo;   // after ps_stage_reorder: [P][4] = (best count, trip limit) the prefix leaves, how many matches at
+                               // the front of the reordered record ALL voters reject, reserved (null: every work-group of
+                               // the stages replays the prefix itself)
 };
 
 // Replay of the sequential selection over counts[0 .. n) by one wavefront (the rule of ps_select_refit part (1)):
@@ -375,7 +379,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)
-                     st.prefInfo != nullptr ? st.prefInfo + 2 * p : nullptr);
+                     st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
         mStageEnd = m1;
         if (m0 >= m1) return; // an earlier stage finished the pair's matches
@@ -599,18 +603,63 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             add_mask(cnt, mIn);
             return execAll & ~(mIn | mOut);
         };
+        // Stage 1 on the reordered record starts with the matches EVERY voter rejected (the wrong correspondences): nearly
+        // every hypothesis rejects them too, and one direction of the test is enough to know -- current point -> previous
+        // image alone.  ps_stage_reorder lays that direction's operands out two MATCHES per record (StageArgs::frontRec), so
+        // one packed chain decides a pair of matches in 19 vector instructions instead of 2 x 23: a lane whose squared error is
+        // above the upper limit is a certain outlier -- the values are the .x lanes of eval() bit for bit (same operations, same
+        // order; the model's .x halves are broadcast), so eval() would say the same -- and every other lane (under 1 %: mostly
+        // the hypotheses that were sampled from that very match) is parked for the value-exact test like an undecided one.
+        // Neither the matches' full records nor the other direction are touched.
+        auto bx2 = [](float v) { return v2f_t{v, v}; };
+        auto not_out2 = [&](const float2 *__restrict__ fr, unsigned long long &ua, unsigned long long &ub) {
+            const unsigned long long *__restrict__ e = reinterpret_cast<const unsigned long long *>(fr);
+            const unsigned long long q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4];
+            const v2f_t cx = __builtin_bit_cast(v2f_t, q0), cy = __builtin_bit_cast(v2f_t, q1), cz = __builtin_bit_cast(v2f_t, q2),
+                        kx = __builtin_bit_cast(v2f_t, q3), ky = __builtin_bit_cast(v2f_t, q4);
+            const v2f_t X = pk_fma(bx2(F.r00.x), cx, pk_fma(bx2(F.r01.x), cy, pk_fma(bx2(F.r02.x), cz, bx2(F.t0.x))));
+            const v2f_t Y = pk_fma(bx2(F.r10.x), cx, pk_fma(bx2(F.r11.x), cy, pk_fma(bx2(F.r12.x), cz, bx2(F.t1.x))));
+            const v2f_t Z = pk_fma(bx2(F.r20.x), cx, pk_fma(bx2(F.r21.x), cy, pk_fma(bx2(F.r22.x), cz, bx2(F.t2.x))));
+            const v2f_t A = pk_fma(kx, Z, X), B = pk_fma(ky, Z, Y);
+            const v2f_t ss = pk_fma(A, A, B * B);
+            const v2f_t q = Z * Z;
+            const float za = Z.x, zb = Z.y;
+            float ba, bb;
+            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(ba) : "v"(cL), "v"(za), "v"(G2));
+            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(bb) : "v"(cL), "v"(zb), "v"(G2));
+            const v2f_t hi = pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, q, v2f_t{ba, bb});
+            const float sa = ss.x, sb = ss.y, ha = hi.x, hb2 = hi.y;
+            ua = execAll & ~__builtin_amdgcn_ballot_w64(sa > ha); // (NaN: not "above": parked)
+            ub = execAll & ~__builtin_amdgcn_ballot_w64(sb > hb2);
+        };
+        // (only stage 1 sweeps the front; and only errorVersion 2, whose evaluation is 40 instructions: -8 % of its scoring
+        // step.  With errorVersion 1 -- 23 instructions -- the same code measured +1.5 %, profiles/r03n.)
+        constexpr bool PRE = KIND == 1 && EUCLID;
+        int mFront = m0; // matches [m0, mFront): the all-reject front of the reordered record
+        // (the launch passes the front record as recE, which the packed-record build does not read otherwise: only loads
+        // through a __restrict__ kernel argument become scalar loads -- through the pointer inside StageArgs they were
+        // vector loads of one address by 64 lanes)
+        const float2 *__restrict__ pfr = reinterpret_cast<const float2 *>(recE) + (size_t)p * ((size_t)((cap + 1) >> 1) * 5);
+        if (PRE && st.frontRec != nullptr && st.prefInfo != nullptr) {
+            const int f = __builtin_amdgcn_readfirstlane(st.prefInfo[4 * p + 2]); // (uniform: keep the loop's branch scalar)
+            mFront = f < m1 ? f : m1;
+        }
         // Two matches per trip, both records requested before the first is used: a wavefront that is alone on its SIMD (the
         // stages with few hypotheses, a single pair) otherwise waits out one scalar load per match.  The undecided lanes of
         // both are parked afterwards, in ONE copy of the parking code (it holds the drain).
         for (int m = m0; m < m1; m += 2) {
             const bool two = m + 1 < m1; // (wave-uniform)
-            Rec ra = load_rec(m), rb = load_rec(two ? m + 1 : m);
-            // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
-            asm volatile("" : "+s"(ra.q[0]), "+s"(ra.q[1]), "+s"(ra.q[2]), "+s"(ra.q[3]), "+s"(ra.q[4]), "+s"(rb.q[0]), "+s"(rb.q[1]),
-                         "+s"(rb.q[2]), "+s"(rb.q[3]), "+s"(rb.q[4]));
-            const unsigned long long ua = eval(ra);
-            unsigned long long ub = 0ull;
-            if (two) ub = eval(rb);
+            unsigned long long ua, ub = 0ull;
+            if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
+                not_out2(pfr + 5 * (m >> 1), ua, ub);
+            } else {
+                Rec ra = load_rec(m), rb = load_rec(two ? m + 1 : m);
+                // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
+                asm volatile("" : "+s"(ra.q[0]), "+s"(ra.q[1]), "+s"(ra.q[2]), "+s"(ra.q[3]), "+s"(ra.q[4]), "+s"(rb.q[0]),
+                             "+s"(rb.q[1]), "+s"(rb.q[2]), "+s"(rb.q[3]), "+s"(rb.q[4]));
+                ua = eval(ra);
+                if (two) ub = eval(rb);
+            }
             if ((ua | ub) != 0ull) {
 #pragma nounroll
                 for (int j = 0; j < 2; ++j) {
@@ -732,7 +781,8 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                                                            const int32_t *__restrict__ mvalid, ModelArgs ma, ScoreConsts k,
                                                            SelectArgs sa, int prefix, int nTopMax, int H, int cap, int minRun,
                                                            const int32_t *__restrict__ counts, float2 *__restrict__ recF2,
-                                                           int32_t *__restrict__ perm, int32_t *__restrict__ prefInfo)
+                                                           int32_t *__restrict__ perm, int32_t *__restrict__ prefInfo,
+                                                           float2 *__restrict__ frontRec)
 {
     constexpr bool EUCLID_REC = MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR; // hot record = RecPtrs::G
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? 16 : 12;
@@ -753,8 +803,9 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         int b, l, bi;
         wave_replay_prefix(cnts, prefix, sa, M, b, l, bi);
         if (lane == 0) { // what every work-group of the stages needs (stage_prefix)
-            prefInfo[2 * p] = b;
-            prefInfo[2 * p + 1] = l;
+            prefInfo[4 * p] = b;
+            prefInfo[4 * p + 1] = l;
+            prefInfo[4 * p + 2] = 0; // (the all-reject front: known after the sort)
         }
         int n = 0;
         const bool idle = b > 0 && l <= prefix; // (without a record nothing can be cut: the stages sweep everything)
@@ -851,6 +902,11 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         }
     }
     __syncthreads();
+    // matches every voter rejects (bucket 0; without a voter there is no such verdict)
+    const int front = nTop >= 1 ? s_tab[(1 * nChunks) * (kBlock / 64)] : 0;
+    if (tid == 0) prefInfo[4 * p + 2] = front;
+    float *__restrict__ frOut =
+        (EUCLID_REC || frontRec == nullptr) ? nullptr : reinterpret_cast<float *>(frontRec) + (size_t)p * ((size_t)((cap + 1) >> 1) * 10);
     const float *__restrict__ gIn = reinterpret_cast<const float *>(recF) + (size_t)p * ((size_t)((cap + 1) >> 1) * RF);
     float *__restrict__ gOut = reinterpret_cast<float *>(recF2) + (size_t)p * ((size_t)((cap + 1) >> 1) * RF);
     for (int c = 0; c < nChunks; ++c) {
@@ -873,6 +929,11 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                 float2 *dst = recF2 + 5 * (rbase + pos);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) dst[i] = src[i];
+                if (frOut != nullptr && pos < front) { // one direction's operands, two matches per record (stage 1's pre-test)
+                    float *fd = frOut + (size_t)(pos >> 1) * 10 + (pos & 1);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) fd[2 * i] = src[i].x;
+                }
             }
         }
     }
