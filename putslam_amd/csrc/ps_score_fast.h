@@ -342,6 +342,9 @@ PS_D int list_cover(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : kBlock); }
 // traffic per 499 pairs, profiles/r03i) against 56 VGPRs, no scratch memory and eight waves without (profiles/r03l).  The
 // epilogues still derive the hypothesis index again instead of keeping it across the loops.
 // One pass of a work-group: the hypotheses [hBase + bx * 256, + 256) (kinds 0 / 1) or one pass over the survivor list (kind 2).
+#ifndef PS_PRETEST_E1
+#define PS_PRETEST_E1 0 // (trial switch: the pre-test of stage 1's front for errorVersion 1 too, profiles/r03n)
+#endif
 template <int MODE, bool BIG, int KIND>
 PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                           const float4 *__restrict__ recE, const float2 *__restrict__ recF,
@@ -634,7 +637,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         };
         // (only stage 1 sweeps the front; and only errorVersion 2, whose evaluation is 40 instructions: -8 % of its scoring
         // step.  With errorVersion 1 -- 23 instructions -- the same code measured +1.5 %, profiles/r03n.)
-        constexpr bool PRE = KIND == 1 && EUCLID;
+        constexpr bool PRE = KIND == 1 && (EUCLID || PS_PRETEST_E1);
         int mFront = m0; // matches [m0, mFront): the all-reject front of the reordered record
         // (the launch passes the front record as recE, which the packed-record build does not read otherwise: only loads
         // through a __restrict__ kernel argument become scalar loads -- through the pointer inside StageArgs they were
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
     __shared__ int s_top[kReorderTopMax + 1];                              // [0] = how many, then the hypotheses
     __shared__ uint8_t s_rej[PS_MAX_KPTS];                                 // per match: how many of them reject it
     __shared__ float s_vote[kReorderTopMax][24];                           // the voters' models and their inverses
-    __shared__ int s_tab[(kReorderTopMax + 1) * kMaxChunks * (kBlock / 64)]; // bucket-major counts -> start positions
+    __shared__ int s_tab[(kReorderTopMax + 2) * kMaxChunks * (kBlock / 64)]; // bucket-major counts -> start positions
     const int p = blockIdx.x;
     const int M = mvalid[p];
     if (M < minRun) return;
@@ -857,6 +860,7 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
     for (int m = tid; m < M; m += kBlock) { // (the thread's own matches)
         const float4 A = pa[m], B = pb[m], C = pc[m];
         int rej = 0;
+        bool far = (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) && nTop >= 1;
         for (int t = 0; t < nTop; ++t) {
             Rigid mdl, inv;
 #pragma unroll
@@ -870,23 +874,36 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                 inv.t[i] = s_vote[t][21 + i];
             }
             rej += inlier_test<MODE>(mdl, inv, k, A, B, C) ? 0 : 1;
+            if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR) {
+                // FAR off in the direction stage 1's pre-test looks at (current point -> previous image): more than four
+                // thresholds (a heuristic for the order only; plain float arithmetic)
+                float ex, ey, ez, pu, pv;
+                xform(mdl, B.x, B.y, B.z, ex, ey, ez);
+                project(ex, ey, ez, k.fx, k.fy, k.cx, k.cy, pu, pv);
+                const float du = pu - C.x, dv = pv - C.y;
+                far = far && (du * du + dv * dv > 16.0f * (float)k.boundR);
+            }
         }
-        s_rej[m] = (uint8_t)rej;
+        // bucket of the counting sort: 0 = every voter rejects it AND it is far off for each (the wrong correspondences
+        // proper), then 1 + (nTop - rejections): rejected by all but close for some voter (marginal true correspondences:
+        // in doubt for every good hypothesis), ..., accepted by all
+        s_rej[m] = (uint8_t)(far && rej == nTop ? 0 : 1 + nTop - rej);
     }
-    // Stable counting sort by "rejected by how many" (descending): bucket d = nTop - rejections.  Counts per (bucket,
-    // chunk of 256 matches, wave) -> exclusive prefix in that order -> position = start + lanes below in the same bucket.
+    // Stable counting sort by bucket.  Counts per (bucket, chunk of 256 matches, wave) -> exclusive prefix in that order
+    // -> position = start + lanes below in the same bucket.
+    const int nB = nTop + 2; // buckets
     const int nChunks = (M + kBlock - 1) / kBlock;
     for (int c = 0; c < nChunks; ++c) {
         const int m = c * kBlock + tid;
-        const int d = m < M ? nTop - (int)s_rej[m] : -1;
-        for (int b = 0; b <= nTop; ++b) {
+        const int d = m < M ? (int)s_rej[m] : -1;
+        for (int b = 0; b < nB; ++b) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(d == b);
             if (lane == 0) s_tab[(b * nChunks + c) * (kBlock / 64) + wv] = __popcll(bal);
         }
     }
     __syncthreads();
     if (wv == 0) {
-        const int n = (nTop + 1) * nChunks * (kBlock / 64);
+        const int n = nB * nChunks * (kBlock / 64);
         int carry = 0;
         for (int e0 = 0; e0 < n; e0 += 64) {
             const int e = e0 + lane;
@@ -902,8 +919,8 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         }
     }
     __syncthreads();
-    // matches every voter rejects (bucket 0; without a voter there is no such verdict)
-    const int front = nTop >= 1 ? s_tab[(1 * nChunks) * (kBlock / 64)] : 0;
+    // matches every voter rejects and finds far off (bucket 0; empty without a voter and for the Euclidean metrics)
+    const int front = s_tab[(1 * nChunks) * (kBlock / 64)];
     if (tid == 0) prefInfo[4 * p + 2] = front;
     float *__restrict__ frOut =
         (EUCLID_REC || frontRec == nullptr) ? nullptr : reinterpret_cast<float *>(frontRec) + (size_t)p * ((size_t)((cap + 1) >> 1) * 10);
@@ -911,9 +928,9 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
     float *__restrict__ gOut = reinterpret_cast<float *>(recF2) + (size_t)p * ((size_t)((cap + 1) >> 1) * RF);
     for (int c = 0; c < nChunks; ++c) {
         const int m = c * kBlock + tid;
-        const int d = m < M ? nTop - (int)s_rej[m] : -1;
+        const int d = m < M ? (int)s_rej[m] : -1;
         int pos = 0;
-        for (int b = 0; b <= nTop; ++b) {
+        for (int b = 0; b < nB; ++b) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(d == b);
             if (d == b) pos = s_tab[(b * nChunks + c) * (kBlock / 64) + wv] + lanes_below(bal);
         }
