@@ -308,7 +308,8 @@ int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, u
  * code, and (hypothesis, match) evaluations it made in all (lanes of partially filled wavefronts included). */
 int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations);
 /* All eight counters of the last scoring step: [0] parked, [1] evaluations made (with the staged scoring: what is left of
- * the complete sweep of H hypotheses x M matches); [2..7] reserved (0). */
+ * the complete sweep of H hypotheses x M matches); [2] / [3] trips (wavefront x two matches) of stage 1's pre-test that left
+ * no lane / some lane to the value-exact test; [4..7] reserved (0). */
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* Staged scoring: hypotheses of every pair that survived stage 1 (out[0..P)) and stage 2 (out[P..2P)) of the last call
  * that was scored in stages (the last P pairs' counters; zeros if none was). */

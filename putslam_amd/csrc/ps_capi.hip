@@ -89,6 +89,8 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
+    int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (PUTSLAM_HIP_REORDER_GRAN: 2 .. 64; finer cuts
+                          // shorten stage 1 and lengthen stages 2 / 3 by as much, profiles/r03n)
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
     int listGroups2 = 64, listGroups3 = 1; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
@@ -586,8 +588,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
     // swept by one wavefront per SIMD pays the full latency of every record load, 0.25 us per match)
     auto list_rsplit = [&](int stage) { return (pl.reorder && stage == kStages) ? ctx->listRsplit3 : 1; };
-    // stage 1's one-direction pre-test on the all-reject front: errorVersion 2 only (ps_score_fast.h)
-    const bool usePretest = pl.reorder && ctx->pretest != 0 && pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR;
+    // stage 1's one-direction pre-test on the far-off front of the reordered record: the reprojection metrics (ps_score_fast.h)
+    const bool usePretest = pl.reorder && ctx->pretest != 0 &&
+                            (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || pl.mode == PS_REPROJECTION_ERROR);
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
@@ -602,6 +605,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
         if (stage == 1 && usePretest) st.frontRec = (const float2 *)ctx->frontRec.p;
         st.margin = ctx->reorderMargin;
+        st.gran = with_euclid_fast(ctx, pl.mode) ? 64 : ctx->reorderGran;
         st.c2div = ctx->reorderC2div;
         return st;
     };
@@ -906,6 +910,10 @@ int ps_context_create(int device, PsContext **out)
         ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER")) ctx->reorder = std::min(std::max(std::atoi(v), 0), 2);
+    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_GRAN")) {
+        const int g = std::atoi(v);
+        if (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->reorderGran = g;
+    }
     if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);

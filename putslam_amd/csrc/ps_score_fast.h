@@ -180,6 +180,8 @@ struct StageArgs {
                                // per record: (cur.x) (cur.y) (cur.z) (cx - uOld) (cy - vOld) of matches 2k | 2k + 1 -- the
                                // operands of the one-direction pre-test of stage 1 (null: no pre-test)
     int margin, c2div;         // reordered sweep: where stages 1 and 2 end (stage_range)
+    int gran;                  // the stage cuts are multiples of this (64: the Euclidean kernel recounts blocks of 64 matches;
+                               // 8 for the reprojection kernels, which only need even cuts)
     const int32_t *prefInfo;   // after ps_stage_reorder: [P][4] = (best count, trip limit) the prefix leaves, how many matches at
                                // the front of the reordered record ALL voters reject, reserved (null: every work-group of
                                // the stages replays the prefix itself)
@@ -240,7 +242,8 @@ PS_D void stage_range(const StageArgs &st, int M, int best0, int &lo, int &hi)
     if (best0 > 0) {
         const int miss = M - best0; // a hypothesis is out once it has missed this many matches
         if (reordered) {
-            c1 = (miss + st.margin + 63) & ~63;
+            const int g1 = st.gran - 1; // (gran is a power of two)
+            c1 = (miss + st.margin + g1) & ~g1;
             if (c1 >= M - M / 8) c1 = M;
             if (c1 < M) {
                 const int step = ((M - c1) / st.c2div + 63) & ~63;
@@ -342,9 +345,6 @@ PS_D int list_cover(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : kBlock); }
 // traffic per 499 pairs, profiles/r03i) against 56 VGPRs, no scratch memory and eight waves without (profiles/r03l).  The
 // epilogues still derive the hypothesis index again instead of keeping it across the loops.
 // One pass of a work-group: the hypotheses [hBase + bx * 256, + 256) (kinds 0 / 1) or one pass over the survivor list (kind 2).
-#ifndef PS_PRETEST_E1
-#define PS_PRETEST_E1 0 // (trial switch: the pre-test of stage 1's front for errorVersion 1 too, profiles/r03n)
-#endif
 template <int MODE, bool BIG, int KIND>
 PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                           const float4 *__restrict__ recE, const float2 *__restrict__ recF,
@@ -635,9 +635,9 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             ua = execAll & ~__builtin_amdgcn_ballot_w64(sa > ha); // (NaN: not "above": parked)
             ub = execAll & ~__builtin_amdgcn_ballot_w64(sb > hb2);
         };
-        // (only stage 1 sweeps the front; and only errorVersion 2, whose evaluation is 40 instructions: -8 % of its scoring
-        // step.  With errorVersion 1 -- 23 instructions -- the same code measured +1.5 %, profiles/r03n.)
-        constexpr bool PRE = KIND == 1 && (EUCLID || PS_PRETEST_E1);
+        // (only stage 1 sweeps the front.  profiles/r03n: stage 1 640 -> 563 us with errorVersion 1, -11 % of the scoring step
+        // with errorVersion 2; the pre-test leaves 0.9 % of its trips with a lane to park.)
+        constexpr bool PRE = KIND == 1;
         int mFront = m0; // matches [m0, mFront): the all-reject front of the reordered record
         // (the launch passes the front record as recE, which the packed-record build does not read otherwise: only loads
         // through a __restrict__ kernel argument become scalar loads -- through the pointer inside StageArgs they were
@@ -655,6 +655,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             unsigned long long ua, ub = 0ull;
             if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
                 not_out2(pfr + 5 * (m >> 1), ua, ub);
+                if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua | ub) == 0ull ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
             } else {
                 Rec ra = load_rec(m), rb = load_rec(two ? m + 1 : m);
                 // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
