@@ -33,15 +33,20 @@ def _cpu_stamp():
 def build(force=False):
     """Compile the oracle with gcc (seconds). Building the checker is not using it."""
     srcs = [os.path.join(_HERE, f) for f in ("putslam_oracle.c", "putslam_oracle.h", "po_svd.inc")]
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
     stamp_file = os.path.join(_HERE, "_build", "cpu.stamp")
     stamp = _cpu_stamp()
-    fresh = (os.path.exists(_SO) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp
-             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs))
-    if not force and fresh:
-        return _SO
-    subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
-    with open(stamp_file, "w") as f:
-        f.write(stamp)
+    # (check + build under a file lock: several processes starting together -- the soak's workers on a fresh box, whose CPU
+    # stamp differs from the build host's -- would otherwise rebuild at once and load each other's half-written library)
+    import fcntl
+    with open(os.path.join(_HERE, "_build", "build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        fresh = (os.path.exists(_SO) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp
+                 and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs))
+        if force or not fresh:
+            subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+            with open(stamp_file, "w") as f:
+                f.write(stamp)
     return _SO
 
 

@@ -47,6 +47,7 @@ struct PsContext {
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
                 // of the staged scoring (large batches)
     Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
+    Buf validMask;           // staged scoring, stage 0 in two launches: which prefix hypotheses have a model, [P][prefix / 64]
     Buf frontRec;            // staged scoring: the pre-test operands of the all-reject front, [P][cap / 2][10] floats
     Buf prefInfo;            // staged scoring: per pair (best count, trip limit) of the prefix, written by ps_stage_reorder
     Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
@@ -91,6 +92,9 @@ struct PsContext {
     int reorder = 2;
     int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (PUTSLAM_HIP_REORDER_GRAN: 2 .. 64; finer cuts
                           // shorten stage 1 and lengthen stages 2 / 3 by as much, profiles/r03n)
+    int genSplit = 1;    // staged scoring: stage 0 as two launches -- the prefix's models once, then the sweep with the match range
+                         // split over twice as many work-groups (PUTSLAM_HIP_GENSPLIT=0: one launch, every part repeats the
+                         // sample -> SVD chain)
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
     int listGroups2 = 64, listGroups3 = 1; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
@@ -332,6 +336,7 @@ struct Plan {
     SelectArgs sa{};
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
+    bool genSplit = false; // staged scoring: stage 0 as two launches (models, then the sweep)
     bool reorder = false; // staged scoring: stages 1+ sweep the reordered hot record (ps_stage_reorder)
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
@@ -520,7 +525,10 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     if (ctx->forcePrefix > 0 && pl.sa.estimator == PS_EST_FIXED) pl.prefix = ctx->forcePrefix; // (tuning knob)
     pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
+    pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
+    if (pl.genSplit) pl.msplit = pl.msplit * 2 < 32 ? pl.msplit * 2 : 32; // (the parts no longer repeat the prologue)
     if (ctx->forceMsplit > 0) pl.msplit = ctx->forceMsplit;
+    if (pl.msplit <= 1) pl.genSplit = false;
     pl.pa.zeroCounts = pl.msplit > 1 ? (int32_t *)ctx->counts.p : nullptr;
     pl.pa.zeroH = pl.prune ? pl.prefix : H;
     pl.pa.zeroStride = H;
@@ -545,6 +553,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
         PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
         PS_ENSURE(ctx->survB, (size_t)P * H * sizeof(int32_t));
         PS_ENSURE(ctx->survN, (size_t)2 * P * sizeof(int32_t));
+        if (pl.genSplit) PS_ENSURE(ctx->validMask, (size_t)P * ((pl.prefix + 63) / 64) * sizeof(unsigned long long));
         pl.reorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
         if (pl.reorder) {
             const size_t n = (size_t)P * cap;
@@ -621,6 +630,15 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                                (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p,                            \
                                usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr);                            \
     } while (0)
+    // stage 0 as two launches: models + validity, then the sweep reading them back
+    auto stage0_args = [&](bool gen) {
+        StageArgs st = stage_args(0);
+        if (pl.genSplit) {
+            st.validMask = (unsigned long long *)ctx->validMask.p;
+            st.genOnly = gen ? 1 : 0;
+        }
+        return st;
+    };
     StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
     stAll.hCount = pl.H;
 #define PS_LAUNCH_EUCLID_ONE(MODE, KIND, ST, HCOUNT, MSPLIT)                                                           \
@@ -633,7 +651,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
 #define PS_LAUNCH_EUCLID(MODE)                                                                                         \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
-            PS_LAUNCH_EUCLID_ONE(MODE, 0, stage_args(0), pl.prefix, msplit);                                           \
+            if (pl.genSplit) PS_LAUNCH_EUCLID_ONE(MODE, 0, stage0_args(true), pl.prefix, 1);                           \
+            PS_LAUNCH_EUCLID_ONE(MODE, 0, stage0_args(false), pl.prefix, msplit);                                      \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
             for (int sg = 2; sg <= kStages; ++sg)                                                                      \
@@ -682,10 +701,13 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
 #define PS_LAUNCH_FAST(MODE, BIGLIMIT)                                                                                 \
     do {                                                                                                               \
         if (pl.prune) {                                                                                                \
-            if ((unsigned)msplit * (unsigned)P > (BIGLIMIT))                                                           \
-                PS_LAUNCH_FAST_ONE(MODE, true, 0, stage_args(0), pl.prefix, msplit);                                   \
-            else                                                                                                       \
-                PS_LAUNCH_FAST_ONE(MODE, false, 0, stage_args(0), pl.prefix, msplit);                                  \
+            if ((unsigned)msplit * (unsigned)P > (BIGLIMIT)) {                                                         \
+                if (pl.genSplit) PS_LAUNCH_FAST_ONE(MODE, true, 0, stage0_args(true), pl.prefix, 1);                   \
+                PS_LAUNCH_FAST_ONE(MODE, true, 0, stage0_args(false), pl.prefix, msplit);                              \
+            } else {                                                                                                   \
+                if (pl.genSplit) PS_LAUNCH_FAST_ONE(MODE, false, 0, stage0_args(true), pl.prefix, 1);                  \
+                PS_LAUNCH_FAST_ONE(MODE, false, 0, stage0_args(false), pl.prefix, msplit);                             \
+            }                                                                                                          \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
             for (int sg = 2; sg <= kStages; ++sg)                                                                      \
@@ -914,6 +936,7 @@ int ps_context_create(int device, PsContext **out)
         const int g = std::atoi(v);
         if (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->reorderGran = g;
     }
+    if (const char *v = std::getenv("PUTSLAM_HIP_GENSPLIT")) ctx->genSplit = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);
@@ -943,7 +966,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};

@@ -637,6 +637,14 @@ PS_D int lanes_below(unsigned long long mask)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+// a 64-bit value that is the same in every lane, moved to scalar registers (loaded through a pointer the compiler cannot
+// prove uniform it sits in vector registers)
+PS_D unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 PS_D bool lane_in(unsigned long long mask)
 {
     int x;

@@ -164,12 +164,22 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
             load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
             valid = true;
         }
+    } else if (KIND == 0 && st.validMask != nullptr && !st.genOnly) {
+        // stage 0, second launch: models and validity read back (ps_score_fast.h)
+        const unsigned long long vm = uniform64(st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)]);
+        valid = h < hEnd && lane_in(vm);
+        if (h < hEnd) load_model(ma, (size_t)p * H + h, mdl);
     } else {
         if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H); // (ps_score_fast.h)
             if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+        }
+        if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+            if (lane == 0) st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)] = vm;
+            return;
         }
     }
 #pragma unroll

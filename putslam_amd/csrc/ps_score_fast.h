@@ -180,6 +180,9 @@ struct StageArgs {
                                // per record: (cur.x) (cur.y) (cur.z) (cx - uOld) (cy - vOld) of matches 2k | 2k + 1 -- the
                                // operands of the one-direction pre-test of stage 1 (null: no pre-test)
     int margin, c2div;         // reordered sweep: where stages 1 and 2 end (stage_range)
+    unsigned long long *validMask; // stage 0 in two launches (models once, then the sweep split over many work-groups): [P][hCount/64]
+    int genOnly;               // 1 = this launch only generates the models of [hBase, hBase + hCount), parks them and writes
+                               // validMask; 0 with validMask set = this launch reads both back instead of generating
     int gran;                  // the stage cuts are multiples of this (64: the Euclidean kernel recounts blocks of 64 matches;
                                // 8 for the reprojection kernels, which only need even cuts)
     const int32_t *prefInfo;   // after ps_stage_reorder: [P][4] = (best count, trip limit) the prefix leaves, how many matches at
@@ -424,12 +427,23 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
             valid = true;
         }
+    } else if (KIND == 0 && st.validMask != nullptr && !st.genOnly) {
+        // stage 0, second launch: the models were generated once by the first (the sweep is split over msplit work-groups,
+        // each of which would otherwise repeat the sample -> SVD chain: 63 % of stage 0's instructions with four parts)
+        const unsigned long long vm = uniform64(st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)]);
+        valid = h < hEnd && lane_in(vm);
+        if (h < hEnd) load_model(ma, (size_t)p * H + h, mdl);
     } else {
         if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
             if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+        }
+        if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+            if (lane == 0) st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)] = vm;
+            return;
         }
     }
 #pragma unroll

@@ -157,6 +157,7 @@ def main():
     modes = tuple(int(x) for x in a.modes.split(","))
     if a.procs > 1:
         import subprocess
+        po.lib()  # (build the oracle once, before the workers start)
         per = (a.iters + a.procs - 1) // a.procs
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--iters", str(per), "--seed", str(a.seed + i),
                                 "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else [])
