@@ -22,7 +22,7 @@ EXPORTED = [
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
-    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stamps",
+    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stage_order", "ps_debug_stamps",
     "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
     "ps_abi_sizeof_frameset", "ps_abi_sizeof_results",
 ]
@@ -79,6 +79,7 @@ def load():
     L.ps_debug_score_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ps_debug_score_stats_ex.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ps_debug_stage_survivors.argtypes = [vp, i32, vp]
+    L.ps_debug_stage_order.argtypes = [vp, i32, i32, vp, vp]
     L.ps_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ps_last_error.argtypes = [vp]
     L.ps_last_error.restype = C.c_char_p

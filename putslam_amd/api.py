@@ -81,6 +81,13 @@ class Context:
         self._chk(self._L.ps_debug_stage_survivors(self._h, int(P), out.ctypes.data))
         return out
 
+    def stage_order(self, P, cap):
+        """(perm (P, cap), front (P,)): the order stages 1+ of the last staged scoring step swept the matches in."""
+        perm = np.zeros((int(P), int(cap)), np.int32)
+        front = np.zeros(int(P), np.int32)
+        self._chk(self._L.ps_debug_stage_order(self._h, int(P), int(cap), perm.ctypes.data, front.ctypes.data))
+        return perm, front
+
     def stamps(self):
         """Shader-clock stamps of kernels 2 and 4 of the last call (needs set_option("stamps", 1)); ps_debug_stamps."""
         out = (C.c_uint64 * 16)()

@@ -1388,6 +1388,26 @@ int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out)
     return PS_OK;
 }
 
+// Diagnostic: the order in which stages 1+ of the LAST staged, reordered scoring step swept every pair's matches
+// (ps_stage_reorder): perm[p][i] = match of the original record arrays at position i, front[p] = how many of the leading
+// positions hold matches every voter rejected and found far off.  PS_ERR_BAD_ARG if the context holds no such order for
+// P pairs of `cap` matches.
+int ps_debug_stage_order(PsContext *ctx, int P, int cap, int32_t *perm, int32_t *front)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!perm || !front || P <= 0 || cap <= 0) return PS_ERR_BAD_ARG;
+    if (!ctx->permBuf.p || ctx->permBuf.cap < (size_t)P * cap * sizeof(int32_t) || !ctx->prefInfo.p ||
+        ctx->prefInfo.cap < (size_t)4 * P * sizeof(int32_t))
+        return fail(ctx, PS_ERR_BAD_ARG, "no reordered scoring step of that size in this context");
+    std::vector<int32_t> info((size_t)4 * P);
+    PS_HIP(hipMemcpyAsync(perm, ctx->permBuf.p, (size_t)P * cap * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipMemcpyAsync(info.data(), ctx->prefInfo.p, info.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < P; ++p) front[p] = info[(size_t)4 * p + 2];
+    return PS_OK;
+}
+
 // Diagnostic: the shader-clock stamps kernels 2 and 4 of the LAST call wrote (option "stamps"): out16[0..3] = kernel 2
 // (start, best[q] built, matches compacted + records, end), out16[4..9] = kernel 4 (start, selection, inlier pass,
 // refit, re-selection, end), of work-group 0.  Differences are shader-clock ticks (s_memtime).

@@ -107,3 +107,31 @@ def test_prune_ties_and_late_records(oracle):
             full = _run(seq, prm, cfg, 0)
             _same(pruned, full, P)
             _same(_run(seq, prm, cfg, 1, reorder=0), full, P)
+
+
+def test_reordered_record_is_a_permutation_with_the_rejected_matches_in_front(oracle):
+    """ps_stage_reorder only changes the ORDER the stages sweep the matches in: per pair the order is a permutation of the
+    depth-valid matches, and the matches of its pre-test front are rejected by the pair's selected hypothesis (one of the
+    voters unless a later hypothesis beat the prefix -- then nearly all; the property asserted is the permutation, the
+    front is reported)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(60, 700, config=3, index=4242, inlier_frac=0.7, noise=0.004)
+    P = len(seq["pairs"])
+    for mode in (REPROJECTION_ERROR, EUCLIDEAN_ERROR):
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(EST_FIXED, 4096, seed=5)
+        c = api.Context(0)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        perm, front = c.stage_order(P, fs.max_kpts)
+        c.close()
+        for p in range(P):
+            M = int(g["stats"][p]["numMatchesValid"])
+            assert sorted(perm[p, :M].tolist()) == list(range(M)), (mode, p)
+            assert 0 <= front[p] <= M
+        if mode == REPROJECTION_ERROR:
+            assert front.sum() > 0   # (how much of the miss budget is FAR off depends on the data: 40 % here, 75 % in the bench)
+        else:
+            assert (front == 0).all()   # (the pre-test front exists for the reprojection metrics only)
