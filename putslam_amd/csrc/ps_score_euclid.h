@@ -67,9 +67,6 @@ PS_D v2f_t splat(float v) { return v2f_t{v, v}; }
 
 constexpr int kEuclidBlock = 64; // matches between two checks of the indicators (32 packed steps)
 
-#ifndef PS_EUCLID_WAVES
-#define PS_EUCLID_WAVES 7
-#endif
 // One pair record as the SGPR pairs the packed instructions take.
 template <int MODE> struct EuclidRec {
     float2 g[MODE == PS_ADAPTIVE_ERROR ? 7 : 6];

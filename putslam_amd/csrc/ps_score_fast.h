@@ -312,7 +312,8 @@ PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t
 
 // The hypothesis of a lane, derived AGAIN at the end of a staged launch from values that cost no vector register in between
 // (the scalar work-group offset passes through an empty asm, so that the compiler cannot keep the first derivation -- or
-// the 64-bit addresses built on it -- alive across the loops: at seven waves per SIMD it kept them in scratch memory).
+// the 64-bit addresses built on it -- alive across the loops: with the vectorisers on, at seven waves per SIMD, it kept
+// them in scratch memory; kept for the registers it still saves).
 // base = first hypothesis (or list entry) of the work-group's pass, slot = the lane's place in it.
 PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int base, int slot, int p, int H)
 {
