@@ -97,7 +97,7 @@ struct PsContext {
                          // sample -> SVD chain)
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
-    int listGroups2 = 64, listGroups3 = 1; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
+    int listGroups2 = 64, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
     int forcePrefix = 0; // PUTSLAM_HIP_PREFIX: hypotheses stage 0 scores completely under the fixed schedule (64 .. 256)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
@@ -591,7 +591,10 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // stages 2+: work-groups per pair (they loop over longer lists; after the reordered stage 1 few hypotheses are left)
     auto list_groups = [&](int stage) {
         const int all = (pl.H - pl.prefix + kBlock - 1) / kBlock;
-        const int want = pl.reorder ? (stage == 2 ? ctx->listGroups2 : ctx->listGroups3) : all;
+        // (stage 3 by default: one looping group per eight possible ones -- 1 for H = 4096, where 21 of 3840 hypotheses per
+        // pair are left, 48 for the stress configuration's H = 100 000, which one group swept in 4.3 ms instead of 1.0)
+        const int auto3 = all / 8 > 1 ? all / 8 : 1;
+        const int want = pl.reorder ? (stage == 2 ? ctx->listGroups2 : (ctx->listGroups3 > 0 ? ctx->listGroups3 : auto3)) : all;
         return want < all ? want : all;
     };
     // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
@@ -940,7 +943,7 @@ int ps_context_create(int device, PsContext **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);
-    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG3")) ctx->listGroups3 = std::min(std::max(std::atoi(v), 1), 64);
+    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG3")) ctx->listGroups3 = std::min(std::max(std::atoi(v), 0), 512); // 0 = automatic
     if (const char *v = std::getenv("PUTSLAM_HIP_PREFIX")) ctx->forcePrefix = std::min(std::max(std::atoi(v) & ~63, 64), 256);
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_TOP")) ctx->reorderTop = std::min(std::max(std::atoi(v), 1), kReorderTopMax);
     if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_MARGIN")) ctx->reorderMargin = std::min(std::max(std::atoi(v), 1), 4096);

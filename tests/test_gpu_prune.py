@@ -60,6 +60,10 @@ CASES = [  # (errorVersion, estimator, H, frames, kpts, inlier_frac, noise)
     (REPROJECTION_ERROR, EST_FIXED, 1161, 132, 270, 0.94, 0.0014),
     (EUCLIDEAN_ERROR, EST_FIXED, 1500, 120, 150, 0.80, 0.002),
     (ADAPTIVE_ERROR, EST_FIXED, 1161, 140, 90, 0.90, 0.001),
+    # many hypotheses, few pairs (the stress configuration's shape): the survivor lists are long, the list stages loop over
+    # them in several passes and with several work-groups per pair
+    (REPROJECTION_ERROR, EST_FIXED, 20000, 7, 900, 0.45, 0.008),
+    (EUCLIDEAN_ERROR, EST_FIXED, 30000, 5, 800, 0.35, 0.01),
 ]
 
 
