@@ -523,7 +523,10 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     const size_t mbytes = (size_t)P * H * 12 * sizeof(float);
     pl.prefix = pl.sa.estimator == PS_EST_FIXED ? kPrefixFixed : kPrefixAdaptive;
     if (ctx->forcePrefix > 0 && pl.sa.estimator == PS_EST_FIXED) pl.prefix = ctx->forcePrefix; // (tuning knob)
-    pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= 256 && mbytes <= ((size_t)8 << 30);
+    // (the staged form is six or seven dependent launches, 0.23 ms at the least with the reprojection kernels and 0.08 ms with
+    // the Euclidean ones: it pays from about 48 / 16 pairs of H = 4096 on, profiles/r03p/small_batches.txt)
+    const long long stagedFrom = with_euclid_fast(ctx, pl.mode) ? 256 : 768;
+    pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
     if (pl.genSplit) pl.msplit = pl.msplit * 2 < 32 ? pl.msplit * 2 : 32; // (the parts no longer repeat the prologue)

@@ -93,7 +93,8 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
                   (EST_FIXED, int(rng.integers(257, 6000)))][int(rng.integers(0, 3))]
         hb = (H + 255) // 256
         kpts = int(rng.integers(40, 900))
-        frames = int(max(6, min(400, 300 // max(hb - 1, 1) + int(rng.integers(2, 60)))))  # P (hb - 1) >= 256 most of the time
+        # (staged from P (hb - 1) >= 256 (Euclidean kernels) / 768 (reprojection kernels) on: most batches are above)
+        frames = int(max(6, min(400, 800 // max(hb - 1, 1) + int(rng.integers(2, 60)))))
         frac = float(rng.uniform(0.05, 0.95))
         noise = float(10 ** rng.uniform(-4, -1.5))
         seq = synth.make_sequence(frames, kpts, config=3, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)

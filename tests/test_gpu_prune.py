@@ -51,18 +51,18 @@ CASES = [  # (errorVersion, estimator, H, frames, kpts, inlier_frac, noise)
     (EUCLIDEAN_ERROR, EST_USAC, 3000, 40, 500, 0.30, 0.01),
     (ADAPTIVE_ERROR, EST_FIXED, 3001, 30, 601, 0.50, 0.006),        # odd sizes
     (ADAPTIVE_ERROR, EST_RANSAC, 1157, 90, 400, 0.10, 0.02),
-    (REPROJECTION_ERROR, EST_FIXED, 4096, 24, 700, 0.70, 0.004),
-    (REPROJECTION_ERROR, EST_RANSAC, 1157, 90, 400, 0.12, 0.03),
-    (REPROJECTION_ERROR, EST_USAC, 3000, 40, 500, 0.30, 0.01),
-    (EUCLIDEAN_AND_REPROJECTION_ERROR, EST_FIXED, 2048, 40, 500, 0.60, 0.005),
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 60, 700, 0.70, 0.004),   # (reprojection: staged from P (ceil(H/256) - 1) >= 768 on)
+    (REPROJECTION_ERROR, EST_RANSAC, 1157, 200, 400, 0.12, 0.03),
+    (REPROJECTION_ERROR, EST_USAC, 3000, 80, 500, 0.30, 0.01),
+    (EUCLIDEAN_AND_REPROJECTION_ERROR, EST_FIXED, 2048, 120, 500, 0.60, 0.005),
     # few matches: the stage cuts (multiples of 64) come close to each other and to M -- no stage may be left empty while
     # a later one still expects its survivors (round 3: stage 2 was, with M - c1 < 16)
-    (REPROJECTION_ERROR, EST_FIXED, 1161, 132, 270, 0.94, 0.0014),
+    (REPROJECTION_ERROR, EST_FIXED, 1161, 200, 270, 0.94, 0.0014),
     (EUCLIDEAN_ERROR, EST_FIXED, 1500, 120, 150, 0.80, 0.002),
     (ADAPTIVE_ERROR, EST_FIXED, 1161, 140, 90, 0.90, 0.001),
     # many hypotheses, few pairs (the stress configuration's shape): the survivor lists are long, the list stages loop over
     # them in several passes and with several work-groups per pair
-    (REPROJECTION_ERROR, EST_FIXED, 20000, 7, 900, 0.45, 0.008),
+    (REPROJECTION_ERROR, EST_FIXED, 20000, 12, 900, 0.45, 0.008),
     (EUCLIDEAN_ERROR, EST_FIXED, 30000, 5, 800, 0.35, 0.01),
 ]
 
@@ -97,7 +97,7 @@ def test_prune_ties_and_late_records(oracle):
     one must still be found."""
     from putslam_amd._abi import DMATCH_DTYPE  # noqa: F401
     rng = np.random.default_rng(8)
-    frames, kpts = 30, 400
+    frames, kpts = 70, 400
     seq = synth.make_sequence(frames, kpts, config=3, index=999, inlier_frac=0.6, noise=0.0)   # noise-free: exact ties
     # quantise the points so that many 3-point samples give bit-identical models and counts
     seq["pts"] = (np.round(seq["pts"] * 64) / 64).astype(np.float32)
