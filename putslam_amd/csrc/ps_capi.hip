@@ -95,6 +95,7 @@ struct PsContext {
     int genSplit = 1;    // staged scoring: stage 0 as two launches -- the prefix's models once, then the sweep with the match range
                          // split over twice as many work-groups (PUTSLAM_HIP_GENSPLIT=0: one launch, every part repeats the
                          // sample -> SVD chain)
+    int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (PUTSLAM_HIP_SINGLEREST=0)
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
     int listGroups2 = 64, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
@@ -525,7 +526,8 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     if (ctx->forcePrefix > 0 && pl.sa.estimator == PS_EST_FIXED) pl.prefix = ctx->forcePrefix; // (tuning knob)
     // (the staged form is six or seven dependent launches, 0.23 ms at the least with the reprojection kernels and 0.08 ms with
     // the Euclidean ones: it pays from about 48 / 16 pairs of H = 4096 on, profiles/r03p/small_batches.txt)
-    const long long stagedFrom = with_euclid_fast(ctx, pl.mode) ? 256 : 768;
+    // (adaptive schedules: the trip limit the prefix leaves cuts most of the work whatever the batch size)
+    const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
     pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
@@ -606,6 +608,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // stage 1's one-direction pre-test on the far-off front of the reordered record: the reprojection metrics (ps_score_fast.h)
     const bool usePretest = pl.reorder && ctx->pretest != 0 &&
                             (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || pl.mode == PS_REPROJECTION_ERROR);
+    // adaptive schedules without reordering: ONE stage after the prefix (all matches, hypotheses below the trip limit only)
+    const int lastStage = (pl.sa.estimator != PS_EST_FIXED && !pl.reorder && ctx->singleRest != 0) ? 1 : kStages;
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
@@ -619,6 +623,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
         if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
         if (stage == 1 && usePretest) st.frontRec = (const float2 *)ctx->frontRec.p;
+        st.single = lastStage == 1 ? 1 : 0;
         st.margin = ctx->reorderMargin;
         st.gran = with_euclid_fast(ctx, pl.mode) ? 64 : ctx->reorderGran;
         st.c2div = ctx->reorderC2div;
@@ -661,7 +666,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stage0_args(false), pl.prefix, msplit);                                      \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
-            for (int sg = 2; sg <= kStages; ++sg)                                                                      \
+            for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));              \
         } else                                                                                                         \
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stAll, pl.H, msplit);                                                        \
@@ -716,7 +721,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             }                                                                                                          \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
             PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
-            for (int sg = 2; sg <= kStages; ++sg)                                                                      \
+            for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));          \
         } else if (grid.x > (BIGLIMIT))                                                                                \
             PS_LAUNCH_FAST_ONE(MODE, true, 0, stAll, pl.H, msplit);                                                    \
@@ -943,6 +948,7 @@ int ps_context_create(int device, PsContext **out)
         if (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->reorderGran = g;
     }
     if (const char *v = std::getenv("PUTSLAM_HIP_GENSPLIT")) ctx->genSplit = std::atoi(v) != 0 ? 1 : 0;
+    if (const char *v = std::getenv("PUTSLAM_HIP_SINGLEREST")) ctx->singleRest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
     if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);

@@ -183,6 +183,8 @@ struct StageArgs {
     unsigned long long *validMask; // stage 0 in two launches (models once, then the sweep split over many work-groups): [P][hCount/64]
     int genOnly;               // 1 = this launch only generates the models of [hBase, hBase + hCount), parks them and writes
                                // validMask; 0 with validMask set = this launch reads both back instead of generating
+    int single;                // 1 = stage 1 sweeps ALL matches and is the only stage after the prefix (adaptive schedules
+                               // without reordering: what their trip limit leaves is little, two more launches cost more)
     int gran;                  // the stage cuts are multiples of this (64: the Euclidean kernel recounts blocks of 64 matches;
                                // 8 for the reprojection kernels, which only need even cuts)
     const int32_t *prefInfo;   // after ps_stage_reorder: [P][4] = (best count, trip limit) the prefix leaves, how many matches at
@@ -242,15 +244,17 @@ PS_D void stage_range(const StageArgs &st, int M, int best0, int &lo, int &hi)
     const int stage = st.stage;
     const bool reordered = st.perm != nullptr;
     int c1 = M, c2 = M;
-    if (best0 > 0) {
+    if (best0 > 0 && !st.single) {
         const int miss = M - best0; // a hypothesis is out once it has missed this many matches
         if (reordered) {
             const int g1 = st.gran - 1; // (gran is a power of two)
             c1 = (miss + st.margin + g1) & ~g1;
             if (c1 >= M - M / 8) c1 = M;
             if (c1 < M) {
-                const int step = ((M - c1) / st.c2div + 63) & ~63;
-                c2 = c1 + (step > 0 ? step : 64); // (never an empty stage 2: it hands the survivors on)
+                // (stage 2 ends where it would with stage 1 cut at a multiple of 64, whatever stage 1's granularity)
+                const int c64 = (c1 + 63) & ~63;
+                const int step = ((M - c64) / st.c2div + 63) & ~63;
+                c2 = c64 + (step > 0 ? step : 64); // (never an empty stage 2: it hands the survivors on)
                 if (c2 >= M - M / 16) c2 = M;
             }
         } else {
