@@ -386,7 +386,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     constexpr bool pruned = KIND >= 1;
     int cover = kBlock, slot = tid, part = 0; // kind 2: hypotheses per pass, the lane's place, its part of the match range
     int mStageEnd = m1;
-    if (LIST) s_tot[tid] = 0;
+    if (LIST) {
+        s_tot[tid] = 0;
+        __syncthreads(); // (a part with a short range must not add into a slot another wavefront has yet to clear)
+    }
     if (pruned) { // (msplit == 1 in these stages)
         int hLimit;
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)

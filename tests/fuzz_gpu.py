@@ -169,6 +169,9 @@ def main():
             out, _ = p.communicate()
             tail = [l for l in out.splitlines() if l.startswith("fuzz done") or l.startswith("MISMATCH")]
             print(f"[worker {i}, seed {a.seed + i}] " + " | ".join(tail[-4:]), flush=True)
+            if p.returncode != 0 and not any(l.startswith("fuzz done") for l in tail):
+                # the worker died (not a mismatch): show why
+                print(f"[worker {i}] exit code {p.returncode}; last output:\n  " + "\n  ".join(out.splitlines()[-8:]), flush=True)
             rc |= p.returncode
         print(f"fuzz done: {per * a.procs} iterations over {a.procs} workers, modes {a.modes}, "
               f"{'no mismatches' if rc == 0 else 'MISMATCHES'}")
