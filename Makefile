@@ -7,15 +7,11 @@ DROPIN := putslam_amd/libputslam_dropin.so
 
 all: $(LIB) $(DROPIN) oracle
 
-$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_score_mfma.h $(CSRC)/ps_device_math.h include/putslam_hip.h
+$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_device_math.h include/putslam_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
 
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I$(CSRC)/dropin $< -o $@ -Lputslam_amd -lputslam_hip '-Wl,-rpath,$$ORIGIN'
-
-# A/B build of kernel 1 with the query tiles staged through LDS (profiles/scripts/r02h_matcher_direct.sh)
-putslam_amd/libputslam_hip_lds.so: $(LIB)
-	$(HIPCC) $(HIPFLAGS) -DPS_MFMA_DIRECT=0 -shared $(CSRC)/ps_capi.hip -o $@
 
 oracle:
 	$(MAKE) -C oracle

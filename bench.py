@@ -95,6 +95,10 @@ def parse():
                     help="N > 1: 'pairs' = one sequence per GPU (BASELINE configs[3], weak scaling); 'sequence' = ONE "
                          "sequence of --frames frames split over the ranks with a one-frame halo "
                          "(sharding.shard_sequence; strong scaling)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 control flow (RCCL process group, parameter broadcast, per-chain asynchronous gather "
+                         "of device-resident records, fence) even with ONE rank: the only way to execute that branch on a "
+                         "one-GPU box (also PUTSLAM_BENCH_FORCE_DIST=1)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
@@ -127,16 +131,25 @@ def main():
     # PUTSLAM_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 control flow run with several ranks on ONE GPU
     # (records staged through the host); the measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("PUTSLAM_BENCH_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
+    # --force-dist: the distributed branch with a world of one (RCCL initialised, collectives on device tensors)
+    dist_on = world > 1 or args.force_dist or os.environ.get("PUTSLAM_BENCH_FORCE_DIST", "0") == "1"
+    ndev = max(torch.cuda.device_count(), 1)          # (device_count does not initialise the GPU)
     dev = torch.device(f"cuda:{local_rank % ndev if backend != 'nccl' else local_rank}")
-    torch.cuda.set_device(dev)
-    if world > 1:
+    if dist_on:
+        # the process group comes FIRST, before any other GPU call of this process (RCCL picks the device up from device_id)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.cuda.set_device(dev)
     xdev = dev if backend == "nccl" else torch.device("cpu")       # where collective payloads live
 
     from putslam_amd import api, synth
@@ -151,7 +164,7 @@ def main():
     vrank = rank if args.as_rank is None else args.as_rank   # which rank's sequence / seed this process works on
     cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + vrank)
 
-    if world > 1:
+    if dist_on:
         # the run's parameter block comes from rank 0 (one ~120 B broadcast at start, outside the timed region)
         from putslam_amd import sharding as _sh
         prm, _K, est, _H, _seed = _sh.broadcast_params(prm, TUM_FR1_K, est, args.hyp, 0xB0B0, src=0, device=xdev)
@@ -193,14 +206,14 @@ def main():
         gsize = [(Pmax * (i + 1) // S) - (Pmax * i // S) for i in range(S)]
         bounds = [min(P, Pmax * i // S) for i in range(S)] + [P]
     gathered = ([[torch.zeros((gsize[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
-                  for _ in range(world)] for i in range(S)] if (world > 1 and rank == 0) else [None] * S)
+                  for _ in range(world)] for i in range(S)] if (dist_on and rank == 0) else [None] * S)
     pending = [None] * S     # per chain: (in-flight gather of the previous step, the record block it reads)
 
     def step():
         # S sub-batches of the step on S streams (device_batch.run_pairs_split); with --join end the chains are
         # ordered only within their own stream, so consecutive steps pipeline into each other
         run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds, join=join)
-        if world > 1:
+        if dist_on:
             # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI -- one
             # gather per chain, queued behind that chain's kernels and issued asynchronously: it completes beside
             # the next step's kernels and is waited for before the chain's next gather (or the closing fence)
@@ -219,7 +232,7 @@ def main():
                     pending[i] = (work, rec)
 
     def fence():
-        if world > 1:
+        if dist_on:
             for i in range(S):
                 if pending[i] is not None:
                     with torch.cuda.stream(chains[i]):
@@ -242,7 +255,7 @@ def main():
             step()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([el], dtype=torch.float64, device=xdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -331,10 +344,10 @@ def main():
                                  "score_kernel": "fast" if c0.get_option("score") >= 1 else "exact"}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
-        if world > 1 and rank == 0:
+        if dist_on and rank == 0:
             blocks = [np.concatenate([gathered[i][r].cpu().numpy() for i in range(S)]) for r in range(world)]
             np.save(args.dump_records, np.stack(blocks))
-        elif world == 1:
+        elif not dist_on:
             st32 = res["stats"].view(np.int32).reshape(P, -1)
             rec = sharding.pack_records(torch.from_numpy(res["pose"]), torch.from_numpy(st32[:, 5].copy()),
                                         torch.from_numpy(st32[:, 0].copy()))
@@ -438,8 +451,9 @@ def main():
                              ("; configs[3]: one sequence per GPU, RCCL gather of 72 B/pair to rank 0" if world > 1
                               else "")),
                 "pairs_per_step": P_total_per_step, "kpts": args.kpts, "hypotheses": args.hyp,
-                "world_size": (dist.get_world_size() if world > 1 else 1),
-                "backend": (dist.get_backend() if world > 1 else None), "shard": args.shard,
+                "world_size": (dist.get_world_size() if dist_on else 1),
+                "backend": (dist.get_backend() if dist_on else None), "shard": args.shard,
+                "force_dist": bool(dist_on and world == 1),
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "join": args.join,
                 "matcher_kernel": matcher + ("-fused" if matcher_fused else ""), "score_kernel": score,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
@@ -475,7 +489,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -66,25 +66,25 @@ template <class MapFeatureT>
 double matchFeatureLoopClosure(FrameMatcher &hot, std::vector<MapFeatureT> featureSets[2], int framesIds[2],
                                std::vector<std::pair<int, int>> &pairedFeatures, Eigen::Matrix4f &estimatedTransformation)
 {
-    cv::Mat extractedDescriptors[2];
-    std::vector<Eigen::Vector3f> points3D[2];
-    for (int i = 0; i < 2; ++i) {
-        std::vector<MapFeatureT> &analyzedSet = featureSets[i];
-        extractedDescriptors[i] = detail::stackRows32(analyzedSet.size());
-        points3D[i].reserve(analyzedSet.size());
-        size_t row = 0;
-        for (auto &feature : analyzedSet) {
-            auto &ext = feature.descriptors[framesIds[i]];
-            points3D[i].push_back(Eigen::Vector3f((float)ext.point3D.x(), (float)ext.point3D.y(), (float)ext.point3D.z()));
-            feature.u = ext.point2DUndist.x;
-            feature.v = ext.point2DUndist.y;
-            detail::putRow32(extractedDescriptors[i], row++, ext.descriptor);
+    // marshalling only: one 32-byte descriptor row and one float point per feature and side, in feature order
+    cv::Mat descRows[2];
+    std::vector<Eigen::Vector3f> xyz[2];
+    for (int side = 0; side < 2; ++side) {
+        std::vector<MapFeatureT> &feats = featureSets[side];
+        const int view = framesIds[side];
+        descRows[side] = detail::stackRows32(feats.size());
+        xyz[side].resize(feats.size());
+        for (size_t k = 0; k < feats.size(); ++k) {
+            auto &seen = feats[k].descriptors[view];
+            xyz[side][k] = Eigen::Vector3f((float)seen.point3D.x(), (float)seen.point3D.y(), (float)seen.point3D.z());
+            feats[k].u = seen.point2DUndist.x; // (the reference refreshes u, v from the chosen view, :821-822)
+            feats[k].v = seen.point2DUndist.y;
+            detail::putRow32(descRows[side], k, seen.descriptor);
         }
     }
-    if (points3D[0].size() < 10 || points3D[1].size() < 10) return 0;
+    if (xyz[0].size() < 10 || xyz[1].size() < 10) return 0;
     std::vector<cv::DMatch> inlierMatches;
-    const double ratio = hot.matchFeatureLoopClosure(extractedDescriptors[0], points3D[0], extractedDescriptors[1], points3D[1],
-                                                     estimatedTransformation, inlierMatches);
+    const double ratio = hot.matchFeatureLoopClosure(descRows[0], xyz[0], descRows[1], xyz[1], estimatedTransformation, inlierMatches);
     if (ratio == -1.0) return -1.0;
     pairedFeatures.clear();
     for (auto &m : inlierMatches) pairedFeatures.push_back(std::make_pair(m.queryIdx, m.trainIdx));
@@ -122,24 +122,24 @@ double matchXYZ(FrameMatcher &hot, std::vector<MapFeatureT> mapFeatures, int sen
     const double ratio = hot.matchXYZ(xyz, currentPoseDescriptors, currentPoseFeatures3D, octaves, currentPoseDetDists,
                                       estimatedTransformation, inlierMatches, computationNumber);
     if (ratio == -1.0) return -1.0;
+    // inlier (map feature, current key point) pairs back to the caller's MapFeature type (:770-792): the map feature's id,
+    // the key point's image position, 3-D point, descriptor row, octave and detection distance, seen from sensorPoseId
+    typedef typename std::remove_reference<decltype(mapFeatures[0].position)>::type PositionT;
     foundInlierMapFeatures.clear();
-    for (auto &m : inlierMatches) {
-        const int mapId = m.queryIdx, currentPoseId = m.trainIdx;
-        MapFeatureT mapFeature;
-        mapFeature.id = mapFeatures[(size_t)mapId].id;
-        mapFeature.u = prevFeaturesUndistorted[(size_t)currentPoseId].x;
-        mapFeature.v = prevFeaturesUndistorted[(size_t)currentPoseId].y;
-        const Eigen::Vector3f &p = currentPoseFeatures3D[(size_t)currentPoseId];
-        typedef typename std::remove_reference<decltype(mapFeature.position)>::type PositionT;
-        mapFeature.position = PositionT((double)p[0], (double)p[1], (double)p[2]);
-        mapFeature.posesIds.push_back(sensorPoseId);
-        cv::Mat row(1, PUTSLAM_HIP_DESC_BYTES, CV_8UC1,
-                    currentPoseDescriptors.data + (size_t)currentPoseId * (size_t)currentPoseDescriptors.step);
-        mapFeature.descriptors[sensorPoseId] =
-            ExtendedDescriptorT(prevFeaturesUndistorted[(size_t)currentPoseId], prevFeaturesDistorted[(size_t)currentPoseId],
-                                mapFeature.position, row, currentPoseKeyPoints[(size_t)currentPoseId].octave,
-                                currentPoseDetDists[(size_t)currentPoseId]);
-        foundInlierMapFeatures.push_back(mapFeature);
+    foundInlierMapFeatures.reserve(inlierMatches.size());
+    for (const cv::DMatch &m : inlierMatches) {
+        const size_t qi = (size_t)m.queryIdx, ti = (size_t)m.trainIdx;
+        const Eigen::Vector3f &pt = currentPoseFeatures3D[ti];
+        MapFeatureT out;
+        out.id = mapFeatures[qi].id;
+        out.u = prevFeaturesUndistorted[ti].x;
+        out.v = prevFeaturesUndistorted[ti].y;
+        out.position = PositionT((double)pt[0], (double)pt[1], (double)pt[2]);
+        out.posesIds.push_back(sensorPoseId);
+        cv::Mat row(1, PUTSLAM_HIP_DESC_BYTES, CV_8UC1, currentPoseDescriptors.data + ti * (size_t)currentPoseDescriptors.step);
+        out.descriptors[sensorPoseId] = ExtendedDescriptorT(prevFeaturesUndistorted[ti], prevFeaturesDistorted[ti], out.position, row,
+                                                            currentPoseKeyPoints[ti].octave, currentPoseDetDists[ti]);
+        foundInlierMapFeatures.push_back(out);
     }
     return ratio;
 }

@@ -7,7 +7,6 @@
 #include "ps_kernels.h"
 #include "ps_matcher_mfma.h"
 #include "ps_score_fast.h"
-#include "ps_score_mfma.h"
 #include "ps_score_euclid.h"
 
 #include <cfloat>
@@ -38,12 +37,13 @@ struct PsContext {
     int device = 0;
     hipStream_t own = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t handoff = nullptr; // recorded behind every asynchronous call: a newly selected stream waits for it
+    hipEvent_t handoff = nullptr; // recorded at every exit of the asynchronous call (ps_vo_pairs_device) once it has queued work:
+                                  // a newly selected stream waits for it
     bool handoffPending = false;
     std::string err;
     char arch[64] = {0};
     // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, recE, recF, recH, recS, counts, mvalid, cmax, idxList, raw;
+    Buf keys, recA, recB, recC, recD, recE, recF, counts, mvalid, cmax, idxList, raw;
     Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
                 // of the staged scoring (large batches)
     Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
@@ -77,9 +77,9 @@ struct PsContext {
     // matrix-core matcher: 1 = the work-group expands its query tiles itself through LDS (default), 0 = round 2's form
     // with the FP4 image of the query frames written to HBM by a launch of its own (option "matcher_fused")
     int matcherFused = 1;
-    // errorVersion 1: 1 = decision-exact VALU kernel (ps_score_fast.h, default), 2 = decision-exact scoring with the
-    // transforms on the matrix cores (ps_score_mfma.h: correct, measured 8 % slower, profiles/r02f),
-    // 0 = value-exact ps_ransac_score<1>
+    // 1 = the decision-exact kernels (ps_score_fast.h / ps_score_euclid.h, default), 0 = the value-exact ps_ransac_score<MODE>
+    // (the matrix-core scoring experiment of round 2 -- split-f16 transforms on v_mfma_f32_32x32x16_f16, correct, no gain on
+    // the headline -- left the tree in round 4: profiles/variants/ps_score_mfma.h.txt)
     int scoreFast = 1;
     int scoreStats = 0;
     // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
@@ -99,10 +99,17 @@ struct PsContext {
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
     int listGroups2 = 64, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
-    int forcePrefix = 0; // PUTSLAM_HIP_PREFIX: hypotheses stage 0 scores completely under the fixed schedule (64 .. 256)
+    int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
+    int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
+    // Every (re)allocation of an arena block bumps this: captured graphs (ps_vo_stream_push) carry the pointers of the
+    // blocks they were captured with and are dropped when the generation they saw is no longer the current one.
+    unsigned long long arenaGen = 0;
+    // what the LAST scoring step left in the staged-scoring buffers (ps_debug_stage_survivors / ps_debug_stage_order):
+    // pairs and capacity the survivor counters / the order were laid out with, 0 = that step was not staged / not reordered
+    int stagedP = 0, stagedCap = 0, reorderedP = 0;
 };
 
 namespace {
@@ -140,6 +147,7 @@ int ensure(PsContext *ctx, Buf &b, size_t bytes)
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) return fail(ctx, PS_ERR_ALLOC, "hipMalloc", e);
     b.cap = want;
+    ctx->arenaGen++;
     return PS_OK;
 }
 #define PS_ENSURE(buf, bytes)                        \
@@ -454,18 +462,6 @@ void tick(PsContext *ctx, int slot, bool stop)
     }
 }
 
-int cap_h(int cap) { return (cap + 31) & ~31; } // per-pair row count of recH: cap rounded up to whole 32-match tiles
-
-// The f16 operands of the matrix-core scoring kernel are written (by kernel 2) only when that kernel will read them.
-bool with_split(const PsContext *ctx, int mode) { return ctx->scoreFast == 2 && mode == PS_REPROJECTION_ERROR; }
-
-int ensure_split(PsContext *ctx, int P, int cap)
-{
-    PS_ENSURE(ctx->recH, (size_t)P * 6 * cap_h(cap) * 32);
-    PS_ENSURE(ctx->recS, (size_t)P * sizeof(int2));
-    return PS_OK;
-}
-
 // The Euclidean fast scoring kernel reads its own pair-interleaved record, kept in the block the reprojection kernels use
 // for theirs (recF): kernel 2 writes one or the other.
 bool with_euclid_fast(const PsContext *ctx, int mode)
@@ -480,10 +476,6 @@ RecPtrs rec_ptrs(PsContext *ctx, int cap, int mode)
     r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
     r.E = (float4 *)ctx->recE.p;
     r.F = (float2 *)ctx->recF.p;
-    const bool split = with_split(ctx, mode);
-    r.H = split ? (uint4 *)ctx->recH.p : nullptr;
-    r.S = split ? (int2 *)ctx->recS.p : nullptr;
-    r.capH = cap_h(cap);
     return r;
 }
 
@@ -511,7 +503,9 @@ void launch_score(PsContext *ctx, dim3 grid, const Plan &pl, int cap, int msplit
 // launches of the reprojection kernels with more work-groups than this use the packed match record (ps_score_fast.h, BIG)
 unsigned big_limit(int mode) { return mode == PS_REPROJECTION_ERROR ? 1536u : 1280u; }
 
-int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
+// complete = true: every hypothesis is scored completely whatever the batch size (ps_debug_ransac_counts returns the counts
+// themselves: the staged scoring leaves lower bounds for abandoned hypotheses)
+int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false)
 {
     const int H = pl.H;
     PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
@@ -528,7 +522,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
     // the Euclidean ones: it pays from about 48 / 16 pairs of H = 4096 on, profiles/r03p/small_batches.txt)
     // (adaptive schedules: the trip limit the prefix leaves cuts most of the work whatever the batch size)
     const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
-    pl.prune = ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
+    pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
     if (pl.genSplit) pl.msplit = pl.msplit * 2 < 32 ? pl.msplit * 2 : 32; // (the parts no longer repeat the prologue)
@@ -552,7 +546,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
         const unsigned bigLimit = big_limit(pl.mode);
         const bool firstBig = (unsigned)pl.msplit * (unsigned)P * (pl.prune ? 1u : (unsigned)hb) > bigLimit;
         pl.pa.skipF = !(fastRep && (pl.prune || firstBig));
-        pl.pa.skipE = !(fastRep && !firstBig) && !with_split(ctx, pl.mode); // (the matrix-core scoring's operands are built from E)
+        pl.pa.skipE = !(fastRep && !firstBig);
     }
     if (pl.prune) {
         PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
@@ -570,6 +564,9 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap)
         pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
         pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
     }
+    ctx->stagedP = pl.prune ? P : 0;
+    ctx->stagedCap = pl.prune ? cap : 0;
+    ctx->reorderedP = (pl.prune && pl.reorder) ? P : 0;
     return PS_OK;
 }
 
@@ -679,19 +676,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             launch_score<PS_EUCLIDEAN_ERROR>(ctx, grid, pl, cap, msplit);
         break;
     case PS_REPROJECTION_ERROR:
-        if (ctx->scoreFast == 2) {
-            unsigned long long *dbg = nullptr;
-            if (ctx->scoreStats) {
-                PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
-                PS_HIP(hipMemsetAsync(ctx->dbgCnt.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-                dbg = (unsigned long long *)ctx->dbgCnt.p;
-            }
-            hipLaunchKernelGGL(ps_ransac_score_mfma<PS_REPROJECTION_ERROR>, grid, dim3(kBlock), 0, ctx->stream,
-                               (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
-                               (const uint4 *)ctx->recH.p, (const int2 *)ctx->recS.p, (const int32_t *)ctx->mvalid.p,
-                               (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, pl.H, cap, cap_h(cap), pl.minRun, msplit,
-                               (int32_t *)ctx->counts.p, dbg);
-        } else if (ctx->scoreFast == 1) {
+        if (ctx->scoreFast >= 1) {
             unsigned long long *dbg = nullptr;
             if (ctx->scoreStats) {
                 PS_ENSURE(ctx->dbgCnt, 8 * sizeof(unsigned long long));
@@ -798,10 +783,6 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     if (withRecords) {
         int rc = ensure_records(ctx, (size_t)P, (size_t)cap);
         if (rc != PS_OK) return rc;
-        if (with_split(ctx, pa.mode)) {
-            rc = ensure_split(ctx, P, cap);
-            if (rc != PS_OK) return rc;
-        }
     }
     // by batch size: VALU sweep 1.85 us, MFMA sweep 0.43 us per 2000 x 2000 pair on a full chip, + ~7 us for the extra launch
     const bool useMfma = ctx->matcher == 1 || (ctx->matcher == 2 && (double)P * cap * cap > 2.0e7);
@@ -904,6 +885,69 @@ int bind(PsContext *ctx)
     return PS_OK;
 }
 
+
+// ---- options: one table for ps_context_set_option / ps_context_get_option / the PUTSLAM_HIP_* environment ----
+// Every kernel variant and every tuning knob of the staged scoring is settable per context (the environment only
+// supplies the initial value), so that tests can run each twin next to the default in one process.
+struct OptDesc {
+    const char *name;      // option name of ps_context_set_option
+    const char *env;       // PUTSLAM_HIP_<env>: initial value (nullptr: none)
+    int PsContext::*field;
+    int lo, hi;            // accepted range
+    const char *what;      // error text
+};
+const OptDesc kOptions[] = {
+    {"matcher", "MATCHER", &PsContext::matcher, 0, 2, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)"},
+    {"matcher_fused", "MATCHER_FUSED", &PsContext::matcherFused, 0, 1, "matcher_fused: 0 or 1"},
+    {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
+    {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
+    {"prune", "PRUNE", &PsContext::prune, 0, 1, "prune: 0 or 1"},
+    {"reorder", "REORDER", &PsContext::reorder, 0, 2, "reorder: 0, 1 or 2"},
+    {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024"},
+    {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024"},
+    // staged scoring (ps_score_fast.h): the twins of its launch forms ...
+    {"gensplit", "GENSPLIT", &PsContext::genSplit, 0, 1, "gensplit: 0 (stage 0 as one launch) or 1 (models, then the sweep)"},
+    {"singlerest", "SINGLEREST", &PsContext::singleRest, 0, 1, "singlerest: 0 (three stages) or 1 (one stage after the prefix, adaptive schedules)"},
+    {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)"},
+    // ... and its tuning knobs
+    {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over"},
+    {"list_g2", "LISTG2", &PsContext::listGroups2, 1, 64, "list_g2: 1 .. 64 work-groups per pair of stage 2"},
+    {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3"},
+    {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)"},
+    {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kReorderTopMax, "reorder_top: 1 .. 16 voters"},
+    {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches"},
+    {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64"},
+    {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64"},
+    {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
+};
+const OptDesc *find_option(const char *name)
+{
+    for (const OptDesc &o : kOptions)
+        if (strcmp(name, o.name) == 0) return &o;
+    return nullptr;
+}
+// value checks beyond the range
+bool option_value_ok(const OptDesc &o, int v)
+{
+    if (v < o.lo || v > o.hi) return false;
+    if (strcmp(o.name, "prefix") == 0) return (v & 63) == 0;
+    if (strcmp(o.name, "reorder_gran") == 0) return (v & (v - 1)) == 0;
+    return true;
+}
+int parse_option_text(const OptDesc &o, const char *v)
+{
+    if (strcmp(o.name, "score") == 0) {
+        if (strcmp(v, "exact") == 0) return 0;
+        if (strcmp(v, "fast") == 0) return 1;
+    }
+    if (strcmp(o.name, "matcher") == 0) {
+        if (strcmp(v, "valu") == 0) return 0;
+        if (strcmp(v, "mfma") == 0) return 1;
+        if (strcmp(v, "auto") == 0) return 2;
+    }
+    return std::atoi(v);
+}
+
 } // namespace
 
 extern "C" {
@@ -937,29 +981,14 @@ int ps_context_create(int device, PsContext **out)
         return PS_ERR_HIP;
     }
     ctx->stream = ctx->own;
-    if (const char *v = std::getenv("PUTSLAM_HIP_QSPLIT")) ctx->forceQsplit = std::atoi(v);
-    if (const char *v = std::getenv("PUTSLAM_HIP_MSPLIT")) ctx->forceMsplit = std::atoi(v);
-    if (const char *v = std::getenv("PUTSLAM_HIP_SCORE"))
-        ctx->scoreFast = (strcmp(v, "exact") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "mfma") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
-    if (const char *v = std::getenv("PUTSLAM_HIP_PRUNE")) ctx->prune = std::atoi(v) != 0 ? 1 : 0;
-    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER")) ctx->reorder = std::min(std::max(std::atoi(v), 0), 2);
-    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_GRAN")) {
-        const int g = std::atoi(v);
-        if (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ctx->reorderGran = g;
+    for (const OptDesc &o : kOptions) { // initial values from the environment (out-of-range values are ignored)
+        if (!o.env) continue;
+        const std::string name = std::string("PUTSLAM_HIP_") + o.env;
+        if (const char *v = std::getenv(name.c_str())) {
+            const int x = parse_option_text(o, v);
+            if (option_value_ok(o, x)) ctx->*(o.field) = x;
+        }
     }
-    if (const char *v = std::getenv("PUTSLAM_HIP_GENSPLIT")) ctx->genSplit = std::atoi(v) != 0 ? 1 : 0;
-    if (const char *v = std::getenv("PUTSLAM_HIP_SINGLEREST")) ctx->singleRest = std::atoi(v) != 0 ? 1 : 0;
-    if (const char *v = std::getenv("PUTSLAM_HIP_PRETEST")) ctx->pretest = std::atoi(v) != 0 ? 1 : 0;
-    if (const char *v = std::getenv("PUTSLAM_HIP_LISTR3")) ctx->listRsplit3 = std::min(std::max(std::atoi(v), 1), 32);
-    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG2")) ctx->listGroups2 = std::min(std::max(std::atoi(v), 1), 64);
-    if (const char *v = std::getenv("PUTSLAM_HIP_LISTG3")) ctx->listGroups3 = std::min(std::max(std::atoi(v), 0), 512); // 0 = automatic
-    if (const char *v = std::getenv("PUTSLAM_HIP_PREFIX")) ctx->forcePrefix = std::min(std::max(std::atoi(v) & ~63, 64), 256);
-    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_TOP")) ctx->reorderTop = std::min(std::max(std::atoi(v), 1), kReorderTopMax);
-    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_MARGIN")) ctx->reorderMargin = std::min(std::max(std::atoi(v), 1), 4096);
-    if (const char *v = std::getenv("PUTSLAM_HIP_REORDER_C2DIV")) ctx->reorderC2div = std::min(std::max(std::atoi(v), 1), 64);
-    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER_FUSED")) ctx->matcherFused = std::atoi(v) != 0 ? 1 : 0;
-    if (const char *v = std::getenv("PUTSLAM_HIP_MATCHER"))
-        ctx->matcher = (strcmp(v, "valu") == 0 || strcmp(v, "0") == 0) ? 0 : ((strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? 2 : 1);
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
@@ -978,7 +1007,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recH, &ctx->recS, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
@@ -1009,36 +1038,6 @@ int ps_context_set_stream(PsContext *ctx, void *s)
 int ps_context_set_option(PsContext *ctx, const char *name, int value)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;
-    if (strcmp(name, "matcher") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)");
-        ctx->matcher = value;
-        return PS_OK;
-    }
-    if (strcmp(name, "matcher_fused") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "matcher_fused: 0 or 1");
-        ctx->matcherFused = value;
-        return PS_OK;
-    }
-    if (strcmp(name, "score") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "score: 0 (value-exact), 1 (fast VALU) or 2 (MFMA)");
-        ctx->scoreFast = value;
-        return PS_OK;
-    }
-    if (strcmp(name, "score_stats") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "score_stats: 0 or 1");
-        ctx->scoreStats = value;
-        return PS_OK;
-    }
-    if (strcmp(name, "prune") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "prune: 0 or 1");
-        ctx->prune = value;
-        return PS_OK;
-    }
-    if (strcmp(name, "reorder") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, PS_ERR_BAD_ARG, "reorder: 0, 1 or 2");
-        ctx->reorder = value;
-        return PS_OK;
-    }
     if (strcmp(name, "stamps") == 0) {
         if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "stamps: 0 or 1");
         if (value) {
@@ -1050,28 +1049,22 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
         ctx->stampsOn = value;
         return PS_OK;
     }
-    if (strcmp(name, "qsplit") == 0 || strcmp(name, "msplit") == 0) { // 0 = automatic
-        if (value < 0 || value > 1024) return fail(ctx, PS_ERR_BAD_ARG, "split: 0..1024");
-        (name[0] == 'q' ? ctx->forceQsplit : ctx->forceMsplit) = value;
-        return PS_OK;
-    }
-    return fail(ctx, PS_ERR_BAD_ARG, "unknown option");
+    const OptDesc *o = find_option(name);
+    if (!o) return fail(ctx, PS_ERR_BAD_ARG, "unknown option");
+    if (!option_value_ok(*o, value)) return fail(ctx, PS_ERR_BAD_ARG, o->what);
+    ctx->*(o->field) = value;
+    return PS_OK;
 }
 
 int ps_context_get_option(const PsContext *ctx, const char *name)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;
-    if (strcmp(name, "matcher") == 0) return ctx->matcher;
     if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
-    if (strcmp(name, "matcher_fused") == 0) return ctx->matcherFused;
-    if (strcmp(name, "score") == 0) return ctx->scoreFast;
-    if (strcmp(name, "score_stats") == 0) return ctx->scoreStats;
-    if (strcmp(name, "prune") == 0) return ctx->prune;
-    if (strcmp(name, "reorder") == 0) return ctx->reorder;
     if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
-    if (strcmp(name, "qsplit") == 0) return ctx->forceQsplit;
-    if (strcmp(name, "msplit") == 0) return ctx->forceMsplit;
-    return PS_ERR_BAD_ARG;
+    if (strcmp(name, "last_staged_pairs") == 0) return ctx->stagedP;       // pairs of the last scoring step if it was staged, else 0
+    if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
+    const OptDesc *o = find_option(name);
+    return o ? ctx->*(o->field) : (int)PS_ERR_BAD_ARG;
 }
 
 int ps_context_synchronize(PsContext *ctx)
@@ -1235,7 +1228,7 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
                               ctx->stream));
         pl.ma.raw = (const uint32_t *)ctx->raw.p;
     }
-    rc = prepare_score(ctx, pl, 1, cap);
+    rc = prepare_score(ctx, pl, 1, cap, countsOut != nullptr);
     if (rc) return rc;
     PS_ENSURE(ctx->sMisc0, (size_t)(nprev > 0 ? nprev : 1) * 12);
     PS_ENSURE(ctx->sMisc1, (size_t)(ncur > 0 ? ncur : 1) * 12);
@@ -1248,10 +1241,6 @@ static int ransac_host_entry(PsContext *ctx, const PsRansacParams *params, const
     PS_ENSURE(ctx->cmax, sizeof(float2));
     rc = ensure_records(ctx, 1, (size_t)cap);
     if (rc) return rc;
-    if (with_split(ctx, pl.pa.mode)) {
-        rc = ensure_split(ctx, 1, cap);
-        if (rc) return rc;
-    }
     if (nprev > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc0.p, prev, (size_t)nprev * 12, hipMemcpyHostToDevice, ctx->stream));
     if (ncur > 0) PS_HIP(hipMemcpyAsync(ctx->sMisc1.p, cur, (size_t)ncur * 12, hipMemcpyHostToDevice, ctx->stream));
     if (m > 0)
@@ -1394,6 +1383,9 @@ int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out)
     if (rc) return rc;
     if (!out || P <= 0) return PS_ERR_BAD_ARG;
     memset(out, 0, (size_t)2 * P * sizeof(int32_t));
+    if (ctx->stagedP == 0) return PS_OK; // the last scoring step was not staged
+    if (P != ctx->stagedP) // (the counters are laid out [2][P] with the P of the call that wrote them)
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_debug_stage_survivors: the last staged scoring step had a different number of pairs");
     if (!ctx->survN.p || ctx->survN.cap < (size_t)2 * P * sizeof(int32_t)) return PS_OK;
     PS_HIP(hipMemcpyAsync(out, ctx->survN.p, (size_t)2 * P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     PS_HIP(hipStreamSynchronize(ctx->stream));
@@ -1409,7 +1401,8 @@ int ps_debug_stage_order(PsContext *ctx, int P, int cap, int32_t *perm, int32_t 
     int rc = bind(ctx);
     if (rc) return rc;
     if (!perm || !front || P <= 0 || cap <= 0) return PS_ERR_BAD_ARG;
-    if (!ctx->permBuf.p || ctx->permBuf.cap < (size_t)P * cap * sizeof(int32_t) || !ctx->prefInfo.p ||
+    if (P != ctx->reorderedP || cap != ctx->stagedCap || !ctx->permBuf.p ||
+        ctx->permBuf.cap < (size_t)P * cap * sizeof(int32_t) || !ctx->prefInfo.p ||
         ctx->prefInfo.cap < (size_t)4 * P * sizeof(int32_t))
         return fail(ctx, PS_ERR_BAD_ARG, "no reordered scoring step of that size in this context");
     std::vector<int32_t> info((size_t)4 * P);
@@ -1674,15 +1667,28 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     }
     rc = prepare_score(ctx, pl, P, cap);
     if (rc) return rc;
+    // This call returns with its work still queued.  Whatever happens after the first launch -- success or an error half
+    // way (an allocation failure for a later block, a launch failure) -- the end of what WAS queued is marked for a
+    // later ps_context_set_stream: the new stream must not touch the shared arena before that work has finished.
+    struct Handoff {
+        PsContext *c;
+        ~Handoff()
+        {
+            if (!c->handoff && hipEventCreateWithFlags(&c->handoff, hipEventDisableTiming) != hipSuccess) {
+                c->handoff = nullptr;
+                (void)hipStreamSynchronize(c->stream); // no event to wait on: drain instead
+                return;
+            }
+            if (hipEventRecord(c->handoff, c->stream) == hipSuccess)
+                c->handoffPending = true;
+            else
+                (void)hipStreamSynchronize(c->stream);
+        }
+    } handoffGuard{ctx};
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);
-    if (rc) return rc;
-    // this call returns with its work still queued: mark where it ends, for a later ps_context_set_stream
-    if (!ctx->handoff) PS_HIP(hipEventCreateWithFlags(&ctx->handoff, hipEventDisableTiming));
-    PS_HIP(hipEventRecord(ctx->handoff, ctx->stream));
-    ctx->handoffPending = true;
-    return PS_OK;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1710,9 +1716,12 @@ struct PsVoStream {
     bool warm = false;          // an un-captured push has run with `key`
     struct Key {
         PsRansacParams prm;
-        int estimator, numHypotheses, variant;
+        int estimator, numHypotheses;
         float K[9];
-        const void *arena[17]; // scratch and table blocks the captured launches point at (they move when they grow)
+        int options[32];               // every option of the context (kernel variants, the staged scoring's knobs), stamps
+        unsigned long long arenaGen;   // PsContext::arenaGen the captured launches' pointers belong to: ANY block of the
+                                       // context that is (re)allocated afterwards -- by this stream or by another call on
+                                       // the same context -- invalidates the graphs
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
@@ -1874,13 +1883,16 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
     key.prm.usedPairs = params->usedPairs;
     key.prm.iterationCount = params->iterationCount;
-    key.variant = ctx->matcher | (ctx->scoreFast << 2) | (ctx->scoreStats << 4) | (ctx->prune << 5) | (ctx->stampsOn << 6) | (ctx->matcherFused << 7) | (ctx->reorder << 8); // disjoint bit fields
+    {
+        static_assert(sizeof kOptions / sizeof kOptions[0] + 1 <= sizeof key.options / sizeof key.options[0], "key.options too small");
+        int n = 0;
+        for (const OptDesc &o : kOptions) key.options[n++] = ctx->*(o.field);
+        key.options[n++] = ctx->stampsOn;
+    }
     key.estimator = cfg->estimator;
     key.numHypotheses = cfg->numHypotheses;
     if (K) memcpy(key.K, K, sizeof key.K);
-    const void *arena[17] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                             ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recF.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
-    memcpy(key.arena, arena, sizeof arena);
+    key.arenaGen = ctx->arenaGen; // (make_plan / prepare_score above may already have grown a block: then no replay)
     const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
     if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
         for (hipGraphExec_t &g : s->gexec)
@@ -1918,10 +1930,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (!launched) {
         rc = enqueue((size_t)n);
         if (rc) return rc;
-        const void *after[17] = {ctx->keys.p, ctx->recA.p, ctx->recB.p, ctx->recC.p, ctx->recD.p, ctx->counts.p,
-                                 ctx->mvalid.p, ctx->cmax.p, ctx->idxList.p, ctx->tabR.p, ctx->tabU.p, ctx->xq.p, ctx->recE.p, ctx->recF.p, ctx->recH.p, ctx->recS.p, ctx->models.p};
-        memcpy(key.arena, after, sizeof after);
-        s->key = key;
+        key.arenaGen = ctx->arenaGen; // the blocks as this ordinary push left them
+        memcpy(&s->key, &key, sizeof key); // (bytewise, padding included: the key is compared with memcmp)
         s->warm = true;
     }
     PS_HIP(hipStreamSynchronize(ctx->stream));

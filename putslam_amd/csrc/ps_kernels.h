@@ -221,80 +221,7 @@ struct RecPtrs {
     float *G;   // the Euclidean fast scoring kernel's pair-interleaved record (ps_score_euclid.h), [P][ceil(cap/2)][12 or 16]:
                 // match 2k in the even floats, match 2k+1 in the odd ones; null unless that kernel will run (it then
                 // replaces E and F, which only the reprojection kernels read)
-    uint4 *H;   // f16 match operands of the matrix-core scoring kernel, [P][6 kinds][capH][2 K-blocks] (ps_score_mfma.h)
-    int2 *S;    // per pair: (eP, kappa), the power-of-two scales those operands were written with
-    int capH;   // cap rounded up to whole 32-match tiles
 };
-
-// ---- f16 operand split of the matrix-core scoring kernel (ps_score_mfma.h) ----
-// A scaled f32 value v (|v| <= 2^14) as hi + lo with hi = f16(v), lo = f16(v - hi):  |v - hi - lo| <= 2^-22 |v| + 2^-25
-// (v - hi is exact in f32; subnormal halfs are produced by v_cvt_f16_f32 and honoured by the f16 MFMA on gfx950,
-// profiles/microbench/mfma_f16_denorm.hip).
-PS_D void split_f16(float v, uint32_t &hi, uint32_t &lo)
-{
-    const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)(v - (float)h);
-    hi = (uint32_t)__builtin_bit_cast(unsigned short, h);
-    lo = (uint32_t)__builtin_bit_cast(unsigned short, l);
-}
-// x <= 2^n for finite x > 0 (0 -> 0)
-PS_D int exp_ceil(float x)
-{
-    int n;
-    (void)frexpf(x, &n);
-    return n;
-}
-// The pair-level scales: points are written times 2^eP (largest |coordinate| or the constant 1 -> at most 2^13), the
-// offset-times-point rows times 2^(eP - kappa) with 2^kappa >= max(Umax, fx, fy, 1).
-PS_D int2 split_scales(float cmax, float umax, float fx, float fy)
-{
-    const int nC = exp_ceil(fmaxf(cmax, 1.0f));
-    const int nU = umax > 0.0f ? exp_ceil(umax) : -126;
-    const int nF = exp_ceil(fmaxf(fmaxf(fabsf(fx), fabsf(fy)), 1.0f));
-    int kap = nU > nF ? nU : nF;
-    kap = kap < 1 ? 1 : (kap > 60 ? 60 : kap);
-    int eP = 13 - nC;
-    eP = eP < -100 ? -100 : eP; // (non-finite bounds: the scoring kernel does not use the operands of such a pair)
-    return make_int2(eP, kap);
-}
-// One K-block (two coordinates) of a match-side operand row: slots (hi, hi, lo, lo) per coordinate.
-PS_D uint4 match_block(float c0, float c1)
-{
-    uint32_t h0, l0, h1, l1;
-    split_f16(c0, h0, l0);
-    split_f16(c1, h1, l1);
-    return make_uint4(h0 | (h0 << 16), l0 | (l0 << 16), h1 | (h1 << 16), l1 | (l1 << 16));
-}
-// Second pass of kernel 2 (all threads of the pair's work-group, after the records and the pair bounds are known):
-// the six f16 operand rows of every depth-valid match -- for each direction the point (x, y, z, 1) and the point times
-// the two image offsets k = c - real, so that the matrix cores produce  A~ = fx X + k Z  directly (ps_score_mfma.h).
-template <int BLOCK>
-PS_D void write_split_operands(const PrepArgs &a, const RecPtrs &r, int p, int M, float cmax, float umax)
-{
-    if (r.H == nullptr) return;
-    const int2 sc = split_scales(cmax, umax, a.fx, a.fy);
-    if (threadIdx.x == 0) r.S[p] = sc;
-    const int eP = sc.x, eK = sc.x - sc.y;
-    uint4 *base = r.H + (size_t)p * 6 * r.capH * 2;
-    for (int v = threadIdx.x; v < M; v += BLOCK) {
-        const size_t slot = (size_t)p * a.cap + (size_t)v;
-        const float4 prev = r.A[slot], cur = r.B[slot], e = r.E[slot];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            // direction 0: current point -> previous image (offsets of realOld); 1: previous point -> current image
-            const float px = d ? prev.x : cur.x, py = d ? prev.y : cur.y, pz = d ? prev.z : cur.z;
-            const float kx = d ? e.y : e.x, ky = d ? e.w : e.z;
-            uint4 *row = base + ((size_t)(3 * d) * r.capH + v) * 2;
-            const size_t kind = (size_t)r.capH * 2;
-            row[0] = match_block(ldexpf(px, eP), ldexpf(py, eP));
-            row[1] = match_block(ldexpf(pz, eP), ldexpf(1.0f, eP));
-            row[kind + 0] = match_block(ldexpf(kx * px, eK), ldexpf(kx * py, eK));
-            row[kind + 1] = match_block(ldexpf(kx * pz, eK), ldexpf(kx, eK));
-            row[2 * kind + 0] = match_block(ldexpf(ky * px, eK), ldexpf(ky * py, eK));
-            row[2 * kind + 1] = match_block(ldexpf(ky * pz, eK), ldexpf(ky, eK));
-        }
-    }
-}
 
 // Builds the records of depth-valid match number v of pair p; returns the largest |offset| of E.
 PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int srcIdx, int q, int t, float px, float py,
@@ -433,8 +360,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         float c = block_max<BLOCK>(cm, s_red);
         float u = block_max<BLOCK>(um, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
-        write_split_operands<BLOCK>(a, rec, p, vbase, c, u); // (block_max ends with a barrier: the records are visible)
-        if (threadIdx.x == 0) finish_pair_records(a, rec, p, vbase);
+        if (threadIdx.x == 0) finish_pair_records(a, rec, p, vbase); // (block_max ends with a barrier: the records are visible)
         if (a.zeroCounts)
             for (int i = threadIdx.x; i < a.zeroH; i += BLOCK) a.zeroCounts[(size_t)p * a.zeroStride + i] = 0;
     }
@@ -487,9 +413,12 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         cmaxOut[0] = make_float2(c, u);
         finish_pair_records(a, rec, 0, vbase);
     }
-    write_split_operands<kBlock>(a, rec, 0, vbase, c, u);
     if (a.zeroCounts)
         for (int i = threadIdx.x; i < a.zeroH; i += kBlock) a.zeroCounts[i] = 0;
+    if (threadIdx.x == 0 && a.zeroSurvA) { // the staged scoring's survivor counters (one pair), as ps_crosscheck_prep does
+        a.zeroSurvA[0] = 0;
+        a.zeroSurvB[0] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

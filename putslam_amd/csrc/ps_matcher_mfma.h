@@ -26,7 +26,7 @@
 // hits).  The first form staged the query tiles through LDS (double-buffered, one barrier per tile, shared by the
 // four waves): 0.211 ms against 0.186 ms per 499 pairs -- the barrier tied the waves of a work-group together, and
 // with one wave of each of two work-groups per SIMD the matrix and the vector phases of all of them coincided
-// (PS_MFMA_DIRECT=0 rebuilds that form; profiles/r02h).
+// (that form left the tree in round 4; the A/B is on file in profiles/r02h).
 // Any consistent assignment of descriptor bits to (k-step, lane half, element) is valid because both
 // operands use the same one: lane (r = lane & 31, h = lane >> 5) holds, for k-step s, the 32 bits of dword
 // 2s + h of row r.
@@ -139,11 +139,8 @@ constexpr float kMfmaBase = 8388608.0f; // 2^23: unit spacing up to 2^24
 // wave each TT of them) and sweeps the query tiles [T0, T1) of its split.  qsplit > 1 merges with atomicMin
 // on the packed key (hamming << 16 | query), the same key kernel 2 reads from ps_hamming_nn.
 // ------------------------------------------------------------------------------------------
-// 1 (default): every wave loads its own query tiles straight into registers; 0: the first form, query tiles staged
-// through LDS and shared by the work-group's four waves (kept for A/B: profiles/r02h).
-#ifndef PS_MFMA_DIRECT
-#define PS_MFMA_DIRECT 1
-#endif
+// Every wave loads its own query tiles straight into registers (the first form staged them through LDS with a barrier
+// per tile, shared by the work-group's four waves: 14 % slower, profiles/r02h).
 #ifndef PS_MFMA_WAVES
 #define PS_MFMA_WAVES 1
 #endif
@@ -154,9 +151,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
                                                           int groups, int qsplit, const uint4 *__restrict__ Xq,
                                                           uint32_t *__restrict__ keys)
 {
-#if !PS_MFMA_DIRECT
-    __shared__ uint4 s_a[2][kTileU4];
-#endif
     const unsigned perPair = (unsigned)(groups * qsplit);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int p = (int)(L / perPair);
@@ -192,7 +186,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
     }
 
     const uint4 *__restrict__ xq = Xq + (size_t)p * tpf * kTileU4;
-#if PS_MFMA_DIRECT
     // Every wave fetches its own copy of the query tile (4 x 16 B per lane, served by L1 / L2 for the other waves of the
     // work-group) one tile ahead into registers: no LDS staging, no barrier, the waves of a work-group drift apart freely.
     uint4 an[4];
@@ -210,20 +203,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
 #pragma unroll
             for (int s = 0; s < 4; ++s) an[s] = xq[(size_t)(T + 1) * kTileU4 + s * 64 + lane];
         }
-#else
-    if (T0 < T1) s_a[0][tid] = xq[(size_t)T0 * kTileU4 + tid];
-    __syncthreads();
-    for (int T = T0; T < T1; ++T) {
-        const int buf = (T - T0) & 1;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (T + 1 < T1) nxt = xq[(size_t)(T + 1) * kTileU4 + tid];
-        v4i_t A[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint4 a = s_a[buf][s * 64 + lane];
-            A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
-        }
-#endif
         v16f_t Cin = C;
         if (T * kTileRows + kTileRows > nq) { // last, partial query tile: rows beyond nq can never win
 #pragma unroll
@@ -242,10 +221,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
                 bestT[i] = T;
             }
         }
-#if !PS_MFMA_DIRECT
-        if (T + 1 < T1) s_a[buf ^ 1][tid] = nxt;
-        __syncthreads();
-#endif
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
@@ -277,18 +252,12 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
 // 2000-row frame repeat each other's expansion, which costs about what the separate launch did (0.036 ms per 499 pairs)
 // and removes 0.29 GB of traffic per step and one launch.
 // ------------------------------------------------------------------------------------------
-// PS_MFMA_SCALED: block-scaled MFMA + add/max epilogue (10 instead of 13 vector instructions per 32 x 32 tile);
-// PS_MFMA_LUT: the 8 bits -> 8 nibbles expansion through a 256-entry table in LDS (2 vector instructions + one LDS read per
-// byte instead of 7).  On gfx950 MFMA and vector instructions of a SIMD do not overlap -- not across waves and, as the
+// The MFMA runs in its block-scaled form with an add/max epilogue (10 instead of 13 vector instructions per 32 x 32 tile);
+// the 8 bits -> 8 nibbles expansion goes through a 256-entry table in LDS (2 vector instructions + one LDS read per byte
+// instead of 7).  (The unscaled / table-free sub-forms measured in profiles/r03h left the tree in round 4.)  On gfx950 MFMA and vector instructions of a SIMD do not overlap -- not across waves and, as the
 // software-pipelined epilogue tried here showed (profiles/r03h: 0.232 ms either way), not inside one wave either -- so this
 // kernel's time is its 512 matrix cycles PLUS its ~90 vector instructions per query tile and wave, and only removing
 // vector instructions shortens it.
-#ifndef PS_MFMA_SCALED
-#define PS_MFMA_SCALED 1
-#endif
-#ifndef PS_MFMA_LUT
-#define PS_MFMA_LUT 1
-#endif
 constexpr int kFuseChunk = 4; // query tiles per chunk: 2 x 4 x 4 KiB = 32 KiB of LDS per work-group
 
 template <int TT>
@@ -298,10 +267,8 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
                                                                 int groups, int qsplit, uint32_t *__restrict__ keys)
 {
     __shared__ uint4 s_a[2][kFuseChunk][kTileU4];
-#if PS_MFMA_LUT
     __shared__ uint32_t s_lut[256]; // byte -> its 8 FP4 nibbles
     s_lut[threadIdx.x] = fp4_from_byte(threadIdx.x);
-#endif
     const unsigned perPair = (unsigned)(groups * qsplit);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int p = (int)(L / perPair);
@@ -328,17 +295,10 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     }
     v16f_t C;
 #pragma unroll
-#if PS_MFMA_SCALED
     for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)((1 << 21) + 31 - tile_row(reg, h));
-#else
-    for (int reg = 0; reg < 16; ++reg) C[reg] = kMfmaBase + (float)(kMfmaBias - 4096 - tile_row(reg, h));
-#endif
-    int best[TT], bestT[TT];
+    int best[TT];
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-        best[i] = 0; // below every valid entry (their patterns are >= 0x4B000000)
-        bestT[i] = 0;
-    }
+    for (int i = 0; i < TT; ++i) best[i] = 0; // below every valid entry (their patterns are >= 0x4B000000)
 
     // expansion role of this thread: piece o = s * 64 + h * 32 + r of a tile = dword 2 s + h of row r
     const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
@@ -352,7 +312,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     auto expand_tile = [&](uint4 *dst, int T) {
         const int row = T * kTileRows + er;
         v4i_t e = {0, 0, 0, 0}; // rows beyond the frame: 0.0 in FP4 (masked by the accumulator start anyway)
-#if PS_MFMA_LUT
         if (row < nq) {
             const uint32_t w = q32[(size_t)row * 8 + 2 * es + eh];
             e.x = (int)s_lut[w & 0xFFu];
@@ -360,9 +319,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
             e.z = (int)s_lut[(w >> 16) & 0xFFu];
             e.w = (int)s_lut[w >> 24];
         }
-#else
-        if (row < nq) e = fp4_from_dword(q32[(size_t)row * 8 + 2 * es + eh]);
-#endif
         dst[tid] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
     };
     auto expand_chunk = [&](int buf, int Tc) {
@@ -378,7 +334,6 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
             const uint4 a = tile[s * 64 + lane];
             A[s].x = (int)a.x; A[s].y = (int)a.y; A[s].z = (int)a.z; A[s].w = (int)a.w;
         }
-#if PS_MFMA_SCALED
         // block-scaled MFMA: every product carries 2^9, the accumulator's mantissa is 2^14 (256 - hamming) + (31 - row);
         // adding the tile's 16352 - 32 T turns it into 2^14 (256 - hamming) + (16383 - query row), whose maximum over rows
         // AND tiles is the nearest query, lowest index first: 8 v_max3 + add + max per 32 x 32 tile
@@ -391,24 +346,8 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
             acc = mfma_fp4s(A[3], B[i][3], acc);
             best[i] = max(best[i], max16(acc) + cT);
         }
-#else
-#pragma unroll
-        for (int i = 0; i < TT; ++i) {
-            v16f_t acc = mfma_fp4(A[0], B[i][0], Cin);
-            acc = mfma_fp4(A[1], B[i][1], acc);
-            acc = mfma_fp4(A[2], B[i][2], acc);
-            acc = mfma_fp4(A[3], B[i][3], acc);
-            const int m = max16(acc);
-            if (m > (best[i] | 31)) { // strictly smaller distance only: the earlier (lower) query tile keeps a tie
-                best[i] = m;
-                bestT[i] = T;
-            }
-        }
-#endif
     };
-#if PS_MFMA_LUT
     __syncthreads(); // the table is complete
-#endif
     if (T0 < Tm) expand_chunk(0, T0);
     __syncthreads();
     int c = 0;
@@ -434,17 +373,10 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     for (int i = 0; i < TT; ++i) {
         const int t = (tile0 + i) * kTileRows + r;
         uint32_t key = kNoKey;
-#if PS_MFMA_SCALED
         if (best[i] > 0) {
             const int d = best[i] & 0x7FFFFF; // 2^14 (256 - hamming) + (16383 - query row)
             key = ((uint32_t)(256 - (d >> 14)) << 16) | (uint32_t)(16383 - (d & 0x3FFF));
         }
-#else
-        if (best[i] > 0) {
-            const int v = kMfmaBias - (best[i] & 0x7FFFFF); // 32 * hamming + row of the tile
-            key = ((uint32_t)(v >> 5) << 16) | (uint32_t)(bestT[i] * kTileRows + (v & 31));
-        }
-#endif
         const uint32_t other = (uint32_t)__shfl_xor((int)key, 32, 64); // the other half's 16 rows of every tile
         key = other < key ? other : key;
         if (h == 0 && t < nt) {

@@ -117,27 +117,36 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
             outs[pr] = pb.download()
         a = outs[1]
         P = len(seq["pairs"])
+        why = []   # what differs, for the log: (against what, pair, field)
+
+        def note(cond, *what):
+            if not cond and len(why) < 12:
+                why.append(what)
+            return bool(cond)
+
         ok = True
-        for b in (outs[2], outs[0]):
-            ok &= a["pose"].tobytes() == b["pose"].tobytes() and np.array_equal(a["numMatches"], b["numMatches"])
+        for tag, b in (("staged/original order", outs[2]), ("complete", outs[0])):
+            ok &= note(np.array_equal(a["numMatches"], b["numMatches"]), tag, "numMatches")
             for p in range(P):
                 n = int(a["numMatches"][p])
-                ok &= np.array_equal(a["inlierMask"][p, :n], b["inlierMask"][p, :n])
+                ok &= note(a["pose"][p].tobytes() == b["pose"][p].tobytes(), tag, p, "pose")
+                ok &= note(np.array_equal(a["inlierMask"][p, :n], b["inlierMask"][p, :n]), tag, p, "mask")
                 for f in STAT_FIELDS:
                     x, y = a["stats"][p][f], b["stats"][p][f]
-                    ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+                    ok &= note(bool(x == y or (np.isnan(x) and np.isnan(y))), tag, p, f, x, y)
         for p in rng.integers(0, P, oracle_pairs):
             cfgp, _ = make_config(est, H, seed=base + int(p))
             c = po.vo_pairs(prm, cfgp, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][p:p + 1], threads=1)
             n = int(c["numMatches"][0])
-            ok &= n == int(a["numMatches"][p]) and np.array_equal(a["inlierMask"][p, :n], c["inlierMask"][0, :n])
-            ok &= a["pose"][p].tobytes() == c["pose"][0].tobytes()
+            ok &= note(n == int(a["numMatches"][p]) and np.array_equal(a["inlierMask"][p, :n], c["inlierMask"][0, :n]), "oracle", int(p), "mask")
+            ok &= note(a["pose"][p].tobytes() == c["pose"][0].tobytes(), "oracle", int(p), "pose")
             for f in STAT_FIELDS:
                 x, y = a["stats"][p][f], c["stats"][0][f]
-                ok &= bool(x == y or (np.isnan(x) and np.isnan(y)))
+                ok &= note(bool(x == y or (np.isnan(x) and np.isnan(y))), "oracle", int(p), f, x, y)
         if not ok:
             bad += 1
-            print("MISMATCH", dict(it=it, mode=mode, est=est, H=H, frames=frames, kpts=kpts, frac=frac, noise=noise, seed=base), flush=True)
+            print("MISMATCH", dict(it=it, mode=mode, est=est, H=H, frames=frames, kpts=kpts, frac=frac, noise=noise, seed=base),
+                  "differences:", why, flush=True)
         if verbose and (it + 1) % 20 == 0:
             print(f"{it + 1} batches, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     for c in ctxs.values():
@@ -146,6 +155,8 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()   # a worker that dies on a signal leaves its Python stack in its log
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
@@ -154,28 +165,50 @@ def main():
     ap.add_argument("--counts", action="store_true", help="also compare every hypothesis's inlier count")
     ap.add_argument("--procs", type=int, default=1, help="worker processes (seeds seed, seed+1, ...), iterations split evenly")
     ap.add_argument("--batch", action="store_true", help="random batches: staged scoring vs complete scoring vs oracle")
+    ap.add_argument("--log-dir", default=None,
+                    help="where every worker's FULL output is kept (default: gpurun_out/fuzz_logs under the repository)")
+    ap.add_argument("--tag", default="", help="label for the log files of this run")
     a = ap.parse_args()
     modes = tuple(int(x) for x in a.modes.split(","))
     if a.procs > 1:
         import subprocess
         po.lib()  # (build the oracle once, before the workers start)
         per = (a.iters + a.procs - 1) // a.procs
-        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--iters", str(per), "--seed", str(a.seed + i),
-                                "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else [])
-                               + (["--batch"] if a.batch else []),
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(a.procs)]
-        rc = 0
+        log_dir = a.log_dir or os.path.join(ROOT, "gpurun_out", "fuzz_logs")
+        os.makedirs(log_dir, exist_ok=True)
+        stamp = f"{a.tag or 'run'}_{'batch' if a.batch else 'single'}_{int(time.time())}_{os.getpid()}"
+        ps, logs = [], []
+        for i in range(a.procs):
+            # every worker's complete output goes to a file of its own (round 3 lost the only failing worker's output to a
+            # `tail -1`): nothing a worker printed before it died can be lost, whatever the caller does with this
+            # process's stdout
+            path = os.path.join(log_dir, f"{stamp}_worker{i}_seed{a.seed + i}.log")
+            f = open(path, "w")
+            logs.append((path, f))
+            ps.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), "--iters", str(per), "--seed", str(a.seed + i),
+                                        "--max-kpts", str(a.max_kpts), "--modes", a.modes] + (["--counts"] if a.counts else [])
+                                       + (["--batch"] if a.batch else []), stdout=f, stderr=subprocess.STDOUT, text=True))
+        failed = 0
         for i, p in enumerate(ps):
-            out, _ = p.communicate()
-            tail = [l for l in out.splitlines() if l.startswith("fuzz done") or l.startswith("MISMATCH")]
-            print(f"[worker {i}, seed {a.seed + i}] " + " | ".join(tail[-4:]), flush=True)
-            if p.returncode != 0 and not any(l.startswith("fuzz done") for l in tail):
-                # the worker died (not a mismatch): show why
-                print(f"[worker {i}] exit code {p.returncode}; last output:\n  " + "\n  ".join(out.splitlines()[-8:]), flush=True)
-            rc |= p.returncode
+            p.wait()
+            path, f = logs[i]
+            f.close()
+            out = open(path).read()
+            lines = out.splitlines()
+            tail = [l for l in lines if l.startswith("fuzz done") or l.startswith("MISMATCH")]
+            print(f"[worker {i}, seed {a.seed + i}, rc {p.returncode}] " + " | ".join(tail[-4:]), flush=True)
+            finished = any(l.startswith("fuzz done") for l in lines)
+            if p.returncode != 0 or not finished:
+                failed += 1
+                # ANY non-zero exit or missing summary line fails the run and is shown in full (last 60 lines), whether it was a
+                # mismatch, a Python exception, a HIP error or a signal (negative return code)
+                kind = "MISMATCH" if any(l.startswith("MISMATCH") for l in lines) else \
+                    (f"killed by signal {-p.returncode}" if p.returncode < 0 else "died")
+                print(f"[worker {i}] {kind}: exit code {p.returncode}, full log kept at {path}; last output:\n  "
+                      + "\n  ".join(lines[-60:]), flush=True)
         print(f"fuzz done: {per * a.procs} iterations over {a.procs} workers, modes {a.modes}, "
-              f"{'no mismatches' if rc == 0 else 'MISMATCHES'}")
-        return rc
+              f"{'no mismatches' if failed == 0 else f'{failed} WORKER(S) FAILED (MISMATCHES or crashes, see above)'}")
+        return 1 if failed else 0
     if a.batch:
         bad = run_batch(a.iters, a.seed, modes=tuple(m for m in modes if m != 3))
     else:

@@ -134,3 +134,31 @@ def test_bench_one_sequence_sharded_eight_ways_equals_unsharded(tmp_path):
     inc = back[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
     assert sharding.compose_trajectory(inc).tobytes() == \
         sharding.compose_trajectory(want[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)).tobytes()
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_bench_rccl_branch_with_a_world_of_one(tmp_path, streams):
+    """The RCCL branch itself (backend "nccl", device-resident payloads): `bench.py --force-dist` initialises the process
+    group with ONE rank before any other GPU call and then runs the real N > 1 control flow -- parameter broadcast on the
+    device, per-chain asynchronous gather of device tensors on the chains' streams, the waits under torch.cuda.stream(),
+    the fence.  The records rank 0 'gathers' must equal the non-distributed run's byte for byte.  (the only
+    sequential step, pose composition PUTSLAM.cpp:735-740, happens on rank 0 after this gather.)"""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = _env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(),
+               HSA_ENABLE_IPC_MODE_LEGACY=0)
+    env.pop("PUTSLAM_BENCH_BACKEND", None)
+    dist_npy, plain_npy = tmp_path / "dist.npy", tmp_path / "plain.npy"
+    p = subprocess.run([sys.executable, bench, "--gpus", "1", "--force-dist", "--streams", str(streams), "--dump-records",
+                        str(dist_npy)] + ARGS, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["config"]["backend"] == "nccl" and j["config"]["world_size"] == 1 and j["config"]["force_dist"] is True
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    q = subprocess.run([sys.executable, bench, "--gpus", "1", "--streams", str(streams), "--dump-records", str(plain_npy)] + ARGS,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert q.returncode == 0, q.stdout + q.stderr
+    got, want = np.load(dist_npy), np.load(plain_npy)
+    assert got.shape == want.shape == (1, 13, 18)
+    assert got.tobytes() == want.tobytes()
+    assert np.abs(got[0, :, :16]).sum() > 0 and (got[0, :, 17] > 0).all()      # real records: poses and match counts

@@ -18,12 +18,15 @@ STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierC
                "accepted", "bestInlierRatio", "pointInlierRatio")
 
 
-def _run(seq, prm, cfg, prune, reorder=1):
+def _run(seq, prm, cfg, prune, reorder=1, **options):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     c = api.Context(0)
     c.set_option("prune", prune)
     c.set_option("reorder", reorder)   # 1 = also under the adaptive schedules (the default reorders the fixed one only)
     assert c.get_option("reorder") == reorder
+    for name, value in options.items():   # the staged scoring's twins and tuning knobs (ps_context_set_option)
+        c.set_option(name, value)
+        assert c.get_option(name) == value
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
     run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
@@ -139,3 +142,164 @@ def test_reordered_record_is_a_permutation_with_the_rejected_matches_in_front(or
             assert front.sum() > 0   # (how much of the miss budget is FAR off depends on the data: 40 % here, 75 % in the bench)
         else:
             assert (front == 0).all()   # (the pre-test front exists for the reprojection metrics only)
+
+
+# ---- every twin / tuning knob of the staged scoring, per context (round 3 could only set them through the environment) ----
+# The selection rule all of them must preserve: strict '>' first-best with the adaptive trip limit, RANSAC.cpp:438-455.
+TWINS = [
+    dict(pretest=0), dict(gensplit=0), dict(singlerest=0), dict(bail=0),
+    dict(prefix=64), dict(prefix=128),
+    dict(list_g2=1, list_g3=1, list_r3=1), dict(list_g2=7, list_g3=3, list_r3=32), dict(list_r3=2, list_g3=512),
+    dict(reorder_top=1), dict(reorder_top=16, reorder_margin=1), dict(reorder_margin=300, reorder_c2div=1),
+    dict(reorder_c2div=64, reorder_gran=2), dict(reorder_gran=8, pretest=0),
+    dict(msplit=3), dict(msplit=32, gensplit=0),
+]
+TWIN_CASES = [  # (errorVersion, estimator, H, frames, kpts, inlier_frac, noise)
+    (EUCLIDEAN_ERROR, EST_FIXED, 4096, 24, 700, 0.70, 0.004),
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 60, 700, 0.70, 0.004),
+    (EUCLIDEAN_AND_REPROJECTION_ERROR, EST_FIXED, 2048, 120, 500, 0.45, 0.008),
+    (ADAPTIVE_ERROR, EST_RANSAC, 1157, 90, 400, 0.10, 0.02),
+    (REPROJECTION_ERROR, EST_USAC, 3000, 80, 500, 0.30, 0.01),
+    (REPROJECTION_ERROR, EST_FIXED, 1161, 200, 270, 0.94, 0.0014),   # cuts close to each other and to M
+    (EUCLIDEAN_ERROR, EST_FIXED, 2000, 40, 500, 0.12, 0.02),         # hopeless data: the one-stage exit of the reorder launch
+]
+_FULL = {}
+
+
+@pytest.mark.parametrize("case", range(len(TWIN_CASES)))
+@pytest.mark.parametrize("twin", TWINS, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()))
+def test_staged_twins_equal_complete(twin, case):
+    mode, est, H, frames, kpts, frac, noise = TWIN_CASES[case]
+    seq = synth.make_sequence(frames, kpts, config=3, index=7000 + case, inlier_frac=frac, noise=noise)
+    P = len(seq["pairs"])
+    prm = default_ransac_params(mode, lc=(H == 1157))
+    cfg, _ = make_config(est, H, seed=1234)
+    if case not in _FULL:   # the complete sweep (prune = 0) once per case; test_pruned_equals_unpruned_equals_oracle ties it to the oracle
+        _FULL[case] = _run(seq, prm, cfg, 0)
+    _same(_run(seq, prm, cfg, 1, reorder=1, **twin), _FULL[case], P)
+    if "msplit" not in twin:
+        _same(_run(seq, prm, cfg, 1, reorder=2, **twin), _FULL[case], P)   # the default: reordered for the fixed schedule only
+
+
+def test_option_names_and_ranges():
+    c = api.Context(0)
+    for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "reorder", "qsplit", "msplit", "gensplit",
+                 "singlerest", "pretest", "bail", "list_r3", "list_g2", "list_g3", "prefix", "reorder_top", "reorder_margin",
+                 "reorder_c2div", "reorder_gran", "stamps"):
+        v = c.get_option(name)
+        c.set_option(name, v)   # every default is a legal value
+    for name, bad in (("prefix", 100), ("prefix", 320), ("reorder_gran", 12), ("reorder_gran", 1), ("list_r3", 0),
+                      ("reorder_top", 17), ("prune", 2), ("no_such_option", 0)):
+        with pytest.raises(api.PsError):
+            c.set_option(name, bad)
+    c.close()
+
+
+# ---- the staged scoring behind the host-pointer and streaming entry points (one pair, very many hypotheses) ----
+def _one_pair(n, index, frac=0.6, noise=0.004):
+    a, b = synth.make_pair(n, config=2, index=index, inlier_frac=frac, noise=noise)
+    return a, b
+
+
+@pytest.mark.parametrize("mode,est,H", [
+    (EUCLIDEAN_ERROR, EST_FIXED, 70000),          # staged from ceil(H/256) - 1 >= 256 on (Euclidean kernels)
+    (ADAPTIVE_ERROR, EST_USAC, 850000),           # USAC's own default maxHypotheses (USAC_wrapper.cpp:70)
+    (REPROJECTION_ERROR, EST_FIXED, 200000),      # ... >= 768 (reprojection kernels, fixed schedule)
+    (REPROJECTION_ERROR, EST_USAC, 850000),
+])
+def test_host_entry_with_staged_scoring_two_calls_one_context(oracle, mode, est, H):
+    """ps_ransac_rigid3d on ONE context, twice (the second call meets the survivor counters and lists the first left), and a
+    smaller call in between: staged == complete == oracle.  Round 3's host entry never cleared the counters."""
+    a, b = _one_pair(260, 31)
+    a2, b2 = _one_pair(420, 32, frac=0.35, noise=0.01)
+    prm = default_ransac_params(mode)
+    prm.minimalInlierRatioThreshold = 0.05
+    K = TUM_FR1_K
+    staged, full = api.Context(0), api.Context(0)
+    staged.set_option("reorder", 1)
+    full.set_option("prune", 0)
+    for rep, (x, y, seed) in enumerate(((a, b, 5), (a2, b2, 6), (a, b, 5), (a2, b2, 7))):
+        cfg, _ = make_config(est, H, seed=seed)
+        m = oracle.match_hamming256(x["desc"], y["desc"])
+        g = staged.ransac_rigid3d(prm, cfg, K, x["pts"], y["pts"], m)
+        f = full.ransac_rigid3d(prm, cfg, K, x["pts"], y["pts"], m)
+        o = oracle.ransac_rigid3d(prm, cfg, K, x["pts"], y["pts"], m)
+        for r in (f, o):
+            assert np.array_equal(g["mask"], r["mask"]) and g["pose"].tobytes() == r["pose"].tobytes(), (rep, mode, est)
+            for fld in STAT_FIELDS:
+                u, v = g["stats"][fld], r["stats"][fld]
+                assert u == v or (np.isnan(u) and np.isnan(v)), (rep, fld, u, v)
+    staged.close()
+    full.close()
+
+
+def test_debug_counts_are_complete_counts_whatever_the_size(oracle):
+    """ps_debug_ransac_counts returns every hypothesis's own count: never the staged scoring's lower bounds."""
+    a, b = _one_pair(200, 41)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 70000, seed=9)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    c = api.Context(0)
+    c.set_option("reorder", 1)
+    c.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)          # a staged call first
+    cg = c.debug_ransac_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    cc, _ = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+    assert np.array_equal(cg, cc[: len(cg)])
+    assert np.array_equal(c.stage_survivors(1), np.zeros((2, 1), np.int32))   # that call was not staged
+    c.close()
+
+
+@pytest.mark.parametrize("mode,est,H", [(EUCLIDEAN_ERROR, EST_FIXED, 70000), (REPROJECTION_ERROR, EST_USAC, 850000),
+                                        (REPROJECTION_ERROR, EST_FIXED, 200000)])
+def test_stream_push_with_staged_scoring(oracle, mode, est, H):
+    """ps_vo_stream_push (one pair per push; hipGraph replay from the third push on) with the staged scoring on, while
+    another call on the SAME context grows staged-scoring blocks in between (round 3's graph key did not see them)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(7, 300, config=3, index=515, inlier_frac=0.6, noise=0.004)
+    big = synth.make_sequence(40, 300, config=3, index=516, inlier_frac=0.6, noise=0.004)
+    prm = default_ransac_params(mode)
+    prm.minimalInlierRatioThreshold = 0.05
+    c = api.Context(0)
+    c.set_option("reorder", 1)
+    vs = api.VoStream(c, 300)
+    for f in range(7):
+        cfg, _ = make_config(est, H, seed=100 + f)
+        r = vs.push(prm, cfg, TUM_FR1_K, seq["desc"][f], seq["pts"][f])
+        if f == 0:
+            assert r is None
+            continue
+        if f == 4:   # a batch with more pairs on the same context: validMask / survN / prefInfo / permBuf grow
+            cfgb, _ = make_config(EST_FIXED, 4096, seed=1)
+            fs = FrameSetDevice(big["desc"], big["pts"], big["nkpts"])
+            pb = PairBatchDevice(big["pairs"], fs.max_kpts)
+            run_pairs(c, prm, cfgb, TUM_FR1_K, fs, pb)
+            pb.download()
+        o = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][f - 1:f], threads=1)
+        n = int(o["numMatches"][0])
+        assert len(r["matches"]) == n and np.array_equal(r["mask"], o["inlierMask"][0, :n]), f
+        assert r["pose"].tobytes() == np.ascontiguousarray(o["pose"][0].reshape(4, 4).T).tobytes(), f
+        for fld in STAT_FIELDS:
+            u, v = r["stats"][fld], o["stats"][0][fld]
+            assert u == v or (np.isnan(u) and np.isnan(v)), (f, fld, u, v)
+    vs.close()
+    c.close()
+
+
+def test_stage_diagnostics_reject_another_batch_shape():
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(30, 400, config=3, index=61, inlier_frac=0.7, noise=0.004)
+    c = api.Context(0)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=3)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+    pb.download()
+    P = len(seq["pairs"])
+    assert c.stage_survivors(P).shape == (2, P)
+    c.stage_order(P, fs.max_kpts)
+    with pytest.raises(api.PsError):
+        c.stage_survivors(P - 1)
+    with pytest.raises(api.PsError):
+        c.stage_order(P - 1, fs.max_kpts)
+    c.close()
