@@ -99,6 +99,9 @@ def parse():
                     help="run the N > 1 control flow (RCCL process group, parameter broadcast, per-chain asynchronous gather "
                          "of device-resident records, fence) even with ONE rank: the only way to execute that branch on a "
                          "one-GPU box (also PUTSLAM_BENCH_FORCE_DIST=1)")
+    ap.add_argument("--warm-seconds", type=float, default=0.6,
+                    help="after the --warmup steps, keep stepping (untimed) until this much wall time has passed: the timed "
+                         "regions start on a chip at its steady clock")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
@@ -244,6 +247,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # ... and until the chip has been busy for --warm-seconds in all (clock ramp: round 3's first timed region was 8 % slower
+    # than the rest whatever --warmup said); whole steps, fenced, outside the timed regions
+    warm_steps = args.warmup
+    tw0 = time.perf_counter()
+    while time.perf_counter() - tw0 < args.warm_seconds:
+        for _ in range(20):
+            step()
+        fence()
+        warm_steps += 20
     for c in ctxs:
         c.enable_timing(True)                                          # HIP events on the launch stream(s)
     # --repeats timed regions of exactly --steps steps, each bracketed by barrier + synchronize on both sides; the
@@ -315,14 +327,21 @@ def main():
     if world == 1 and not args.no_other_modes:
         other_modes = {}
         pb2 = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
-        prm0 = default_ransac_params(0)
-        for name, est2, hyp2 in (("E0/fixed/4096", EST_FIXED, 4096), ("E0/ransac/487", EST_RANSAC, 487)):
+        legs = [("E0/fixed/4096", 0, EST_FIXED, 4096, 1), ("E0/ransac/487", 0, EST_RANSAC, 487, 1)]
+        if args.preset is None:
+            # the timed workload itself with the staged scoring OFF (every hypothesis scored completely): what the
+            # staged form saves on THIS data is a measured figure, not a derived one
+            legs.append(("E%d/%s/%d/prune0" % (args.error_version, args.estimator, args.hyp), args.error_version, est, args.hyp, 0))
+        for name, ev2, est2, hyp2, prune2 in legs:
             if args.preset == "stress" and est2 == EST_FIXED:
                 hyp2, name = args.hyp, "E0/fixed/%d" % args.hyp
             cfg2, _ = make_config(est2, hyp2, seed=cfg.seed)
+            prm2 = default_ransac_params(ev2)
+            prune_was = c0.get_option("prune")
+            c0.set_option("prune", prune2 if prune_was else 0)
 
             def leg_step():
-                run_pairs_split([c0], [chains[0]], prm0, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=[0, P], join=False)
+                run_pairs_split([c0], [chains[0]], prm2, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=[0, P], join=False)
 
             leg_step()
             torch.cuda.synchronize(dev)
@@ -335,13 +354,28 @@ def main():
             leg_ms = (time.perf_counter() - tl0) / n_leg * 1e3
             kms = {k: v[0] / max(v[1], 1) for k, v in c0.kernel_time_totals().items()}
             c0.enable_timing(False)
+            c0.set_option("prune", prune_was)
             st2 = pb2.download()["stats"]
             other_modes[name] = {"ms_per_step": leg_ms, "pairs_per_s": P / (leg_ms * 1e-3), "kernel_ms": kms,
                                  "kernel_ms_sum": sum(kms.values()), "steps": n_leg,
                                  "mean_iterations_run": float(st2["iterationsRun"].mean()),
                                  "mean_inliers": float(st2["numInliers"].mean()),
-                                 "accepted_pairs": int(st2["accepted"].sum()),
+                                 "accepted_pairs": int(st2["accepted"].sum()), "staged_scoring": bool(prune2),
                                  "score_kernel": "fast" if c0.get_option("score") >= 1 else "exact"}
+            if name == "E0/ransac/487" and S > 1:
+                # the reference's own regime submitted like the timed region: S chains on S streams, steps pipelined
+                def chains_step():
+                    run_pairs_split(ctxs, chains, prm2, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=bounds, join=False)
+                for _ in range(3):
+                    chains_step()
+                torch.cuda.synchronize(dev)
+                n_ch = 20
+                tc0 = time.perf_counter()
+                for _ in range(n_ch):
+                    chains_step()
+                torch.cuda.synchronize(dev)
+                ch_ms = (time.perf_counter() - tc0) / n_ch * 1e3
+                other_modes[name]["chains"] = {"streams": S, "ms_per_step": ch_ms, "pairs_per_s": P / (ch_ms * 1e-3), "steps": n_ch}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
@@ -421,22 +455,50 @@ def main():
                 # pipe-busy fractions of the same profiled workload (SQ counters of the rocprofv3 pass next to the
                 # traffic pass): share of the kernel's cycles in which the vector ALU / the matrix pipe of a SIMD is busy
                 sq = json.load(open(os.path.join(ROOT, os.path.dirname(t[key]["_source"]), "sq_counters.json")))
+                src = os.path.dirname(t[key]["_source"]) + "/sq_counters.json (profiled run, not this one)"
+                step_of = {"ps_ransac_score_fast": "ps_ransac_score", "ps_stage_reorder": "ps_ransac_score",
+                           "ps_ransac_score_euclid": "ps_ransac_score", "ps_hamming_mfma_fused": "ps_hamming_mfma"}
+                acc, parts = {}, {}
                 for kname, c in sq.items():
                     short = kname.split("<")[0]
-                    short = {"ps_ransac_score_fast": "ps_ransac_score", "ps_ransac_score_mfma": "ps_ransac_score",
-                             "ps_stage_reorder": "ps_ransac_score",
-                             "ps_ransac_score_euclid": "ps_ransac_score", "ps_hamming_mfma_fused": "ps_hamming_mfma"}.get(short, short)
-                    if short in bounds_solo and c.get("GRBM_GUI_ACTIVE"):
-                        cyc = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0      # kernel cycles x SIMDs (8 XCDs report separately)
-                        bounds_solo[short]["pipe_busy_pmc"] = {
-                            "valu_active_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / cyc,
-                            "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / cyc,
-                            "source": os.path.dirname(t[key]["_source"]) + "/sq_counters.json (profiled run, not this one)"}
+                    short = step_of.get(short, short)
+                    if not c.get("GRBM_GUI_ACTIVE"):
+                        continue
+                    a_ = acc.setdefault(short, {})
+                    for cn in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                        a_[cn] = a_.get(cn, 0.0) + float(c.get(cn, 0.0))
+                    parts.setdefault(short, {})[kname] = c
+
+                def busy(c):
+                    cyc = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0      # kernel cycles x SIMDs (8 XCDs report separately)
+                    return {"valu_active_frac": 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / cyc,
+                            "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / cyc}
+
+                for short, c in acc.items():
+                    if short not in bounds_solo:
+                        continue
+                    # the STEP's figure: the counters of every launch of the step summed (the scoring step is six launches
+                    # of four kernels; round 3's line let the last kernel of the file win)
+                    pb_ = busy(c)
+                    pb_["source"] = src
+                    if len(parts[short]) > 1:
+                        pb_["by_kernel"] = {k: busy(v) for k, v in parts[short].items()}
+                    bounds_solo[short]["pipe_busy_pmc"] = pb_
+                    if short in rk and c.get("SQ_INSTS_VALU"):
+                        # ALL vector instructions the step issued (prologue, stages, reorder included) over the step's
+                        # own duration in THIS run: the all-in rate next to the loops-only `frac`
+                        allin = c["SQ_INSTS_VALU"] * 64.0 / (rk[short] * 1e-3) / 1e12
+                        bounds_solo[short]["all_in"] = {"valu_wave_instructions_per_step": c["SQ_INSTS_VALU"],
+                                                        "salu_instructions_per_step": c.get("SQ_INSTS_SALU"),
+                                                        "achieved": allin, "unit": "T lane-instructions/s",
+                                                        "frac": allin / VALU_PEAK_TOPS,
+                                                        "note": "SQ_INSTS_VALU of the profiled run / this run's duration"}
             except Exception:
                 pass
         out = {
             "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warm_steps_before_region_1": warm_steps,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if shard_seq else "weak",
             "value_min": P_total_per_step * args.steps / max(region_s), "value_max": P_total_per_step * args.steps / min(region_s),

@@ -304,6 +304,11 @@ int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M
 /* Runs blocks*256*perThread random (a0, a1, b) triples through the scoring kernel's shared-reciprocal
  * division and through the '/' operator; *mismatches must come back 0 (bitwise comparison). */
 int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, uint64_t *mismatches, uint64_t *tested);
+/* The exact short forms of sqrt / reciprocal / shared-denominator quotients inside the hypothesis prologue (the float
+ * Umeyama + Jacobi SVD of RANSAC.cpp:207-244 and the 4x4 inverse of :337-338) against sqrtf and '/', bit for bit; *mismatches
+ * must come back 0.  mode 0: every float from 1.0f to +inf and beyond (elements = 0x40001000), 1: every float of [1, 2]
+ * (0x00800001), 2: y / |y|, 3: 1 / d and u / d with d = sqrt(1 + u u), 4: nine numerators over one denominator (random). */
+int ps_debug_mathcheck(PsContext *ctx, int mode, uint64_t seed, uint64_t elements, uint64_t *mismatches, uint64_t *tested);
 /* After a scoring launch with option "score_stats" = 1: evaluations the fast kernel parked for the value-exact
  * code, and (hypothesis, match) evaluations it made in all (lanes of partially filled wavefronts included). */
 int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations);

@@ -174,6 +174,12 @@ class Context:
         self._chk(self._L.ps_debug_fastdiv(self._h, int(seed), int(blocks), int(per_thread), C.byref(bad), C.byref(n)))
         return bad.value, n.value
 
+    def debug_mathcheck(self, mode, elements, seed=1):
+        """(mismatches, tested): ps_debug_mathcheck -- the prologue's exact short sqrt / reciprocal / quotient forms vs the operators."""
+        bad, n = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.ps_debug_mathcheck(self._h, int(mode), int(seed), int(elements), C.byref(bad), C.byref(n)))
+        return bad.value, n.value
+
     # ---- A7 ----
     def umeyama_f32(self, src, dst):
         """src, dst: (nsets, k, 3) or (k, 3). Returns (T (nsets,4,4) row/col matrices, valid (nsets,))."""

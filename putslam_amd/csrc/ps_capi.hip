@@ -77,6 +77,7 @@ struct PsContext {
     // matrix-core matcher: 1 = the work-group expands its query tiles itself through LDS (default), 0 = round 2's form
     // with the FP4 image of the query frames written to HBM by a launch of its own (option "matcher_fused")
     int matcherFused = 1;
+    int matcherWaves = 4; // fused matrix-core matcher: wavefronts per work-group (option "matcher_waves": 4 or 8, round 4's A/B)
     // 1 = the decision-exact kernels (ps_score_fast.h / ps_score_euclid.h, default), 0 = the value-exact ps_ransac_score<MODE>
     // (the matrix-core scoring experiment of round 2 -- split-f16 transforms on v_mfma_f32_32x32x16_f16, correct, no gain on
     // the headline -- left the tree in round 4: profiles/variants/ps_score_mfma.h.txt)
@@ -634,7 +635,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             hipLaunchKernelGGL(ps_stage_reorder<MODE>, dim3((unsigned)P), dim3(kBlock), 0, ctx->stream,                \
                                (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,  \
                                (const float2 *)ctx->recF.p, (const int32_t *)ctx->mvalid.p, pl.ma, pl.sc, pl.sa,       \
-                               pl.prefix, ctx->reorderTop, pl.H, cap, pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p, \
+                               pl.prefix, ctx->reorderTop,                                                              \
+                               (ctx->bail != 0 && with_euclid_fast(ctx, pl.mode)) ? 64 : 0, ctx->reorderMargin, pl.H, cap,  \
+                               pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p,                       \
                                (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p,                            \
                                usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr);                            \
     } while (0)
@@ -794,18 +797,24 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
 #endif
         constexpr int TT = PS_MFMA_TT;
         const int tpf = (cap + kTileRows - 1) / kTileRows;
-        const int groups = (tpf + kWavesPerWG * TT - 1) / (kWavesPerWG * TT);
+        const int wavesWG = (ctx->matcherFused && ctx->matcherWaves == 8) ? 8 : kWavesPerWG;
+        const int groups = (tpf + wavesWG * TT - 1) / (wavesWG * TT);
         int qsplit = pick_split((long long)P * groups, tpf, 1, tpf);
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
         if (ctx->matcherFused) {
             // fused expansion: every work-group of a query split expands its own share of the query tiles, so a split only
             // pays when the groups do not fill the chip by themselves; the keys are then cleared by a memset
-            if (ctx->forceQsplit <= 0 && (long long)P * groups >= 1024) qsplit = 1;
+            if (ctx->forceQsplit <= 0 && (long long)P * groups * (wavesWG / kWavesPerWG) >= 1024) qsplit = 1;
             if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
             tick(ctx, 5, false);
-            hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
-                               ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
-                               (uint32_t *)ctx->keys.p);
+            if (wavesWG == 8)
+                hipLaunchKernelGGL((ps_hamming_mfma_fused<TT, 8>), dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(512), 0,
+                                   ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                                   (uint32_t *)ctx->keys.p);
+            else
+                hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
+                                   ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                                   (uint32_t *)ctx->keys.p);
             tick(ctx, 5, true);
             PS_HIP(hipGetLastError());
         } else {
@@ -899,6 +908,7 @@ struct OptDesc {
 const OptDesc kOptions[] = {
     {"matcher", "MATCHER", &PsContext::matcher, 0, 2, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)"},
     {"matcher_fused", "MATCHER_FUSED", &PsContext::matcherFused, 0, 1, "matcher_fused: 0 or 1"},
+    {"matcher_waves", "MATCHER_WAVES", &PsContext::matcherWaves, 4, 8, "matcher_waves: 4 or 8 wavefronts per work-group"},
     {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
     {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
     {"prune", "PRUNE", &PsContext::prune, 0, 1, "prune: 0 or 1"},
@@ -932,6 +942,7 @@ bool option_value_ok(const OptDesc &o, int v)
     if (v < o.lo || v > o.hi) return false;
     if (strcmp(o.name, "prefix") == 0) return (v & 63) == 0;
     if (strcmp(o.name, "reorder_gran") == 0) return (v & (v - 1)) == 0;
+    if (strcmp(o.name, "matcher_waves") == 0) return v == 4 || v == 8;
     return true;
 }
 int parse_option_text(const OptDesc &o, const char *v)
@@ -1333,6 +1344,31 @@ int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, u
     PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
     hipLaunchKernelGGL(ps_fastdiv_check, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, seed, perThread,
                        (unsigned long long *)ctx->sMisc2.p, (unsigned long long *)ctx->sMisc2.p + 1);
+    PS_HIP(hipGetLastError());
+    uint64_t h[2] = {0, 0};
+    PS_HIP(hipMemcpyAsync(h, ctx->sMisc2.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches = h[0];
+    *tested = h[1];
+    return PS_OK;
+}
+
+// Diagnostic: the exact short forms of the square root / reciprocal / shared-denominator quotients (ps_device_math.h)
+// against sqrtf and '/', bit for bit (modes: see ps_mathcheck).  `elements` = how many elements to test: modes 0 / 1 walk
+// consecutive float patterns from 1.0f (0x40001000 of them reach past +inf, 0x00800001 cover [1, 2]), modes 2 .. 4 draw
+// random operands.
+int ps_debug_mathcheck(PsContext *ctx, int mode, uint64_t seed, uint64_t elements, uint64_t *mismatches, uint64_t *tested)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!mismatches || !tested || mode < 0 || mode > 4 || elements < 1 || elements > ((uint64_t)1 << 34)) return PS_ERR_BAD_ARG;
+    PS_ENSURE(ctx->sMisc2, 16);
+    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
+    const int perThread = 1024;
+    const uint64_t threads = (elements + perThread - 1) / perThread;
+    const unsigned blocks = (unsigned)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(ps_mathcheck, dim3(blocks), dim3(kBlock), 0, ctx->stream, mode, seed, perThread,
+                       (unsigned long long)elements, (unsigned long long *)ctx->sMisc2.p, (unsigned long long *)ctx->sMisc2.p + 1);
     PS_HIP(hipGetLastError());
     uint64_t h[2] = {0, 0};
     PS_HIP(hipMemcpyAsync(h, ctx->sMisc2.p, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -35,6 +35,146 @@ PS_HD double ps_sqrt(double x) { return sqrt(x); }
 PS_HD float ps_abs(float x) { return fabsf(x); }
 PS_HD double ps_abs(double x) { return fabs(x); }
 
+
+// ---- exact float sqrt / reciprocal / quotients with the range fix-ups removed (device, float only) ----------------
+// hipcc expands a correctly rounded sqrtf(x) into 16 vector instructions: three that rescale a tiny argument
+// (x < 2^-96), v_sqrt_f32, the one-ulp correction (two FMAs on the neighbours, two compares, two selects), two that scale
+// the result back and a v_cmp_class + select that returns the argument for +-0 and +inf.  For an argument that is known to be
+// >= 1 (or +inf, or NaN) the rescaling is a no-op and the class select changes nothing (v_sqrt_f32(+inf) = +inf and the
+// correction's compares are false for it; NaN stays NaN), so the nine instructions below ARE the compiler's sequence and
+// return the same bits.  Every square root of the Jacobi SVD has the form sqrt(v * v + 1).  Likewise a correctly rounded
+// a / b is div_scale x 2, rcp, 3 + 3 FMA / MUL, div_fmas, div_fixup: with numerator and denominator inside the window
+// where neither div_scale rescales and div_fixup passes its first operand through (ps_kernels.h, div2_shared) the plain
+// FMA chain below is that sequence.  ps_debug_mathcheck compares each of these with the operator bit for bit
+// (tests/test_gpu_parity.py: every float >= 1 for the square root, every float of [1, 2] for the reciprocal, 10^9 random
+// operands for the quotients).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PS_FAST_EXACT 1 // (the PS_HD functions below take the short forms in the device pass only)
+#endif
+constexpr float kExactDivLo = 9.094947017729282e-13f; // 2^-40
+constexpr float kExactDivHi = 1.099511627776e12f;     // 2^+40
+PS_D bool wave_every(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+
+// sqrtf(x) for x >= 1, x = +inf or x = NaN
+PS_D float sqrt_ge1(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float hi = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
+    float r = (0.0f >= rl) ? lo : s;
+    r = (0.0f < rh) ? hi : r;
+    return r;
+}
+// the reciprocal chain shared by the quotients below: rcp + one Newton step (the compiler's first three instructions)
+PS_D float rcp_refined(float b)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+// a / b given r1 = rcp_refined(b), operands inside the window
+PS_D float div_with(float a, float b, float r1)
+{
+    const float m = a * r1;
+    const float f = __builtin_fmaf(-b, m, a);
+    const float g = __builtin_fmaf(f, r1, m);
+    const float h = __builtin_fmaf(-b, g, a);
+    return __builtin_fmaf(h, r1, g);
+}
+// 1 / b for 1 <= b <= 2^40 (no window check needed by the callers that know the range)
+PS_D float rcp_exact_in_window(float b)
+{
+    const float r1 = rcp_refined(b);
+    const float f = __builtin_fmaf(-b, r1, 1.0f);
+    const float g = __builtin_fmaf(f, r1, r1);
+    const float h = __builtin_fmaf(-b, g, 1.0f);
+    return __builtin_fmaf(h, r1, g);
+}
+// y / |y| for |y| >= FLT_MIN (the caller's guard), +-inf or NaN: +-1, NaN for the non-finite ones -- three instructions
+// instead of a division
+PS_D float unit_sign(float y) { return __builtin_copysignf(1.0f, y) + (y - y); }
+
+// 1 / d and u / d for d = sqrt(1 + u * u) >= 1 (JacobiSVD's real_2x2_jacobi_svd): one reciprocal for both inside the
+// window, the wavefront's ordinary divisions otherwise
+PS_HD void inv_and_quot(float u, float d, float &inv, float &quo)
+{
+#ifdef PS_FAST_EXACT
+    // d >= 1 and |u| < d by construction; a zero, tiny or NaN numerator and a huge denominator leave the window
+    if (wave_every(ps_abs(u) >= kExactDivLo && d <= kExactDivHi)) {
+        const float r1 = rcp_refined(d);
+        inv = div_with(1.0f, d, r1);
+        quo = div_with(u, d, r1);
+        return;
+    }
+#endif
+    inv = 1.0f / d;
+    quo = u / d;
+}
+PS_HD void inv_and_quot(double u, double d, double &inv, double &quo)
+{
+    inv = 1.0 / d;
+    quo = u / d;
+}
+// W = A / scale, entry by entry (JacobiSVD's m_workMatrix = matrix / scale): nine quotients with one denominator
+PS_HD void scale_down3(const float (&A)[3][3], float scale, float (&W)[3][3])
+{
+#ifdef PS_FAST_EXACT
+    float lo = fminf(fminf(ps_abs(A[0][0]), ps_abs(A[0][1])), ps_abs(A[0][2]));
+    lo = fminf(fminf(lo, ps_abs(A[1][0])), ps_abs(A[1][1]));
+    lo = fminf(fminf(lo, ps_abs(A[1][2])), ps_abs(A[2][0]));
+    lo = fminf(fminf(lo, ps_abs(A[2][1])), ps_abs(A[2][2]));
+    // (scale = the largest |entry|: with the smallest one and the scale itself inside the window every operand is; a NaN
+    // entry is skipped by fminf and yields NaN on either path; a NaN scale fails the comparison)
+    if (wave_every(lo >= kExactDivLo && scale <= kExactDivHi)) {
+        const float r1 = rcp_refined(scale);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) W[i][j] = div_with(A[i][j], scale, r1);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) W[i][j] = A[i][j] / scale;
+}
+PS_HD void scale_down3(const double (&A)[3][3], double scale, double (&W)[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) W[i][j] = A[i][j] / scale;
+}
+PS_HD float sqrt_1p(float v2) // sqrt(v2 + 1) for v2 = a square (>= 0, +inf or NaN)
+{
+#ifdef PS_FAST_EXACT
+    return sqrt_ge1(v2 + 1.0f);
+#else
+    return sqrtf(v2 + 1.0f);
+#endif
+}
+PS_HD double sqrt_1p(double v2) { return sqrt(v2 + 1.0); }
+PS_HD float rcp_1to2(float x) // 1 / x for x in [1, 2] (or NaN)
+{
+#ifdef PS_FAST_EXACT
+    return rcp_exact_in_window(x);
+#else
+    return 1.0f / x;
+#endif
+}
+PS_HD double rcp_1to2(double x) { return 1.0 / x; }
+PS_HD float unit_of(float y) // y / |y|
+{
+#ifdef PS_FAST_EXACT
+    return unit_sign(y);
+#else
+    return y / fabsf(y);
+#endif
+}
+PS_HD double unit_of(double y) { return y / fabs(y); }
+
 // Plane rotation of a scalar pair: x' = c*x + s*y, y' = -s*x + c*y.
 template <typename T> PS_HD void rot_pair(T &x, T &y, T c, T s)
 {
@@ -53,15 +193,16 @@ template <typename T> PS_HD void make_jacobi(T x, T y, T z, T &c, T &s)
         return;
     }
     T tau = (x - z) / deno;
-    T w = ps_sqrt(tau * tau + T(1));
+    T w = sqrt_1p(tau * tau); // (tau * tau + 1 rounds the product first, then the sum: the same two operations)
     T t;
     if (tau > T(0))
         t = T(1) / (tau + w);
     else
         t = T(1) / (tau - w);
     T sign_t = t > T(0) ? T(1) : T(-1);
-    T n = T(1) / ps_sqrt(t * t + T(1));
-    s = (((-sign_t) * (y / ps_abs(y))) * ps_abs(t)) * n;
+    // |t| <= 1 (|tau +- w| >= w >= 1), so t * t + 1 lies in [1, 2] and its root in [1, 1.4143]
+    T n = rcp_1to2(sqrt_1p(t * t));
+    s = (((-sign_t) * unit_of(y)) * ps_abs(t)) * n;
     c = n;
 }
 
@@ -83,13 +224,11 @@ template <typename T> PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T
             if (a > scale) scale = a;
         }
     if (scale == T(0)) scale = T(1);
+    scale_down3(A, scale, W);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            W[i][j] = A[i][j] / scale;
-            U[i][j] = V[i][j] = (i == j) ? T(1) : T(0);
-        }
+        for (int j = 0; j < 3; ++j) U[i][j] = V[i][j] = (i == j) ? T(1) : T(0);
     const T precision = T(2) * Lim<T>::eps();
     const T considerAsZero = Lim<T>::min_normal();
     T maxDiag = ps_abs(W[0][0]);
@@ -117,9 +256,8 @@ template <typename T> PS_HD void jacobi_svd3(const T (&A)[3][3], T (&U)[3][3], T
                     c1 = T(1);
                 } else {
                     T u = t / d;
-                    T tmp = ps_sqrt(T(1) + u * u);
-                    s1 = T(1) / tmp;
-                    c1 = u / tmp;
+                    T tmp = sqrt_1p(u * u); // (1 + u * u: the sum is commutative)
+                    inv_and_quot(u, tmp, s1, c1); // s1 = 1 / tmp, c1 = u / tmp
                 }
                 if (!(c1 == T(1) && s1 == T(0))) {
                     rot_pair(m00, m10, c1, s1);
@@ -291,6 +429,34 @@ PS_HD void inverse_rigid_general(const Rigid &M, Rigid &Inv)
     const float r20 = adj4<0, 2>(M), r21 = adj4<1, 2>(M), r22 = adj4<2, 2>(M), r23 = adj4<3, 2>(M);
     const float p0 = mat4_at<0, 0>(M) * r00, p1 = mat4_at<1, 0>(M) * r01, p2 = mat4_at<2, 0>(M) * r02, p3 = 0.0f * r03;
     const float det = (p0 + p1) + (p2 + p3);
+#ifdef PS_FAST_EXACT
+    {
+        // twelve quotients with one denominator: one reciprocal inside the window (a rigid model has det ~ 1 and rotation /
+        // translation cofactors far above 2^-40 unless an entry is exactly zero: then the ordinary divisions run)
+        float lo = fminf(fminf(ps_abs(r00), ps_abs(r01)), ps_abs(r02));
+        lo = fminf(fminf(lo, ps_abs(r03)), ps_abs(r10));
+        lo = fminf(fminf(lo, ps_abs(r11)), ps_abs(r12));
+        lo = fminf(fminf(lo, ps_abs(r13)), ps_abs(r20));
+        lo = fminf(fminf(lo, ps_abs(r21)), ps_abs(r22));
+        lo = fminf(fminf(lo, ps_abs(r23)), ps_abs(det));
+        float hi = fmaxf(fmaxf(ps_abs(r00), ps_abs(r01)), ps_abs(r02));
+        hi = fmaxf(fmaxf(hi, ps_abs(r03)), ps_abs(r10));
+        hi = fmaxf(fmaxf(hi, ps_abs(r11)), ps_abs(r12));
+        hi = fmaxf(fmaxf(hi, ps_abs(r13)), ps_abs(r20));
+        hi = fmaxf(fmaxf(hi, ps_abs(r21)), ps_abs(r22));
+        hi = fmaxf(fmaxf(hi, ps_abs(r23)), ps_abs(det));
+        if (wave_every(lo >= kExactDivLo && hi <= kExactDivHi)) {
+            const float q = rcp_refined(det);
+            Inv.R[0][0] = div_with(r00, det, q); Inv.R[0][1] = div_with(r01, det, q); Inv.R[0][2] = div_with(r02, det, q);
+            Inv.t[0] = div_with(r03, det, q);
+            Inv.R[1][0] = div_with(r10, det, q); Inv.R[1][1] = div_with(r11, det, q); Inv.R[1][2] = div_with(r12, det, q);
+            Inv.t[1] = div_with(r13, det, q);
+            Inv.R[2][0] = div_with(r20, det, q); Inv.R[2][1] = div_with(r21, det, q); Inv.R[2][2] = div_with(r22, det, q);
+            Inv.t[2] = div_with(r23, det, q);
+            return;
+        }
+    }
+#endif
     Inv.R[0][0] = r00 / det; Inv.R[0][1] = r01 / det; Inv.R[0][2] = r02 / det; Inv.t[0] = r03 / det;
     Inv.R[1][0] = r10 / det; Inv.R[1][1] = r11 / det; Inv.R[1][2] = r12 / det; Inv.t[1] = r13 / det;
     Inv.R[2][0] = r20 / det; Inv.R[2][1] = r21 / det; Inv.R[2][2] = r22 / det; Inv.t[2] = r23 / det;

@@ -1658,6 +1658,69 @@ __global__ __launch_bounds__(kBlock) void ps_fastdiv_check(uint64_t seed, int pe
     atomicAdd(tested, n);
 }
 
+// Diagnostic (ps_debug_mathcheck): the exact short forms of ps_device_math.h against the operators, bit for bit.
+//   mode 0  sqrt_ge1(x) vs sqrtf(x) for EVERY float pattern from 1.0f up to +inf and the NaN patterns just above it
+//           (element e of the sweep = pattern 0x3F800000 + e; 0x40001000 elements cover them)
+//   mode 1  rcp_exact_in_window(x) vs 1.0f / x for every float of [1, 2] (0x00800001 elements)
+//   mode 2  unit_sign(y) vs y / |y| for random y of every exponent (+-inf and NaN included; NaN == NaN here)
+//   mode 3  JacobiSVD's pair 1 / d, u / d with d = sqrt(1 + u * u): div_with on random u inside the window
+//   mode 4  nine numerators over one denominator (scale_down3 / inverse_rigid_general): div_with on random operands of
+//           the window [2^-40, 2^40]
+__global__ __launch_bounds__(kBlock) void ps_mathcheck(int mode, uint64_t seed, int perThread, unsigned long long total,
+                                                       unsigned long long *mismatch, unsigned long long *tested)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, n = 0;
+    auto bits = [](float f) { return __builtin_bit_cast(uint32_t, f); };
+    auto same = [&](float a, float b) { return bits(a) == bits(b) || (a != a && b != b); };
+    auto in_window = [](uint32_t r) { // random sign, exponent in [2^-40, 2^40), random mantissa
+        const uint32_t ex = 87u + ((r >> 23) & 0xFFu) % 80u;
+        return __builtin_bit_cast(float, (r & 0x80000000u) | (ex << 23) | (r & 0x007FFFFFu));
+    };
+    for (int i = 0; i < perThread; ++i) {
+        const uint64_t e = (uint64_t)i * nthreads + tid; // (consecutive threads take consecutive elements)
+        if (mode <= 1 && e >= total) break;
+        const uint64_t r0 = mix64(seed ^ mix64(e));
+        const uint64_t r1 = mix64(r0);
+        if (mode == 0) {
+            const float x = __builtin_bit_cast(float, (uint32_t)(0x3F800000ull + e));
+            bad += same(sqrt_ge1(x), sqrtf(x)) ? 0 : 1;
+            n += 1;
+        } else if (mode == 1) {
+            const float x = __builtin_bit_cast(float, (uint32_t)(0x3F800000ull + e));
+            bad += same(rcp_exact_in_window(x), 1.0f / x) ? 0 : 1;
+            n += 1;
+        } else if (mode == 2) {
+            float y = __builtin_bit_cast(float, (uint32_t)r0);
+            if (!(fabsf(y) >= 5.877471754111438e-39f) && y == y) y = 1.0f; // (the caller's guard: 2 |y| >= FLT_MIN)
+            bad += same(unit_sign(y), y / fabsf(y)) ? 0 : 1;
+            n += 1;
+        } else if (mode == 3) {
+            float u = in_window((uint32_t)r0);
+            if (i & 1) u = (float)((int)((r0 >> 40) & 0xFFFF) - 32768) * 1.0e-3f + 1.0e-6f; // the regime of the SVD: |u| ~ 0 .. 30
+            const float d = sqrt_ge1(u * u + 1.0f);
+            if (!(fabsf(u) >= kExactDivLo && d <= kExactDivHi)) continue;
+            const float q = rcp_refined(d);
+            bad += (same(div_with(1.0f, d, q), 1.0f / d) ? 0 : 1) + (same(div_with(u, d, q), u / d) ? 0 : 1);
+            n += 2;
+        } else {
+            const float b = in_window((uint32_t)r1);
+            const float q = rcp_refined(b);
+            uint64_t r = r0;
+#pragma unroll 1
+            for (int k = 0; k < 9; ++k) {
+                const float a = in_window((uint32_t)r);
+                bad += same(div_with(a, b, q), a / b) ? 0 : 1;
+                r = mix64(r);
+            }
+            n += 9;
+        }
+    }
+    atomicAdd(mismatch, bad);
+    atomicAdd(tested, n);
+}
+
 // Diagnostic: tabulates the device-side trip limits so tests can compare them with the direct
 // libm evaluation (RANSAC.cpp:457-461, USAC.h:944-971) for every (count, M).
 __global__ void ps_limits_table(SelectArgs a, int M, int32_t *__restrict__ out)

@@ -805,7 +805,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restrict__ recA, const float4 *__restrict__ recB,
                                                            const float4 *__restrict__ recC, const float2 *__restrict__ recF,
                                                            const int32_t *__restrict__ mvalid, ModelArgs ma, ScoreConsts k,
-                                                           SelectArgs sa, int prefix, int nTopMax, int H, int cap, int minRun,
+                                                           SelectArgs sa, int prefix, int nTopMax, int bailGran, int bailMargin,
+                                                           int H, int cap, int minRun,
                                                            const int32_t *__restrict__ counts, float2 *__restrict__ recF2,
                                                            int32_t *__restrict__ perm, int32_t *__restrict__ prefInfo,
                                                            float2 *__restrict__ frontRec)
@@ -832,10 +833,20 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
             prefInfo[4 * p] = b;
             prefInfo[4 * p + 1] = l;
             prefInfo[4 * p + 2] = 0; // (the all-reject front: known after the sort)
+            prefInfo[4 * p + 3] = 0; // (1: the vote was skipped, see below)
         }
         int n = 0;
         const bool idle = b > 0 && l <= prefix; // (without a record nothing can be cut: the stages sweep everything)
-        if (b > 0 && !idle) {
+        // Nothing to gain from an order (option "bail", Euclidean metrics): the prefix's best hypothesis misses so many
+        // matches that stage 1 sweeps the whole list whatever the order (stage_range puts its cut at M) -- hopeless data, no
+        // pair accepted.  The vote (nTop value-exact tests per match) is skipped and the record is handed on in its
+        // original order.  The reprojection metrics always vote: their pre-test front pays even when nothing can be abandoned.
+        bool bail = false;
+        if (bailGran > 0 && b > 0) {
+            const int c1 = (M - b + bailMargin + bailGran - 1) & ~(bailGran - 1);
+            bail = c1 >= M - M / 8; // (the rule of stage_range for the reordered sweep)
+        }
+        if (b > 0 && !idle && !bail) {
             // the nTopMax best counts of the prefix (first of equals first): (count, 0xFFFF - index) keys, lane i holds
             // hypotheses i, i + 64, ...
             int key[4];
@@ -855,7 +866,10 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                     if (key[j] == m) key[j] = 0;
             }
         }
-        if (lane == 0) s_top[0] = idle ? -1 : n; // (no record: no votes, one bucket, the original order)
+        if (lane == 0) {
+            s_top[0] = idle ? -1 : n; // (no record: no votes, one bucket, the original order)
+            if (bail) prefInfo[4 * p + 3] = 1;
+        }
     }
     __syncthreads();
     const int nTop = s_top[0];

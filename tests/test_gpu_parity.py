@@ -320,6 +320,22 @@ def test_shared_reciprocal_division_is_ieee(ctx):
     assert n > 1_500_000_000 and bad == 0, (bad, n)
 
 
+@pytest.mark.parametrize("mode,elements,least", [
+    (0, 0x40001000, 0x40001000),      # sqrt: EVERY float pattern from 1.0f to +inf and 4096 NaN patterns beyond
+    (1, 0x00800001, 0x00800001),      # reciprocal: every float of [1, 2]
+    (2, 1 << 30, 1 << 30),            # y / |y|
+    (3, 1 << 30, 1_500_000_000),      # 1 / d, u / d with d = sqrt(1 + u u)   (two quotients per element)
+    (4, 1 << 27, 1_000_000_000),      # nine numerators over one denominator
+])
+def test_prologue_short_forms_are_the_operators_bit_for_bit(ctx, mode, elements, least):
+    """The hypothesis prologue (float Umeyama + Jacobi SVD, RANSAC.cpp:207-244; general inverse, :337-338) takes its square
+    roots, reciprocals and shared-denominator quotients through the compiler's own instruction sequences with the range
+    fix-ups removed where the operand range is known (ps_device_math.h).  Exhaustive where the domain allows it, > 10^9
+    random operands elsewhere: 0 differences from sqrtf / '/'."""
+    bad, n = ctx.debug_mathcheck(mode, elements, seed=20261004 + mode)
+    assert n >= least and bad == 0, (mode, bad, n)
+
+
 # ---------------------------------------------------------------- N2 guided map matching (matchXYZ core)
 @pytest.mark.parametrize("nmap,ncur", [(1, 1), (300, 1000), (1500, 2000), (65, 63)])
 def test_match_xyz_parity(ctx, oracle, nmap, ncur):
