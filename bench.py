@@ -256,8 +256,12 @@ def main():
             step()
         fence()
         warm_steps += 20
-    for c in ctxs:
-        c.enable_timing(True)                                          # HIP events on the launch stream(s)
+    timed_events = os.environ.get("PUTSLAM_BENCH_TIMED_EVENTS", "0") == "1"
+    if timed_events:
+        # (round 4: off by default.  The HIP events around every kernel put a ~10 us bubble behind each of them on the
+        # stream -- 3 % of a single chain's step; per-launch durations of the contended region are an optional extra leg now)
+        for c in ctxs:
+            c.enable_timing(True)                                      # HIP events on the launch stream(s)
     # --repeats timed regions of exactly --steps steps, each bracketed by barrier + synchronize on both sides; the
     # region time is the max over ranks; the line reports the median region (and the spread)
     region_s = []

@@ -28,6 +28,7 @@ EXPORTED = [
 ]
 
 _lib = None
+_by_path = {}
 
 
 class HipLibraryMissing(RuntimeError):
@@ -58,6 +59,16 @@ def load():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _lib = load_path(LIB_PATH)
+    return _lib
+
+
+def load_path(path):
+    """Binds ONE build of the library (profiling hook: several builds side by side in one process for A/B timing on the
+    same box, clock state and data -- profiles/scripts/ab_libs.py; entry points a build lacks are left unbound)."""
+    path = os.path.abspath(path)
+    if path in _by_path:
+        return _by_path[path]
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Loading it first lets
     # the dynamic linker satisfy our DT_NEEDED libamdhip64.so.7 with the copy torch uses, so torch tensors,
     # torch streams and our kernels share one runtime (two runtimes in one process cannot both see the GPU).
@@ -67,7 +78,22 @@ def load():
             import torch  # noqa: F401
         except Exception:  # torch absent: stand-alone use
             pass
-    L = C.CDLL(LIB_PATH)
+    real = C.CDLL(path)
+
+    class _Tolerant:
+        """argtypes / restype assignments on symbols an older build does not export are dropped."""
+        class _Missing:
+            pass
+
+        def __getattr__(self, name):
+            try:
+                return getattr(real, name)
+            except AttributeError:
+                if path == os.path.abspath(LIB_PATH):
+                    raise
+                return _Tolerant._Missing()
+
+    L = _Tolerant()
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     L.ps_context_create.argtypes = [i32, C.POINTER(vp)]
     L.ps_context_destroy.argtypes = [vp]
@@ -117,8 +143,8 @@ def load():
     L.ps_context_enable_timing.argtypes = [vp, i32]
     for n in ("dmatch", "params", "config", "stats", "frameset", "results"):
         getattr(L, "ps_abi_sizeof_" + n).restype = sz
-    _lib = L
-    return L
+    _by_path[path] = real
+    return real
 
 
 def struct_sizes():

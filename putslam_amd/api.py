@@ -26,8 +26,8 @@ def _p(a):
 class Context:
     """One HIP stream + scratch arena (PsContext).  Not shared between threads."""
 
-    def __init__(self, device=0):
-        self._L = _lib.load()
+    def __init__(self, device=0, lib=None):
+        self._L = _lib.load() if lib is None else _lib.load_path(lib)   # (lib: another build, A/B timing only)
         h = C.c_void_p()
         rc = self._L.ps_context_create(int(device), C.byref(h))
         if rc != PS_OK:
