@@ -77,7 +77,6 @@ struct PsContext {
     // matrix-core matcher: 1 = the work-group expands its query tiles itself through LDS (default), 0 = round 2's form
     // with the FP4 image of the query frames written to HBM by a launch of its own (option "matcher_fused")
     int matcherFused = 1;
-    int matcherWaves = 4; // fused matrix-core matcher: wavefronts per work-group (option "matcher_waves": 4 or 8, round 4's A/B)
     // 1 = the decision-exact kernels (ps_score_fast.h / ps_score_euclid.h, default), 0 = the value-exact ps_ransac_score<MODE>
     // (the matrix-core scoring experiment of round 2 -- split-f16 transforms on v_mfma_f32_32x32x16_f16, correct, no gain on
     // the headline -- left the tree in round 4: profiles/variants/ps_score_mfma.h.txt)
@@ -111,6 +110,17 @@ struct PsContext {
     // what the LAST scoring step left in the staged-scoring buffers (ps_debug_stage_survivors / ps_debug_stage_order):
     // pairs and capacity the survivor counters / the order were laid out with, 0 = that step was not staged / not reordered
     int stagedP = 0, stagedCap = 0, reorderedP = 0;
+    // "Nothing to gain" policy of the staged scoring (option "bail", Euclidean metrics, batched calls): ps_stage_reorder counts
+    // the pairs it replayed and those whose prefix leaves nothing to abandon (stage 1 sweeps every match: hopeless data, no
+    // pair accepted); kernel 4 forwards the two counters to mapped host memory.  While the last observation says "most pairs",
+    // the next calls score completely -- one launch, what the staged form costs on such data is its extra launches, 14 - 19 %
+    // (profiles/r03p/data_sweep.txt) -- and every 16th call probes with the staged form again.  Results are bit-identical
+    // either way; the observation arrives asynchronously, so the switch lags the data by a call or two.
+    Buf bailCnt;                  // device: {pairs replayed, pairs with nothing to gain}, monotonic
+    unsigned *bailHost = nullptr; // mapped host mirror [2]
+    unsigned *bailHostDev = nullptr;
+    unsigned bailSeen[2] = {0, 0};
+    int hopeless = 0, hopelessCalls = 0;
 };
 
 namespace {
@@ -349,6 +359,7 @@ struct Plan {
     bool genSplit = false; // staged scoring: stage 0 as two launches (models, then the sweep)
     bool reorder = false; // staged scoring: stages 1+ sweep the reordered hot record (ps_stage_reorder)
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
+    bool bailWatch = false; // this staged call feeds the "nothing to gain" policy (PsContext::bailHost)
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
 };
 
@@ -506,7 +517,7 @@ unsigned big_limit(int mode) { return mode == PS_REPROJECTION_ERROR ? 1536u : 12
 
 // complete = true: every hypothesis is scored completely whatever the batch size (ps_debug_ransac_counts returns the counts
 // themselves: the staged scoring leaves lower bounds for abandoned hypotheses)
-int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false)
+int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false, bool adaptive = false)
 {
     const int H = pl.H;
     PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
@@ -524,6 +535,35 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     // (adaptive schedules: the trip limit the prefix leaves cuts most of the work whatever the batch size)
     const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
     pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
+    pl.bailWatch = false;
+    const bool willReorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
+    if (adaptive && pl.prune && willReorder && ctx->bail != 0 && with_euclid_fast(ctx, pl.mode)) {
+        if (!ctx->bailHost) {
+            if (hipHostMalloc((void **)&ctx->bailHost, 2 * sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer((void **)&ctx->bailHostDev, ctx->bailHost, 0) == hipSuccess) {
+                ctx->bailHost[0] = ctx->bailHost[1] = 0;
+                if (ensure(ctx, ctx->bailCnt, 2 * sizeof(unsigned)) == PS_OK)
+                    (void)hipMemsetAsync(ctx->bailCnt.p, 0, 2 * sizeof(unsigned), ctx->stream);
+            } else {
+                (void)hipGetLastError();
+                ctx->bailHostDev = nullptr; // (no mapped memory here: the policy stays off)
+            }
+        }
+        if (ctx->bailHostDev && ctx->bailCnt.p) {
+            const unsigned s0 = ((volatile unsigned *)ctx->bailHost)[0], s1 = ((volatile unsigned *)ctx->bailHost)[1];
+            if (s0 != ctx->bailSeen[0]) { // a new observation has landed
+                const unsigned d0 = s0 - ctx->bailSeen[0], d1 = s1 - ctx->bailSeen[1];
+                const int was = ctx->hopeless;
+                ctx->hopeless = (2ull * d1 > d0) ? 1 : 0;
+                if (ctx->hopeless != was) ctx->hopelessCalls = 0;
+                ctx->bailSeen[0] = s0;
+                ctx->bailSeen[1] = s1;
+            }
+            if (ctx->hopeless && (++ctx->hopelessCalls & 15) != 0)
+                pl.prune = false; // complete scoring while nothing can be abandoned; every 16th call looks again
+            pl.bailWatch = pl.prune;
+        }
+    }
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
     if (pl.genSplit) pl.msplit = pl.msplit * 2 < 32 ? pl.msplit * 2 : 32; // (the parts no longer repeat the prologue)
@@ -639,7 +679,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                                (ctx->bail != 0 && with_euclid_fast(ctx, pl.mode)) ? 64 : 0, ctx->reorderMargin, pl.H, cap,  \
                                pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p,                       \
                                (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p,                            \
-                               usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr);                            \
+                               usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr,                             \
+                               pl.bailWatch ? (unsigned *)ctx->bailCnt.p : (unsigned *)nullptr);                       \
     } while (0)
     // stage 0 as two launches: models + validity, then the sweep reading them back
     auto stage0_args = [&](bool gen) {
@@ -756,7 +797,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                        (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p,
                        (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
                        dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
-                       dMask, dStats, ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr);
+                       dMask, dStats, ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr,
+                       (pl.bailWatch && pl.reorder) ? (const unsigned *)ctx->bailCnt.p : (const unsigned *)nullptr,
+                       (pl.bailWatch && pl.reorder) ? ctx->bailHostDev : (unsigned *)nullptr);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -797,24 +840,18 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
 #endif
         constexpr int TT = PS_MFMA_TT;
         const int tpf = (cap + kTileRows - 1) / kTileRows;
-        const int wavesWG = (ctx->matcherFused && ctx->matcherWaves == 8) ? 8 : kWavesPerWG;
-        const int groups = (tpf + wavesWG * TT - 1) / (wavesWG * TT);
+        const int groups = (tpf + kWavesPerWG * TT - 1) / (kWavesPerWG * TT);
         int qsplit = pick_split((long long)P * groups, tpf, 1, tpf);
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
         if (ctx->matcherFused) {
             // fused expansion: every work-group of a query split expands its own share of the query tiles, so a split only
             // pays when the groups do not fill the chip by themselves; the keys are then cleared by a memset
-            if (ctx->forceQsplit <= 0 && (long long)P * groups * (wavesWG / kWavesPerWG) >= 1024) qsplit = 1;
+            if (ctx->forceQsplit <= 0 && (long long)P * groups >= 1024) qsplit = 1;
             if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
             tick(ctx, 5, false);
-            if (wavesWG == 8)
-                hipLaunchKernelGGL((ps_hamming_mfma_fused<TT, 8>), dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(512), 0,
-                                   ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
-                                   (uint32_t *)ctx->keys.p);
-            else
-                hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
-                                   ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
-                                   (uint32_t *)ctx->keys.p);
+            hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
+                               ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                               (uint32_t *)ctx->keys.p);
             tick(ctx, 5, true);
             PS_HIP(hipGetLastError());
         } else {
@@ -908,7 +945,6 @@ struct OptDesc {
 const OptDesc kOptions[] = {
     {"matcher", "MATCHER", &PsContext::matcher, 0, 2, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)"},
     {"matcher_fused", "MATCHER_FUSED", &PsContext::matcherFused, 0, 1, "matcher_fused: 0 or 1"},
-    {"matcher_waves", "MATCHER_WAVES", &PsContext::matcherWaves, 4, 8, "matcher_waves: 4 or 8 wavefronts per work-group"},
     {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
     {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
     {"prune", "PRUNE", &PsContext::prune, 0, 1, "prune: 0 or 1"},
@@ -942,7 +978,6 @@ bool option_value_ok(const OptDesc &o, int v)
     if (v < o.lo || v > o.hi) return false;
     if (strcmp(o.name, "prefix") == 0) return (v & 63) == 0;
     if (strcmp(o.name, "reorder_gran") == 0) return (v & (v - 1)) == 0;
-    if (strcmp(o.name, "matcher_waves") == 0) return v == 4 || v == 8;
     return true;
 }
 int parse_option_text(const OptDesc &o, const char *v)
@@ -1018,13 +1053,14 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
     for (Buf *b : all) release(*b);
     for (hipEvent_t e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->bailHost) (void)hipHostFree(ctx->bailHost);
     if (ctx->handoff) (void)hipEventDestroy(ctx->handoff);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
@@ -1073,6 +1109,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
     if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
     if (strcmp(name, "last_staged_pairs") == 0) return ctx->stagedP;       // pairs of the last scoring step if it was staged, else 0
+    if (strcmp(name, "hopeless") == 0) return ctx->hopeless;               // the "nothing to gain" policy's current state
     if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
     const OptDesc *o = find_option(name);
     return o ? ctx->*(o->field) : (int)PS_ERR_BAD_ARG;
@@ -1701,7 +1738,7 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
         ctx->slotMask[ctx->curCall] = 0;
         ctx->timedCalls++;
     }
-    rc = prepare_score(ctx, pl, P, cap);
+    rc = prepare_score(ctx, pl, P, cap, false, true);
     if (rc) return rc;
     // This call returns with its work still queued.  Whatever happens after the first launch -- success or an error half
     // way (an allocation failure for a later block, a launch failure) -- the end of what WAS queued is marked for a

@@ -894,9 +894,16 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
                                                           int32_t *__restrict__ idxList, float *__restrict__ poseOut,
                                                           uint8_t *__restrict__ maskOut,
                                                           PsRansacStats *__restrict__ statsOut,
-                                                          unsigned long long *__restrict__ stamps)
+                                                          unsigned long long *__restrict__ stamps,
+                                                          const unsigned *__restrict__ bailDev, unsigned *__restrict__ bailHost)
 {
     phase_stamp(stamps, 4);
+    // the staged scoring's "nothing to gain" counters (ps_stage_reorder) on their way to the host's policy: two plain stores
+    // into mapped host memory by one thread of the launch that follows every stage (nobody waits for them)
+    if (bailHost != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        bailHost[0] = bailDev[0];
+        bailHost[1] = bailDev[1];
+    }
     extern __shared__ __align__(16) uint32_t s_bits[]; // two bitmaps over train indices: 2 * ceil(trainRange/32) words
     __shared__ int s_wsum[BLOCK / 64];
     __shared__ unsigned long long s_red[BLOCK / 64];

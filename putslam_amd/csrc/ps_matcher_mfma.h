@@ -260,17 +260,18 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
 // vector instructions shortens it.
 constexpr int kFuseChunk = 4; // query tiles per chunk: 2 x 4 x 4 KiB = 32 KiB of LDS per work-group
 
-// W = wavefronts per work-group (4: the default; 8: round 4's A/B -- twice the train rows per work-group, hence half as many
-// work-groups expanding every query tile, option "matcher_waves").
-template <int TT, int W = kWavesPerWG>
-__global__ __launch_bounds__(64 * W, PS_MFMA_WAVES) void ps_hamming_mfma_fused(const uint32_t *__restrict__ desc,
+// (Round 4 tried eight wavefronts per work-group -- twice the train rows per work-group, half as many work-groups expanding
+// every query tile, 145 instead of 165 VGPRs: 0.213 against 0.190 ms per 499 pairs, profiles/r04b/ab_short_forms_and_options.txt
+// row "w8"; the patch is profiles/variants/matcher_8_waves.patch.txt.)
+template <int TT>
+__global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(const uint32_t *__restrict__ desc,
                                                                 const int32_t *__restrict__ nkpts,
                                                                 const int32_t *__restrict__ pairs, int cap, int tpf,
                                                                 int groups, int qsplit, uint32_t *__restrict__ keys)
 {
     __shared__ uint4 s_a[2][kFuseChunk][kTileU4];
     __shared__ uint32_t s_lut[256]; // byte -> its 8 FP4 nibbles
-    if (W == kWavesPerWG || threadIdx.x < 256) s_lut[threadIdx.x & 255] = fp4_from_byte(threadIdx.x & 255);
+    s_lut[threadIdx.x] = fp4_from_byte(threadIdx.x);
     const unsigned perPair = (unsigned)(groups * qsplit);
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int p = (int)(L / perPair);
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(64 * W, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     const int g = inner / qsplit, qs = inner - g * qsplit;
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1]; // query = previous frame, train = current
     const int nq = nkpts[fq], nt = nkpts[ft];
-    if (g * (W * TT * kTileRows) >= nt) return; // whole work-group beyond the train rows
+    if (g * (kWavesPerWG * TT * kTileRows) >= nt) return; // whole work-group beyond the train rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int tile0 = (g * W + wave) * TT;
+    const int tile0 = (g * kWavesPerWG + wave) * TT;
     const int nqTiles = (nq + kTileRows - 1) / kTileRows;
     const int T0 = (int)(((long long)nqTiles * qs) / qsplit), T1 = (int)(((long long)nqTiles * (qs + 1)) / qsplit);
 
@@ -304,10 +305,7 @@ __global__ __launch_bounds__(64 * W, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
 
     // expansion role of this thread: piece o = s * 64 + h * 32 + r of a tile = dword 2 s + h of row r
     const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
-    // (with W > 4 the work-group's threads beyond 255 take the same pieces of the NEXT tile of the chunk)
-    const int ep = tid & 255, esub = tid >> 8;
-    const int es = ep >> 6, eh = (ep >> 5) & 1, er = ep & 31;
-    constexpr int kExp = W / kWavesPerWG; // tiles expanded per pass of the work-group
+    const int es = tid >> 6, eh = (tid >> 5) & 1, er = tid & 31;
     // The last query tile of a frame may be partial (rows beyond nq must never win: their accumulators start from -1e30).
     // It is taken out of the main loop: left inside, the compiler turns the rare masking into 16 compares + 16 selects for
     // EVERY tile (50 of the 126 vector instructions per tile this kernel had, profiles/r03h).
@@ -324,12 +322,12 @@ __global__ __launch_bounds__(64 * W, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
             e.z = (int)s_lut[(w >> 16) & 0xFFu];
             e.w = (int)s_lut[w >> 24];
         }
-        dst[ep] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+        dst[tid] = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
     };
     auto expand_chunk = [&](int buf, int Tc) {
 #pragma unroll
-        for (int j = 0; j < kFuseChunk; j += kExp)
-            if (Tc + j + esub < Tm) expand_tile(s_a[buf][j + esub], Tc + j + esub);
+        for (int j = 0; j < kFuseChunk; ++j)
+            if (Tc + j < Tm) expand_tile(s_a[buf][j], Tc + j);
     };
     // one query tile against this wave's TT train tiles
     auto tile_body = [&](int T, const uint4 *__restrict__ tile, const v16f_t &Cin) {
@@ -366,7 +364,7 @@ __global__ __launch_bounds__(64 * W, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
         __syncthreads(); // chunk c + 1 is complete, chunk c may be overwritten
     }
     if (hasPartial) { // (work-group uniform)
-        if (esub == 0) expand_tile(s_a[0][0], lastT);
+        expand_tile(s_a[0][0], lastT);
         __syncthreads();
         v16f_t Cin = C;
 #pragma unroll

@@ -809,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
                                                            int H, int cap, int minRun,
                                                            const int32_t *__restrict__ counts, float2 *__restrict__ recF2,
                                                            int32_t *__restrict__ perm, int32_t *__restrict__ prefInfo,
-                                                           float2 *__restrict__ frontRec)
+                                                           float2 *__restrict__ frontRec, unsigned *__restrict__ bailCount)
 {
     constexpr bool EUCLID_REC = MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR; // hot record = RecPtrs::G
     constexpr int RF = MODE == PS_ADAPTIVE_ERROR ? 16 : 12;
@@ -869,6 +869,10 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
         if (lane == 0) {
             s_top[0] = idle ? -1 : n; // (no record: no votes, one bucket, the original order)
             if (bail) prefInfo[4 * p + 3] = 1;
+            if (bailCount != nullptr) { // what the host's "nothing to gain" policy looks at (ps_capi.hip, prepare_score)
+                atomicAdd(&bailCount[0], 1u);
+                if (bail || b <= 0) atomicAdd(&bailCount[1], 1u);
+            }
         }
     }
     __syncthreads();

@@ -303,3 +303,49 @@ def test_stage_diagnostics_reject_another_batch_shape():
     with pytest.raises(api.PsError):
         c.stage_order(P - 1, fs.max_kpts)
     c.close()
+
+
+def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
+    """Option "bail" (Euclidean metrics, batched calls): on data whose prefix leaves nothing to abandon the context scores the
+    next calls completely and looks again with the staged form every 16th call; on good data it stays staged.  Every call's
+    outputs are identical (selection rule RANSAC.cpp:438-455 untouched: the policy only chooses between two bit-identical forms)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    bad = synth.make_sequence(41, 500, config=9, index=15, inlier_frac=0.12, noise=0.02)
+    good = synth.make_sequence(41, 500, config=9, index=70, inlier_frac=0.7, noise=0.004)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=11)
+    c = api.Context(0)
+
+    def call(seq):
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()       # (synchronises: the observation of this call has landed before the next one is planned)
+        return g, c.get_option("last_staged_pairs") > 0
+
+    ref_bad = _run(bad, prm, cfg, 0)
+    ref_good = _run(good, prm, cfg, 0)
+    staged = []
+    for i in range(40):
+        g, was_staged = call(bad)
+        _same(g, ref_bad, len(bad["pairs"]))
+        staged.append(was_staged)
+    assert staged[0] and c.get_option("hopeless") == 1
+    assert sum(staged) <= 5 and any(staged[2:])          # complete scoring except the first call(s) and the periodic probes
+    staged = []
+    for i in range(40):
+        g, was_staged = call(good)
+        _same(g, ref_good, len(good["pairs"]))
+        staged.append(was_staged)
+    assert c.get_option("hopeless") == 0 and all(staged[-16:])   # a probe saw the good data: staged again, and stays so
+    c.set_option("bail", 0)
+    c2 = api.Context(0)
+    c2.set_option("bail", 0)
+    c.close()
+    c, staged = c2, []
+    for i in range(6):
+        g, was_staged = call(bad)
+        _same(g, ref_bad, len(bad["pairs"]))
+        staged.append(was_staged)
+    assert all(staged)                                    # policy off: always the staged form
+    c.close()
