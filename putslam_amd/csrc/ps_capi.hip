@@ -1773,6 +1773,7 @@ struct PsVoStream {
     int cap = 0;
     long long frames = 0;   // frames pushed so far
     int curSlot = 0;        // slot of the most recent frame
+    int32_t nkSlot[2] = {0, 0}; // row count of the frame resident in each slot
     Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot, seedLo, seedHi}
     // One contiguous result block on the device and its pinned host mirror, so a push needs ONE
     // device-to-host copy and ONE synchronisation: [PsRansacStats][pose 16 f32][numMatches i32 + pad]
@@ -1882,18 +1883,22 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     // synchronisation that ends the previous push)
     uint8_t *hd = s->hin;
     float *hp = reinterpret_cast<float *>(s->hin + cap * 32);
-    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44); // {n, prevSlot, slot, pad, seedLo, seedHi}
+    // meta block exactly as it lies on the device: {nk[slot 0], nk[slot 1], prevSlot, slot, seedLo, seedHi} -- ONE copy per push
+    // (round 3 sent the row count, the slot pair and the seed as three copies: each is a node of the captured graph with a few
+    // microseconds of its own)
+    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44);
     for (int i = 0; i < n; ++i) memcpy(hd + (size_t)i * 32, desc + (size_t)i * descStep, 32);
     if (n > 0) memcpy(hp, pts, (size_t)n * 12);
-    hm[0] = n;
-    hm[1] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
-    hm[2] = slot;
-    hm[3] = 0;
+    hm[slot] = n;
+    hm[1 - slot] = s->nkSlot[1 - slot];
+    hm[2] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
+    hm[3] = slot;
     memcpy(&hm[4], &cfg->seed, sizeof(uint64_t));
     // The stream's state (curSlot, frames) is committed only when the push has succeeded: after a failed push
     // (bad parameters, a HIP error) the resident frame is still the previous one and the next push matches against it.
     auto commit = [&]() {
         s->curSlot = slot;
+        s->nkSlot[slot] = n;
         s->frames++;
     };
     auto copy_in = [&](size_t rows) -> int {
@@ -1903,9 +1908,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
             PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, hp, rows * 12, hipMemcpyHostToDevice,
                                   ctx->stream));
         }
-        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + slot, &hm[0], sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 2, &hm[1], 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        PS_HIP(hipMemcpyAsync((int32_t *)s->meta.p + 4, &hm[4], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        PS_HIP(hipMemcpyAsync(s->meta.p, hm, 6 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         return PS_OK;
     };
     if (first) { // detectInitFeatures (matcher.cpp:17-64): nothing to match against yet

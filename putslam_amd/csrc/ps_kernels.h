@@ -1062,6 +1062,16 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         }
     };
 
+    // a final inlier: its flag in the caller's mask and -- pointInlierRatio's numerator (RANSAC.h:56-66) -- its train index
+    // in the second bitmap, where it is found (round 3 walked all input matches once more for this and read the mask back)
+    auto note_inlier = [&](const int4 &d) { // d = (index in the match list, queryIdx, trainIdx, 0)
+        mask[d.x] = 1;
+        if (d.z >= 0 && d.z < a.trainRange) {
+            const uint32_t bit = 1u << (d.z & 31);
+            const uint32_t old = atomicOr(&s_bits[words + (d.z >> 5)], bit);
+            ui += (old & bit) ? 0 : 1;
+        }
+    };
     if (run && a.estimator != PS_EST_USAC) {
         // ---- (3) refit on the best inliers (wave 0), re-selection with the Euclid/adaptive rule ----
         if (wv != 0) all_matches_pass(tid - 64, BLOCK - 64);
@@ -1097,32 +1107,20 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             }
             int total;
             block_scan_flag<BLOCK>(in, total, s_wsum);
-            if (in && accepted) mask[recD[rbase + i].x] = 1;
+            if (in && accepted) note_inlier(recD[rbase + i]);
             nfinal += total;
         }
         if (!accepted) nfinal = 0; // identity + inliers cleared (RANSAC.cpp:161-164)
     } else if (run) {
         // USAC: no refit (USAC_wrapper.cpp:204-222 commented out); the loop's inliers are returned even
         // when the ratio gate replaces the pose by identity (USAC_wrapper.cpp:139-141).
-        for (int j = tid; j < kin; j += BLOCK) mask[recD[rbase + list[j]].x] = 1;
+        for (int j = tid; j < kin; j += BLOCK) note_inlier(recD[rbase + list[j]]);
         nfinal = kin;
         all_matches_pass(tid, BLOCK);
     } else
         all_matches_pass(tid, BLOCK);
-    __syncthreads();
 
-    phase_stamp(stamps, 8); // (3b) Euclidean re-selection, mask
-    // ---- (4) pointInlierRatio: unique trainIdx among the final inliers ----
-    for (int i = tid; i < nIn; i += BLOCK) {
-        if (mask[i]) {
-            const int t = mm[i].trainIdx;
-            if (t >= 0 && t < a.trainRange) {
-                const uint32_t bit = 1u << (t & 31);
-                const uint32_t old = atomicOr(&s_bits[words + (t >> 5)], bit);
-                ui += (old & bit) ? 0 : 1;
-            }
-        }
-    }
+    phase_stamp(stamps, 8); // (3b) Euclidean re-selection, mask, (4) unique trainIdx among the final inliers
     atomicAdd(&s_uniq[0], ua);
     atomicAdd(&s_uniq[1], ui);
     __syncthreads();
