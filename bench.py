@@ -277,6 +277,14 @@ def main():
             el = float(tt.item())
         region_s.append(el)
     elapsed = float(np.median(region_s))
+    if not timed_events:
+        # per-launch durations under the contended submission (and the only per-kernel figures of a multi-rank run): a few
+        # extra steps with HIP events on, outside the timed regions
+        for c in ctxs:
+            c.enable_timing(True)
+        for _ in range(max(2, min(5, args.steps))):
+            step()
+        fence()
     totals = {}
     for c in ctxs:
         for kname, (ms_sum, n) in c.kernel_time_totals().items():
