@@ -251,11 +251,17 @@ def main():
     # than the rest whatever --warmup said); whole steps, fenced, outside the timed regions
     warm_steps = args.warmup
     tw0 = time.perf_counter()
-    while time.perf_counter() - tw0 < args.warm_seconds:
+    warmed = 0.0
+    while warmed < args.warm_seconds:
         for _ in range(20):
             step()
         fence()
         warm_steps += 20
+        warmed = time.perf_counter() - tw0
+        if dist_on:   # every rank must leave this loop after the same number of steps (collectives inside): agree on the clock
+            tt = torch.tensor([warmed], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            warmed = float(tt.item())
     timed_events = os.environ.get("PUTSLAM_BENCH_TIMED_EVENTS", "0") == "1"
     if timed_events:
         # (round 4: off by default.  The HIP events around every kernel put a ~10 us bubble behind each of them on the
