@@ -116,26 +116,6 @@ struct PsContext {
     // the next calls score completely -- one launch, what the staged form costs on such data is its extra launches, 14 - 19 %
     // (profiles/r03p/data_sweep.txt) -- and every 16th call probes with the staged form again.  Results are bit-identical
     // either way; the observation arrives asynchronously, so the switch lags the data by a call or two.
-    // ps_vo_pairs_device: the launch chain of a call that repeats the previous one exactly (same buffers, sizes, parameters,
-    // seed, options; the reference's call shape is one such call per frame, PUTSLAM.cpp:578-589,733) is replayed as ONE
-    // captured hipGraph -- a chain of 6 - 9 dependent launches costs 20 - 35 us of gaps otherwise (option "graph")
-    int graphOn = 1;
-    struct PairsKey {
-        PsRansacParams prm;
-        int estimator, numHypotheses;
-        unsigned long long seed;
-        float K[9];
-        PsFrameSet frames;
-        const void *pairs;
-        int P;
-        PsPairResults out;
-        int options[32];
-        int prune, bailWatch;
-        unsigned long long arenaGen;
-    } pgKey{};
-    bool pgWarm = false;
-    hipGraphExec_t pgExec = nullptr;
-    long long pgLaunches = 0;
     Buf bailCnt;                  // device: {pairs replayed, pairs with nothing to gain}, monotonic
     unsigned *bailHost = nullptr; // mapped host mirror [2]
     unsigned *bailHostDev = nullptr;
@@ -984,7 +964,6 @@ const OptDesc kOptions[] = {
     {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches"},
     {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64"},
     {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64"},
-    {"graph", "GRAPH", &PsContext::graphOn, 0, 1, "graph: 0 or 1 (replay of an exactly repeated ps_vo_pairs_device call as one hipGraph)"},
     {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
 };
 const OptDesc *find_option(const char *name)
@@ -1081,7 +1060,6 @@ void ps_context_destroy(PsContext *ctx)
     for (Buf *b : all) release(*b);
     for (hipEvent_t e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->pgExec) (void)hipGraphExecDestroy(ctx->pgExec);
     if (ctx->bailHost) (void)hipHostFree(ctx->bailHost);
     if (ctx->handoff) (void)hipEventDestroy(ctx->handoff);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
@@ -1132,7 +1110,6 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
     if (strcmp(name, "last_staged_pairs") == 0) return ctx->stagedP;       // pairs of the last scoring step if it was staged, else 0
     if (strcmp(name, "hopeless") == 0) return ctx->hopeless;               // the "nothing to gain" policy's current state
-    if (strcmp(name, "graph_launches") == 0) return (int)(ctx->pgLaunches & 0x7FFFFFFF); // calls replayed as a captured graph
     if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
     const OptDesc *o = find_option(name);
     return o ? ctx->*(o->field) : (int)PS_ERR_BAD_ARG;
@@ -1781,88 +1758,11 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
                 (void)hipStreamSynchronize(c->stream);
         }
     } handoffGuard{ctx};
-    auto enqueue = [&]() -> int {
-        int r = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
-        if (r) return r;
-        return run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);
-    };
-    // ---- replay of an exactly repeated call ----
-    PsContext::PairsKey key;
-    memset(&key, 0, sizeof key);
-    const bool graphable = ctx->graphOn != 0 && !ctx->timing && !ctx->scoreStats && !ctx->stampsOn;
-    if (graphable) {
-        // field by field: the caller's structs may carry indeterminate padding bytes, the key is compared with memcmp
-        key.prm.verbose = params->verbose;
-        key.prm.errorVersion = params->errorVersion;
-        key.prm.errorVersionVO = params->errorVersionVO;
-        key.prm.errorVersionMap = params->errorVersionMap;
-        key.prm.inlierThresholdEuclidean = params->inlierThresholdEuclidean;
-        key.prm.inlierThresholdReprojection = params->inlierThresholdReprojection;
-        key.prm.inlierThresholdMahalanobis = params->inlierThresholdMahalanobis;
-        key.prm.minimalInlierRatioThreshold = params->minimalInlierRatioThreshold;
-        key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
-        key.prm.usedPairs = params->usedPairs;
-        key.prm.iterationCount = params->iterationCount;
-        key.estimator = cfg->estimator;
-        key.numHypotheses = cfg->numHypotheses;
-        key.seed = cfg->seed;
-        if (K) memcpy(key.K, K, sizeof key.K);
-        key.frames.desc = frames->desc;
-        key.frames.pts = frames->pts;
-        key.frames.nkpts = frames->nkpts;
-        key.frames.numFrames = frames->numFrames;
-        key.frames.maxKpts = frames->maxKpts;
-        key.pairs = pairs;
-        key.P = P;
-        key.out.matches = out->matches;
-        key.out.numMatches = out->numMatches;
-        key.out.inlierMask = out->inlierMask;
-        key.out.pose = out->pose;
-        key.out.stats = out->stats;
-        int n = 0;
-        for (const OptDesc &o : kOptions) key.options[n++] = ctx->*(o.field);
-        key.prune = pl.prune ? 1 : 0;       // (the "nothing to gain" policy may have switched the form of this call)
-        key.bailWatch = pl.bailWatch ? 1 : 0;
-        key.arenaGen = ctx->arenaGen;
-        const bool same = ctx->pgWarm && memcmp(&key, &ctx->pgKey, sizeof key) == 0;
-        if (!same && ctx->pgExec) {
-            (void)hipGraphExecDestroy(ctx->pgExec);
-            ctx->pgExec = nullptr;
-        }
-        if (same) {
-            if (!ctx->pgExec) { // the second identical call: capture (the first sized every block, nothing is allocated now)
-                hipGraph_t graph = nullptr;
-                if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    const int r = enqueue();
-                    const hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
-                    if (r != PS_OK || e2 != hipSuccess || !graph ||
-                        hipGraphInstantiate(&ctx->pgExec, graph, nullptr, nullptr, 0) != hipSuccess)
-                        ctx->pgExec = nullptr;
-                    if (graph) (void)hipGraphDestroy(graph);
-                }
-                if (!ctx->pgExec) { // capture is not available here (or a launch failed under it): ordinary launches from now on
-                    ctx->graphOn = 0;
-                    (void)hipGetLastError();
-                    ctx->err.clear();
-                }
-            }
-            if (ctx->pgExec) {
-                PS_HIP(hipGraphLaunch(ctx->pgExec, ctx->stream));
-                ctx->pgLaunches++;
-                return PS_OK;
-            }
-        }
-    }
-    rc = enqueue();
-    if (rc == PS_OK && graphable) {
-        key.arenaGen = ctx->arenaGen; // the blocks as this ordinary call left them
-        memcpy(&ctx->pgKey, &key, sizeof key);
-        ctx->pgWarm = true;
-    } else
-        ctx->pgWarm = false;
+    rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
+    if (rc) return rc;
+    rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);
     return rc;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Streaming form of Matcher::match (reference src/Matcher/matcher.cpp:452-516): the previous frame's

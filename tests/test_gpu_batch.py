@@ -423,45 +423,3 @@ def test_stream_graph_key_separates_kernel_variants(oracle):
             assert r["pose"].tobytes() == want["pose"].tobytes(), f
     st.close()
     c.close()
-
-
-def test_repeated_call_is_replayed_as_a_graph_and_follows_the_data(oracle):
-    """ps_vo_pairs_device replays an exactly repeated call (same buffers, sizes, parameters, seed, options) as one captured
-    hipGraph from the third call on.  The replay reads the buffers' CURRENT contents, so new frames written into the same
-    buffers are processed like any other call; anything in the key that changes (the seed here) goes back to ordinary
-    launches.  The reference's call shape is exactly such a repeated call, one per frame (PUTSLAM.cpp:578-589,733)."""
-    import torch
-    from putslam_amd import api
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
-    seqs = [synth.make_sequence(9, 600, config=3, index=300 + i) for i in range(3)]
-    prm = default_ransac_params(REPROJECTION_ERROR)
-    cfg, _ = make_config(EST_RANSAC, 487, seed=21)
-    c, plain = api.Context(0), api.Context(0)
-    plain.set_option("graph", 0)
-    fs = FrameSetDevice(seqs[0]["desc"], seqs[0]["pts"], seqs[0]["nkpts"])
-    pb = PairBatchDevice(seqs[0]["pairs"], fs.max_kpts)
-    fs2 = FrameSetDevice(seqs[0]["desc"], seqs[0]["pts"], seqs[0]["nkpts"])
-    pb2 = PairBatchDevice(seqs[0]["pairs"], fs2.max_kpts)
-    for it in range(9):
-        seq = seqs[it % 3]
-        for f in (fs, fs2):                       # new frames into the SAME device buffers
-            f.desc.copy_(torch.from_numpy(seq["desc"]))
-            f.pts.copy_(torch.from_numpy(seq["pts"]))
-            f.nkpts.copy_(torch.from_numpy(seq["nkpts"]))
-        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
-        g = pb.download()
-        run_pairs(plain, prm, cfg, TUM_FR1_K, fs2, pb2)
-        r = pb2.download()
-        assert g["pose"].tobytes() == r["pose"].tobytes() and np.array_equal(g["inlierMask"], r["inlierMask"]), it
-        assert g["stats"].tobytes() == r["stats"].tobytes() and g["matches"].tobytes() == r["matches"].tobytes(), it
-    assert c.get_option("graph_launches") == 8      # call 0 ordinary (sizes the arena), calls 1..8 captured once, then replayed
-    assert plain.get_option("graph_launches") == 0
-    n0 = c.get_option("graph_launches")
-    cfg2, _ = make_config(EST_RANSAC, 487, seed=22)   # another hypothesis stream: not the captured call
-    run_pairs(c, prm, cfg2, TUM_FR1_K, fs, pb)
-    g2 = pb.download()
-    assert c.get_option("graph_launches") == n0
-    o = oracle.vo_pairs(prm, cfg2, TUM_FR1_K, seqs[2]["desc"], seqs[2]["pts"], seqs[2]["nkpts"], seqs[2]["pairs"][:1], threads=1)
-    assert g2["pose"][0].tobytes() == o["pose"][0].tobytes()
-    c.close()
-    plain.close()
