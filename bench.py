@@ -53,16 +53,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one wave64 instruction per SIMD every 2 cycles)
 MFMA_FP4_PEAK_TFLOPS = 10066.0  # dense FP4: 32x32x64 per 32 cycles per SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md)
-# VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane),
-# counted in the ISA (profiles/isa_mix.json, regenerate with profiles/isa_mix.py)
-VALU_PER_UNIT = {"ps_hamming_nn": 18, "ps_ransac_score_exact<0>": 19, "ps_ransac_score_exact<1>": 61,
-                 "ps_ransac_score_exact<4>": 19, "ps_ransac_score_exact<2>": 61,
-                 "ps_ransac_score_fast<0>": 9.5, "ps_ransac_score_fast<4>": 9.5,
-                 "ps_ransac_score_fast<1>": 23, "ps_ransac_score_mfma<1>": 16.6}
-# of those, packed two-lane f32 instructions (v_pk_*_f32: two f32 operations per lane, issued over 4 cycles -- the same
-# f32 rate as two plain instructions at 2 cycles): counted twice in `lane_ops`
-PK_PER_UNIT = {"ps_ransac_score_fast<1>": 16, "ps_ransac_score_mfma<1>": 7.0, "ps_ransac_score_fast<0>": 9.0,
+# VALU instructions per unit of the hot loops (unit = one descriptor pair / one (hypothesis, match) evaluation per lane), counted
+# in the ISA: read from profiles/isa_mix.json (regenerate with profiles/isa_mix.py); the constants below are only the fallback
+# when that file is missing.  PK_PER_UNIT: of those, packed two-lane f32 instructions (v_pk_*_f32: two f32 operations per
+# lane, issued over 4 cycles -- the same f32 rate as two plain instructions at 2 cycles): counted twice in `lane_ops`
+VALU_PER_UNIT = {"ps_hamming_nn": 17.5, "ps_ransac_score_exact<0>": 15, "ps_ransac_score_exact<1>": 61,
+                 "ps_ransac_score_exact<4>": 15, "ps_ransac_score_exact<2>": 71,
+                 "ps_ransac_score_fast<0>": 9.5, "ps_ransac_score_fast<4>": 11.5,
+                 "ps_ransac_score_fast<1>": 23, "ps_ransac_score_fast<2>": 40}
+PK_PER_UNIT = {"ps_ransac_score_fast<1>": 16, "ps_ransac_score_fast<2>": 16, "ps_ransac_score_fast<0>": 9.0,
                "ps_ransac_score_fast<4>": 9.0}
+ISA_MIX_SOURCE = "built-in fallback constants"
+
+
+def _load_isa_mix():
+    global ISA_MIX_SOURCE
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+        for m in (1, 2):
+            e = j["ps_ransac_score_fast<%d> stage1" % m]
+            VALU_PER_UNIT["ps_ransac_score_fast<%d>" % m] = e["valu"]
+            PK_PER_UNIT["ps_ransac_score_fast<%d>" % m] = e["packed"]
+        for m in (0, 4):
+            e = j["ps_ransac_score_euclid<%d>" % m]
+            VALU_PER_UNIT["ps_ransac_score_fast<%d>" % m] = e["valu_per_match"]
+            PK_PER_UNIT["ps_ransac_score_fast<%d>" % m] = e["packed_per_match"]
+        for m in (0, 1, 2, 4):
+            VALU_PER_UNIT["ps_ransac_score_exact<%d>" % m] = j["ps_ransac_score<%d>" % m]["valu_per_match"]
+        VALU_PER_UNIT["ps_hamming_nn"] = j["ps_hamming_nn"]["valu_per_pair"]
+        ISA_MIX_SOURCE = "profiles/isa_mix.json"
+    except (OSError, KeyError, ValueError):
+        pass
+
+
+_load_isa_mix()
 
 
 def parse():
@@ -283,12 +307,14 @@ def main():
             el = float(tt.item())
         region_s.append(el)
     elapsed = float(np.median(region_s))
+    instrumented_steps = 0
     if not timed_events:
         # per-launch durations under the contended submission (and the only per-kernel figures of a multi-rank run): a few
         # extra steps with HIP events on, outside the timed regions
         for c in ctxs:
             c.enable_timing(True)
-        for _ in range(max(2, min(5, args.steps))):
+        instrumented_steps = max(2, min(5, args.steps))
+        for _ in range(instrumented_steps):
             step()
         fence()
     totals = {}
@@ -441,7 +467,7 @@ def main():
             for name, (per_unit, wave_units) in vk.items():
                 if name in kms and per_unit:
                     ach = wave_units * per_unit * 64.0 / (kms[name] * 1e-3) / 1e12
-                    out[name] = {"bound": "valu", "valu_instructions_per_unit": per_unit, "achieved": ach,
+                    out[name] = {"bound": "valu", "valu_instructions_per_unit": per_unit, "instruction_counts_from": ISA_MIX_SOURCE, "achieved": ach,
                                  "peak": VALU_PEAK_TOPS, "unit": "T lane-instructions/s", "frac": ach / VALU_PEAK_TOPS}
                     pk = PK_PER_UNIT.get("%s_%s<%d>" % (name, score, args.error_version)) if name == "ps_ransac_score" else None
                     if pk:
@@ -451,9 +477,10 @@ def main():
                         out[name]["frac_lane_ops"] = out[name]["achieved_lane_ops"] / VALU_PEAK_TOPS
                     if name == "ps_ransac_score" and evals_made:
                         out[name]["note"] = ("instructions of the evaluation loops only (evaluations really made x instructions "
-                                             "per evaluation); the per-hypothesis prologue (sample -> Umeyama -> SVD, ~4200 "
-                                             "vector instructions per wavefront of 64 hypotheses) and the reorder launch are "
-                                             "inside the time but not in the count")
+                                             "per evaluation; stage 1's pre-tested front costs less than that per evaluation); the "
+                                             "per-hypothesis prologue (sample -> Umeyama -> SVD: measured per wavefront in "
+                                             "profiles/<tag>/sq_counters_by_grid.json) and the reorder launch are inside the time "
+                                             "but not in the count; `all_in` next to this has every vector instruction of the step")
                         out[name]["complete_sweep_equivalent"] = Hs * m_valid * pairs_per_launch * per_unit / (kms[name] * 1e-3) / 1e12
             return out
 
@@ -517,6 +544,10 @@ def main():
             "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "warm_steps_before_region_1": warm_steps,
+            # calls of the step in launch order (profiles/summarize.py attributes a kernel trace's launches with it)
+            "launch_sequence": {"warm": warm_steps, "timed": args.steps * len(region_s), "instrumented": instrumented_steps,
+                                "leg_warm": 1 if solo else 0, "leg": (solo_steps if solo else 0),
+                                "stats": 1 if evals_made else 0},
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if shard_seq else "weak",
             "value_min": P_total_per_step * args.steps / max(region_s), "value_max": P_total_per_step * args.steps / min(region_s),

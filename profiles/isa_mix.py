@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Static VALU instruction mix of the two sweep loops + their modelled issue time.
+"""Static vector-instruction mix of the hot loops and of the per-hypothesis prologue (round 4 rewrite).
 
-Compiles ps_capi.hip to gfx950 assembly, finds the hot loop of ps_hamming_nn<2> and of every
-ps_ransac_score<MODE>, counts VALU instructions per unit of work (descriptor pair / (hypothesis, match)
-evaluation per wave) and prices them with the per-instruction issue costs measured on the MI355X box by
-profiles/microbench/valu_rates (cycles per wave64 instruction per SIMD, normalised to 2.4 GHz).
-Writes profiles/isa_mix.json; bench.py's VALU_PER_UNIT table (instructions per unit of the hot loops) is taken from it.
-"""
+Compiles ps_capi.hip (and profiles/microbench/prologue_isa.hip) to gfx950 assembly with the library's flags and counts, per
+basic block, the VALU instructions of
+  * the evaluation blocks of every scoring kernel in the default build (ps_ransac_score_fast<1 / 2>: one block = one
+    (hypothesis, match) evaluation per lane, ending in the add-with-carry that counts; its pre-test block = TWO matches in one
+    direction; ps_ransac_score_euclid<0 / 4>: one block = two packed steps = four matches; the value-exact ps_ransac_score<M>),
+  * the main loop of the matrix-core matcher (per query tile and wave: 16 MFMAs) and of its VALU twin,
+  * ps_stage_reorder's vote loop, and
+  * the prologue's parts (sampler, Umeyama + SVD with its sweep loop, general inverse): static counts and the number of
+    division / square-root expansions by kind.  The DYNAMIC count per wavefront is measured, not modelled: SQ_INSTS_VALU of
+    stage 0's models-only launch (one work-group per pair) in profiles/<tag>/sq_counters_by_grid.json.
+bench.py reads VALU_PER_UNIT / PK_PER_UNIT from the JSON this writes (profiles/isa_mix.json)."""
 import json
 import os
 import re
@@ -16,150 +21,113 @@ import tempfile
 from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RATES = os.path.join(ROOT, "profiles", "microbench", "valu_rates_mi355x.txt")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-S", "--cuda-device-only"]
 
 
-def load_costs():
-    cost = {}
-    for line in open(RATES):
-        parts = line.split()
-        if len(parts) >= 4 and parts[0].startswith("v_"):
-            try:
-                cost[" ".join(parts[:-3])] = float(parts[-1])
-            except ValueError:
-                pass
-    return cost
+def asm_of(src, td, name):
+    out = os.path.join(td, name)
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read()
 
 
-def price(mn, cost):
-    table = [("v_pk_", cost.get("v_pk_mul_f32", 4.4)), ("v_fma_f32", cost.get("v_fma_f32 (3 regs)", 3.0)),
-             ("v_fmac_f32", cost.get("v_fmac_f32", 2.8)), ("v_mul_f32", cost.get("v_mul_f32", 2.6)),
-             ("v_add_f32", cost.get("v_add_f32", 2.6)), ("v_sub_f32", cost.get("v_add_f32", 2.6)),
-             ("v_rcp_f32", cost.get("v_rcp_f32", 8.3)), ("v_sqrt_f32", cost.get("v_sqrt_f32", 8.3)),
-             ("v_xor_b32", cost.get("v_xor_b32", 2.4)), ("v_and_b32", cost.get("v_and_b32", 2.4)),
-             ("v_add_u32", cost.get("v_add_u32", 2.4)), ("v_addc", cost.get("v_add_u32", 2.4)),
-             ("v_mov_b32", cost.get("v_mov_b32", 2.3)), ("v_bcnt", cost.get("v_bcnt_u32_b32", 4.4)),
-             ("v_min_u32", cost.get("v_min_u32", 4.2)), ("v_lshl_or", cost.get("v_lshl_or_b32", 4.45))]
-    for pre, c in table:
-        if mn.startswith(pre):
-            return c
-    return 4.2  # compares, min3/max3, f64, cvt, div_*, cndmask, ...: the half-rate class
+def body_of(s, sym):
+    a = s.index("\n" + sym)
+    return s[a:s.index(".Lfunc_end", a)]
 
 
-def hot_loop(body, key):
-    """The innermost loop block with the most occurrences of `key`."""
-    blocks = re.split(r"\n(\.LBB\d+_\d+):", body)
-    best = None
-    for i in range(1, len(blocks), 2):
-        n = blocks[i + 1].count(key)
-        if best is None or n > best[0]:
-            best = (n, blocks[i + 1])
-    return best[1]
+def blocks_of(body):
+    parts = re.split(r"\n(\.LBB\d+_\d+:|; %bb\.\d+:)", body)
+    return [(parts[i], parts[i + 1]) for i in range(1, len(parts), 2)]
 
 
-def valu_of(txt):
-    ins = [l.split()[0] for l in txt.split("\n") if l.strip().startswith("v_")]
-    return Counter(ins)
+def valu(txt):
+    return Counter(re.sub(r"_e(32|64)$", "", l.split()[0]) for l in txt.split("\n") if l.strip().startswith("v_"))
+
+
+def summary(c):
+    n = sum(c.values())
+    pk = sum(v for k, v in c.items() if k.startswith("v_pk_"))
+    return {"valu": n, "packed": pk, "mix": dict(c)}
 
 
 def main():
-    cost = load_costs()
+    out = {"source": "hipcc -S of putslam_amd/csrc/ps_capi.hip and profiles/microbench/prologue_isa.hip with the library's flags"}
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                               "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-S", "--cuda-device-only", "-o", asm, os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip")],
-                              stderr=subprocess.DEVNULL)
-        s = open(asm).read()
-    out = {"cost_source": "profiles/microbench/valu_rates_mi355x.txt (cycles per wave64 instruction per SIMD @ 2.4 GHz)"}
-    # Hamming sweep: the 4-query unrolled loop evaluates 4 queries x TPL(2) train rows per lane
-    a = s.index("\n_ZN5psdev13ps_hamming_nnILi2EE")
-    body = s[a:s.index(".Lfunc_end", a)]
-    c = valu_of(hot_loop(body, "v_bcnt"))
-    pairs = c["v_bcnt_u32_b32"] / 8.0
-    out["ps_hamming_nn"] = {"unit": "descriptor pair per wave", "valu_per_unit": sum(c.values()) / pairs,
-                            "model_cycles_per_unit": sum(price(k, cost) * v for k, v in c.items()) / pairs,
-                            "mix": dict(c)}
+        s = asm_of(os.path.join(ROOT, "putslam_amd", "csrc", "ps_capi.hip"), td, "capi.s")
+        pro = asm_of(os.path.join(ROOT, "profiles", "microbench", "prologue_isa.hip"), td, "pro.s")
+    # ---- decision-exact reprojection kernels: evaluation block (ends in v_addc) and pre-test block (packed, no v_addc) ----
+    for mode in (1, 2):
+        for kind, label in ((0, "stage0"), (1, "stage1")):
+            bl = blocks_of(body_of(s, "_ZN5psdev20ps_ransac_score_fastILi%dELb1ELi%dEE" % (mode, kind)))
+            evals = [valu(t) for _, t in bl if "v_addc_co_u32" in t and t.count("v_pk_") >= 8]
+            pre = [valu(t) for _, t in bl if "v_addc_co_u32" not in t and t.count("v_pk_") >= 12 and "ds_" not in t]
+            e = {"unit": "(hypothesis, match) evaluation per wave"}
+            if evals:
+                e.update(summary(evals[0]))
+                e["evaluation_blocks"] = len(evals)
+            if pre and kind == 1:
+                e["pretest"] = dict(summary(pre[0]), unit="TWO matches, one direction, per wave")
+            out["ps_ransac_score_fast<%d> %s" % (mode, label)] = e
+    # ---- decision-exact Euclidean kernels: the block with the clamped indicator FMAs ----
+    for mode in (0, 4):
+        bl = blocks_of(body_of(s, "_ZN5psdev22ps_ransac_score_euclidILi%dELi1EE" % mode))
+        hot = [(t.count("clamp"), valu(t)) for _, t in bl if "clamp" in t]
+        hot.sort(key=lambda x: -x[0])
+        steps = hot[0][0]   # packed steps in the block (one clamp each), two matches per step
+        out["ps_ransac_score_euclid<%d>" % mode] = dict(summary(hot[0][1]), unit="block of %d packed steps = %d matches per wave" % (steps, 2 * steps),
+                                                        valu_per_match=sum(hot[0][1].values()) / (2.0 * steps),
+                                                        packed_per_match=sum(v for k, v in hot[0][1].items() if k.startswith("v_pk_")) / (2.0 * steps))
+    # ---- value-exact kernels: the innermost match loop (hot path = its blocks without the '/' and double fallbacks) ----
     for mode in (0, 1, 2, 4):
-        a = s.index("\n_ZN5psdev15ps_ransac_scoreILi%dEE" % mode)
-        body = s[a:s.index(".Lfunc_end", a)]
-        # basic blocks (explicit labels and the assembler's "; %bb.N:" fall-through blocks), grouped by the loop
-        # header LLVM annotates them with ("in Loop: Header=BBx_y")
-        blocks = re.split(r"\n(\.LBB\d+_\d+:|; %bb\.\d+:)", body)
+        bl = blocks_of(body_of(s, "_ZN5psdev15ps_ransac_scoreILi%dEE" % mode))
         loops = {}
-        names = [blocks[i] for i in range(1, len(blocks), 2)]
-        texts = [blocks[i + 1] for i in range(1, len(blocks), 2)]
-        for i, t in enumerate(texts):
+        for n, t in bl:
             first = t.split("\n", 1)[0]
-            if "This Inner Loop Header" in first and "Depth=1" in first:
-                hdr = re.sub(r"^\.L", "", names[i]).rstrip(":")
-                last = i
-                for j in range(i + 1, len(texts)):
-                    f2 = texts[j].split("\n", 1)[0]
-                    if ("Header=" + hdr + " ") in f2 + " ":
-                        last = j
-                    elif "Loop Header" in f2:
-                        break
-                loops[hdr] = texts[i:last + 1]   # contiguous body: header .. last block annotated with this header
-        reproj = mode in (1, 2)
-        best = None
-        for hdr, ts in loops.items():
-            alltxt = "\n".join(ts)
-            if reproj:
-                if "v_pk_fma_f32" not in alltxt or "v_max3_f32" in alltxt:
-                    continue  # want the match loop whose upper window bound is hoisted (the common one)
-            else:
-                if "s_load_dwordx4" not in alltxt or "v_pk_mul_f32" not in alltxt:
-                    continue
-            n = sum(valu_of(t).total() for t in ts)
-            if best is None or n > best[0]:
-                best = (n, ts)
-        ts = best[1]
-        tot, cold = Counter(), Counter()
-        for t in ts:
-            if "v_div_scale_f32" in t or "v_cvt_f64_f32" in t:
-                cold += valu_of(t)   # '/' fallback and double fallback: taken only outside the window / inside the band
-            else:
-                tot += valu_of(t)
-        per = 1.0
-        if not reproj:
-            per = max(1, "\n".join(ts).count("s_load_dwordx4") // 2)  # unrolled: 2 record loads per match
-        out["ps_ransac_score<%d>" % mode] = {"unit": "(hypothesis, match) evaluation per wave",
-                                             "valu_per_unit": sum(tot.values()) / per,
-                                             "model_cycles_per_unit": sum(price(k, cost) * v for k, v in tot.items()) / per,
-                                             "mix": dict(tot), "cold_fallback_valu": sum(cold.values()) / per}
-    # ---- round 2 kernels ----
-    # decision-exact scoring kernel: the hot path of one evaluation runs from the loop header to the add-with-carry
-    a = s.index("\n_ZN5psdev20ps_ransac_score_fastILi1ELb1EE")
-    body = s[a:s.index(".Lfunc_end", a)]
-    end = body.rindex("v_addc_co_u32")
-    start = body.rindex("This Loop Header", 0, end)
-    c = valu_of(body[start:body.index("\n", end)])
-    out["ps_ransac_score_fast<1>"] = {"unit": "(hypothesis, match) evaluation per wave", "valu_per_unit": sum(c.values()),
-                                      "model_cycles_per_unit": sum(price(k, cost) * v for k, v in c.items()), "mix": dict(c)}
-    # matrix-core Hamming sweep: the main loop = the innermost loop with 16 MFMAs (4 train tiles x 4 k-steps) per trip
-    a = s.index("\n_ZN5psdev15ps_hamming_mfmaILi4EE")
-    body = s[a:s.index(".Lfunc_end", a)]
-    hdrs = [m.start() for m in re.finditer(r"=>This Inner Loop Header", body)]
-    best = None
-    for h0 in hdrs:
-        seg = body[h0:]
-        m = re.search(r"s_cbranch_\w+ \.LBB\d+_\d+\n(?=\.LBB|; %bb)", seg)
-        nxt = body.find("Loop Header", h0 + 40)
-        seg = body[h0:nxt if nxt > 0 else len(body)]
-        n = seg.count("v_mfma_f32_32x32x64_f8f6f4")
-        if n and (best is None or n > best[0]):
-            best = (n, seg)
-    c = valu_of(best[1])
-    nm = c.pop("v_mfma_f32_32x32x64_f8f6f4")
-    out["ps_hamming_mfma<4>"] = {"unit": "query tile x 4 train tiles per wave (4096 distances)", "mfma_per_unit": nm,
-                                 "valu_per_unit": sum(c.values()), "valu_per_mfma": sum(c.values()) / nm,
-                                 "note": "the block includes the cold partial-last-tile masking (16 compares/selects)",
-                                 "mix": dict(c)}
+            m = re.search(r"Header=(BB\d+_\d+)", first)
+            hdr = m.group(1) if m else (n.strip(".:L") if "Loop Header" in first else None)
+            if hdr:
+                loops.setdefault(hdr, []).append(t)
+        best = max(loops.values(), key=lambda ts: sum(t.count("s_load_dwordx4") for t in ts))   # the loop that streams match records
+        hot = Counter()
+        for t in best:
+            if "v_div_scale_f32" not in t and "v_cvt_f64_f32" not in t:
+                hot += valu(t)
+        per = max(1, "\n".join(best).count("s_load_dwordx4") // 2) if mode in (0, 4) else 1
+        out["ps_ransac_score<%d>" % mode] = dict(summary(hot), unit="match loop body per wave (%d matches)" % per, valu_per_match=sum(hot.values()) / per)
+    # ---- matchers ----
+    bl = blocks_of(body_of(s, "_ZN5psdev21ps_hamming_mfma_fusedILi4EE"))
+    mf = max((t for _, t in bl), key=lambda t: t.count("v_mfma"))
+    c = valu(mf)
+    nm = sum(v for k, v in c.items() if k.startswith("v_mfma"))
+    for k in [k for k in c if k.startswith("v_mfma")]:
+        del c[k]
+    out["ps_hamming_mfma_fused<4>"] = dict(summary(c), unit="query tile x 4 train tiles per wave (4096 distances)", mfma_per_unit=nm)
+    bl = blocks_of(body_of(s, "_ZN5psdev13ps_hamming_nnILi2EE"))
+    hb = max((t for _, t in bl), key=lambda t: t.count("v_bcnt"))
+    c = valu(hb)
+    out["ps_hamming_nn"] = dict(summary(c), unit="block of %d descriptor pairs per wave" % (c["v_bcnt_u32_b32"] // 8),
+                                valu_per_pair=sum(c.values()) / (c["v_bcnt_u32_b32"] / 8.0))
+    # ---- prologue parts ----
+    for sym in ("k_sample", "k_umeyama", "k_inverse"):
+        bl = blocks_of(body_of(pro, sym + ":"))
+        tot, loop = Counter(), Counter()
+        for n, t in bl:
+            c = valu(t)
+            tot += c
+            if "in Loop:" in t.split("\n", 1)[0] or "Loop Header" in t.split("\n", 1)[0]:
+                loop += c
+        full_div = tot["v_div_fixup_f32"]
+        out["prologue " + sym] = {"static_valu": sum(tot.values()), "static_valu_in_loops": sum(loop.values()),
+                                  "full_ieee_divisions": full_div, "reciprocal_chains": tot["v_rcp_f32"],
+                                  "square_roots": tot["v_sqrt_f32"], "moves_and_selects": tot["v_mov_b32"] + tot["v_cndmask_b32"],
+                                  "note": "static: both sides of every window check are in the count (short form AND the '/' fallback); "
+                                          "the dynamic figure per wavefront is measured (sq_counters_by_grid.json, stage 0's models-only launch)"}
     with open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():
         if isinstance(v, dict):
-            print(k, round(v["valu_per_unit"], 1), "VALU,", round(v.get("model_cycles_per_unit", float("nan")), 1), "cycles per", v["unit"])
+            print(k, {a: b for a, b in v.items() if a not in ("mix", "note", "pretest")}, ("pretest %s" % {a: b for a, b in v["pretest"].items() if a != "mix"}) if "pretest" in v else "")
 
 
 if __name__ == "__main__":

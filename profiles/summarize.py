@@ -69,11 +69,15 @@ def main():
     sq = os.path.join(src, "sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        bygrid = collections.defaultdict(lambda: collections.defaultdict(list))
         nstep = 0
         for r in csv.DictReader(open(sq)):
             k = r["Kernel_Name"]
             if "psdev::" in k:
-                agg[k.split("psdev::")[1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                name = k.split("psdev::")[1].split("(")[0]
+                agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+                bygrid[f"{name} grid {grid}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
             if k.startswith("ps_crosscheck_prep"):
                 nstep = max(nstep, max(len(v) for v in cs.values()))
@@ -81,6 +85,11 @@ def main():
         with open(os.path.join(dst, "sq_counters.json"), "w") as f:
             json.dump({k: dict({c: sum(v) / nstep for c, v in cs.items()}, launches_per_step=max(len(v) for v in cs.values()) / nstep)
                        for k, cs in agg.items()}, f, indent=1)
+        # the same per launch shape (a kernel launched twice per step with different grids does different things: stage 0 =
+        # models only (one work-group per pair: the pure sample -> Umeyama -> SVD prologue), then the sweep)
+        with open(os.path.join(dst, "sq_counters_by_grid.json"), "w") as f:
+            json.dump({k: dict({c: sum(v) / nstep for c, v in cs.items()}, launches_per_step=max(len(v) for v in cs.values()) / nstep)
+                       for k, cs in bygrid.items()}, f, indent=1)
     # per-step durations from the kernel trace, in launch order (the --stats average mixes warm-up launches, the timed
     # region and bench.py's single-chain leg).  Launch order of bench.py --streams 1 --repeats 1 --no-other-modes:
     # W warm-up steps, K timed, 1 leg warm-up, L = max(3, min(8, K)) leg steps (what `kernel_ms` averages), 1 statistics pass
@@ -94,9 +103,11 @@ def main():
         step_starts = sorted(t for t, _ in launches.get("ps_crosscheck_prep", []))
         out = {}
         K = W = None
+        seq = None
         try:
             line = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())
             K, W = int(line["steps"]), int(line["warmup"])
+            seq = line.get("launch_sequence")
         except Exception:
             pass
         import bisect
@@ -113,7 +124,12 @@ def main():
                     per_step[i] += ms
             ms_list = [round(x, 4) for x in per_step]
             leg = None
-            if K is not None:
+            if seq is not None:   # round 4: bench.py reports its own call sequence
+                L, tail = int(seq["leg"]), int(seq["stats"])
+                total = sum(int(seq[x]) for x in ("warm", "timed", "instrumented", "leg_warm", "leg", "stats"))
+                if L and len(ms_list) == total:
+                    leg = sum(ms_list[len(ms_list) - tail - L:len(ms_list) - tail]) / L
+            elif K is not None:
                 L = max(3, min(8, K))
                 if len(ms_list) == W + K + 1 + L + 1:
                     leg = sum(ms_list[-(L + 1):-1]) / L
