@@ -124,13 +124,9 @@ int ps_context_synchronize(PsContext *ctx);
  *   "score":   1 = decision-exact fast scoring kernels (cheap evaluation with a proven error band, in-band evaluations
  *              re-done by the value-exact code; default): ps_ransac_score_euclid for errorVersion 0 / 4 (the metric every
  *              shipped reference config runs), ps_ransac_score_fast for errorVersion 1 / 2;
- *              2 = EXPERIMENTAL, errorVersion 1 only: the same scheme with the two rigid transforms and the image-offset
- *              products on the matrix cores in split f16 (ps_ransac_score_mfma, v_mfma_f32_32x32x16_f16); its error band
- *              rests on an MFMA accumulation bound that is measured on the device (tests/test_gpu_mfma_accuracy.py), not
- *              documented by the ISA, and on source-operand fences described in ps_score_mfma.h; other error versions
- *              run the "1" kernels;
- *              0 = value-exact ps_ransac_score<M> for every evaluation (PUTSLAM_HIP_SCORE=fast|mfma|exact).
- *              Per-hypothesis counts are identical between 0 and 1 by proof + tests, between 0 and 2 by tests.
+ *              0 = value-exact ps_ransac_score<M> for every evaluation (PUTSLAM_HIP_SCORE=fast|exact).
+ *              Per-hypothesis counts are identical between 0 and 1 by proof + tests.  (Round 2's matrix-core experiment,
+ *              value 2, left the library in round 4: profiles/variants/ps_score_mfma.h.txt.)
  *   "prune":   1 (default) = staged scoring of large batches: the first 256 hypotheses of every pair are scored
  *              completely, the later ones in three stages over growing match ranges; between the stages every
  *              hypothesis that cannot become a record of the sequential selection any more (count so far + matches left
@@ -144,6 +140,19 @@ int ps_context_synchronize(PsContext *ctx);
  *              all matches, so the order changes no output.  1 = always, 0 = original match order, 2 (default) = with the
  *              fixed schedule only (under the adaptive ones the trip limit usually ends the scoring before the stages
  *              start and the launch would buy nothing)  (PUTSLAM_HIP_REORDER=0|1|2).
+ *   "bail":    1 (default) = "nothing to gain" handling of the staged scoring for the Euclidean metrics: a pair whose prefix
+ *              leaves a miss budget so large that the first stage sweeps every match anyway skips the reorder vote, and while
+ *              most pairs of the last observed batched call were such pairs the context scores the next batched calls
+ *              completely, probing with the staged form every 16th call (identical outputs either way; "hopeless", read
+ *              only, is the policy's state).  0 = always the staged form.
+ *   the staged scoring's twins and tuning knobs, each also PUTSLAM_HIP_<NAME> at context creation (tests run every one of
+ *   them next to the default, tests/test_gpu_prune.py): "gensplit" (1: stage 0 as two launches, models then sweep),
+ *   "singlerest" (1: one stage after the prefix under the adaptive schedules), "pretest" (1: stage 1's one-direction
+ *   pre-test on the far-off front), "prefix" (0 = default, or 64 / 128 / 192 / 256 hypotheses of stage 0, fixed schedule),
+ *   "list_g2" / "list_g3" / "list_r3" (work-groups per pair of stages 2 / 3, range split of stage 3), "reorder_top" (voters,
+ *   1 .. 16), "reorder_margin" (matches past the miss budget where stage 1 ends), "reorder_c2div", "reorder_gran" (cut
+ *   granularity, a power of two 2 .. 64).  "last_staged_pairs" / "last_reordered_pairs" (read only): pairs of the last
+ *   scoring step if it was staged / reordered, else 0.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.
