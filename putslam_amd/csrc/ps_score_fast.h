@@ -482,13 +482,12 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     int cnt = 0;
     {
         FastModel F;
-        float cL, G2, S;
+        float kLo, kHi, G2p, S; // per-hypothesis coefficients of the two limits (see rebuild)
         float U[3][4];          // EUCLID: the unfolded model (R | t), current point -> previous frame
         float loE = 0.0f, hiE = 0.0f; // EUCLID: per-lane limits of the squared residual (ps_score_euclid.h)
         // uniform part of the band: E = lambda S, |e_z - Z~| <= 8 u S, G = (sqrt2 lambda + 8 u T') S = g S
         const float lam = 1.05f * kEpsU * (14.0f * fc.fmaxK + 11.0f * umax + 4.0f * fc.cmaxK);
         const float g = 1.4143f * lam + 8.0f * kEpsU * fc.thrUp;
-        const float up4 = 1.0f + 4.0f * kEpsU;
         auto rebuild = [&]() {
             Rigid md, iv;
 #pragma unroll
@@ -506,8 +505,22 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             model_norms(iv, rho2, tau2);
             S = (rho2 * cmax + tau2) * 1.001f;
             const float G = S * g;
-            cL = (2.0f * fc.thrUp * G) * (1.00001f * up4);   // 2 T' G, rounded up
-            G2 = (G * G) * 1.0001f;
+            // The limits  T^2 (1 - 16u) w^2 - 2 T' G w  and  T'^2 w^2 + 2 T' G w + G^2 (1 + 1e-4)  (w = |Z~|) with the linear term
+            // bounded by the quadratic one:  2 T' G w <= T' G (eps w^2 + 1 / eps)  for ANY eps > 0 (AM-GM), so
+            //     lower limit >= (T^2 (1 - 16u) - T' G eps) q - T' G / eps - G^2 (1 + 1e-4),   q = Z~^2
+            //     upper limit <= (T'^2          + T' G eps) q + T' G / eps + G^2 (1 + 1e-4)
+            // are valid limits too -- a little wider than the exact ones except at w = 1 / eps -- and have per-HYPOTHESIS
+            // coefficients: one packed FMA per limit on q, no |Z~| and no per-match band (round 3: two plain v_fma_f32 with the
+            // |.| modifier per evaluation; 23 -> 21 vector instructions, 19 -> 17 per pre-tested pair of matches).
+            // eps = 2 / cmax puts the tangent point in the middle of the pair's depth range; the band is 0.1 % of the
+            // evaluations wide either way.  Roundings: 1e-6 / 1e-5 relative slack on every constant covers the few float
+            // roundings of the constants themselves (<= 6e-8 each), the rounding of q (u) and of the limit's FMA (u).
+            const float eps = 2.0f / cmax;
+            const float TG = (fc.thrUp * G) * 1.00001f;
+            const float cQ = (TG * eps) * 1.00001f;
+            G2p = ((TG / eps) * 1.00001f + (G * G) * 1.0001f) * 1.00002f;
+            kLo = fc.bIn0 * 0.999999f - cQ; // (negative for a band wider than the threshold: then never "certainly inside")
+            kHi = fc.thr2Up * 1.000001f + cQ;
             if (EUCLID) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -600,17 +613,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const v2f_t ss = fast_sq2(F, e0, e1, e2, e3, e4, Z);
             // the match's current and previous point (wave-uniform)
             const float cxm = e0.x, cym = e1.x, czm = e2.x, pxm = e0.y, pym = e1.y, pzm = e2.y;
-            // limits  T^2 (1 - 20u) Z~^2 - band  and  T'^2 Z~^2 + band  with  band = 2 T' G |Z~| + G^2: the linear term as
-            // a plain FMA with the |.| source modifier (no separate |Z~|), the quadratic one on Z~^2
+            // limits  kLo Z~^2 - G2p  and  kHi Z~^2 + G2p  with the per-hypothesis coefficients of rebuild()
             const v2f_t q = Z * Z;
-            // (inline asm: written with fabsf() the compiler packs the two FMAs again and spends two v_and on |Z~|)
-            const float zx = Z.x, zy = Z.y;
-            float bx, by;
-            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(bx) : "v"(cL), "v"(zx), "v"(G2));
-            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(by) : "v"(cL), "v"(zy), "v"(G2));
-            const v2f_t band = {bx, by};
-            const v2f_t lo = pk_fma(v2f_t{fc.bIn0, fc.bIn0}, q, -band);
-            const v2f_t hi = pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, q, band);
+            const v2f_t lo = pk_fma(v2f_t{kLo, kLo}, q, v2f_t{-G2p, -G2p});
+            const v2f_t hi = pk_fma(v2f_t{kHi, kHi}, q, v2f_t{G2p, G2p});
             // (scalar copies: comparisons on vector-element expressions; any NaN makes all four comparisons false)
             const float se = ss.x, sn = ss.y, loe = lo.x, lon = lo.y, hie = hi.x, hin = hi.y;
             unsigned long long mIn =
@@ -648,11 +654,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const v2f_t A = pk_fma(kx, Z, X), B = pk_fma(ky, Z, Y);
             const v2f_t ss = pk_fma(A, A, B * B);
             const v2f_t q = Z * Z;
-            const float za = Z.x, zb = Z.y;
-            float ba, bb;
-            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(ba) : "v"(cL), "v"(za), "v"(G2));
-            asm("v_fma_f32 %0, %1, |%2|, %3" : "=v"(bb) : "v"(cL), "v"(zb), "v"(G2));
-            const v2f_t hi = pk_fma(v2f_t{fc.thr2Up, fc.thr2Up}, q, v2f_t{ba, bb});
+            const v2f_t hi = pk_fma(v2f_t{kHi, kHi}, q, v2f_t{G2p, G2p}); // (the same limit as eval()'s, bit for bit)
             const float sa = ss.x, sb = ss.y, ha = hi.x, hb2 = hi.y;
             ua = execAll & ~__builtin_amdgcn_ballot_w64(sa > ha); // (NaN: not "above": parked)
             ub = execAll & ~__builtin_amdgcn_ballot_w64(sb > hb2);
