@@ -7,7 +7,7 @@
 // per evaluation).  This kernel takes the decision from a cheap evaluation with a proven error band and hands the
 // evaluations that fall inside the band to the value-exact code:
 //
-//   fast evaluation (23 VALU instructions, 16 of them v_pk_*_f32 over the two directions): both transforms as FMA
+//   fast evaluation (21 VALU instructions, 16 of them v_pk_*_f32 over the two directions): both transforms as FMA
 //   chains with the camera constants folded into the model rows (X~ = fx (R p + t)_x, ..., Z~ = (R p + t)_z) and the
 //   test taken in the MULTIPLIED domain, without any division:
 //       reference:  dx = fl(fl(fl(e_x fx) / e_z) + cx) - u_real,   inlier <=> dx^2 + dy^2 < boundR  (both directions)
@@ -30,12 +30,12 @@
 //       s~ < w (T^2 (1 - 16u) w - 2 T' G)                   =>  the reference's test passes      (certain inlier)
 //       s~ > w (T'^2 w + 2 T' G) + G^2 (1 + 1e-4)           =>  it fails                          (certain outlier:
 //                                                                had it passed, s~ would be below this limit)
-//   with T' = T (1 + 1e-5).  Evaluated as  T^2 (1 - 20u) q - band  and  T'^2 q + band  with  q = Z~^2  and ONE
-//   band = fl(2 T' G |Z~| + G^2 (1 + 1e-4)) for both (the lower limit only gets stricter by G^2; 4u more on the
-//   quadratic coefficient for the rounding of q and of the band): one packed multiply, two plain FMAs with the |.|
-//   source modifier and two packed FMAs, the constants rounded to the safe side.  No
-//   depth floor is needed: the errors are absolute, not divided by Z~; for |Z~| -> 0 the lower limit turns negative
-//   (never "inlier") and the upper one tends to G^2, the noise level of s~ itself (then "uncertain", not "outlier").
+//   with T' = T (1 + 1e-5).  Round 4 evaluates both with per-HYPOTHESIS coefficients: 2 T' G w <= T' G (eps w^2 + 1 / eps) for
+//   any eps > 0, so  (T^2 (1 - 20u) - T' G eps) q - T' G / eps - G^2  and  (T'^2 + T' G eps) q + T' G / eps + G^2 (1 + 1e-4),  q = Z~^2,
+//   are valid (slightly wider) limits: one packed FMA each on q, constants rounded to the safe side (rebuild()).  (Round 3 had a
+//   per-match band 2 T' G |Z~| + G^2: two plain FMAs with the |.| source modifier more per evaluation.)  No depth floor is
+//   needed: the errors are absolute, not divided by Z~; for |Z~| -> 0 the lower limit turns negative (never "inlier") and the
+//   upper one tends to its constant term, the noise level of s~ itself (then "uncertain", not "outlier").
 //   Anything else -- inside the band, NaN -- is "uncertain".
 //
 //   uncertain evaluations are parked as (match, lane) in a wave-private LDS queue and evaluated later by the
