@@ -98,7 +98,7 @@ struct PsContext {
     int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (PUTSLAM_HIP_SINGLEREST=0)
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
     int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
-    int listGroups2 = 64, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (PUTSLAM_HIP_LISTG2 / _LISTG3)
+    int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
     int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
     int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
@@ -637,7 +637,13 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         // (stage 3 by default: one looping group per eight possible ones -- 1 for H = 4096, where 21 of 3840 hypotheses per
         // pair are left, 48 for the stress configuration's H = 100 000, which one group swept in 4.3 ms instead of 1.0)
         const int auto3 = all / 8 > 1 ? all / 8 : 1;
-        const int want = pl.reorder ? (stage == 2 ? ctx->listGroups2 : (ctx->listGroups3 > 0 ? ctx->listGroups3 : auto3)) : all;
+        // (stage 2 by default: every possible group with the reprojection kernels -- a fifth of the hypotheses survives stage 1
+        // there --, two looping groups with the Euclidean ones, whose counts saturate: hardly anything survives and the
+        // launch is mostly work-groups that find nothing, 2 - 3 % of the step at every inlier share tried,
+        // profiles/r04b/ab_euclid_list_groups.txt)
+        const int auto2 = with_euclid_fast(ctx, pl.mode) ? 2 : 64;
+        const int want = pl.reorder ? (stage == 2 ? (ctx->listGroups2 > 0 ? ctx->listGroups2 : auto2)
+                                                  : (ctx->listGroups3 > 0 ? ctx->listGroups3 : auto3)) : all;
         return want < all ? want : all;
     };
     // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
@@ -957,7 +963,7 @@ const OptDesc kOptions[] = {
     {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)"},
     // ... and its tuning knobs
     {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over"},
-    {"list_g2", "LISTG2", &PsContext::listGroups2, 1, 64, "list_g2: 1 .. 64 work-groups per pair of stage 2"},
+    {"list_g2", "LISTG2", &PsContext::listGroups2, 0, 64, "list_g2: 0 (automatic) .. 64 work-groups per pair of stage 2"},
     {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3"},
     {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)"},
     {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kReorderTopMax, "reorder_top: 1 .. 16 voters"},
