@@ -641,7 +641,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         // there --, two looping groups with the Euclidean ones, whose counts saturate: hardly anything survives and the
         // launch is mostly work-groups that find nothing, 2 - 3 % of the step at every inlier share tried,
         // profiles/r04b/ab_euclid_list_groups.txt)
-        const int auto2 = with_euclid_fast(ctx, pl.mode) ? 2 : 64;
+        const int auto2 = with_euclid_fast(ctx, pl.mode) ? (all / 8 > 2 ? all / 8 : 2) : 64; // (many hypotheses: lists can be long)
         const int want = pl.reorder ? (stage == 2 ? (ctx->listGroups2 > 0 ? ctx->listGroups2 : auto2)
                                                   : (ctx->listGroups3 > 0 ? ctx->listGroups3 : auto3)) : all;
         return want < all ? want : all;
