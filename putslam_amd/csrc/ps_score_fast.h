@@ -114,6 +114,21 @@ PS_D void model_norms(const Rigid &m, float &rho, float &tau)
 }
 
 PS_D v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(a, b, c); }
+// The two limits of the reprojection test from TWO register pairs, K = (kLo, kHi) and G = (G2p, -G2p), with the halves
+// broadcast by op_sel:   lower = kLo * q - G2p   (K.x, q, G.y)      upper = kHi * q + G2p   (K.y, q, G.x)
+// (inline asm: left to the register allocator the broadcasts became v_mov pairs inside the hot loop in two of the builds)
+PS_D v2f_t limit_lower(v2f_t K, v2f_t q, v2f_t G)
+{
+    v2f_t r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(K), "v"(q), "v"(G));
+    return r;
+}
+PS_D v2f_t limit_upper(v2f_t K, v2f_t q, v2f_t G)
+{
+    v2f_t r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(K), "v"(q), "v"(G));
+    return r;
+}
 
 // The two directions are .x: predictedOld - realOld and .y: predictedNew - realNew.  Operand pairs (cur, prev) of the three
 // coordinates and the offset pairs (cx - uOld, cx - uNew), (cy - vOld, cy - vNew).
@@ -482,7 +497,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     int cnt = 0;
     {
         FastModel F;
-        float kLo, kHi, G2p, S; // per-hypothesis coefficients of the two limits (see rebuild)
+        // per-hypothesis coefficients of the two limits (see rebuild), held as TWO register pairs whose halves the packed FMAs
+        // broadcast through op_sel (limit_lower / limit_upper)
+        v2f_t KL, GG; // KL = (kLo, kHi), GG = (G2p, -G2p)
+        float S;
         float U[3][4];          // EUCLID: the unfolded model (R | t), current point -> previous frame
         float loE = 0.0f, hiE = 0.0f; // EUCLID: per-lane limits of the squared residual (ps_score_euclid.h)
         // uniform part of the band: E = lambda S, |e_z - Z~| <= 8 u S, G = (sqrt2 lambda + 8 u T') S = g S
@@ -518,9 +536,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const float eps = 2.0f / cmax;
             const float TG = (fc.thrUp * G) * 1.00001f;
             const float cQ = (TG * eps) * 1.00001f;
-            G2p = ((TG / eps) * 1.00001f + (G * G) * 1.0001f) * 1.00002f;
-            kLo = fc.bIn0 * 0.999999f - cQ; // (negative for a band wider than the threshold: then never "certainly inside")
-            kHi = fc.thr2Up * 1.000001f + cQ;
+            const float G2p = ((TG / eps) * 1.00001f + (G * G) * 1.0001f) * 1.00002f;
+            // (kLo is negative for a band wider than the threshold: then never "certainly inside")
+            KL = v2f_t{fc.bIn0 * 0.999999f - cQ, fc.thr2Up * 1.000001f + cQ};
+            GG = v2f_t{G2p, -G2p};
             if (EUCLID) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -615,8 +634,8 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const float cxm = e0.x, cym = e1.x, czm = e2.x, pxm = e0.y, pym = e1.y, pzm = e2.y;
             // limits  kLo Z~^2 - G2p  and  kHi Z~^2 + G2p  with the per-hypothesis coefficients of rebuild()
             const v2f_t q = Z * Z;
-            const v2f_t lo = pk_fma(v2f_t{kLo, kLo}, q, v2f_t{-G2p, -G2p});
-            const v2f_t hi = pk_fma(v2f_t{kHi, kHi}, q, v2f_t{G2p, G2p});
+            const v2f_t lo = limit_lower(KL, q, GG);
+            const v2f_t hi = limit_upper(KL, q, GG);
             // (scalar copies: comparisons on vector-element expressions; any NaN makes all four comparisons false)
             const float se = ss.x, sn = ss.y, loe = lo.x, lon = lo.y, hie = hi.x, hin = hi.y;
             unsigned long long mIn =
@@ -654,7 +673,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const v2f_t A = pk_fma(kx, Z, X), B = pk_fma(ky, Z, Y);
             const v2f_t ss = pk_fma(A, A, B * B);
             const v2f_t q = Z * Z;
-            const v2f_t hi = pk_fma(v2f_t{kHi, kHi}, q, v2f_t{G2p, G2p}); // (the same limit as eval()'s, bit for bit)
+            const v2f_t hi = limit_upper(KL, q, GG); // (eval()'s limit, bit for bit)
             const float sa = ss.x, sb = ss.y, ha = hi.x, hb2 = hi.y;
             ua = execAll & ~__builtin_amdgcn_ballot_w64(sa > ha); // (NaN: not "above": parked)
             ub = execAll & ~__builtin_amdgcn_ballot_w64(sb > hb2);
