@@ -610,12 +610,14 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         auto pair64 = [](float lo, float hi) {
             return (unsigned long long)__builtin_bit_cast(uint32_t, lo) | ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
         };
-        auto load_rec = [&](int m) {
+        // (BIG: rp = the packed record of match m, kept as a running pointer -- recomputed from the index every trip it cost a
+        // multiply, a sign extension, a 64-bit shift and a 64-bit add per record on the scalar unit, which the probe of round 4
+        // showed to be nearly as loaded as the vector ALU in this loop)
+        auto load_rec = [&](int m, const unsigned long long *__restrict__ rp) {
             Rec r;
             if (BIG) {
-                const unsigned long long *__restrict__ e = reinterpret_cast<const unsigned long long *>(pf + 5 * m);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) r.q[i] = e[i];
+                for (int i = 0; i < 5; ++i) r.q[i] = rp[i];
             } else {
                 const float4 A = pa[m], B = pb[m], E = pe[m];
                 r.q[0] = pair64(B.x, A.x); r.q[1] = pair64(B.y, A.y); r.q[2] = pair64(B.z, A.z);
@@ -693,14 +695,16 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         // Two matches per trip, both records requested before the first is used: a wavefront that is alone on its SIMD (the
         // stages with few hypotheses, a single pair) otherwise waits out one scalar load per match.  The undecided lanes of
         // both are parked afterwards, in ONE copy of the parking code (it holds the drain).
-        for (int m = m0; m < m1; m += 2) {
+        const unsigned long long *__restrict__ rp = reinterpret_cast<const unsigned long long *>(pf) + 5 * (size_t)m0;
+        const float2 *__restrict__ fr2 = pfr + 5 * (size_t)(m0 >> 1); // (the front record of the pair of matches m, m + 1)
+        for (int m = m0; m < m1; m += 2, rp += 10, fr2 += (PRE ? 5 : 0)) {
             const bool two = m + 1 < m1; // (wave-uniform)
             unsigned long long ua, ub = 0ull;
             if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
-                not_out2(pfr + 5 * (m >> 1), ua, ub);
+                not_out2(fr2, ua, ub);
                 if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua | ub) == 0ull ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
             } else {
-                Rec ra = load_rec(m), rb = load_rec(two ? m + 1 : m);
+                Rec ra = load_rec(m, rp), rb = load_rec(two ? m + 1 : m, two ? rp + 5 : rp);
                 // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
                 asm volatile("" : "+s"(ra.q[0]), "+s"(ra.q[1]), "+s"(ra.q[2]), "+s"(ra.q[3]), "+s"(ra.q[4]), "+s"(rb.q[0]),
                              "+s"(rb.q[1]), "+s"(rb.q[2]), "+s"(rb.q[3]), "+s"(rb.q[4]));
