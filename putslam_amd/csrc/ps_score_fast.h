@@ -394,8 +394,11 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     int32_t *__restrict__ cout = counts + (size_t)p * H;
     int h = st.hBase + (int)bx * kBlock + tid;
     int hEnd = st.hBase + st.hCount; // this lane scores hypothesis h if h < hEnd
-    int m0 = (int)(((long long)M * by) / msplit);
-    int m1 = (int)(((long long)M * (by + 1)) / msplit);
+    // (the match range is split on match PAIRS: the loop takes two matches per trip, only the pair's last range can be odd)
+    const int npair = (M + 1) >> 1;
+    int m0 = 2 * (int)(((long long)npair * by) / msplit);
+    int m1 = 2 * (int)(((long long)npair * (by + 1)) / msplit);
+    m1 = m1 < M ? m1 : M;
     int best0 = 0;
     constexpr bool LIST = KIND == 2; // stage >= 2: hypotheses from the survivor list, models from HBM
     constexpr bool pruned = KIND >= 1;
@@ -697,19 +700,21 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         // both are parked afterwards, in ONE copy of the parking code (it holds the drain).
         const unsigned long long *__restrict__ rp = reinterpret_cast<const unsigned long long *>(pf) + 5 * (size_t)m0;
         const float2 *__restrict__ fr2 = pfr + 5 * (size_t)(m0 >> 1); // (the front record of the pair of matches m, m + 1)
-        for (int m = m0; m < m1; m += 2, rp += 10, fr2 += (PRE ? 5 : 0)) {
-            const bool two = m + 1 < m1; // (wave-uniform)
-            unsigned long long ua, ub = 0ull;
+        // (whole pairs only: no "is there a second match" select on the scalar unit in every trip; the odd last match of a
+        // pair's last range goes to the value-exact code for every lane, below)
+        const int mPairs = m0 + ((m1 - m0) & ~1);
+        for (int m = m0; m < mPairs; m += 2, rp += 10, fr2 += (PRE ? 5 : 0)) {
+            unsigned long long ua, ub;
             if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
                 not_out2(fr2, ua, ub);
                 if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua | ub) == 0ull ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
             } else {
-                Rec ra = load_rec(m, rp), rb = load_rec(two ? m + 1 : m, two ? rp + 5 : rp);
+                Rec ra = load_rec(m, rp), rb = load_rec(m + 1, rp + 5);
                 // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
                 asm volatile("" : "+s"(ra.q[0]), "+s"(ra.q[1]), "+s"(ra.q[2]), "+s"(ra.q[3]), "+s"(ra.q[4]), "+s"(rb.q[0]),
                              "+s"(rb.q[1]), "+s"(rb.q[2]), "+s"(rb.q[3]), "+s"(rb.q[4]));
                 ua = eval(ra);
-                if (two) ub = eval(rb);
+                ub = eval(rb);
             }
             if ((ua | ub) != 0ull) {
 #pragma nounroll
@@ -725,6 +730,12 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                     qn += n;
                 }
             }
+        }
+        if (mPairs < m1) { // the odd last match: every lane's evaluation is handed to the value-exact code
+            const int n = __popcll(execAll);
+            if (qn + n > kQueueCap) drain();
+            s_q[wv][qn + lanes_below(execAll)] = ((uint32_t)mPairs << 6) | (uint32_t)lane;
+            qn += n;
         }
         drain();
         cnt += s_cnt[tid];
