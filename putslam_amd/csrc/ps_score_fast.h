@@ -628,7 +628,8 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             }
             return r;
         };
-        // decides one match for the 64 hypotheses of the wavefront: counts the certain inliers, returns the undecided lanes
+        // decides one match for the 64 hypotheses of the wavefront: counts the certain inliers, returns the DECIDED lanes
+        // (the undecided ones are worked out only when a trip has any: two scalar instructions less per evaluation)
         auto eval = [&](const Rec &r) -> unsigned long long {
             v2f_t Z;
             const v2f_t e0 = __builtin_bit_cast(v2f_t, r.q[0]), e1 = __builtin_bit_cast(v2f_t, r.q[1]),
@@ -656,7 +657,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                 mOut |= __builtin_amdgcn_ballot_w64(sE > hiE);
             }
             add_mask(cnt, mIn);
-            return execAll & ~(mIn | mOut);
+            return mIn | mOut;
         };
         // Stage 1 on the reordered record starts with the matches EVERY voter rejected (the wrong correspondences): nearly
         // every hypothesis rejects them too, and one direction of the test is enough to know -- current point -> previous
@@ -680,8 +681,8 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             const v2f_t q = Z * Z;
             const v2f_t hi = limit_upper(KL, q, GG); // (eval()'s limit, bit for bit)
             const float sa = ss.x, sb = ss.y, ha = hi.x, hb2 = hi.y;
-            ua = execAll & ~__builtin_amdgcn_ballot_w64(sa > ha); // (NaN: not "above": parked)
-            ub = execAll & ~__builtin_amdgcn_ballot_w64(sb > hb2);
+            ua = __builtin_amdgcn_ballot_w64(sa > ha); // decided = certainly out (NaN: not "above": parked)
+            ub = __builtin_amdgcn_ballot_w64(sb > hb2);
         };
         // (only stage 1 sweeps the front.  profiles/r03n: stage 1 640 -> 563 us with errorVersion 1, -11 % of the scoring step
         // with errorVersion 2; the pre-test leaves 0.9 % of its trips with a lane to park.)
@@ -707,7 +708,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             unsigned long long ua, ub;
             if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
                 not_out2(fr2, ua, ub);
-                if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua | ub) == 0ull ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
+                if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua & ub) == execAll ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
             } else {
                 Rec ra = load_rec(m, rp), rb = load_rec(m + 1, rp + 5);
                 // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
@@ -716,10 +717,10 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                 ua = eval(ra);
                 ub = eval(rb);
             }
-            if ((ua | ub) != 0ull) {
+            if ((ua & ub) != execAll) { // (ua, ub: the lanes eval() / the pre-test decided)
 #pragma nounroll
                 for (int j = 0; j < 2; ++j) {
-                    const unsigned long long mU = j ? ub : ua;
+                    const unsigned long long mU = execAll & ~(j ? ub : ua);
                     if (mU == 0ull) continue;
                     const int n = __popcll(mU);
                     if (qn + n > kQueueCap) {
