@@ -704,11 +704,11 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         // (whole pairs only: no "is there a second match" select on the scalar unit in every trip; the odd last match of a
         // pair's last range goes to the value-exact code for every lane, below)
         const int mPairs = m0 + ((m1 - m0) & ~1);
+        int frontParkTrips = 0; // trips of the pre-tested front that left a lane to the value-exact test (wave-uniform)
         for (int m = m0; m < mPairs; m += 2, rp += 10, fr2 += (PRE ? 5 : 0)) {
             unsigned long long ua, ub;
             if (PRE && m + 2 <= mFront) { // (m0 = 0 in stage 1: m is even)
                 not_out2(fr2, ua, ub);
-                if (dbg != nullptr && lane == 0) atomicAdd(&dbg[(ua & ub) == execAll ? 2 : 3], 1ull); // (ps_debug_score_stats_ex)
             } else {
                 Rec ra = load_rec(m, rp), rb = load_rec(m + 1, rp + 5);
                 // (an empty asm that takes both records: the compiler otherwise sinks the second load below the first evaluation)
@@ -718,6 +718,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                 ub = eval(rb);
             }
             if ((ua & ub) != execAll) { // (ua, ub: the lanes eval() / the pre-test decided)
+                if (PRE && m + 2 <= mFront) ++frontParkTrips; // (statistics: counted here, in the rare path, not per trip)
 #pragma nounroll
                 for (int j = 0; j < 2; ++j) {
                     const unsigned long long mU = execAll & ~(j ? ub : ua);
@@ -743,6 +744,11 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         if (dbg != nullptr && lane == 0) {
             atomicAdd(&dbg[0], parked);
             atomicAdd(&dbg[1], (unsigned long long)(m1 - m0) * 64ull);
+            if (PRE) { // (ps_debug_score_stats_ex: [2] / [3] = pre-test trips without / with a lane left to the value-exact test)
+                const int frontTrips = mFront > m0 ? ((mFront < mPairs ? mFront : mPairs) - m0) >> 1 : 0;
+                atomicAdd(&dbg[3], (unsigned long long)frontParkTrips);
+                atomicAdd(&dbg[2], (unsigned long long)(frontTrips - frontParkTrips));
+            }
         }
         }
     }
