@@ -67,9 +67,9 @@ struct PsContext {
     int curCall = 0;            // ring slot of the call being recorded
     int nTimed = 0;             // highest timed slot + 1
     unsigned slotMask[kTimingRing] = {0}; // per kept call: which slots were recorded
-    // tuning overrides (PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT, read once; 0 = automatic)
+    // tuning overrides (options "qsplit" / "msplit"; 0 = automatic)
     int forceQsplit = 0, forceMsplit = 0;
-    // kernel variants (ps_context_set_option / PUTSLAM_HIP_MATCHER): 1 = FP4 MFMA matcher, 0 = integer VALU matcher,
+    // kernel variants (option "matcher"): 1 = FP4 MFMA matcher, 0 = integer VALU matcher,
     // 2 = by batch size (default): the MFMA form costs one more launch (the FP4 expansion), which a handful of pairs does
     // not earn back
     int matcher = 2;
@@ -90,18 +90,18 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
-    int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (PUTSLAM_HIP_REORDER_GRAN: 2 .. 64; finer cuts
+    int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (option "reorder_gran": 2 .. 64; finer cuts
                           // shorten stage 1 and lengthen stages 2 / 3 by as much, profiles/r03n)
     int genSplit = 1;    // staged scoring: stage 0 as two launches -- the prefix's models once, then the sweep with the match range
-                         // split over twice as many work-groups (PUTSLAM_HIP_GENSPLIT=0: one launch, every part repeats the
+                         // split over twice as many work-groups (option "gensplit" = 0: one launch, every part repeats the
                          // sample -> SVD chain)
-    int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (PUTSLAM_HIP_SINGLEREST=0)
-    int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (PUTSLAM_HIP_PRETEST=0 turns it off)
-    int listRsplit3 = 4; // PUTSLAM_HIP_LISTR3
+    int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (option "singlerest")
+    int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (option "pretest")
+    int listRsplit3 = 4; // option "list_r3": work-groups the last stage's match range is split over
     int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
     int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
     int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
-    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (tuning knobs: PUTSLAM_HIP_REORDER_TOP / _MARGIN / _C2DIV)
+    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (options "reorder_top" / "reorder_margin" / "reorder_c2div")
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
     // Every (re)allocation of an arena block bumps this: captured graphs (ps_vo_stream_push) carry the pointers of the
