@@ -326,11 +326,13 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
  * no lane / some lane to the value-exact test; [4..7] reserved (0). */
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* Staged scoring: hypotheses of every pair that survived stage 1 (out[0..P)) and stage 2 (out[P..2P)) of the last call
- * that was scored in stages (the last P pairs' counters; zeros if none was). */
+ * that was scored in stages: zeros if the LAST scoring step of the context was not staged, PS_ERR_BAD_ARG if P is not that
+ * step's number of pairs (the counters are laid out with it). */
 int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out);
 /* Staged scoring with the reordered match record: perm[P][cap] = for every pair, the match (index into its depth-valid
  * matches) at each position of the order stages 1+ swept; front[P] = leading positions whose matches every voting hypothesis
- * rejected and found far off (stage 1's pre-test range).  Entries beyond a pair's number of valid matches are unspecified. */
+ * rejected and found far off (stage 1's pre-test range).  Entries beyond a pair's number of valid matches are unspecified.
+ * PS_ERR_BAD_ARG unless the context's last scoring step was staged AND reordered with exactly this P and cap. */
 int ps_debug_stage_order(PsContext *ctx, int P, int cap, int32_t *perm, int32_t *front);
 /* Latency study (option "stamps" = 1): the shader-clock stamps (s_memtime) work-group 0 of kernels 2 and 4 of the last call
  * wrote into a private buffer: out16[0..3] = ps_crosscheck_prep (start, best[q] built, matches compacted + records written,
