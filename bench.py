@@ -123,7 +123,7 @@ def parse():
                     help="run the N > 1 control flow (RCCL process group, parameter broadcast, per-chain asynchronous gather "
                          "of device-resident records, fence) even with ONE rank: the only way to execute that branch on a "
                          "one-GPU box (also PUTSLAM_BENCH_FORCE_DIST=1)")
-    ap.add_argument("--warm-seconds", type=float, default=0.6,
+    ap.add_argument("--warm-seconds", type=float, default=1.0,
                     help="after the --warmup steps, keep stepping (untimed) until this much wall time has passed: the timed "
                          "regions start on a chip at its steady clock")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
