@@ -121,6 +121,12 @@ struct PsContext {
     unsigned *bailHostDev = nullptr;
     unsigned bailSeen[2] = {0, 0};
     int hopeless = 0, hopelessCalls = 0;
+    // The keys block is all-ones at rest: kernel 2 puts kNoKey back into every entry it reads, so the matcher forms that merge
+    // their query splits with atomicMin need no clearing launch in front of them (a single pair paid a memset launch and its
+    // gap for that on every call: 6 of 96 us).  keysCleanPtr / keysCleanBytes = the block and the leading bytes the invariant
+    // holds for once the stream's queued work has drained; a fresh or regrown block is cleared once, completely.
+    void *keysCleanPtr = nullptr;
+    size_t keysCleanBytes = 0;
 };
 
 namespace {
@@ -166,6 +172,16 @@ int ensure(PsContext *ctx, Buf &b, size_t bytes)
         int rc_ = ensure(ctx, (buf), (bytes));       \
         if (rc_ != PS_OK) return rc_;                \
     } while (0)
+
+// The matcher forms that merge with atomicMin start from an all-ones keys block (see PsContext::keysCleanPtr).
+int keys_clean(PsContext *ctx, size_t bytes)
+{
+    if (ctx->keysCleanPtr == ctx->keys.p && ctx->keysCleanBytes >= bytes) return PS_OK;
+    PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, ctx->keys.cap, ctx->stream));
+    ctx->keysCleanPtr = ctx->keys.p;
+    ctx->keysCleanBytes = ctx->keys.cap;
+    return PS_OK;
+}
 
 void release(Buf &b)
 {
@@ -839,6 +855,16 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     // by batch size: VALU sweep 1.85 us, MFMA sweep 0.43 us per 2000 x 2000 pair on a full chip, + ~7 us for the extra launch
     const bool useMfma = ctx->matcher == 1 || (ctx->matcher == 2 && (double)P * cap * cap > 2.0e7);
     ctx->matcherUsed = useMfma ? 1 : 0;
+    const size_t keyBytes = (size_t)P * cap * sizeof(uint32_t);
+    // from the matcher's launch until kernel 2 has been queued behind it the keys block is in use; kernel 2 leaves what it
+    // read all-ones again, so a block that was clean before this call is clean after it
+    const size_t cleanBefore = ctx->keysCleanPtr == ctx->keys.p ? ctx->keysCleanBytes : 0;
+    struct KeysInUse {
+        PsContext *c;
+        size_t restore;
+        bool done = false;
+        ~KeysInUse() { c->keysCleanBytes = done ? restore : 0; }
+    } keysInUse{ctx, cleanBefore};
     if (useMfma) {
         // matrix-core form: expand every pair's query frame to FP4 once, then the MFMA sweep
 #ifndef PS_MFMA_TT
@@ -853,7 +879,11 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
             // fused expansion: every work-group of a query split expands its own share of the query tiles, so a split only
             // pays when the groups do not fill the chip by themselves; the keys are then cleared by a memset
             if (ctx->forceQsplit <= 0 && (long long)P * groups >= 1024) qsplit = 1;
-            if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+            if (qsplit > 1) {
+                int rc = keys_clean(ctx, keyBytes);
+                if (rc != PS_OK) return rc;
+                keysInUse.restore = ctx->keysCleanBytes;
+            }
             tick(ctx, 5, false);
             hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
                                ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
@@ -881,7 +911,11 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
         int qsplit = pick_split((long long)P * tiles, 64, 16, cap); // single pair: 256 work-groups of >= 16 query rows
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
-        if (qsplit > 1) PS_HIP(hipMemsetAsync(ctx->keys.p, 0xFF, (size_t)P * cap * sizeof(uint32_t), ctx->stream));
+        if (qsplit > 1) {
+            int rc = keys_clean(ctx, keyBytes);
+            if (rc != PS_OK) return rc;
+            keysInUse.restore = ctx->keysCleanBytes;
+        }
         tick(ctx, slot0, false);
         hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
                            (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, tiles, qsplit, (uint32_t *)ctx->keys.p);
@@ -893,7 +927,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     const bool wide = P <= kWidePairs; // a handful of pairs: 1024-thread work-groups shorten the per-pair serial walk
 #define PS_LAUNCH_PREP(REC, BLK)                                                                                       \
     hipLaunchKernelGGL((ps_crosscheck_prep<REC, BLK>), dim3((unsigned)P), dim3(BLK), lds, ctx->stream, fs.pts, fs.nkpts, \
-                       dPairs, (const uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, rp,                           \
+                       dPairs, (uint32_t *)ctx->keys.p, pa, dMatches, dNumMatches, rp,                                 \
                        (int32_t *)ctx->mvalid.p, (float2 *)ctx->cmax.p,                                                \
                        ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr)
     RecPtrs rp{};
@@ -912,6 +946,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
 #undef PS_LAUNCH_PREP
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
+    keysInUse.done = true;
     return PS_OK;
 }
 
@@ -1936,6 +1971,10 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     if (rc) return rc;
     pl.ma.seedDev = reinterpret_cast<const uint64_t *>((const int32_t *)s->meta.p + 4);
     rc = prepare_score(ctx, pl, 1, s->cap);
+    if (rc) return rc;
+    // (outside the capture: a captured push then holds no clearing node, and a replay finds the block as its capture did)
+    PS_ENSURE(ctx->keys, (size_t)s->cap * sizeof(uint32_t));
+    rc = keys_clean(ctx, (size_t)s->cap * sizeof(uint32_t));
     if (rc) return rc;
     uint8_t *dres = (uint8_t *)s->res.p;
     auto enqueue = [&](size_t rows) -> int {

@@ -3,7 +3,7 @@
 // Data layout in HBM (one "frame set" + one "pair batch", see include/putslam_hip.h):
 //   desc   [F][cap][32 B]      binary descriptors (ORB / LDB, 256 bit)
 //   pts    [F][cap][3] f32     back-projected 3-D points (Eigen::Vector3f storage)
-//   keys   [P][cap]    u32     per train row: (hamming << 16) | nearest query   (scratch)
+//   keys   [P][cap]    u32     per train row: (hamming << 16) | nearest query   (scratch; all-ones again after kernel 2)
 //   recA/B/C/D [P][cap] 16 B   per depth-valid match: prev xyz + squared Euclid bound |
 //                              cur xyz | projections of prev and cur | indices    (scratch)
 //   counts [P][H]      i32     inlier count of every hypothesis                   (scratch)
@@ -291,7 +291,7 @@ template <bool WITH_RECORDS, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restrict__ pts,
                                                              const int32_t *__restrict__ nkpts,
                                                              const int32_t *__restrict__ pairs,
-                                                             const uint32_t *__restrict__ keys, PrepArgs a,
+                                                             uint32_t *__restrict__ keys, PrepArgs a,
                                                              PsDMatch *__restrict__ matches,
                                                              int32_t *__restrict__ numMatches, RecPtrs rec,
                                                              int32_t *__restrict__ mvalid, float2 *__restrict__ cmaxOut,
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         if (key != kNoKey) {
             uint32_t q = key & 0xFFFFu, d = key >> 16;
             atomicMin(&s_best[q], (d << 16) | (uint32_t)t);
+            keys[(size_t)p * cap + t] = kNoKey; // the block is all-ones at rest: the next call's matcher merges with atomicMin
         }
     }
     __syncthreads();

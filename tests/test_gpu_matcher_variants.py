@@ -118,3 +118,43 @@ def test_variants_agree_on_a_batch(oracle):
         n0, n1 = int(seq["nkpts"][f0]), int(seq["nkpts"][f1])
         m = oracle.match_hamming256(seq["desc"][f0][:n0], seq["desc"][f1][:n1])
         assert a["matches"][p][:len(m)].tobytes() == m.tobytes() and int(a["numMatches"][p]) == len(m)
+
+
+def test_keys_block_is_all_ones_at_rest(oracle):
+    """The matcher forms that merge their query splits with atomicMin start from an all-ones keys block and no longer clear
+    it themselves: kernel 2 puts kNoKey back into every entry it has read.  One context, every matcher form in turn, shrinking
+    and growing frames, forced and automatic query splits, single pairs and a batch in between: every list equals the oracle's
+    (a stale key left by an earlier call would win an atomicMin and show up as a wrong match)."""
+    from putslam_amd._abi import EST_RANSAC, TUM_FR1_K, default_ransac_params, make_config
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    c = api.Context(0)
+    rng = np.random.default_rng(991)
+    forms = [(0, 0, 0), (1, 1, 3), (0, 0, 7), (1, 0, 2), (1, 1, 1), (0, 0, 0), (1, 1, 0), (0, 0, 1), (0, 0, 64)]
+    sizes = [(2000, 1900), (700, 2000), (1999, 64), (33, 1500), (1200, 1200), (5, 2000), (2000, 2000), (300, 40), (1500, 1700)]
+    seq = synth.make_sequence(8, 900, config=3, index=17)
+    seq["nkpts"][2] = 401
+    prm = default_ransac_params(0)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=99)
+    try:
+        for rnd, ((kind, fused, qsplit), (nq, nt)) in enumerate(zip(forms, sizes)):
+            c.set_option("matcher", kind)
+            c.set_option("matcher_fused", fused)
+            c.set_option("qsplit", qsplit)
+            q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+            k = min(nq, nt) // 2
+            t[:k] = q[rng.permutation(nq)[:k]] ^ np.packbits(rng.random((k, 256)) < 0.04, axis=1)
+            assert c.match_hamming256(q, t).tobytes() == oracle.match_hamming256(q, t).tobytes(), (rnd, kind, fused, qsplit)
+            if rnd % 3 == 1:  # a batch on the same context in between (its own pair count and row stride)
+                fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+                pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+                run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb, use_torch_stream=False)
+                c.synchronize()
+                got = pb.download()
+                for p in (0, 1, 2, 6):
+                    f0, f1 = seq["pairs"][p]
+                    n0, n1 = int(seq["nkpts"][f0]), int(seq["nkpts"][f1])
+                    m = oracle.match_hamming256(seq["desc"][f0][:n0], seq["desc"][f1][:n1])
+                    assert int(got["numMatches"][p]) == len(m) and got["matches"][p][:len(m)].tobytes() == m.tobytes(), (rnd, p)
+    finally:
+        c.close()
