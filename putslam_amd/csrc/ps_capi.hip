@@ -811,8 +811,13 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     tick(ctx, slot0, true);
     PS_HIP(hipGetLastError());
     SelectArgs sa = pl.sa;
-    sa.stageCap = cap < 1536 ? cap : 1536; // 36 KiB of LDS for the refit's operands
-    size_t lds = 2 * (size_t)((sa.trainRange + 31) / 32) * sizeof(uint32_t) + (size_t)sa.stageCap * 6 * sizeof(float);
+    // LDS of kernel 4: the two bitmaps over train indices, then up to 48 KiB for the refit's and the re-selection's operands
+    // (what is left of the 64 KiB a work-group gets without an attribute, with room for the kernel's static 1 KiB)
+    const size_t bitmapBytes = (((2 * (size_t)((sa.trainRange + 31) / 32)) + 3) & ~(size_t)3) * sizeof(uint32_t);
+    const size_t stageRoom = ((size_t)63 << 10) - bitmapBytes;
+    sa.stageCap = cap < 1536 ? cap : 1536;
+    if ((size_t)sa.stageCap * 32 > stageRoom) sa.stageCap = (int)(stageRoom / 32);
+    size_t lds = bitmapBytes + (size_t)sa.stageCap * 8 * sizeof(float);
     tick(ctx, slot0 + 1, false);
     // (1024-thread work-groups were measured for this kernel too: 48 us instead of 40 for a single pair)
     hipLaunchKernelGGL(ps_select_refit<kBlock>, dim3((unsigned)P), dim3(kBlock), lds, ctx->stream,

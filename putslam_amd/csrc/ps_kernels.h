@@ -181,6 +181,71 @@ PS_D void block_scan_flags2(bool flagA, bool flagB, int &posA, int &totalA, int 
     totalB = tot >> 16;
 }
 
+// The same scans with ONE barrier per call: the wave sums alternate between two slots (`parity` = the call's number, uniform
+// over the work-group).  A slot is written again two calls later, behind the barrier of the call in between, which every
+// thread reaches only after it has read the slot.
+template <int BLOCK = kBlock> PS_D int block_scan_flag_alt(bool flag, int &total, int *wsum2, int parity)
+{
+    int *wsum = wsum2 + (parity & 1) * (BLOCK / 64);
+    unsigned long long bal = __ballot(flag);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) {
+        int s = wsum[i];
+        if (i < w) off += s;
+        total += s;
+    }
+    return off + pre;
+}
+
+template <int BLOCK = kBlock>
+PS_D void block_scan_flags2_alt(bool flagA, bool flagB, int &posA, int &totalA, int &posB, int &totalB, int *wsum2, int parity)
+{
+    int *wsum = wsum2 + (parity & 1) * (BLOCK / 64);
+    const unsigned long long ba = __ballot(flagA), bb = __ballot(flagB);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) wsum[w] = __popcll(ba) | (__popcll(bb) << 16);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) {
+        const int sv = wsum[i];
+        if (i < w) off += sv;
+        tot += sv;
+    }
+    posA = (off & 0xFFFF) + __popcll(ba & below);
+    posB = (off >> 16) + __popcll(bb & below);
+    totalA = tot & 0xFFFF;
+    totalB = tot >> 16;
+}
+
+// workgroup-wide maxima of two non-negative floats with one pair of barriers
+template <int BLOCK = kBlock> PS_D void block_max2(float &a, float &b, float2 *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmaxf(a, __shfl_down(a, o, 64));
+        b = fmaxf(b, __shfl_down(b, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(a, b);
+    __syncthreads();
+    float2 r = red[0];
+#pragma unroll
+    for (int i = 1; i < BLOCK / 64; ++i) {
+        r.x = fmaxf(r.x, red[i].x);
+        r.y = fmaxf(r.y, red[i].y);
+    }
+    __syncthreads();
+    a = r.x;
+    b = r.y;
+}
+
 // workgroup-wide maximum of a non-negative float (4 waves)
 template <int BLOCK = kBlock> PS_D float block_max(float v, float *red)
 {
@@ -299,8 +364,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
 {
     extern __shared__ __align__(16) uint32_t s_best[];
     phase_stamp(stamps, 0);
-    __shared__ int s_wsum[BLOCK / 64];
-    __shared__ float s_red[BLOCK / 64];
+    __shared__ int s_wsum[2 * (BLOCK / 64)];
+    __shared__ float2 s_red[BLOCK / 64];
     float cm = 0.0f; // largest |coordinate| among this pair's depth-valid matches
     float um = 0.0f; // largest |c - projection| among them (NaN offsets are skipped by fmaxf; they only ever score "out")
     const int p = blockIdx.x;
@@ -324,21 +389,39 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
     const float *pp = pts + (size_t)fq * cap * 3;
     const float *cp = pts + (size_t)ft * cap * 3;
     int base = 0, vbase = 0;
-    for (int q0 = 0; q0 < nq; q0 += BLOCK) {
+    // one candidate per thread and trip; the next trip's key and points are fetched before this trip's scan, so that the
+    // gather's latency (the points were written by another launch: nothing is cached) runs beside it instead of in front of
+    // every trip (a single pair with 1024 threads makes two trips)
+    struct Cand {
+        uint32_t key;
+        float px, py, pz, cx, cy, cz;
+    };
+    auto fetch = [&](int q, Cand &c) {
+        c.key = (q < nq) ? s_best[q] : kNoKey;
+        c.px = c.py = c.pz = c.cx = c.cy = c.cz = 0.0f;
+        if (WITH_RECORDS && c.key != kNoKey) {
+            const int t = (int)(c.key & 0xFFFFu);
+            c.px = pp[3 * q]; c.py = pp[3 * q + 1]; c.pz = pp[3 * q + 2];
+            c.cx = cp[3 * t]; c.cy = cp[3 * t + 1]; c.cz = cp[3 * t + 2];
+        }
+    };
+    Cand cur;
+    fetch((int)threadIdx.x, cur);
+    int trip = 0;
+    for (int q0 = 0; q0 < nq; q0 += BLOCK, ++trip) {
         const int q = q0 + threadIdx.x;
-        uint32_t key = (q < nq) ? s_best[q] : kNoKey;
+        Cand nxt;
+        nxt.key = kNoKey;
+        nxt.px = nxt.py = nxt.pz = nxt.cx = nxt.cy = nxt.cz = 0.0f;
+        if (q0 + BLOCK < nq) fetch(q + BLOCK, nxt);
+        const uint32_t key = cur.key;
         const bool has = key != kNoKey;
         const int t = (int)(key & 0xFFFFu);
-        float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
-        bool ok = false;
-        if (WITH_RECORDS && has) {
-            px = pp[3 * q]; py = pp[3 * q + 1]; pz = pp[3 * q + 2];
-            cx_ = cp[3 * t]; cy_ = cp[3 * t + 1]; cz_ = cp[3 * t + 2];
-            ok = depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
-        }
-        // both ordered compactions (cross-check survivors; depth-valid ones among them) with one pair of barriers
+        const float px = cur.px, py = cur.py, pz = cur.pz, cx_ = cur.cx, cy_ = cur.cy, cz_ = cur.cz;
+        const bool ok = WITH_RECORDS && has && depth_ok(px, py, pz) && depth_ok(cx_, cy_, cz_);
+        // both ordered compactions (cross-check survivors; depth-valid ones among them) with one barrier
         int pos, total, vpos, vtotal;
-        block_scan_flags2<BLOCK>(has, ok, pos, total, vpos, vtotal, s_wsum);
+        block_scan_flags2_alt<BLOCK>(has, ok, pos, total, vpos, vtotal, s_wsum, trip);
         if (has) {
             PsDMatch m;
             m.queryIdx = q;
@@ -355,11 +438,12 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             vbase += vtotal;
         }
         base += total;
+        cur = nxt;
     }
     phase_stamp(stamps, 2); // matches compacted, records written
     if (WITH_RECORDS) {
-        float c = block_max<BLOCK>(cm, s_red);
-        float u = block_max<BLOCK>(um, s_red);
+        float c = cm, u = um;
+        block_max2<BLOCK>(c, u, s_red);
         if (threadIdx.x == 0) cmaxOut[p] = make_float2(c, u);
         if (threadIdx.x == 0) finish_pair_records(a, rec, p, vbase); // (block_max ends with a barrier: the records are visible)
         if (a.zeroCounts)
@@ -829,7 +913,7 @@ struct SelectArgs {
     const double *usacTab;   // non-increasing; usacTab[k] = smallest p with stopping(p) <= k+1
     int usacTabN;
     int trainRange;      // train indices are < trainRange (size of the uniqueness bitmaps, 0 = skip)
-    int stageCap;        // inlier correspondences staged in LDS for the refit (6 floats each)
+    int stageCap;        // inlier correspondences staged in LDS for the refit and the re-selection (8 words each)
 };
 
 // min(Kcap, computeRANSACIteration(r)) through the host-built threshold table (RANSAC.cpp:450-461).
@@ -906,7 +990,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         bailHost[1] = bailDev[1];
     }
     extern __shared__ __align__(16) uint32_t s_bits[]; // two bitmaps over train indices: 2 * ceil(trainRange/32) words
-    __shared__ int s_wsum[BLOCK / 64];
+    __shared__ int s_wsum[2 * (BLOCK / 64)];
     __shared__ unsigned long long s_red[BLOCK / 64];
     __shared__ int s_sel[4];
     __shared__ Rigid s_model;
@@ -915,7 +999,8 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
     const int p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int words = (a.trainRange + 31) >> 5;
-    float *s_stage = reinterpret_cast<float *>(s_bits + 2 * words); // [stageCap][6]: cur xyz (src), prev xyz (dst)
+    // [stageCap][8]: cur xyz (src), prev xyz (dst), the match's Euclidean bound, its index among the depth-valid matches
+    float *s_stage = reinterpret_cast<float *>(s_bits + ((2 * words + 3) & ~3));
     const int M = mvalid[p];
     const int nIn = numMatches[p];
     const size_t rbase = (size_t)p * a.cap;
@@ -931,10 +1016,19 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
     if (run) {
         if (a.estimator == PS_EST_FIXED) {
             unsigned long long key = 0ull;
-            for (int i = tid; i < a.H; i += BLOCK) {
-                unsigned long long kk = ((unsigned long long)(unsigned)cnts[i] << 32) | (0xFFFFFFFFu - (unsigned)i);
+            auto take = [&](int i, int c) {
+                unsigned long long kk = ((unsigned long long)(unsigned)c << 32) | (0xFFFFFFFFu - (unsigned)i);
                 key = kk > key ? kk : key;
+            };
+            int i = tid;
+            for (; i + 7 * BLOCK < a.H; i += 8 * BLOCK) { // eight loads in flight: the counts come from another launch (HBM latency)
+                int c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = cnts[i + u * BLOCK];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) take(i + u * BLOCK, c[u]);
             }
+            for (; i < a.H; i += BLOCK) take(i, cnts[i]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 unsigned long long other = __shfl_down(key, o, 64);
@@ -1006,11 +1100,26 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
         const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
         if (needInv) inverse_rigid_general(mdl, inv);
-        for (int i0 = 0; i0 < M; i0 += BLOCK) {
+        // the next trip's records are fetched before this trip's scan (they were written by another launch: HBM latency)
+        const bool needC = needInv;
+        float4 cA, cB, cC;
+        auto fetch = [&](int i, float4 &A, float4 &B, float4 &C) {
+            A = B = C = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i < M) {
+                A = recA[rbase + i];
+                B = recB[rbase + i];
+                if (needC) C = recC[rbase + i];
+            }
+        };
+        fetch(tid, cA, cB, cC);
+        int trip = 0;
+        for (int i0 = 0; i0 < M; i0 += BLOCK, ++trip) {
             const int i = i0 + tid;
+            float4 nA, nB, nC;
+            fetch(i + BLOCK, nA, nB, nC);
+            const float4 A = cA, B = cB, C = cC;
             bool in = false;
             if (i < M) {
-                float4 A = recA[rbase + i], B = recB[rbase + i], C = recC[rbase + i];
                 switch (a.mode) {
                 case PS_EUCLIDEAN_ERROR: in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, C); break;
                 case PS_ADAPTIVE_ERROR: in = inlier_test<PS_ADAPTIVE_ERROR>(mdl, inv, k, A, B, C); break;
@@ -1022,18 +1131,18 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
                 }
             }
             int total;
-            int pos = block_scan_flag<BLOCK>(in, total, s_wsum);
+            int pos = block_scan_flag_alt<BLOCK>(in, total, s_wsum, trip);
             if (in) {
                 const int slot = kin + pos;
                 list[slot] = i;
-                if (slot < a.stageCap) { // the refit's operands, parked in LDS while they are in registers anyway
-                    float4 A = recA[rbase + i], B = recB[rbase + i];
-                    float *d = s_stage + 6 * slot;
-                    d[0] = B.x; d[1] = B.y; d[2] = B.z;
-                    d[3] = A.x; d[4] = A.y; d[5] = A.z;
+                if (slot < a.stageCap) { // the refit's and the re-selection's operands, parked in LDS while they are in registers
+                    float *d = s_stage + 8 * slot;
+                    reinterpret_cast<float4 *>(d)[0] = make_float4(B.x, B.y, B.z, A.x);
+                    reinterpret_cast<float4 *>(d)[1] = make_float4(A.y, A.z, A.w, __int_as_float(i));
                 }
             }
             kin += total;
+            cA = nA; cB = nB; cC = nC;
         }
         __syncthreads(); // list / staged points visible to the whole workgroup
     }
@@ -1081,9 +1190,10 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             wave_umeyama(kin,
                          [&](int j, float (&s)[3], float (&d)[3]) {
                              if (j < a.stageCap) {
-                                 const float *q = s_stage + 6 * j;
-                                 s[0] = q[0]; s[1] = q[1]; s[2] = q[2];
-                                 d[0] = q[3]; d[1] = q[4]; d[2] = q[5];
+                                 const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
+                                 const float4 u = q[0], v = q[1];
+                                 s[0] = u.x; s[1] = u.y; s[2] = u.z;
+                                 d[0] = u.w; d[1] = v.x; d[2] = v.y;
                              } else {
                                  int i = list[j];
                                  float4 A = recA[rbase + i], B = recB[rbase + i];
@@ -1102,14 +1212,29 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             bool in = false;
             int i = 0;
             if (j < kin) {
-                i = list[j];
-                float4 A = recA[rbase + i], B = recB[rbase + i];
+                float4 A, B;
+                if (j < a.stageCap) { // parked by the inlier pass
+                    const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
+                    const float4 u = q[0], v = q[1];
+                    B = make_float4(u.x, u.y, u.z, 0.0f);
+                    A = make_float4(u.w, v.x, v.y, v.z);
+                    i = __float_as_int(v.w);
+                } else {
+                    i = list[j];
+                    A = recA[rbase + i];
+                    B = recB[rbase + i];
+                }
                 in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, A); // s < A.w : plain or adaptive bound
             }
-            int total;
-            block_scan_flag<BLOCK>(in, total, s_wsum);
             if (in && accepted) note_inlier(recD[rbase + i]);
-            nfinal += total;
+            nfinal += __popcll(__ballot(in));
+        }
+        { // (each wave counted its own: one exchange at the end instead of a scan per trip)
+            if (lane == 0) s_wsum[wv] = nfinal;
+            __syncthreads();
+            nfinal = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; ++w) nfinal += s_wsum[w];
         }
         if (!accepted) nfinal = 0; // identity + inliers cleared (RANSAC.cpp:161-164)
     } else if (run) {
@@ -1122,8 +1247,17 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         all_matches_pass(tid, BLOCK);
 
     phase_stamp(stamps, 8); // (3b) Euclidean re-selection, mask, (4) unique trainIdx among the final inliers
-    atomicAdd(&s_uniq[0], ua);
-    atomicAdd(&s_uniq[1], ui);
+    { // one LDS atomic per wave and tally (the compiler's own form walks the 64 lanes one by one)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ua += __shfl_down(ua, o, 64);
+            ui += __shfl_down(ui, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&s_uniq[0], ua);
+            atomicAdd(&s_uniq[1], ui);
+        }
+    }
     __syncthreads();
 
     if (tid == 0) {

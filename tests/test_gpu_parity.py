@@ -214,6 +214,23 @@ def test_ransac_edge_cases(ctx, oracle):
     c = oracle.ransac_rigid3d(prm, cfg, K, a["pts"], b["pts"], dup)
     _stats_equal(g["stats"], c["stats"])
     assert np.array_equal(g["mask"], c["mask"])
+    # (g) the widest current frame the unique-index bitmaps cover (65 536 rows: kernel 4's LDS is bitmaps + staged operands)
+    # and more inliers than it stages (the refit and the re-selection read the rest from the records)
+    a3, b3 = _pair(4000, 77)
+    m3 = oracle.match_hamming256(a3["desc"], b3["desc"])
+    where = np.sort(np.random.default_rng(12).choice(65536, len(b3["pts"]), replace=False))
+    where[-1] = 65535
+    wide = np.zeros((65536, 3), np.float32)
+    wide[where] = b3["pts"]
+    m3w = m3.copy()
+    m3w["trainIdx"] = where[m3["trainIdx"]]
+    for mode in (EUCLIDEAN_ERROR, REPROJECTION_ERROR):
+        prm3 = default_ransac_params(mode)
+        g = ctx.ransac_rigid3d(prm3, cfg, K, a3["pts"], wide, m3w)
+        c = oracle.ransac_rigid3d(prm3, cfg, K, a3["pts"], wide, m3w)
+        _stats_equal(g["stats"], c["stats"])
+        assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+        assert int(c["stats"]["numInliers"]) > 1536
 
 
 def test_explicit_sample_stream(ctx, oracle):
