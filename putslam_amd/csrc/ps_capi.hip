@@ -914,7 +914,9 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
     } else {
         constexpr int TPL = 2;
         const int tiles = (cap + kBlock * TPL - 1) / (kBlock * TPL);
-        int qsplit = pick_split((long long)P * tiles, 64, 16, cap); // single pair: 256 work-groups of >= 16 query rows
+        // single pair: 500 work-groups of 16 query rows (84.1 us per pair against 84.6 with 64 splits of 31 rows and 85.6
+        // with 250 of 8, profiles/r04g/ab_latency.txt)
+        int qsplit = pick_split((long long)P * tiles, 128, 16, cap);
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit;
         if (qsplit > 1) {
             int rc = keys_clean(ctx, keyBytes);

@@ -289,22 +289,26 @@ struct RecPtrs {
 };
 
 // Builds the records of depth-valid match number v of pair p; returns the largest |offset| of E.
+// `fixedBound` = sq_bound_f32(inlierThresholdEuclidean), the same for every match unless the mode is ADAPTIVE (the caller
+// computes it once: the exact squared-domain bound costs two or three square roots).
 PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int srcIdx, int q, int t, float px, float py,
-                         float pz, float cx_, float cy_, float cz_)
+                         float pz, float cx_, float cy_, float cz_, float fixedBound)
 {
     // Euclid rule of RANSAC.cpp:268-272: thr = inlierThresholdEuclidean (* prev.z in ADAPTIVE mode),
     // turned into its exact squared-domain bound.
-    double thr = a.thrE;
-    if (a.mode == PS_ADAPTIVE_ERROR) thr *= (double)pz;
-    float bound = sq_bound_f32(thr);
-    float ou, ov, nu, nv;
-    project(px, py, pz, a.fx, a.fy, a.cx, a.cy, ou, ov);    // realOld  (RANSAC.cpp:357-358)
-    project(cx_, cy_, cz_, a.fx, a.fy, a.cx, a.cy, nu, nv); // realNew  (RANSAC.cpp:352-353)
+    const float bound = a.mode == PS_ADAPTIVE_ERROR ? sq_bound_f32(a.thrE * (double)pz) : fixedBound;
     const size_t slot = (size_t)p * a.cap + (size_t)v;
     r.A[slot] = make_float4(px, py, pz, bound);
     r.B[slot] = make_float4(cx_, cy_, cz_, 1.0f);
-    r.C[slot] = make_float4(ou, ov, nu, nv);
     r.D[slot] = make_int4(srcIdx, q, t, 0);
+    // the projections (four divisions) are read by the reprojection metrics only
+    const bool euclidOnly = a.mode == PS_EUCLIDEAN_ERROR || a.mode == PS_ADAPTIVE_ERROR;
+    float ou = 0.0f, ov = 0.0f, nu = 0.0f, nv = 0.0f;
+    if (!euclidOnly) {
+        project(px, py, pz, a.fx, a.fy, a.cx, a.cy, ou, ov);    // realOld  (RANSAC.cpp:357-358)
+        project(cx_, cy_, cz_, a.fx, a.fy, a.cx, a.cy, nu, nv); // realNew  (RANSAC.cpp:352-353)
+        r.C[slot] = make_float4(ou, ov, nu, nv);
+    }
     if (r.G != nullptr) {
         // Euclidean metrics: the pair-interleaved operands of ps_ransac_score_euclid; errorVersion 4 normalises the match
         // by its own depth (the adaptive threshold thr * prev.z becomes the constant thr, ps_score_euclid.h)
@@ -321,6 +325,7 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
         }
         return 0.0f;
     }
+    if (euclidOnly) return 0.0f;
     // offsets of the decision-exact scoring paths (ps_score_fast.h): predicted - real = quotient + (c - real)
     // (laid out as the two v_pk_fma_f32 operand pairs: u offsets of both directions, then v offsets)
     const float4 e = make_float4(a.cx - ou, a.cx - nu, a.cy - ov, a.cy - nv);
@@ -372,12 +377,16 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
     const int cap = a.cap;
     const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
     const int nq = nkpts[fq], nt = nkpts[ft];
+    // (the thread's first two keys are on their way while best[] is initialised: they come from the matcher's launch)
+    uint32_t k0 = kNoKey, k1 = kNoKey;
+    if ((int)threadIdx.x < nt) k0 = keys[(size_t)p * cap + threadIdx.x];
+    if ((int)threadIdx.x + BLOCK < nt) k1 = keys[(size_t)p * cap + threadIdx.x + BLOCK];
     for (int q = threadIdx.x; q < nq; q += BLOCK) s_best[q] = kNoKey;
     __syncthreads();
     // step 2 of the cross-check: query q keeps the closest train row among those that chose it,
     // ties to the lowest train index (strict '<' while scanning t ascending).
     for (int t = threadIdx.x; t < nt; t += BLOCK) {
-        uint32_t key = keys[(size_t)p * cap + t];
+        uint32_t key = t < BLOCK ? k0 : (t < 2 * BLOCK ? k1 : keys[(size_t)p * cap + t]);
         if (key != kNoKey) {
             uint32_t q = key & 0xFFFFu, d = key >> 16;
             atomicMin(&s_best[q], (d << 16) | (uint32_t)t);
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
             c.cx = cp[3 * t]; c.cy = cp[3 * t + 1]; c.cz = cp[3 * t + 2];
         }
     };
+    const float fixedBound = (WITH_RECORDS && a.mode != PS_ADAPTIVE_ERROR) ? sq_bound_f32(a.thrE) : 0.0f;
     Cand cur;
     fetch((int)threadIdx.x, cur);
     int trip = 0;
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
         }
         if (WITH_RECORDS) {
             if (ok) {
-                um = fmaxf(um, write_records(a, rec, p, vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_));
+                um = fmaxf(um, write_records(a, rec, p, vbase + vpos, base + pos, q, t, px, py, pz, cx_, cy_, cz_, fixedBound));
                 cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
             }
             vbase += vtotal;
@@ -471,6 +481,7 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
     __shared__ float s_red[kBlock / 64];
     float cm = 0.0f, um = 0.0f;
     int vbase = 0;
+    const float fixedBound = a.mode != PS_ADAPTIVE_ERROR ? sq_bound_f32(a.thrE) : 0.0f;
     for (int i0 = 0; i0 < m; i0 += kBlock) {
         const int i = i0 + threadIdx.x;
         float px = 0, py = 0, pz = 0, cx_ = 0, cy_ = 0, cz_ = 0;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void ps_prep_from_matches(const float *__re
         int vtotal;
         int vpos = block_scan_flag(ok, vtotal, s_wsum);
         if (ok) {
-            um = fmaxf(um, write_records(a, rec, 0, vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_));
+            um = fmaxf(um, write_records(a, rec, 0, vbase + vpos, i, q, t, px, py, pz, cx_, cy_, cz_, fixedBound));
             cm = fmaxf(cm, fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), fmaxf(fabsf(cx_), fmaxf(fabsf(cy_), fabsf(cz_))))));
         }
         vbase += vtotal;
@@ -850,11 +861,25 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
 // 64 strided partials (lane l takes elements l, l+64, ...) and a stride-1,2,4,..,32 tree.
 // getter(j, src[3], dst[3]) yields the j-th correspondence.  All 64 lanes return the model.
 // ------------------------------------------------------------------------------------------
+// (the strides 1 .. 8 stay inside a row of 16 lanes: DPP row shifts, no trip through the LDS crossbar; the partial sums the
+// result depends on -- lanes that are multiples of twice the stride -- read what __shfl_down would hand them; strides 16 and
+// 32 combine the four row sums, read as scalars: (r0 + r16) + (r32 + r48), the tree's own association)
 PS_D float wave_tree_sum(float v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_down(v, o, 64);
-    return __shfl(v, 0, 64);
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, false));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102, 0xF, 0xF, false));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, false));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, false));
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r32 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r48 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r16) + (r32 + r48);
+#else
+    return v;
+#endif
 }
 
 template <typename Getter> PS_D bool wave_umeyama(int k, Getter get, Rigid &mdl)
@@ -1012,6 +1037,20 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
 
     const bool run = !(M < a.minMatches || M < 3);
     int bestIdx = -1, bestCount = 0, trips = 0;
+    // The inlier pass' first records do not depend on the selection: their loads (written by another launch: HBM latency)
+    // are in flight while the schedule is replayed; every later trip fetches the next one's before its scan.
+    const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
+    const bool needC = needInv;
+    float4 cA, cB, cC;
+    auto fetch = [&](int i, float4 &A, float4 &B, float4 &C) {
+        A = B = C = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < M) {
+            A = recA[rbase + i];
+            B = recB[rbase + i];
+            if (needC) C = recC[rbase + i];
+        }
+    };
+    if (run) fetch(tid, cA, cB, cC);
 
     if (run) {
         if (a.estimator == PS_EST_FIXED) {
@@ -1045,6 +1084,49 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
                 s_sel[2] = a.H;
             }
             __syncthreads();
+        } else if (a.estimator == PS_EST_RANSAC && a.H <= 8 * 64 && a.ransacTabN <= 8 * 64) {
+            // The reference's own regime (at most 487 iterations): every wavefront replays the schedule by itself, counts and
+            // stop table in registers (eight of each per lane, index = 64 u + lane), a round = eight ballots and scalar code.
+            // No barrier, no table search through memory: the work-group form below spends 0.8 us per record on its
+            // dependent table loads alone (3.9 of the single pair's 91 us, profiles/r04g).
+            int c[8];
+            float tb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = u * 64 + lane;
+                c[u] = idx < a.H ? cnts[idx] : 0;
+                tb[u] = idx < a.ransacTabN ? a.ransacTab[idx] : 0.0f;
+            }
+            int pos = 0, limit = a.iter0, best = 0, bIdx = -1;
+            for (;;) {
+                int fIdx = -1, fCnt = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = u * 64 + lane;
+                    const unsigned long long mk = __ballot(idx >= pos && idx < limit && c[u] > best);
+                    if (fIdx < 0 && mk != 0ull) { // the first index in [pos, limit) that beats the best
+                        const int l = __ffsll((long long)mk) - 1;
+                        fIdx = u * 64 + l;
+                        fCnt = __builtin_amdgcn_readlane(c[u], l);
+                    }
+                }
+                if (fIdx < 0) break;
+                bIdx = fIdx;
+                best = fCnt;
+                pos = bIdx + 1;
+                const float r = (float)best / (float)M; // ratio as RANSAC.cpp:280
+                // ransac_limit(): the first k with r >= tab[k] of a non-increasing table = the number of k with r < tab[k]
+                int lim = 0;
+                if (!(r <= a.ransacTiny)) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        lim += __popcll(__ballot(u * 64 + lane < a.ransacTabN && r < tb[u]));
+                }
+                limit = lim;
+            }
+            bestIdx = bIdx;
+            bestCount = best;
+            trips = (bIdx + 1 > limit) ? bIdx + 1 : limit;
         } else {
             // Sequential replay.  State changes only at "records" (count > best so far), so the
             // workgroup repeatedly finds the first index in [pos, limit) that beats the best.
@@ -1082,9 +1164,11 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             }
             __syncthreads();
         }
-        bestIdx = s_sel[0];
-        bestCount = s_sel[1];
-        trips = s_sel[2];
+        if (!(a.estimator == PS_EST_RANSAC && a.H <= 8 * 64 && a.ransacTabN <= 8 * 64)) {
+            bestIdx = s_sel[0];
+            bestCount = s_sel[1];
+            trips = s_sel[2];
+        }
     }
 
     phase_stamp(stamps, 5); // (1) selection replayed
@@ -1098,20 +1182,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
             load_model(ma, (size_t)p * a.H + bestIdx, mdl); // parked by kernel 3 (an invalid sample parks the identity)
         else
             gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
-        const bool needInv = (a.mode == PS_REPROJECTION_ERROR || a.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR);
         if (needInv) inverse_rigid_general(mdl, inv);
-        // the next trip's records are fetched before this trip's scan (they were written by another launch: HBM latency)
-        const bool needC = needInv;
-        float4 cA, cB, cC;
-        auto fetch = [&](int i, float4 &A, float4 &B, float4 &C) {
-            A = B = C = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (i < M) {
-                A = recA[rbase + i];
-                B = recB[rbase + i];
-                if (needC) C = recC[rbase + i];
-            }
-        };
-        fetch(tid, cA, cB, cC);
         int trip = 0;
         for (int i0 = 0; i0 < M; i0 += BLOCK, ++trip) {
             const int i = i0 + tid;

@@ -155,6 +155,21 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     // a wavefront without a hypothesis of its own (ps_score_fast.h; not in a pass with a split match range: barrier to come)
     if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return;
 
+    // A launch with a split match range is a small one (a handful of pairs): one wavefront per SIMD, nothing hides a load.
+    // The pair's bound and this work-group's records were written by the previous launch (HBM latency, 2 x 1.5 us exposed
+    // behind the sample -> SVD chain): their lines are requested here, in front of the chain -- the bound itself, and one
+    // dword of every 64-byte line of the record range (a vector load: 64 lines per instruction), whose only use is to be
+    // waited for behind the chain.
+    const float cmaxEarly = (KIND == 0) ? pairBound[p].x : 0.0f;
+    float warm = 0.0f;
+    if (KIND == 0 && msplit > 1) {
+        const float *w0 = reinterpret_cast<const float *>(recG + (size_t)p * ((size_t)((cap + 1) >> 1) * (RF / 2))) +
+                          (size_t)(m0 >> 1) * RF;
+        const int words = ((m1 - m0 + 1) >> 1) * RF;
+        const int at = tid * 16; // (the work-group's 256 lanes cover 16 KiB; a split range is far shorter)
+        if (at < words) warm = w0[at];
+    }
+
     Rigid mdl, inv;
     set_identity(mdl);
     set_identity(inv);
@@ -192,7 +207,8 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     const float4 *__restrict__ pa = recA + rbase;
     const float4 *__restrict__ pb = recB + rbase;
     const float2 *__restrict__ pg = recG + (size_t)p * ((size_t)((cap + 1) >> 1) * (RF / 2));
-    const float cmax = pairBound[p].x;
+    const float cmax = (KIND == 0) ? cmaxEarly : pairBound[p].x;
+    asm volatile("" ::"v"(warm)); // (the warm-up load's destination stays allocated until here)
     // position of the hot record -> match of the original record arrays (stages after ps_stage_reorder; the cold paths)
     const int32_t *__restrict__ pperm = (pruned && st.perm != nullptr) ? st.perm + rbase : nullptr;
     auto orig = [&](int m) { return pperm != nullptr ? pperm[m] : m; };
