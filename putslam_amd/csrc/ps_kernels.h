@@ -882,18 +882,36 @@ PS_D float wave_tree_sum(float v)
 #endif
 }
 
-template <typename Getter> PS_D bool wave_umeyama(int k, Getter get, Rigid &mdl)
+// The correspondences come from two places: j < split through getA (kernel 4: operands parked in LDS), the rest through getB
+// (global memory).  Two loops, not one getter with a branch inside: the compiler merged the branch's two sources into generic
+// pointers and FLAT loads (four per trip, waited for together: 350 cycles a trip) -- and, before that, into arrays in scratch
+// memory (600 cycles a trip; the two passes were 8 of kernel 4's 26 us for a single pair).  A getter yields
+// u = (src.x, src.y, src.z, dst.x), v = (dst.y, dst.z, -, -).  The LDS loop requests the lane's next element before it adds
+// the current one; each lane still adds its elements in ascending order.
+template <typename GetA, typename GetB> PS_D bool wave_umeyama(int k, int split, GetA getA, GetB getB, Rigid &mdl)
 {
     const int lane = threadIdx.x & 63;
     const float one_over_n = 1.0f / (float)k;
+    const int k1 = k < split ? k : split;
+    // the lane's first element behind the split: the smallest j = lane (mod 64) with j >= k1
+    const int jB = lane + (((k1 > lane ? k1 - lane : 0) + 63) >> 6 << 6);
     float ss[3] = {0.0f, 0.0f, 0.0f}, ds[3] = {0.0f, 0.0f, 0.0f};
-    for (int j = lane; j < k; j += 64) {
-        float s[3], d[3];
-        get(j, s, d);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            ss[c] = ss[c] + s[c];
-            ds[c] = ds[c] + d[c];
+    auto add1 = [&](const float4 &u, const float4 &v) {
+        ss[0] = ss[0] + u.x; ss[1] = ss[1] + u.y; ss[2] = ss[2] + u.z;
+        ds[0] = ds[0] + u.w; ds[1] = ds[1] + v.x; ds[2] = ds[2] + v.y;
+    };
+    {
+        float4 u, v, un, vn;
+        if (lane < k1) getA(lane, u, v);
+        for (int j = lane; j < k1; j += 64) {
+            if (j + 64 < k1) getA(j + 64, un, vn);
+            add1(u, v);
+            u = un;
+            v = vn;
+        }
+        for (int j = jB; j < k; j += 64) {
+            getB(j, u, v);
+            add1(u, v);
         }
     }
     float sm[3], dm[3];
@@ -907,13 +925,26 @@ template <typename Getter> PS_D bool wave_umeyama(int k, Getter get, Rigid &mdl)
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[r][c] = 0.0f;
-    for (int j = lane; j < k; j += 64) {
-        float s[3], d[3];
-        get(j, s, d);
+    auto add2 = [&](const float4 &u, const float4 &v) {
+        const float s[3] = {u.x, u.y, u.z}, d[3] = {u.w, v.x, v.y};
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[r][c] = acc[r][c] + (d[r] - dm[r]) * (s[c] - sm[c]);
+    };
+    {
+        float4 u, v, un, vn;
+        if (lane < k1) getA(lane, u, v);
+        for (int j = lane; j < k1; j += 64) {
+            if (j + 64 < k1) getA(j + 64, un, vn);
+            add2(u, v);
+            u = un;
+            v = vn;
+        }
+        for (int j = jB; j < k; j += 64) {
+            getB(j, u, v);
+            add2(u, v);
+        }
     }
     float sigma[3][3];
 #pragma unroll
@@ -1258,19 +1289,17 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         if (wv != 0) all_matches_pass(tid - 64, BLOCK - 64);
         if (wv == 0) {
             Rigid ref;
-            wave_umeyama(kin,
-                         [&](int j, float (&s)[3], float (&d)[3]) {
-                             if (j < a.stageCap) {
-                                 const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
-                                 const float4 u = q[0], v = q[1];
-                                 s[0] = u.x; s[1] = u.y; s[2] = u.z;
-                                 d[0] = u.w; d[1] = v.x; d[2] = v.y;
-                             } else {
-                                 int i = list[j];
-                                 float4 A = recA[rbase + i], B = recB[rbase + i];
-                                 d[0] = A.x; d[1] = A.y; d[2] = A.z;
-                                 s[0] = B.x; s[1] = B.y; s[2] = B.z;
-                             }
+            wave_umeyama(kin, a.stageCap,
+                         [&](int j, float4 &u, float4 &v) { // parked by the inlier pass
+                             const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
+                             u = q[0];
+                             v = q[1];
+                         },
+                         [&](int j, float4 &u, float4 &v) { // more inliers than the LDS holds: from the records
+                             const int i = list[j];
+                             const float4 A = recA[rbase + i], B = recB[rbase + i];
+                             u = make_float4(B.x, B.y, B.z, A.x);
+                             v = make_float4(A.y, A.z, 0.0f, 0.0f);
                          },
                          ref);
             if (lane == 0) s_model = ref;
@@ -1278,29 +1307,26 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         __syncthreads();
         phase_stamp(stamps, 7); // (3a) refit: wave-level Umeyama + Jacobi SVD
         mdl = s_model;
-        for (int j0 = 0; j0 < kin; j0 += BLOCK) {
-            const int j = j0 + tid;
-            bool in = false;
-            int i = 0;
-            if (j < kin) {
-                float4 A, B;
-                if (j < a.stageCap) { // parked by the inlier pass
-                    const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
-                    const float4 u = q[0], v = q[1];
-                    B = make_float4(u.x, u.y, u.z, 0.0f);
-                    A = make_float4(u.w, v.x, v.y, v.z);
-                    i = __float_as_int(v.w);
-                } else {
-                    i = list[j];
-                    A = recA[rbase + i];
-                    B = recB[rbase + i];
-                }
-                in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, A); // s < A.w : plain or adaptive bound
-            }
+        // (two loops, one per source of the operands: a branch inside one loop was compiled into generic pointers and FLAT
+        // loads; the order of the matches does not matter here)
+        auto reselect = [&](const float4 &A, const float4 &B, int i) {
+            const bool in = inlier_test<PS_EUCLIDEAN_ERROR>(mdl, inv, k, A, B, A); // s < A.w : plain or adaptive bound
             if (in && accepted) note_inlier(recD[rbase + i]);
-            nfinal += __popcll(__ballot(in));
+            nfinal += in ? 1 : 0;
+        };
+        const int kLds = kin < a.stageCap ? kin : a.stageCap;
+        for (int j = tid; j < kLds; j += BLOCK) { // parked by the inlier pass
+            const float4 *q = reinterpret_cast<const float4 *>(s_stage + 8 * j);
+            const float4 u = q[0], v = q[1];
+            reselect(make_float4(u.w, v.x, v.y, v.z), make_float4(u.x, u.y, u.z, 0.0f), __float_as_int(v.w));
         }
-        { // (each wave counted its own: one exchange at the end instead of a scan per trip)
+        for (int j = a.stageCap + tid; j < kin; j += BLOCK) {
+            const int i = list[j];
+            reselect(recA[rbase + i], recB[rbase + i], i);
+        }
+        { // (each lane counted its own: one exchange at the end instead of a scan per trip)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nfinal += __shfl_down(nfinal, o, 64);
             if (lane == 0) s_wsum[wv] = nfinal;
             __syncthreads();
             nfinal = 0;
@@ -1520,12 +1546,11 @@ __global__ __launch_bounds__(64) void ps_umeyama_sets(const float *__restrict__ 
     const float *sp = src + (size_t)s * k * 3;
     const float *dp = dst + (size_t)s * k * 3;
     Rigid m;
-    bool ok = wave_umeyama(k,
-                           [&](int j, float (&sv)[3], float (&dv)[3]) {
-                               sv[0] = sp[3 * j]; sv[1] = sp[3 * j + 1]; sv[2] = sp[3 * j + 2];
-                               dv[0] = dp[3 * j]; dv[1] = dp[3 * j + 1]; dv[2] = dp[3 * j + 2];
-                           },
-                           m);
+    auto get = [&](int j, float4 &u, float4 &v) {
+        u = make_float4(sp[3 * j], sp[3 * j + 1], sp[3 * j + 2], dp[3 * j]);
+        v = make_float4(dp[3 * j + 1], dp[3 * j + 2], 0.0f, 0.0f);
+    };
+    bool ok = wave_umeyama(k, 0, get, get, m);
     if ((threadIdx.x & 63) == 0) {
         store_pose(T + (size_t)s * 16, m);
         valid[s] = ok ? 1 : 0;
