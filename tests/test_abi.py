@@ -96,3 +96,34 @@ def test_dropin_library_defines_no_reference_matcher_symbols():
     assert any(n.startswith("putslam_hip::FrameMatcherHIP::performMatching") for n in names)
     assert any(n.startswith("RANSAC::estimateTransformation") for n in names)
     assert any(n.startswith("putslam::createKabschEstimator") for n in names)
+
+
+def test_device_code_has_no_scratch_or_flat_instructions(tmp_path):
+    """Every kernel keeps its data in registers, LDS or global memory reached through global / scalar loads.  hipcc has twice
+    turned a harmless-looking source pattern (a branch that picks between an LDS stage and a global array inside a loop) into
+    arrays in scratch memory and into generic pointers with FLAT loads -- 600 and 350 cycles a trip, 8 us of a 26-us kernel
+    (DESIGN.md section 5, round 4).  The code object of the built library is disassembled and searched for both."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = os.path.join(ROOT, "putslam_amd", "libputslam_hip.so")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib, str(tmp_path / "copy.so")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    asm = subprocess.check_output([tools[2], "-d", co], text=True)
+    kernel, bad, kernels = None, [], 0
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            kernel = m.group(1)
+            kernels += 1
+            continue
+        ins = line.split()
+        if ins and re.match(r"^(scratch_|flat_)", ins[0]):
+            bad.append((kernel, ins[0]))
+    assert kernels >= 30, "disassembly found no kernels"
+    assert not bad, sorted(set(bad))[:10]
