@@ -35,8 +35,10 @@ def run(iters, seed, max_kpts=1500, ctx=None, verbose=True, modes=(0, 1, 2, 4, 3
         noise = float(10 ** rng.uniform(-4, -1.3))
         pa, pb = synth.make_pair(n, config=7, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)
         mode = int(rng.choice(list(modes)))
-        est, H = [(EST_RANSAC, 1157), (EST_USAC, int(rng.integers(50, 3000))), (EST_FIXED, int(rng.integers(1, 3000)))][
-            int(rng.integers(0, 3))]
+        # (RANSAC: the reference's 1157 -- the schedule never needs more than 574 with the default ratios -- or a cap of at most
+        # 520: kernel 4 replays schedules of up to 512 iterations per wavefront out of registers, longer ones as a work-group)
+        est, H = [(EST_RANSAC, [1157, 487, int(rng.integers(1, 520))][int(rng.integers(0, 3))]),
+                  (EST_USAC, int(rng.integers(50, 3000))), (EST_FIXED, int(rng.integers(1, 3000)))][int(rng.integers(0, 3))]
         prm = default_ransac_params(mode, lc=bool(rng.integers(0, 2)))
         prm.inlierThresholdEuclidean = float(10 ** rng.uniform(-3, -0.5))
         prm.inlierThresholdReprojection = float(10 ** rng.uniform(-1, 1.5))
