@@ -972,16 +972,32 @@ struct SelectArgs {
     int stageCap;        // inlier correspondences staged in LDS for the refit and the re-selection (8 words each)
 };
 
+// First k of [0, n) with !(x < tab[k]) -- n if there is none -- for a non-increasing table, found by the whole wavefront: every
+// lane probes one of 64 evenly spaced entries and the ballot narrows the range 64-fold per step (850 000 entries: four
+// dependent loads instead of a binary search's twenty, 0.5 us each from a cold table).  Wave-uniform arguments and result.
+template <typename T> PS_D int table_first_not_below(const T *__restrict__ tab, int n, T x)
+{
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int kq = lo + lane * step;
+        const bool valid = kq < hi;
+        const bool below = valid && (x < tab[valid ? kq : lo]);
+        const int t = __popcll(__ballot(below));     // the probes that are still "below" form a prefix of the lanes
+        const int nvalid = __popcll(__ballot(valid));
+        const int nlo = t > 0 ? lo + (t - 1) * step + 1 : lo;
+        const int nhi = t < nvalid ? lo + t * step : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
 // min(Kcap, computeRANSACIteration(r)) through the host-built threshold table (RANSAC.cpp:450-461).
 PS_D int ransac_limit(const SelectArgs &a, float r)
 {
     if (r <= a.ransacTiny) return 0;
-    int lo = 0, hi = a.ransacTabN; // first k with r >= tab[k]
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (r < a.ransacTab[mid]) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    return table_first_not_below<float>(a.ransacTab, a.ransacTabN, r); // first k with r >= tab[k]
 }
 // min(H, updateStandardStopping(inliers, M, 3)) through the host-built table (USAC.h:944-971).
 PS_D int usac_limit(const SelectArgs &a, unsigned c, unsigned M)
@@ -993,11 +1009,7 @@ PS_D int usac_limit(const SelectArgs &a, unsigned c, unsigned M)
         n_pts *= (double)(unsigned)(M - i);
     }
     double pgood = n_in / n_pts;
-    int lo = 0, hi = a.usacTabN;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (pgood < a.usacTab[mid]) lo = mid + 1; else hi = mid;
-    }
+    const int lo = table_first_not_below<double>(a.usacTab, a.usacTabN, pgood);
     int stop = lo + 1;
     return stop < a.H ? stop : a.H;
 }
@@ -1161,24 +1173,43 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         } else {
             // Sequential replay.  State changes only at "records" (count > best so far), so the
             // workgroup repeatedly finds the first index in [pos, limit) that beats the best.
+            // The range is searched in windows that double (2 Ki, 4 Ki, ... indices; eight loads of a thread in flight): the
+            // first record lies a few indices behind `pos` as a rule, and a thread that had no hit of its own used to walk the
+            // whole range alone, one dependent load at a time -- under USAC's initial limit of 850 000 that was 480 us for a
+            // single pair (profiles/r04g/single_pair_schedules.txt).  A window never reaches beyond `limit`: the same indices
+            // are read as before (counts beyond the trip limit may be stale under the staged scoring).
             int pos = 0, limit = a.iter0, best = 0, bIdx = -1;
             for (;;) {
-                unsigned found = 0xFFFFFFFFu;
-                for (int i = pos + tid; i < limit; i += BLOCK)
-                    if (cnts[i] > best) {
-                        found = (unsigned)i;
-                        break;
+                unsigned f = 0xFFFFFFFFu;
+                int span = 8 * BLOCK;
+                for (int w0 = pos; w0 < limit;) {
+                    const int w1 = (limit - w0 > span) ? w0 + span : limit;
+                    unsigned found = 0xFFFFFFFFu;
+                    for (int i0 = w0 + tid; i0 < w1 && found == 0xFFFFFFFFu; i0 += 8 * BLOCK) {
+                        int c[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * BLOCK;
+                            c[u] = i < w1 ? cnts[i] : (int)0x80000000;
+                        }
+#pragma unroll
+                        for (int u = 7; u >= 0; --u)
+                            if (c[u] > best) found = (unsigned)(i0 + u * BLOCK); // (descending: the smallest index stays)
                     }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    unsigned other = __shfl_down(found, o, 64);
-                    found = other < found ? other : found;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        unsigned other = __shfl_down(found, o, 64);
+                        found = other < found ? other : found;
+                    }
+                    if (lane == 0) s_red[wv] = found;
+                    __syncthreads();
+                    f = (unsigned)s_red[0];
+                    for (int i = 1; i < BLOCK / 64; ++i) f = (unsigned)s_red[i] < f ? (unsigned)s_red[i] : f;
+                    __syncthreads();
+                    if (f != 0xFFFFFFFFu) break;
+                    w0 = w1;
+                    if (span < 512 * BLOCK) span *= 2;
                 }
-                if (lane == 0) s_red[wv] = found;
-                __syncthreads();
-                unsigned f = (unsigned)s_red[0];
-                for (int i = 1; i < BLOCK / 64; ++i) f = (unsigned)s_red[i] < f ? (unsigned)s_red[i] : f;
-                __syncthreads();
                 if (f == 0xFFFFFFFFu) break;
                 bIdx = (int)f;
                 best = cnts[bIdx];
@@ -1959,12 +1990,21 @@ __global__ __launch_bounds__(kBlock) void ps_mathcheck(int mode, uint64_t seed, 
 
 // Diagnostic: tabulates the device-side trip limits so tests can compare them with the direct
 // libm evaluation (RANSAC.cpp:457-461, USAC.h:944-971) for every (count, M).
+// (the limit functions search their table as a wavefront with uniform arguments, as the replays call them: the wave takes
+// its 64 counts one after the other)
 __global__ void ps_limits_table(SelectArgs a, int M, int32_t *__restrict__ out)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (c > M) return;
-    out[c - 1] = (a.estimator == PS_EST_USAC) ? usac_limit(a, (unsigned)c, (unsigned)M)
-                                              : ransac_limit(a, (float)c / (float)M);
+    const int c0 = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) + 1; // the wave's first count
+    const int lane = threadIdx.x & 63;
+    int mine = 0;
+    for (int j = 0; j < 64; ++j) {
+        const int c = c0 + j;
+        if (c > M) break; // (uniform)
+        const int lim = (a.estimator == PS_EST_USAC) ? usac_limit(a, (unsigned)c, (unsigned)M)
+                                                     : ransac_limit(a, (float)c / (float)M);
+        if (lane == j) mine = lim;
+    }
+    if (c0 + lane <= M) out[c0 + lane - 1] = mine;
 }
 
 } // namespace psdev

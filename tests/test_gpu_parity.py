@@ -233,6 +233,25 @@ def test_ransac_edge_cases(ctx, oracle):
         assert int(c["stats"]["numInliers"]) > 1536
 
 
+def test_long_usac_schedule_on_junk_data(ctx, oracle):
+    """USAC with a cap in the hundreds of thousands on data without a model: the trip limit stays at the cap, kernel 4's
+    work-group replay walks the whole range of counts -- through all of its doubling search windows, with records far apart --
+    and the stop table (one entry per hypothesis) is searched 64-ary by the wavefront.  Outputs and the limits equal the
+    oracle's (USAC.h:326,409-414,498-509,944-971)."""
+    rng = np.random.default_rng(31)
+    a, b = _pair(90, 5)
+    m = oracle.match_hamming256(a["desc"], b["desc"])
+    junk = (rng.uniform(-1, 1, b["pts"].shape) + [0, 0, 3]).astype(np.float32)
+    for mode, H in ((EUCLIDEAN_ERROR, 300000), (REPROJECTION_ERROR, 120000)):
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(EST_USAC, H, seed=77)
+        g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], junk, m)
+        c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], junk, m)
+        _stats_equal(g["stats"], c["stats"])
+        assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+        assert int(c["stats"]["iterationsRun"]) > 20000  # the schedule did run long
+
+
 def test_explicit_sample_stream(ctx, oracle):
     a, b = _pair(400, 21)
     m = oracle.match_hamming256(a["desc"], b["desc"])
