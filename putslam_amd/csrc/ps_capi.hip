@@ -264,9 +264,19 @@ void build_usac_table(int H, std::vector<double> &tab)
     double oned = 1.0;
     memcpy(&oneb, &oned, 8);
     uint64_t hiPrev = oneb;
+    // The bisection runs where the rule is monotone.  Below p = 1.07e-9 the quotient exceeds 2^32 and the reference's
+    // (unsigned) cast is undefined (x86 keeps the low 32 bits: pseudo-random in p); a probe in that region that happens to
+    // land below the target sent the bisection to the region's edge and every later entry with it -- rounds 1 to 4 built
+    // tables that were right up to entry 78 774 only, so that schedules that should run longer (fewer than 4 % inliers)
+    // stopped there.  From 2^-29 = 1.86e-9 up the quotient is below 2.5e9: every target (< 850 000) lies above it.
+    // Good-model probabilities below 1.07e-9 (three or four inliers among more than 1777 / 2820 matches) get the cap,
+    // where the reference's cast is undefined and the oracle returns what x86 makes of it.
+    const double pFloor = 1.862645149230957e-09; // 2^-29
+    uint64_t floorb;
+    memcpy(&floorb, &pFloor, 8);
     for (int k = 0; k < n; ++k) {
         unsigned target = (unsigned)k + 1u; // smallest p with stopping(p) <= k+1
-        uint64_t lo = 0, hi = hiPrev;       // stopping(0.0) = maxHyp > target (target < maxHyp here... see below)
+        uint64_t lo = floorb, hi = hiPrev;  // stopping(2^-29) = 2.47e9 > target
         if (target >= kUsacMaxHyp) {
             tab[(size_t)k] = 0.0;
             continue;

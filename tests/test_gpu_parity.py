@@ -316,6 +316,18 @@ def test_usac_limit_table(ctx, oracle):
         assert np.array_equal(dev, ref), (M, np.nonzero(dev != ref)[0][:5])
 
 
+@pytest.mark.parametrize("H", [120000, 850000])
+def test_usac_limit_table_long_schedules(ctx, oracle, H):
+    """The stop table has one entry per hypothesis: with the reference's cap of 850 000 the device's limits equal
+    updateStandardStopping for every inlier count (USAC.h:944-971), also where the schedule runs for hundreds of thousands of
+    iterations (fewer than 4 % inliers).  M stays below 1777: beyond it three inliers make the good-model probability so
+    small that the reference's (unsigned) cast of the quotient is undefined."""
+    for M in (59, 400, 1000, 1700):
+        dev = ctx.debug_limits(EST_USAC, 0.2, H, M)
+        ref = np.array([min(H, oracle.usac_stopping(c, M, 3)) for c in range(1, M + 1)], np.int64)
+        assert np.array_equal(dev, ref), (M, [(int(i) + 1, int(dev[i]), int(ref[i])) for i in np.nonzero(dev != ref)[0][:5]])
+
+
 # ---------------------------------------------------------------- A10 Kabsch (double)
 @pytest.mark.parametrize("n", [3, 100, 500, 4097, 16384, 16385, 100003, 5000000])  # > 16384: multi-wave reduction
 def test_kabsch_f64(ctx, oracle, n):
