@@ -64,7 +64,12 @@ def main():
             pre = [valu(t) for _, t in bl if "v_addc_co_u32" not in t and t.count("v_pk_") >= 12 and "ds_" not in t]
             e = {"unit": "(hypothesis, match) evaluation per wave"}
             if evals:
-                e.update(summary(evals[0]))
+                # a block holds one evaluation per add-with-carry (the hot loop takes a whole PAIR of matches per trip)
+                per_block = max(1, evals[0]["v_addc_co_u32"])
+                sm = summary(evals[0])
+                e.update({"valu": sm["valu"] / per_block, "packed": sm["packed"] / per_block,
+                          "mix": {k: v / per_block for k, v in sm["mix"].items()}})
+                e["evaluations_per_block"] = per_block
                 e["evaluation_blocks"] = len(evals)
             if pre and kind == 1:
                 e["pretest"] = dict(summary(pre[0]), unit="TWO matches, one direction, per wave")

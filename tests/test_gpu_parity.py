@@ -308,6 +308,20 @@ def test_ransac_limit_table(ctx, oracle, min_ratio):
         assert np.array_equal(dev, ref), (M, np.nonzero(dev != ref)[0][:5])
 
 
+def test_ransac_limit_table_long_schedules(ctx, oracle):
+    """minimalInlierRatioThreshold = 0.05 lets the RANSAC schedule run for 36 840 iterations: the stop table then has that
+    many entries (the reference's default ratios never need more than 574).  Every (count, M) against computeRANSACIteration
+    (RANSAC.cpp:450-461)."""
+    H, min_ratio = 50000, 0.05
+    a = oracle.ransac_iterations(min_ratio)
+    assert a > 30000
+    for M in (59, 1200, 4999):
+        dev = ctx.debug_limits(EST_RANSAC, min_ratio, H, M)
+        ref = np.array([min(H, a, oracle.ransac_iterations(float(np.float32(c) / np.float32(M))))
+                        for c in range(1, M + 1)], np.int32)
+        assert np.array_equal(dev, ref), (M, [(int(i) + 1, int(dev[i]), int(ref[i])) for i in np.nonzero(dev != ref)[0][:5]])
+
+
 def test_usac_limit_table(ctx, oracle):
     H = 5000
     for M in (8, 133, 200, 1200, 3000):
