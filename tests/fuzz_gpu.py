@@ -97,10 +97,15 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
         mode = int(rng.choice(list(modes)))
         est, H = [(EST_RANSAC, int(rng.choice([487, 1157, 2000]))), (EST_USAC, int(rng.integers(300, 5000))),
                   (EST_FIXED, int(rng.integers(257, 6000)))][int(rng.integers(0, 3))]
+        long_usac = est == EST_USAC and rng.random() < 0.08
+        if long_usac:  # caps up to the reference's 850 000: one stop-table entry per hypothesis, survivor lists of that length
+            H = int(rng.integers(100000, 850001))
         hb = (H + 255) // 256
-        kpts = int(rng.integers(40, 900))
+        kpts = int(rng.integers(40, 300 if long_usac else 900))
         # (staged from P (hb - 1) >= 256 (Euclidean kernels) / 768 (reprojection kernels) on: most batches are above)
         frames = int(max(6, min(400, 800 // max(hb - 1, 1) + int(rng.integers(2, 60)))))
+        if long_usac:
+            frames = int(rng.integers(3, 9))  # (the oracle walks the schedule hypothesis by hypothesis)
         frac = float(rng.uniform(0.05, 0.95))
         noise = float(10 ** rng.uniform(-4, -1.5))
         seq = synth.make_sequence(frames, kpts, config=3, index=int(rng.integers(0, 2 ** 31)), inlier_frac=frac, noise=noise)

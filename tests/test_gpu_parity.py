@@ -252,6 +252,34 @@ def test_long_usac_schedule_on_junk_data(ctx, oracle):
         assert int(c["stats"]["iterationsRun"]) > 20000  # the schedule did run long
 
 
+def test_forty_thousand_matches_through_the_stand_alone_entry(ctx, oracle):
+    """ps_ransac_rigid3d takes any match list (the map-matching caller hands over far more than a frame's 2000): 40 000
+    matches, 26 000 inliers -- many times what kernel 4 stages in LDS, a train range at the bitmaps' limit, record arrays with a
+    row stride of 40 000."""
+    rng = np.random.default_rng(8)
+    n = 40000
+    prev = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 3.2]).astype(np.float32)
+    ang = 0.07
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    t = np.array([0.05, -0.02, 0.03], np.float32)
+    cur = ((prev - t) @ R).astype(np.float32) + rng.normal(0, 0.004, (n, 3)).astype(np.float32)
+    out = rng.random(n) < 0.35
+    cur[out] = (rng.uniform(-2, 2, (int(out.sum()), 3)) + [0, 0, 3.2]).astype(np.float32)
+    m = np.zeros(n, DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = rng.permutation(n)
+    cur2 = np.zeros_like(cur)
+    cur2[m["trainIdx"]] = cur
+    for mode, est, H in ((EUCLIDEAN_ERROR, EST_RANSAC, 487), (REPROJECTION_ERROR, EST_FIXED, 300), (ADAPTIVE_ERROR, EST_USAC, 2000)):
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(est, H, seed=5)
+        g = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, prev, cur2, m)
+        c = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, prev, cur2, m)
+        _stats_equal(g["stats"], c["stats"])
+        assert np.array_equal(g["mask"], c["mask"]) and g["pose"].tobytes() == c["pose"].tobytes()
+        assert int(c["stats"]["numInliers"]) > 10000
+
+
 def test_explicit_sample_stream(ctx, oracle):
     a, b = _pair(400, 21)
     m = oracle.match_hamming256(a["desc"], b["desc"])
