@@ -258,7 +258,9 @@ typedef struct PsPairResults {
 
 /* pairs: DEVICE array of P (prevFrame, curFrame) index pairs, int32 x 2 each.
  * Hypothesis h of pair p draws from the seeded stream with seed cfg->seed + p
- * (cfg->sampleIdx must be NULL). Asynchronous on the context's stream. */
+ * (cfg->sampleIdx must be NULL). Asynchronous on the context's stream.
+ * A batch whose parked models (48 bytes per pair and hypothesis) would exceed 8 GiB -- more than 210 pairs under USAC's
+ * cap of 850 000 -- is taken in slices of pairs, queued one behind the other; the results are those of one call. */
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);

@@ -1791,6 +1791,32 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     Plan pl;
     rc = make_plan(ctx, params, cfg, K, cap, cap, pl);
     if (rc) return rc;
+    // The staged scoring parks one model per pair and hypothesis (48 bytes) and is refused above 8 GiB of them: a batch of
+    // 499 pairs under USAC's cap of 850 000 would then score every hypothesis of every pair completely -- hours instead of
+    // milliseconds, although the schedules end after a handful of iterations.  Such a batch is taken in slices whose models
+    // fit (pairs are independent: slice s starts at pair `first`, its sample streams at seed + first as in one call).
+    {
+        const size_t perPair = (size_t)pl.H * 12 * sizeof(float);
+        const size_t room = (size_t)8 << 30;
+        const long long fit = (long long)(room / (perPair ? perPair : 1));
+        if ((size_t)P * perPair > room && fit >= 1 && ctx->prune != 0 && pl.H > kPrefixFixed) {
+            const int slice = (int)(fit < P ? fit : P);
+            for (int first = 0; first < P; first += slice) {
+                const int n = P - first < slice ? P - first : slice;
+                PsRansacConfig c2 = *cfg;
+                c2.seed = cfg->seed + (uint64_t)first;
+                PsPairResults o2 = *out;
+                o2.matches = out->matches + (size_t)first * cap;
+                o2.numMatches = out->numMatches + first;
+                o2.inlierMask = out->inlierMask + (size_t)first * cap;
+                o2.pose = out->pose + (size_t)first * 16;
+                o2.stats = out->stats + first;
+                rc = ps_vo_pairs_device(ctx, params, &c2, K, frames, pairs + 2 * (size_t)first, n, &o2);
+                if (rc) return rc;
+            }
+            return PS_OK;
+        }
+    }
     if (ctx->timing) {
         ctx->curCall = (int)(ctx->timedCalls % kTimingRing);
         ctx->slotMask[ctx->curCall] = 0;

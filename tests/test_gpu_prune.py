@@ -349,3 +349,33 @@ def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
         staged.append(was_staged)
     assert all(staged)                                    # policy off: always the staged form
     c.close()
+
+
+def test_batch_under_the_reference_usac_cap_is_taken_in_slices(oracle):
+    """USAC's cap of 850 000 with more pairs than the staged scoring can park models for (48 bytes per pair and hypothesis,
+    8 GiB at most: 210 pairs): ps_vo_pairs_device takes the batch in slices -- complete scoring of 212 x 850 000 hypotheses
+    would run for minutes, the staged slices finish in milliseconds.  Pairs on both sides of the slice boundary equal the
+    oracle (their sample streams are seeded with seed + pair index of the WHOLE batch)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(213, 260, config=3, index=41, inlier_frac=0.6, noise=0.004)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_USAC, 850000, seed=0xABCDEF)
+    c = api.Context(0)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    assert c.get_option("last_staged_pairs") == len(seq["pairs"]) - 210   # the last slice, staged
+    c.close()
+    P = len(seq["pairs"])
+    assert P == 212
+    for p in (0, 1, 100, 208, 209, 210, 211):
+        cfgp, _ = make_config(EST_USAC, 850000, seed=0xABCDEF + p)
+        cp = oracle.vo_pairs(prm, cfgp, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"][p:p + 1], threads=1)
+        n = int(cp["numMatches"][0])
+        assert int(g["numMatches"][p]) == n, p
+        assert np.array_equal(g["inlierMask"][p, :n], cp["inlierMask"][0, :n]), p
+        assert g["pose"][p].tobytes() == cp["pose"][0].tobytes(), p
+        for f in STAT_FIELDS:
+            x, y = g["stats"][p][f], cp["stats"][0][f]
+            assert x == y or (np.isnan(x) and np.isnan(y)), (p, f, x, y)
