@@ -680,6 +680,17 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                             (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || pl.mode == PS_REPROJECTION_ERROR);
     // adaptive schedules without reordering: ONE stage after the prefix (all matches, hypotheses below the trip limit only)
     const int lastStage = (pl.sa.estimator != PS_EST_FIXED && !pl.reorder && ctx->singleRest != 0) ? 1 : kStages;
+    // Stage 1 of an adaptive schedule with a long cap (USAC's 850 000 = 3320 blocks of 256 hypotheses per pair, of which the
+    // trip limit leaves a handful): one work-group per block is hundreds of thousands of work-groups that look at the limit and
+    // leave -- 0.9 ms per 210 pairs.  From 64 blocks per pair on a fixed number of work-groups per pair walks the blocks and
+    // stops at the first one beyond the limit (enough of them to fill the chip when the limit does stay at the cap).
+    const int blocks1 = (pl.H - pl.prefix + kBlock - 1) / kBlock;
+    int loopGroups = 0;
+    if (pl.prune && pl.sa.estimator != PS_EST_FIXED && blocks1 > 64) {
+        loopGroups = (2048 + P - 1) / P;
+        loopGroups = loopGroups < 64 ? 64 : loopGroups;
+        loopGroups = loopGroups > blocks1 ? blocks1 : loopGroups;
+    }
     auto stage_args = [&](int stage) {
         StageArgs st{};
         st.stage = stage;
@@ -693,6 +704,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
         if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
         if (stage == 1 && usePretest) st.frontRec = (const float2 *)ctx->frontRec.p;
+        st.loopGroups = stage == 1 ? loopGroups : 0;
         st.single = lastStage == 1 ? 1 : 0;
         st.margin = ctx->reorderMargin;
         st.gran = with_euclid_fast(ctx, pl.mode) ? 64 : ctx->reorderGran;
@@ -738,7 +750,13 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
             if (pl.genSplit) PS_LAUNCH_EUCLID_ONE(MODE, 0, stage0_args(true), pl.prefix, 1);                           \
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stage0_args(false), pl.prefix, msplit);                                      \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
-            PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                         \
+            if (loopGroups > 0)                                                                                        \
+                hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, 1, true>), dim3((unsigned)loopGroups * (unsigned)P),  \
+                                   dim3(kBlock), 0, ctx->stream, (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, \
+                                   hotF, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.ec, \
+                                   pl.sa, stage_args(1), pl.H, cap, pl.minRun, 1, (int32_t *)ctx->counts.p, dbgE);     \
+            else                                                                                                       \
+                PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
             for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));              \
         } else                                                                                                         \
@@ -781,7 +799,16 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_LAUNCH_FAST_ONE(MODE, false, 0, stage0_args(false), pl.prefix, msplit);                             \
             }                                                                                                          \
             PS_LAUNCH_REORDER(MODE);                                                                                   \
-            PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
+            if (loopGroups > 0) {                                                                                      \
+                const StageArgs st1 = stage_args(1);                                                                   \
+                hipLaunchKernelGGL((ps_ransac_score_fast<MODE, true, 1, true>),                                        \
+                                   dim3((unsigned)loopGroups * (unsigned)P), dim3(kBlock), 0, ctx->stream,             \
+                                   (const float4 *)ctx->recA.p, (const float4 *)ctx->recB.p, (const float4 *)ctx->recC.p, \
+                                   st1.frontRec != nullptr ? (const float4 *)st1.frontRec : (const float4 *)ctx->recE.p, \
+                                   hotF, (const int32_t *)ctx->mvalid.p, (const float2 *)ctx->cmax.p, pl.ma, pl.sc, pl.fc, \
+                                   pl.ec, pl.sa, st1, pl.H, cap, pl.minRun, 1, (int32_t *)ctx->counts.p, dbg);         \
+            } else                                                                                                     \
+                PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                 \
             for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));          \
         } else if (grid.x > (BIGLIMIT))                                                                                \

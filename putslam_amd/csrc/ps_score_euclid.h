@@ -83,7 +83,7 @@ template <int MODE> PS_D EuclidRec<MODE> load_euclid_rec(const float2 *__restric
 // 2 = stages 2+ of the staged scoring.
 // One pass of a work-group (ps_score_fast.h, score_fast_pass): 256 hypotheses, or one pass over the survivor list.
 template <int MODE, int KIND>
-PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
+PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
                             const float2 *__restrict__ pairBound, const ModelArgs &ma, const ScoreConsts &k,
                             const EuclidConsts &ec, const SelectArgs &sa, const StageArgs &st, int H, int cap, int msplit,
                             int32_t *__restrict__ counts, unsigned long long *__restrict__ dbg, const unsigned bx,
@@ -125,16 +125,16 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
                      st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
         mStageEnd = m1;
-        if (m0 >= m1) return; // an earlier stage finished the pair's matches
+        if (m0 >= m1) return true; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
-            if (st.hBase + (int)bx * kBlock >= hEnd) return;
+            if (st.hBase + (int)bx * kBlock >= hEnd) return true;
         } else {
             if (msplit > 1) { // the LAST stage may split its range over work-groups too: their counts meet in counts[]
                 const int blen = (((m1 - m0 + msplit - 1) / msplit) + 63) & ~63;
                 m0 += (int)by * blen;
                 m1 = m1 < m0 + blen ? m1 : m0 + blen;
-                if (m0 >= m1) return;
+                if (m0 >= m1) return false;
             }
             const int n = st.countIn[p];
             cover = list_cover(n);
@@ -153,7 +153,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     }
 
     // a wavefront without a hypothesis of its own (ps_score_fast.h; not in a pass with a split match range: barrier to come)
-    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return;
+    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return false;
 
     // A launch with a split match range is a small one (a handful of pairs): one wavefront per SIMD, nothing hides a load.
     // The pair's bound and this work-group's records were written by the previous launch (HBM latency, 2 x 1.5 us exposed
@@ -194,7 +194,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
             const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
             if (lane == 0) st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)] = vm;
-            return;
+            return false;
         }
     }
 #pragma unroll
@@ -334,7 +334,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         const bool mine = h < hEnd && part == 0;
         if (LIST && msplit > 1) { // (last stage, range split over work-groups: nothing survives it, the counts add up)
             if (mine && valid && cnt) atomicAdd(&cout[h], cnt);
-            return;
+            return false;
         }
         const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
@@ -352,7 +352,7 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
             store_model(ma, (size_t)p * H + h, md);
         }
         if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
-        return;
+        return false;
     }
     h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
     if (h < hEnd) {
@@ -362,11 +362,12 @@ PS_D void score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         else if (cnt)
             atomicAdd(&cout[h], cnt);
     }
+    return false;
 }
 
-// (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast)
-template <int MODE, int KIND = 0>
-__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_euclid(
+// (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast; LOOP: stage 1 of an adaptive schedule with a long cap, same place)
+template <int MODE, int KIND = 0, bool LOOP = false>
+__global__ __launch_bounds__(kBlock, (KIND == 2 || LOOP) ? 5 : 8) void ps_ransac_score_euclid(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
     const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
     EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,
@@ -375,13 +376,21 @@ __global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_euc
     static_assert(MODE == PS_EUCLIDEAN_ERROR || MODE == PS_ADAPTIVE_ERROR, "the Euclidean metrics");
     // hypotheses of this launch: [hBase, hBase + hCount) (plain launch: [0, H); stages 0 / 1), or a survivor list swept by
     // hCount / 256 work-groups per pair (stages 2+)
-    const unsigned hb = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    static_assert(!LOOP || KIND == 1, "the looping form is stage 1's");
+    const unsigned blocks = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    const unsigned hb = LOOP ? (unsigned)st.loopGroups : blocks; // work-groups per pair and part of the match range
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    if (KIND == 2) {
+    if (LOOP) {
+        for (unsigned b = bx; b < blocks; b += hb) {
+            if (b != bx) __syncthreads(); // (the pass before is done with the work-group's LDS)
+            if (score_euclid_pass<MODE, KIND>(recA, recB, recG, pairBound, ma, k, ec, sa, st, H, cap, msplit, counts, dbg, b, by, p, M))
+                break; // (uniform over the work-group)
+        }
+    } else if (KIND == 2) {
         const int n = st.countIn[p];
         const int cover = list_cover(n);
         for (unsigned b = bx; (int)b * cover < n; b += hb) {

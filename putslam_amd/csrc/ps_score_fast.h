@@ -202,6 +202,9 @@ struct StageArgs {
                                // without reordering: what their trip limit leaves is little, two more launches cost more)
     int gran;                  // the stage cuts are multiples of this (64: the Euclidean kernel recounts blocks of 64 matches;
                                // 8 for the reprojection kernels, which only need even cuts)
+    int loopGroups;            // stage 1 of an adaptive schedule with a long cap (USAC's 850 000: 3320 blocks of 256 hypotheses per
+                               // pair, of which the trip limit leaves a handful): this many work-groups per pair take the blocks
+                               // bx, bx + loopGroups, ... and stop at the first block beyond the limit (0: one work-group per block)
     const int32_t *prefInfo;   // after ps_stage_reorder: [P][4] = (best count, trip limit) the prefix leaves, how many matches at
                                // the front of the reordered record ALL voters reject, reserved (null: every work-group of
                                // the stages replays the prefix itself)
@@ -369,7 +372,7 @@ PS_D int list_cover(int n) { return n <= 64 ? 64 : (n <= 128 ? 128 : kBlock); }
 // epilogues still derive the hypothesis index again instead of keeping it across the loops.
 // One pass of a work-group: the hypotheses [hBase + bx * 256, + 256) (kinds 0 / 1) or one pass over the survivor list (kind 2).
 template <int MODE, bool BIG, int KIND>
-PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
+PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                           const float4 *__restrict__ recE, const float2 *__restrict__ recF,
                           const float2 *__restrict__ pairBound, const ModelArgs &ma, const ScoreConsts &k,
                           const FastConsts &fc, const EuclidConsts &ec, const SelectArgs &sa, const StageArgs &st, int H, int cap,
@@ -414,7 +417,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                      st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
         mStageEnd = m1;
-        if (m0 >= m1) return; // an earlier stage finished the pair's matches
+        if (m0 >= m1) return true; // an earlier stage finished the pair's matches
         if (!LIST) {
             hEnd = hEnd < hLimit ? hEnd : hLimit; // beyond the trip limit: never consumed by the selection
         } else {
@@ -422,7 +425,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                 const int blen = (((m1 - m0 + msplit - 1) / msplit) + 63) & ~63;
                 m0 += (int)by * blen;
                 m1 = m1 < m0 + blen ? m1 : m0 + blen;
-                if (m0 >= m1) return;
+                if (m0 >= m1) return false;
             }
             const int n = st.countIn[p];
             cover = list_cover(n);
@@ -438,12 +441,12 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             m1 = m1 < m0 + plen ? m1 : m0 + plen;
             m1 = m1 < m0 ? m0 : m1; // (an empty part: nothing to sweep, no odd last match either)
         }
-        if (!LIST && st.hBase + (int)bx * kBlock >= hEnd) return;
+        if (!LIST && st.hBase + (int)bx * kBlock >= hEnd) return true;
     }
 
     // (a wavefront without a hypothesis of its own has nothing to do -- the 64-hypothesis prefix of the adaptive
     // schedules fills one of the four; a pass with a split match range has no such wavefront, and a barrier to come)
-    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return;
+    if (cover == kBlock && hFirstOfWave(h, lane) >= hEnd) return false;
 
     Rigid mdl;
     set_identity(mdl);
@@ -469,7 +472,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
             const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
             if (lane == 0) st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)] = vm;
-            return;
+            return false;
         }
     }
 #pragma unroll
@@ -764,7 +767,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         const bool mine = h < hEnd && part == 0;
         if (LIST && msplit > 1) { // (last stage, range split over work-groups: nothing survives it, the counts add up)
             if (mine && valid && cnt) atomicAdd(&cout[h], cnt);
-            return;
+            return false;
         }
         const int cnt0 = (LIST && mine) ? cout[h] : 0; // count so far
         const int total = valid ? cnt0 + cnt : 0; // model not computed -> iteration skipped (RANSAC.cpp:107)
@@ -782,7 +785,7 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             store_model(ma, (size_t)p * H + h, md);
         }
         if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
-        return;
+        return false;
     }
     h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
     if (h < hEnd) {
@@ -792,12 +795,15 @@ PS_D void score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         else if (cnt)
             atomicAdd(&cout[h], cnt);
     }
+    return false;
 }
 
 // (kind 2 sweeps short lists with few wavefronts: five per SIMD are plenty, and its loop over the list keeps the kernel
 // arguments alive across the passes -- at seven or eight they went to scratch memory and the inlier counter with them)
-template <int MODE, bool BIG, int KIND = 0>
-__global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_fast(
+// LOOP (kind 1 only): StageArgs::loopGroups work-groups per pair walk the blocks of 256 hypotheses and stop at the first one beyond
+// the trip limit -- a pass returns true when its block, and with it every later one, has nothing to do.
+template <int MODE, bool BIG, int KIND = 0, bool LOOP = false>
+__global__ __launch_bounds__(kBlock, (KIND == 2 || LOOP) ? 5 : 8) void ps_ransac_score_fast(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float4 *__restrict__ recC,
     const float4 *__restrict__ recE, const float2 *__restrict__ recF, const int32_t *__restrict__ mvalid,
     const float2 *__restrict__ pairBound,
@@ -808,13 +814,22 @@ __global__ __launch_bounds__(kBlock, KIND == 2 ? 5 : 8) void ps_ransac_score_fas
                   "the metrics with a reprojection test");
     // hypotheses of this launch: [hBase, hBase + hCount) (plain launch: [0, H); stages 0 / 1), or a survivor list swept by
     // hCount / 256 work-groups per pair (stages 2+)
-    const unsigned hb = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    static_assert(!LOOP || KIND == 1, "the looping form is stage 1's");
+    const unsigned blocks = (unsigned)((st.hCount + kBlock - 1) / kBlock);
+    const unsigned hb = LOOP ? (unsigned)st.loopGroups : blocks; // work-groups per pair and part of the match range
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned bx = L % hb, by = (L / hb) % (unsigned)msplit;
     const int p = (int)(L / (hb * (unsigned)msplit));
     const int M = mvalid[p];
     if (M < minRun) return; // too few matches: kernel 4 returns identity (RANSAC.cpp:77-80)
-    if (KIND == 2) {
+    if (LOOP) {
+        for (unsigned b = bx; b < blocks; b += hb) {
+            if (b != bx) __syncthreads(); // (the pass before is done with the work-group's LDS)
+            if (score_fast_pass<MODE, BIG, KIND>(recA, recB, recC, recE, recF, pairBound, ma, k, fc, ec, sa, st, H, cap, msplit,
+                                                 counts, dbg, b, by, p, M))
+                break; // (uniform over the work-group: the exits that return true are taken by all of its waves)
+        }
+    } else if (KIND == 2) {
         const int n = st.countIn[p];
         const int cover = list_cover(n);
         for (unsigned b = bx; (int)b * cover < n; b += hb) {
