@@ -32,7 +32,8 @@ After the timed regions (never part of `value`) rank 0 of a single-GPU run adds 
     complete hypotheses x matches sweep the staged scoring still evaluates, 1.0 without it);
   * `other_modes`: the same sequence as ONE launch chain in the regimes every shipped reference config runs --
     errorVersion 0 with H = 4096 fixed, and errorVersion 0 with the reference's own adaptive <= 487-iteration schedule
-    (RANSAC.cpp:30,450-453) -- `ms_per_step`, `pairs_per_s` and the kernels' own durations;
+    (RANSAC.cpp:30,450-453) -- `ms_per_step`, `pairs_per_s` and the kernels' own durations; the timed workload with the
+    staged scoring off; USAC at the reference's cap of 850 000 hypotheses;
   * `cpu_baseline`: the oracle on the same workload on all host cores, 5 passes, median, with the SIMD popcount
     matcher (OpenCV's normHamming is vectorised; the scalar-popcnt figure is kept as `scalar_matcher_value`)
     (+ the reference's own <= 487-iteration schedule as `cpu_reference_schedule`).
@@ -376,6 +377,10 @@ def main():
             # the timed workload itself with the staged scoring OFF (every hypothesis scored completely): what the
             # staged form saves on THIS data is a measured figure, not a derived one
             legs.append(("E%d/%s/%d/prune0" % (args.error_version, args.estimator, args.hyp), args.error_version, est, args.hyp, 0))
+            # the reference's other estimator at ITS cap (USAC_wrapper.cpp:66,70: 850 000 hypotheses at most): the schedules end
+            # after a handful of iterations; the batch is taken in slices of 210 pairs (48 B of parked model per pair and
+            # hypothesis), so `kernel_ms` is per SLICE here and `ms_per_step` the whole batch
+            legs.append(("E0/usac/850000", 0, EST_USAC, 850000, 1))
         for name, ev2, est2, hyp2, prune2 in legs:
             if args.preset == "stress" and est2 == EST_FIXED:
                 hyp2, name = args.hyp, "E0/fixed/%d" % args.hyp
@@ -406,6 +411,10 @@ def main():
                                  "mean_inliers": float(st2["numInliers"].mean()),
                                  "accepted_pairs": int(st2["accepted"].sum()), "staged_scoring": bool(prune2),
                                  "score_kernel": "fast" if c0.get_option("score") >= 1 else "exact"}
+            if est2 == EST_USAC:
+                per_pair = hyp2 * 48
+                fit = max(1, (8 << 30) // per_pair)
+                other_modes[name]["slices"] = int(-(-P // fit)) if P * per_pair > (8 << 30) else 1
             if name == "E0/ransac/487" and S > 1:
                 # the reference's own regime submitted like the timed region: S chains on S streams, steps pipelined
                 def chains_step():
