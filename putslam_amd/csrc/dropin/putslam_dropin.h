@@ -93,14 +93,17 @@ class RANSAC_USAC {
     Eigen::Matrix4f estimateTransformation(std::vector<Eigen::Vector3f> prevFeatures, std::vector<Eigen::Vector3f> features,
                                            std::vector<cv::DMatch> matches, std::vector<cv::DMatch> &bestInlierMatches);
     void setSampleSeed(uint64_t seed) { seed_ = seed; }
-    void setMaxHypotheses(int h) { maxHyp_ = h; } // samples made available to the USAC loop (default 4096)
+    // samples made available to the USAC loop; default = the reference's usac_max_hypotheses_ (USAC_wrapper.cpp:70): the loop
+    // stops by its own criterion long before, and a long cap costs 10 us per call (rounds 1-3 defaulted to 4096, which cut
+    // the schedule short below 10 % inliers)
+    void setMaxHypotheses(int h) { maxHyp_ = h; }
     int lastStatus() const { return lastStatus_; }
 
   private:
     cv::Mat cameraMatrix;
     PUTSLAMEstimator::parameters params_;
     uint64_t seed_;
-    int maxHyp_ = 4096;
+    int maxHyp_ = 850000;
     int lastStatus_ = 0;
 };
 
