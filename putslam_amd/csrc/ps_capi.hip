@@ -383,6 +383,7 @@ struct Plan {
     ModelArgs ma{};
     int msplit = 1;   // work-groups the match range of kernel 3 is split over (prepare_score)
     bool genSplit = false; // staged scoring: stage 0 as two launches (models, then the sweep)
+    bool genPlain = false; // complete scoring with a split match range, two pairs or more: the same two launches over [0, H)
     bool reorder = false; // staged scoring: stages 1+ sweep the reordered hot record (ps_stage_reorder)
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
     bool bailWatch = false; // this staged call feeds the "nothing to gain" policy (PsContext::bailHost)
@@ -603,6 +604,25 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
         PS_ENSURE(ctx->models, mbytes);
         pl.ma.models = (float *)ctx->models.p;
     }
+    // Complete scoring with the match range split over msplit work-groups repeats the sample -> SVD chain in every part (16
+    // pairs, H = 4096, errorVersion 1: 23 M of the launch's 45 M instructions).  From two pairs on the models are generated
+    // once by a launch of their own, as stage 0 of the staged scoring does, and the sweep reads them back: 4 to 15 % of the
+    // call for 2 ... 48 pairs (profiles/r04h/ab_gen_plain.txt).  A single pair keeps one launch: the chain's latency is all
+    // there is, and a second launch costs 3 - 5 us more than it saves.
+    pl.genPlain = false;
+    {
+        const bool fastKernels = with_euclid_fast(ctx, pl.mode) || (pl.mode == PS_REPROJECTION_ERROR && ctx->scoreFast == 1) ||
+                                 (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR && ctx->scoreFast != 0);
+#ifndef PS_GENPLAIN_FROM
+#define PS_GENPLAIN_FROM 2
+#endif
+        if (!pl.prune && fastKernels && ctx->genSplit != 0 && pl.msplit > 1 && P >= PS_GENPLAIN_FROM && mbytes <= ((size_t)1 << 30)) {
+            PS_ENSURE(ctx->models, mbytes);
+            pl.ma.models = (float *)ctx->models.p;
+            PS_ENSURE(ctx->validMask, (size_t)P * ((H + 63) / 64) * sizeof(unsigned long long));
+            pl.genPlain = true;
+        }
+    }
     pl.pa.zeroSurvA = pl.pa.zeroSurvB = nullptr;
     {
         // which record form of the reprojection kernels the launches of this call read (kernel 2 writes only those:
@@ -737,6 +757,11 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     };
     StageArgs stAll{}; // the plain launch: every hypothesis of [0, H) completely
     stAll.hCount = pl.H;
+    StageArgs stAllGen = stAll, stAllSweep = stAll; // the same as two launches (Plan::genPlain): models, then the sweep
+    if (pl.genPlain) {
+        stAllGen.validMask = stAllSweep.validMask = (unsigned long long *)ctx->validMask.p;
+        stAllGen.genOnly = 1;
+    }
 #define PS_LAUNCH_EUCLID_ONE(MODE, KIND, ST, HCOUNT, MSPLIT)                                                           \
     hipLaunchKernelGGL((ps_ransac_score_euclid<MODE, KIND>),                                                           \
                        dim3((unsigned)(((HCOUNT) + kBlock - 1) / kBlock) * (unsigned)(MSPLIT) * (unsigned)P),          \
@@ -759,6 +784,9 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_LAUNCH_EUCLID_ONE(MODE, 1, stage_args(1), pl.H - pl.prefix, 1);                                     \
             for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_EUCLID_ONE(MODE, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));              \
+        } else if (pl.genPlain) {                                                                                      \
+            PS_LAUNCH_EUCLID_ONE(MODE, 0, stAllGen, pl.H, 1);                                                          \
+            PS_LAUNCH_EUCLID_ONE(MODE, 0, stAllSweep, pl.H, msplit);                                                   \
         } else                                                                                                         \
             PS_LAUNCH_EUCLID_ONE(MODE, 0, stAll, pl.H, msplit);                                                        \
     } while (0)
@@ -811,10 +839,19 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                 PS_LAUNCH_FAST_ONE(MODE, true, 1, stage_args(1), pl.H - pl.prefix, 1);                                 \
             for (int sg = 2; sg <= lastStage; ++sg)                                                                    \
                 PS_LAUNCH_FAST_ONE(MODE, true, 2, stage_args(sg), list_groups(sg) * kBlock, list_rsplit(sg));          \
-        } else if (grid.x > (BIGLIMIT))                                                                                \
-            PS_LAUNCH_FAST_ONE(MODE, true, 0, stAll, pl.H, msplit);                                                    \
-        else                                                                                                           \
-            PS_LAUNCH_FAST_ONE(MODE, false, 0, stAll, pl.H, msplit);                                                   \
+        } else if (grid.x > (BIGLIMIT)) {                                                                              \
+            if (pl.genPlain) {                                                                                         \
+                PS_LAUNCH_FAST_ONE(MODE, true, 0, stAllGen, pl.H, 1);                                                  \
+                PS_LAUNCH_FAST_ONE(MODE, true, 0, stAllSweep, pl.H, msplit);                                           \
+            } else                                                                                                     \
+                PS_LAUNCH_FAST_ONE(MODE, true, 0, stAll, pl.H, msplit);                                                \
+        } else {                                                                                                       \
+            if (pl.genPlain) {                                                                                         \
+                PS_LAUNCH_FAST_ONE(MODE, false, 0, stAllGen, pl.H, 1);                                                 \
+                PS_LAUNCH_FAST_ONE(MODE, false, 0, stAllSweep, pl.H, msplit);                                          \
+            } else                                                                                                     \
+                PS_LAUNCH_FAST_ONE(MODE, false, 0, stAll, pl.H, msplit);                                               \
+        }                                                                                                              \
     } while (0)
             PS_LAUNCH_FAST(PS_REPROJECTION_ERROR, big_limit(PS_REPROJECTION_ERROR));
         } else

@@ -45,6 +45,25 @@ def test_sequence_batch(ctx, oracle, mode, est, H):
             assert np.abs(T - seq["gt"][p]).max() < (3e-2 if est == EST_USAC else 5e-3)  # USAC: minimal-sample pose, no refit
 
 
+@pytest.mark.parametrize("frames", [2, 3, 4])
+def test_smallest_batches(ctx, oracle, frames):
+    """One pair runs its scoring as one launch, two pairs and more generate the models in a launch of their own and sweep in a
+    second (Plan::genPlain): the boundary, every metric family, fixed and adaptive schedules."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    from putslam_amd._abi import ADAPTIVE_ERROR, EUCLIDEAN_AND_REPROJECTION_ERROR
+    seq = synth.make_sequence(frames, 700, config=3, index=300 + frames)
+    for mode, est, H in ((EUCLIDEAN_ERROR, EST_FIXED, 2000), (REPROJECTION_ERROR, EST_FIXED, 1500), (ADAPTIVE_ERROR, EST_RANSAC, 487),
+                         (EUCLIDEAN_AND_REPROJECTION_ERROR, EST_USAC, 900)):
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(est, H, seed=99)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=2)
+        _compare(g, c, len(seq["pairs"]))
+
+
 def test_ragged_frames_and_arbitrary_pairs(ctx, oracle):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     seq = synth.make_sequence(6, 512, config=3, index=77)
