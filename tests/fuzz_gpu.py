@@ -39,6 +39,10 @@ def run(iters, seed, max_kpts=1500, ctx=None, verbose=True, modes=(0, 1, 2, 4, 3
         # 520: kernel 4 replays schedules of up to 512 iterations per wavefront out of registers, longer ones as a work-group)
         est, H = [(EST_RANSAC, [1157, 487, int(rng.integers(1, 520))][int(rng.integers(0, 3))]),
                   (EST_USAC, int(rng.integers(50, 3000))), (EST_FIXED, int(rng.integers(1, 3000)))][int(rng.integers(0, 3))]
+        if est == EST_RANSAC and n <= 150 and rng.random() < 0.3:
+            # long RANSAC caps: with minimalInlierRatioThreshold = 0.05 the schedule may run for 31 294 iterations (a stop table
+            # of that many floats, the work-group replay, stage 1 walked by looping work-groups)
+            H = int(rng.integers(2000, 60000))
         if est == EST_USAC and n <= 150 and rng.random() < 0.3:
             # long schedules (the reference's cap is 850 000): few matches keep the oracle's loop affordable; the stop table has
             # one entry per hypothesis and the work-group replay walks all of its search windows
