@@ -104,6 +104,9 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
         long_usac = est == EST_USAC and rng.random() < 0.08
         if long_usac:  # caps up to the reference's 850 000: one stop-table entry per hypothesis, survivor lists of that length
             H = int(rng.integers(100000, 850001))
+        if est == EST_FIXED and rng.random() < 0.08:  # many hypotheses, few pairs: long survivor lists, list stages in several passes
+            H = int(rng.integers(20000, 120001))
+            long_usac = True  # (the same shape of batch: few small frames)
         hb = (H + 255) // 256
         kpts = int(rng.integers(40, 300 if long_usac else 900))
         # (staged from P (hb - 1) >= 256 (Euclidean kernels) / 768 (reprojection kernels) on: most batches are above)
