@@ -281,6 +281,18 @@ void build_usac_table(int H, std::vector<double> &tab)
             tab[(size_t)k] = 0.0;
             continue;
         }
+        {
+            // The root of log(0.01) / log(1 - p) = target in closed form brackets the entry to a few thousand neighbouring
+            // doubles; either end is taken only if the rule itself confirms it, so the bisection's invariant -- and its
+            // result -- are those of the wide bracket (850 000 entries: 0.41 s instead of 0.75).
+            const double ps = -std::expm1(std::log(1 - 0.99) / (double)target);
+            const double a = ps * (1.0 - 1e-11), b = ps * (1.0 + 1e-11);
+            uint64_t ab, bb;
+            memcpy(&ab, &a, 8);
+            memcpy(&bb, &b, 8);
+            if (ab > lo && ab < hi && usac_stopping_host(a) > target) lo = ab;
+            if (bb > lo && bb < hi && usac_stopping_host(b) <= target) hi = bb;
+        }
         while (hi - lo > 1) {
             uint64_t mid = lo + (hi - lo) / 2;
             double md;
