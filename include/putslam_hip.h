@@ -329,7 +329,8 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* Staged scoring: hypotheses of every pair that survived stage 1 (out[0..P)) and stage 2 (out[P..2P)) of the last call
  * that was scored in stages: zeros if the LAST scoring step of the context was not staged, PS_ERR_BAD_ARG if P is not that
- * step's number of pairs (the counters are laid out with it). */
+ * step's number of pairs (the counters are laid out with it).  A batch that ps_vo_pairs_device took in slices leaves the
+ * LAST slice's step behind (option "last_staged_pairs" says how many pairs that was). */
 int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out);
 /* Staged scoring with the reordered match record: perm[P][cap] = for every pair, the match (index into its depth-valid
  * matches) at each position of the order stages 1+ swept; front[P] = leading positions whose matches every voting hypothesis
