@@ -968,7 +968,8 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         if (ctx->forceQsplit > 0) qsplit = ctx->forceQsplit < tpf ? ctx->forceQsplit : tpf;
         if (ctx->matcherFused) {
             // fused expansion: every work-group of a query split expands its own share of the query tiles, so a split only
-            // pays when the groups do not fill the chip by themselves; the keys are then cleared by a memset
+            // pays when the groups do not fill the chip by themselves; the splits merge with atomicMin on an all-ones keys block
+            // (kept so by kernel 2: keys_clean)
             if (ctx->forceQsplit <= 0 && (long long)P * groups >= 1024) qsplit = 1;
             if (qsplit > 1) {
                 int rc = keys_clean(ctx, keyBytes);
@@ -1942,7 +1943,7 @@ struct PsVoStream {
     uint8_t *hres = nullptr;   // pinned
     uint8_t *hin = nullptr;    // pinned staging of the incoming frame: [cap x 32 B][cap x 12 B][4 x i32]
     size_t offPose = 0, offNum = 0, offMatches = 0, offMask = 0, resBytes = 0;
-    // A push is launch-bound (three copies in, up to two memsets, four kernels, one copy out): once the scratch
+    // A push is launch-bound (three copies in, four kernels, one copy out): once the scratch
     // arena has been sized by an ordinary push with the same parameters the sequence is captured into one hipGraph
     // per frame slot and replayed with a single launch.  Everything that changes between pushes travels as data:
     // the frame (full-capacity copies from the pinned staging area), its row count and slot (meta) and the seed.
