@@ -7,7 +7,7 @@ DROPIN := putslam_amd/libputslam_dropin.so
 
 all: $(LIB) $(DROPIN) oracle
 
-$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_device_math.h include/putslam_hip.h
+$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_device_math.h $(CSRC)/ps_stream_async.h include/putslam_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
 
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)

@@ -128,6 +128,10 @@ def parse():
                     help="after the --warmup steps, keep stepping (untimed) until this much wall time has passed: the timed "
                          "regions start on a chip at its steady clock")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the streamed legs (frames from pinned host memory)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] legs (5000 keypoints, H = 100 000)")
+    ap.add_argument("--stream-chunk", type=int, default=125, help="frames per chunk of the streamed leg")
+    ap.add_argument("--stream-lanes", type=int, default=6, help="lanes of the streamed leg: chunks in flight + the one being read")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
@@ -138,8 +142,46 @@ def parse():
     return a
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process becomes the launcher.  It never
+    touches the GPU (no torch import, no HIP call): it starts N fresh child processes -- one rank per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would set them -- passes rank 0's stdout (the JSON line) through, and
+    returns the worst exit code.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30.0:
+            for p in procs:                        # a rank died: its peers wait in a collective for ever -- end exactly them
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = p.wait()
+        if rc != 0:
+            worst = rc if worst == 0 else worst
+    return 1 if worst < 0 else worst
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     # The sub-batches of a step run on separate HIP streams; with the runtime's default of four hardware queues two
     # streams can end up sharing one (then they serialise).  Eight queues keep them apart (measured: no effect on two
     # streams, 105 k -> 117 k pairs/s on three).  Must be set before the HIP runtime initialises.
@@ -150,12 +192,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with the launcher's world size", file=sys.stderr)
     # PUTSLAM_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 control flow run with several ranks on ONE GPU
     # (records staged through the host); the measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("PUTSLAM_BENCH_BACKEND", "nccl")
@@ -429,6 +467,19 @@ def main():
                 torch.cuda.synchronize(dev)
                 ch_ms = (time.perf_counter() - tc0) / n_ch * 1e3
                 other_modes[name]["chains"] = {"streams": S, "ms_per_step": ch_ms, "pairs_per_s": P / (ch_ms * 1e-3), "steps": n_ch}
+    if other_modes is not None and args.preset is None and not args.no_streamed:
+        # ---- BASELINE configs[2] as written: the 500 frames STREAMED (frames start in pinned HOST memory, every step uploads
+        # all of them and downloads every pair's matches / mask / pose / stats), ps_vo_stream_push_many + pop_many
+        try:
+            other_modes.update(streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev))
+        except Exception as e:                                    # a leg must never cost the line its headline
+            other_modes["streamed"] = {"error": repr(e)}
+    if other_modes is not None and args.preset is None and not args.no_stress:
+        # ---- BASELINE configs[4] under the driver's clock: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule
+        try:
+            other_modes.update(stress_legs(args, api, c0, chains[0], dev))
+        except Exception as e:
+            other_modes["stress"] = {"error": repr(e)}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
@@ -612,6 +663,182 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PCIE_GEN5_X16_GBS = 63.0        # PCIe 5.0 x16, one direction, after 128b/130b encoding (the MI355X host link)
+
+
+def _link_rate(torch, dev, mb=64, reps=8):
+    """Measured host <-> device copy rates on pinned memory, GB/s (H2D, D2H): the streamed legs' roofline."""
+    n = mb << 20
+    h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    out = []
+    for src, dst in ((h, d), (d, h)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        out.append(n * reps / (time.perf_counter() - t0) / 1e9)
+    return out
+
+
+def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
+    """The timed workload with the frames STREAMED from the host (reference call shape: one frame after the other, previous
+    frame kept as state, src/Matcher/matcher.cpp:452-516 in the loop of src/PUTSLAM/PUTSLAM.cpp:677-740): every step uploads
+    its frames from pinned host memory in chunks, runs each chunk as one batched call on one of several lanes and downloads
+    every pair's matches, mask, pose and stats.  Bound: the host link (88 KB in, 34 KB out per 2000-keypoint pair)."""
+    import torch
+    from putslam_amd._abi import TUM_FR1_K
+    F, cap = seq["desc"].shape[:2]
+    P = F - 1
+    hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
+    hd.array[:] = seq["desc"]
+    hp.array[:] = seq["pts"]
+    nk = np.ascontiguousarray(seq["nkpts"], np.int32)
+    h2d, d2h = _link_rate(torch, dev)
+    out = {}
+
+    def run(chunk, lanes, steps, check):
+        st = api.VoStream(c0, cap)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        lat, sub_t = [], {}
+        state = {"pairs": 0, "inl": 0, "bad": 0, "step": 0}
+
+        def take(wait):
+            b = st.pop_many(wait=wait, copy=False)
+            if b is None:
+                return False
+            now = time.perf_counter()
+            key = (b["epoch"], b["first_pair"])
+            if key in sub_t:
+                lat.append(now - sub_t.pop(key))
+            state["pairs"] += b["count"]
+            state["inl"] += int(b["stats"]["numInliers"].sum())          # the consumer reads what came back
+            if check and b["epoch"] == check:
+                lo = b["first_pair"]
+                if b["pose"].tobytes() != res["pose"][lo:lo + b["count"]].tobytes():
+                    state["bad"] += 1
+            return True
+
+        def one_step():
+            while not st.reset():
+                take(True)
+            ep = state["step"]
+            state["step"] += 1
+            f, first = 0, 0
+            while f < F:
+                n = min(chunk, F - f)
+                t_sub = time.perf_counter()
+                if st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n]):
+                    pairs = n - (1 if f == 0 else 0)
+                    if pairs > 0:
+                        sub_t[(ep + 1, first)] = t_sub            # (epoch = resets before the block's frames)
+                    first += pairs
+                    f += n
+                    while take(False):
+                        pass
+                else:
+                    take(True)
+
+        for _ in range(3):
+            one_step()
+        while take(True):
+            pass
+        lat.clear()
+        pairs0 = state["pairs"]
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        while take(True):
+            pass
+        el = time.perf_counter() - t0
+        done = state["pairs"] - pairs0
+        st.close()
+        lat_ms = np.array(sorted(lat)) * 1e3
+        leg = {"pairs_per_s": done / el, "ms_per_step": el / steps * 1e3, "steps": steps, "pairs": done,
+               "chunk_frames": chunk, "lanes": lanes,
+               "h2d_GBps": steps * F * cap * 44 / el / 1e9, "d2h_GBps": done * (cap * 17 + 108) / el / 1e9,
+               "chunk_latency_ms": ({"p50": float(lat_ms[len(lat_ms) // 2]), "p95": float(lat_ms[int(len(lat_ms) * 0.95)]),
+                                     "max": float(lat_ms[-1]), "n": int(len(lat_ms)),
+                                     "what": "push_many call of the chunk -> its results readable on the host"} if len(lat_ms) else None)}
+        if check:
+            leg["equals_batched_call"] = state["bad"] == 0
+        return leg
+
+    steps = max(10, min(40, 2 * args.steps))
+    main = run(args.stream_chunk, args.stream_lanes, steps, check=3 + steps)    # the last step's poses against the batched call's
+    main["roofline"] = {"bound": "pcie", "achieved": main["h2d_GBps"], "peak": PCIE_GEN5_X16_GBS, "unit": "GB/s",
+                        "frac": main["h2d_GBps"] / PCIE_GEN5_X16_GBS, "measured_link_h2d_GBps": h2d,
+                        "measured_link_d2h_GBps": d2h, "frac_of_measured": main["h2d_GBps"] / h2d,
+                        "bytes_in_per_frame": cap * 44, "bytes_out_per_pair": cap * 17 + 108,
+                        "note": "host -> device bytes of the frames themselves over the timed legs' wall time; uploads, kernels "
+                                "and downloads of consecutive chunks overlap"}
+    main["workload"] = ("BASELINE configs[2] as written: %d frames streamed from pinned host memory per step (ps_vo_stream_push_many, "
+                        "chunks of %d frames on %d lanes), every pair's matches / mask / pose / stats downloaded (pop_many); same "
+                        "parameters as the timed workload" % (F, args.stream_chunk, args.stream_lanes))
+    out["streamed"] = main
+    out["streamed/chunk250"] = run(250, args.stream_lanes, steps, check=0)
+    small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
+    out["streamed/chunk32"] = small
+    one = run(1, args.stream_lanes, 3, check=0)
+    out["streamed/chunk1"] = one
+    hd.close()
+    hp.close()
+    return out
+
+
+def stress_legs(args, api, c0, chain, dev):
+    """BASELINE configs[4]: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule (RANSAC.cpp:87-150 with
+    the adaptive stop disabled), both metrics, one launch chain, HIP events around every kernel."""
+    import torch
+    from putslam_amd import synth
+    from putslam_amd._abi import EST_FIXED, TUM_FR1_K, default_ransac_params, make_config
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
+    frames, kpts, hyp = 9, 5000, 100000
+    seq = synth.make_sequence(frames, kpts, config=3, index=0)
+    P = len(seq["pairs"])
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
+    out = {}
+    for ev in (0, 1):
+        prm = default_ransac_params(ev)
+        cfg, _ = make_config(EST_FIXED, hyp, seed=0xB0B0)
+
+        def step():
+            run_pairs_split([c0], [chain], prm, EST_FIXED, hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=[0, P], join=False)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / n * 1e3
+        c0.enable_timing(True)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        kms = {k: v[0] / max(v[1], 1) for k, v in c0.kernel_time_totals().items()}
+        c0.enable_timing(False)
+        st = pb.download()["stats"]
+        bpp = float(np.mean([api.algorithmic_bytes(kpts, int(x["numMatchesIn"]), int(x["numMatchesValid"]), hyp) for x in st]))
+        dom = max(kms, key=kms.get)
+        ach = bpp * P / (kms[dom] * 1e-3) / 1e9
+        out["stress/E%d" % ev] = {
+            "workload": "BASELINE configs[4]: %d pairs x %d kpts, H = %d fixed, errorVersion %d, one launch chain" % (P, kpts, hyp, ev),
+            "ms_per_step": ms, "pairs_per_s": P / (ms * 1e-3), "steps": n, "kernel_ms": kms, "kernel_ms_sum": sum(kms.values()),
+            "mean_valid_matches": float(st["numMatchesValid"].mean()), "mean_inliers": float(st["numInliers"].mean()),
+            "accepted_pairs": int(st["accepted"].sum()),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": P,
+                         "avg_launch_ms": kms[dom], "traffic": None,
+                         "whole_call_frac": bpp * P / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    return out
 
 
 def usable_cores():

@@ -38,7 +38,8 @@ typedef enum PsStatus {
     PS_ERR_NO_DEVICE = -2,
     PS_ERR_HIP = -3,
     PS_ERR_ALLOC = -4,
-    PS_ERR_UNSUPPORTED = -5
+    PS_ERR_UNSUPPORTED = -5,
+    PS_ERR_BUSY = -6            /* pipelined streaming: every lane holds results the caller has not popped yet */
 } PsStatus;
 
 /* cv::DMatch: same field order and size (16 B) as OpenCV's struct, so a
@@ -284,6 +285,67 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
                       const uint8_t *desc, size_t descStep, const float *pts, int n,
                       PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose, PsRansacStats *stats);
 
+/* ---- A2, PIPELINED streaming form (BASELINE configs[2]: "500 frames streamed through Matcher -> USAC -> Kabsch"):
+ * the same call shape -- frames arrive on the host one after the other, each is matched against its predecessor
+ * (src/Matcher/matcher.cpp:452-516, loop src/PUTSLAM/PUTSLAM.cpp:677-740) -- with the results returned with a LAG instead
+ * of inside the push, so that uploads, kernels and downloads of consecutive frames overlap.  Frames are collected into
+ * chunks of `chunkFrames`; a full chunk is uploaded on a copy stream into a ring of frames resident in HBM (the last
+ * frame of the previous chunk is still there: no halo is sent twice), runs as ONE batched call (ps_vo_pairs_device's
+ * launches) on one of `lanes` private contexts (stream + scratch arena each, so that one chunk's Hamming sweep runs beside
+ * another's scoring sweep), and its results come back in one download into pinned host memory.  chunkFrames = 1 is the
+ * lowest-latency setting, 64..256 the throughput setting; ps_vo_stream_push stays the synchronous per-frame form.
+ *
+ * Pair k of the stream (frames k, k+1 counted from the last reset; frame k is the query = previous frame) draws its
+ * hypotheses from the seeded stream cfg->seed + k: the results are byte for byte those of ONE ps_vo_pairs_device call
+ * over the whole sequence with the same cfg, whatever the chunking.
+ *
+ * ps_vo_stream_configure_async: parameters of the pipelined form, fixed until the next configure (which drains).  chunkFrames
+ *   1..1024 (0 = 128), lanes 2..8 (0 = 4).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
+ * ps_vo_stream_push_async: ONE frame (host pointers, rows of descStep bytes) is copied into the pinned staging area of
+ *   the chunk being collected; the chunk is submitted when it is full.  Returns at once.
+ * ps_vo_stream_push_many: numFrames frames laid out like a PsFrameSet on the HOST (desc numFrames x maxKpts x 32 B,
+ *   pts numFrames x maxKpts x 3 floats, nkpts numFrames) are submitted as chunks of at most chunkFrames.  If desc and pts
+ *   are pinned host memory (ps_host_alloc, hipHostMalloc, hipHostRegister) the upload reads them in place -- they must
+ *   stay untouched until the results of their frames have been popped; pageable memory is staged through pinned buffers.
+ *   Frames staged by push_async before are submitted first, as a chunk of their own.
+ * ps_vo_stream_flush: submits a partly filled chunk.
+ * Flow control: a chunk needs a free lane.  A lane is busy from the submission of its chunk until the view of its results
+ *   has been given back, i.e. until the pop_many / pop call AFTER the one that returned them.  push_async / push_many /
+ *   flush return PS_ERR_BUSY -- and take nothing -- when they would have to submit and no lane is free: pop first.
+ * ps_vo_stream_pop_many: results of the oldest chunk in flight, as HOST pointers into that lane's pinned result block
+ *   (valid until the next pop_many / pop / configure / destroy of this stream).  wait = 0: out->count = 0 if that chunk
+ *   has not finished (or nothing is in flight); wait = 1: blocks until it has.
+ * ps_vo_stream_pop: the same, one pair at a time, copied out (matches / inlierMask: capacity maxKpts; *nmatches = -1 and
+ *   PS_OK when nothing is ready / in flight).
+ * ps_vo_stream_reset on a pipelined stream: the next frame has no predecessor (Matcher::detectInitFeatures) and pair
+ *   numbering restarts at 0; a partly filled chunk is submitted first (PS_ERR_BUSY if that is not possible); chunks in
+ *   flight are unaffected and keep their numbering (`epoch` tells them apart). */
+typedef struct PsHostPairResults {
+    const PsDMatch *matches;      /* count x maxKpts */
+    const int32_t *numMatches;    /* count */
+    const uint8_t *inlierMask;    /* count x maxKpts */
+    const float *pose;            /* count x 16, column-major */
+    const PsRansacStats *stats;   /* count */
+    int64_t firstPair;            /* number of the first pair of the block since the reset it belongs to */
+    int32_t count;                /* pairs in this block; 0 = nothing ready */
+    int32_t maxKpts;
+    int32_t epoch;                /* resets of the stream before this block's frames */
+    int32_t reserved;
+} PsHostPairResults;
+int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                                 int chunkFrames, int lanes);
+int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep, const float *pts, int n);
+int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nkpts, int numFrames);
+int ps_vo_stream_flush(PsVoStream *s);
+int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out);
+int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose,
+                     PsRansacStats *stats);
+/* Pairs submitted or staged whose results have not been popped yet (negative PsStatus on error). */
+int ps_vo_stream_pending(const PsVoStream *s);
+/* Pinned (page-locked) host memory for frames handed to ps_vo_stream_push_many in place; NULL on failure. */
+void *ps_host_alloc(size_t bytes);
+void ps_host_free(void *p);
+
 /* Algorithmic bytes one call of ps_vo_pairs_device moves per SURVEY.md section 8(d):
  * computed from the per-pair stats already on the host (numMatchesIn, numMatchesValid). */
 uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int numHypotheses);
@@ -348,6 +410,7 @@ size_t ps_abi_sizeof_config(void);
 size_t ps_abi_sizeof_stats(void);
 size_t ps_abi_sizeof_frameset(void);
 size_t ps_abi_sizeof_results(void);
+size_t ps_abi_sizeof_host_results(void);
 
 #ifdef __cplusplus
 }

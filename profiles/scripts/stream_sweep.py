@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Pipelined streaming (ps_vo_stream_push_many / pop_many) on the bench workload: pairs/s over chunk size x lanes.
+    python profiles/scripts/stream_sweep.py [--ev 1] [--est fixed] [--hyp 4096] [--frames 500] [--kpts 2000]
+Frames start in pinned host memory; every step uploads all of them and downloads every pair's results."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ev", type=int, default=1)
+    ap.add_argument("--est", default="fixed")
+    ap.add_argument("--hyp", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--kpts", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warm", type=float, default=0.5, help="seconds of untimed steps before every row")
+    ap.add_argument("--grid", default="125x4,125x6,125x8,166x4,166x6,250x4,250x6,64x8,32x8")
+    a = ap.parse_args()
+    from putslam_amd import api, synth
+    from putslam_amd._abi import EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config
+    est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[a.est]
+    seq = synth.make_sequence(a.frames, a.kpts, config=3, index=0)
+    F, cap = seq["desc"].shape[:2]
+    hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
+    hd.array[:] = seq["desc"]
+    hp.array[:] = seq["pts"]
+    nk = np.ascontiguousarray(seq["nkpts"], np.int32)
+    prm = default_ransac_params(a.ev)
+    cfg, _ = make_config(est, a.hyp, seed=0xB0B0)
+    ctx = api.Context(0)
+    for item in a.grid.split(","):
+        chunk, lanes = (int(v) for v in item.split("x"))
+        st = api.VoStream(ctx, cap)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        done = [0]
+
+        def take(wait):
+            b = st.pop_many(wait=wait, copy=False)
+            if b is None:
+                return False
+            done[0] += b["count"]
+            return True
+
+        def step():
+            while not st.reset():
+                take(True)
+            f = 0
+            while f < F:
+                n = min(chunk, F - f)
+                if st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n]):
+                    f += n
+                    while take(False):
+                        pass
+                else:
+                    take(True)
+
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < a.warm:          # (the first rows of an un-warmed sweep ran on a chip at a low clock)
+            step()
+        while take(True):
+            pass
+        d0 = done[0]
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        while take(True):
+            pass
+        el = time.perf_counter() - t0
+        print(f"chunk {chunk:4d} lanes {lanes}: {(done[0] - d0) / el:10.0f} pairs/s  {el / a.steps * 1e3:7.3f} ms/step  "
+              f"H2D {a.steps * F * cap * 44 / el / 1e9:5.1f} GB/s", flush=True)
+        st.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,14 @@ class PsPairResults(C.Structure):
                 ("pose", C.c_void_p), ("stats", C.c_void_p)]
 
 
+class PsHostPairResults(C.Structure):
+    _fields_ = [("matches", C.c_void_p), ("numMatches", C.c_void_p), ("inlierMask", C.c_void_p),
+                ("pose", C.c_void_p), ("stats", C.c_void_p), ("firstPair", C.c_int64), ("count", C.c_int32),
+                ("maxKpts", C.c_int32), ("epoch", C.c_int32), ("reserved", C.c_int32)]
+
+
+PS_ERR_BUSY = -6
+
 DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
 STATS_DTYPE = np.dtype([("numMatchesIn", "<i4"), ("numMatchesValid", "<i4"), ("bestHypothesis", "<i4"),
                         ("bestInlierCount", "<i4"), ("iterationsRun", "<i4"), ("numInliers", "<i4"),

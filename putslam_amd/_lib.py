@@ -6,7 +6,7 @@ object is missing the import fails loudly and tells the caller how to build it.
 import ctypes as C
 import os
 
-from ._abi import PsDMatch, PsFrameSet, PsPairResults, PsRansacConfig, PsRansacParams, PsRansacStats
+from ._abi import PsDMatch, PsFrameSet, PsHostPairResults, PsPairResults, PsRansacConfig, PsRansacParams, PsRansacStats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PUTSLAM_HIP_LIB: A/B hook of the profiling scripts (another build of the same library, e.g. a kernel variant)
@@ -20,11 +20,13 @@ EXPORTED = [
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
+    "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
+    "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
     "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_mathcheck", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stage_order", "ps_debug_stamps",
     "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
-    "ps_abi_sizeof_frameset", "ps_abi_sizeof_results",
+    "ps_abi_sizeof_frameset", "ps_abi_sizeof_results", "ps_abi_sizeof_host_results",
 ]
 
 _lib = None
@@ -133,6 +135,17 @@ def load_path(path):
     L.ps_vo_stream_reset.argtypes = [vp]
     L.ps_vo_stream_push.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, sz, vp, i32, vp,
                                     C.POINTER(i32), vp, vp, vp]
+    L.ps_vo_stream_configure_async.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, i32, i32]
+    L.ps_vo_stream_push_async.argtypes = [vp, vp, sz, vp, i32]
+    L.ps_vo_stream_push_many.argtypes = [vp, vp, vp, vp, i32]
+    L.ps_vo_stream_flush.argtypes = [vp]
+    L.ps_vo_stream_pop_many.argtypes = [vp, i32, C.POINTER(PsHostPairResults)]
+    L.ps_vo_stream_pop.argtypes = [vp, i32, vp, C.POINTER(i32), vp, vp, vp]
+    L.ps_vo_stream_pending.argtypes = [vp]
+    L.ps_host_alloc.argtypes = [sz]
+    L.ps_host_alloc.restype = vp
+    L.ps_host_free.argtypes = [vp]
+    L.ps_host_free.restype = None
     L.ps_vo_pairs_device.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp,
                                      C.POINTER(PsFrameSet), vp, i32, C.POINTER(PsPairResults)]
     L.ps_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
@@ -141,7 +154,7 @@ def load_path(path):
     L.ps_last_kernel_times_ms.argtypes = [vp, vp]
     L.ps_kernel_time_totals.argtypes = [vp, vp, vp]
     L.ps_context_enable_timing.argtypes = [vp, i32]
-    for n in ("dmatch", "params", "config", "stats", "frameset", "results"):
+    for n in ("dmatch", "params", "config", "stats", "frameset", "results", "host_results"):
         getattr(L, "ps_abi_sizeof_" + n).restype = sz
     _by_path[path] = real
     return real
@@ -149,4 +162,5 @@ def load_path(path):
 
 def struct_sizes():
     return dict(dmatch=C.sizeof(PsDMatch), params=C.sizeof(PsRansacParams), config=C.sizeof(PsRansacConfig),
-                stats=C.sizeof(PsRansacStats), frameset=C.sizeof(PsFrameSet), results=C.sizeof(PsPairResults))
+                stats=C.sizeof(PsRansacStats), frameset=C.sizeof(PsFrameSet), results=C.sizeof(PsPairResults),
+                host_results=C.sizeof(PsHostPairResults))

@@ -9,8 +9,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._abi import (DMATCH_DTYPE, STATS_DTYPE, PS_OK, PsFrameSet, PsPairResults, PsRansacConfig,  # noqa: F401
-                   PsRansacParams, default_ransac_params, make_config)
+from ._abi import (DMATCH_DTYPE, STATS_DTYPE, PS_ERR_BUSY, PS_OK, PsFrameSet, PsHostPairResults, PsPairResults,  # noqa: F401
+                   PsRansacConfig, PsRansacParams, default_ransac_params, make_config)
 
 
 class PsError(RuntimeError):
@@ -305,6 +305,106 @@ class VoStream:
             return None
         return dict(matches=matches[: nm.value].copy(), mask=mask[: nm.value].copy(),
                     pose=pose.reshape(4, 4).T.copy(), stats=stats[0].copy())
+
+    # ---- pipelined form (ps_vo_stream_configure_async ...): results come back with a lag, in pair order ----
+    def configure_async(self, params, cfg, K, chunk_frames=0, lanes=0):
+        K = None if K is None else np.ascontiguousarray(K, np.float32)
+        self._ctx._chk(self._ctx._L.ps_vo_stream_configure_async(self._h, C.byref(params), C.byref(cfg), _p(K),
+                                                                 int(chunk_frames), int(lanes)))
+
+    def _rc(self, rc):
+        """PS_ERR_BUSY is flow control, not a failure: returns False for it, True for PS_OK, raises otherwise."""
+        if rc == PS_ERR_BUSY:
+            return False
+        self._ctx._chk(rc)
+        return True
+
+    def push_async(self, desc, pts):
+        """One frame (matcher.cpp:452-516's call shape); False = no free lane, pop first."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32)
+        return self._rc(self._ctx._L.ps_vo_stream_push_async(self._h, _p(desc), 32, _p(pts), desc.shape[0]))
+
+    def push_many(self, desc, pts, nkpts):
+        """desc (F, cap, 32) u8, pts (F, cap, 3) f32, nkpts (F,) i32 -- numpy arrays (pinned ones are read in place: keep them
+        untouched until their results have been popped) or raw (address, address, array) for pre-sliced pinned blocks."""
+        nk = np.ascontiguousarray(nkpts, np.int32)
+        if isinstance(desc, int):
+            dp, pp = C.c_void_p(desc), C.c_void_p(pts)
+        else:
+            assert desc.flags.c_contiguous and pts.flags.c_contiguous and desc.dtype == np.uint8 and pts.dtype == np.float32
+            assert desc.shape[1:] == (self._cap, 32) and pts.shape[1:] == (self._cap, 3)
+            dp, pp = _p(desc), _p(pts)
+        return self._rc(self._ctx._L.ps_vo_stream_push_many(self._h, dp, pp, _p(nk), nk.shape[0]))
+
+    def flush(self):
+        return self._rc(self._ctx._L.ps_vo_stream_flush(self._h))
+
+    def reset(self):
+        return self._rc(self._ctx._L.ps_vo_stream_reset(self._h))
+
+    def pending(self):
+        return self._ctx._L.ps_vo_stream_pending(self._h)
+
+    def pop_many(self, wait=True, copy=True):
+        """Results of the oldest chunk in flight: None if nothing is ready, else dict(first_pair, epoch, matches (n, cap),
+        numMatches, inlierMask, pose (n, 16), stats).  copy=False: views of the pinned block, valid until the next pop."""
+        v = PsHostPairResults()
+        self._ctx._chk(self._ctx._L.ps_vo_stream_pop_many(self._h, 1 if wait else 0, C.byref(v)))
+        if v.count == 0:
+            return None
+        n, cap = v.count, v.maxKpts
+
+        def arr(ptr, nbytes, dtype, shape):
+            a = np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype).reshape(shape)
+            return a.copy() if copy else a
+
+        return dict(first_pair=int(v.firstPair), epoch=int(v.epoch), count=n,
+                    matches=arr(v.matches, n * cap * 16, DMATCH_DTYPE, (n, cap)),
+                    numMatches=arr(v.numMatches, n * 4, np.int32, (n,)),
+                    inlierMask=arr(v.inlierMask, n * cap, np.uint8, (n, cap)),
+                    pose=arr(v.pose, n * 64, np.float32, (n, 16)),
+                    stats=arr(v.stats, n * STATS_DTYPE.itemsize, STATS_DTYPE, (n,)))
+
+    def pop(self, wait=True):
+        """One pair, copied out: None if nothing is ready / in flight, else the dict `push` returns."""
+        matches = np.zeros(max(self._cap, 1), DMATCH_DTYPE)
+        mask = np.zeros(max(self._cap, 1), np.uint8)
+        pose = np.zeros(16, np.float32)
+        stats = np.zeros(1, STATS_DTYPE)
+        nm = C.c_int(0)
+        self._ctx._chk(self._ctx._L.ps_vo_stream_pop(self._h, 1 if wait else 0, _p(matches), C.byref(nm), _p(mask), _p(pose),
+                                                     _p(stats)))
+        if nm.value < 0:
+            return None
+        return dict(matches=matches[: nm.value].copy(), mask=mask[: nm.value].copy(),
+                    pose=pose.reshape(4, 4).T.copy(), stats=stats[0].copy())
+
+
+class PinnedBuffer:
+    """Page-locked host memory from ps_host_alloc, as a numpy array (frames handed to VoStream.push_many in place)."""
+
+    def __init__(self, shape, dtype):
+        self._L = _lib.load()
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(shape)) * self.dtype.itemsize
+        self.ptr = self._L.ps_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MemoryError("ps_host_alloc failed")
+        self.array = np.frombuffer((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr), dtype=self.dtype,
+                                   count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._L.ps_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceFrames:

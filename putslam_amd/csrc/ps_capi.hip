@@ -10,6 +10,7 @@
 #include "ps_score_euclid.h"
 
 #include <cfloat>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -1141,6 +1142,7 @@ size_t ps_abi_sizeof_config(void) { return sizeof(PsRansacConfig); }
 size_t ps_abi_sizeof_stats(void) { return sizeof(PsRansacStats); }
 size_t ps_abi_sizeof_frameset(void) { return sizeof(PsFrameSet); }
 size_t ps_abi_sizeof_results(void) { return sizeof(PsPairResults); }
+size_t ps_abi_sizeof_host_results(void) { return sizeof(PsHostPairResults); }
 
 int ps_context_create(int device, PsContext **out)
 {
@@ -1960,7 +1962,10 @@ struct PsVoStream {
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
+    struct PsVoAsync *async = nullptr; // the pipelined form's state (ps_stream_async.h); null = synchronous stream
 };
+static void async_release(PsVoStream *s); // (ps_stream_async.h)
+static int async_reset(PsVoStream *s);
 
 int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
 {
@@ -1996,6 +2001,7 @@ void ps_vo_stream_destroy(PsVoStream *s)
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    async_release(s);
     for (hipGraphExec_t &g : s->gexec)
         if (g) {
             (void)hipGraphExecDestroy(g);
@@ -2011,6 +2017,7 @@ void ps_vo_stream_destroy(PsVoStream *s)
 int ps_vo_stream_reset(PsVoStream *s)
 {
     if (!s) return PS_ERR_BAD_ARG;
+    if (s->async) return async_reset(s);
     s->frames = 0;
     s->curSlot = 0;
     return PS_OK;
@@ -2032,6 +2039,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         stats->bestHypothesis = -1;
         stats->pointInlierRatio = NAN;
     }
+    if (s->async) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: the stream is configured for the pipelined form (push_async / push_many)");
     if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES || !pose || !nmatches ||
         (n > 0 && (!matches || !inlierMask)) || !cfg)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: bad argument");
@@ -2190,3 +2198,5 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
 }
 
 } // extern "C"
+
+#include "ps_stream_async.h"

@@ -1,0 +1,567 @@
+// ps_stream_async.h -- the PIPELINED streaming form of Matcher::match (include/putslam_hip.h: ps_vo_stream_configure_async,
+// _push_async, _push_many, _flush, _pop_many, _pop).  Included at the end of ps_capi.hip (it uses that file's PsContext,
+// PsVoStream and PS_HIP / PS_ENSURE).
+//
+// Call shape served: reference src/Matcher/matcher.cpp:452-516 (one frame per call, the previous frame kept as state) in the
+// loop of src/PUTSLAM/PUTSLAM.cpp:677-740.  The synchronous ps_vo_stream_push pays a copy in, four kernels, a copy out and a
+// synchronisation per frame (0.1 ms: 10 k frames/s); here frames are collected into chunks, each chunk is one batched call
+// (ps_vo_pairs_device's launches) on one of several lanes, and the results are returned with a lag:
+//
+//   host frames --(copy stream: SDMA uploads)--> ring of frames in HBM --(lane i: kernels 1-4, download)--> pinned result block i --> pop
+//
+//   * the copy stream carries ONLY the two large uploads of every chunk (descriptors, points), which the runtime gives to an
+//     SDMA engine: back to back they keep the link at 48 GB/s of its 55.  The chunk's small meta block (pair list, row counts)
+//     is fetched by a one-work-group kernel on the lane's own stream from mapped pinned memory: as a third hipMemcpyAsync on the
+//     copy stream it was a blit kernel between SDMA transfers, and every change of engine left the link idle for 60 us
+//     (rocprofv3 timeline, profiles/r05a/stream_trace).  Uploads as kernels over mapped pinned memory reach the link rate too
+//     (profiles/microbench/h2d_kernel.hip) but slow the kernels they run beside by 3 - 10 x (profiles/r05b/stream_trace: their
+//     outstanding host reads fill the L2's request queues); SDMA transfers do not.
+//
+//   * ring: (lanes + 2) x chunkFrames frame slots.  A chunk's frames are contiguous in it (a chunk that would not fit before
+//     the end starts at slot 0 again); the frame before the chunk's first one is still resident, so pair (previous chunk's
+//     last frame, this chunk's first frame) needs no second upload.  The chunks in flight read at most the
+//     (lanes - 1) x chunkFrames + 1 slots written last, a jump to slot 0 skips fewer than chunkFrames, the new chunk writes
+//     at most chunkFrames: no slot that is still read is overwritten, with no device-side wait.
+//   * lane = a private PsContext (stream + scratch arena) + device / pinned result blocks + a small meta block (the chunk's
+//     pair list and a snapshot of the ring's row counts, one upload).  Consecutive chunks go to consecutive lanes, so one
+//     chunk's matrix-core Hamming sweep runs beside another's vector scoring sweep, as bench.py's sub-batch chains do.
+//   * per chunk: 2 uploads, the meta kernel, the batched call's launches, 1 download (5 for a partly filled chunk); uploads are
+//     in stream order, so the halo frame needs no event of its own.
+//   * results are those of ONE ps_vo_pairs_device call over the whole sequence: pair k draws from cfg->seed + k.
+#pragma once
+
+namespace psdev {
+
+constexpr int kCopySegs = 5;
+struct CopySegs {
+    const void *src[kCopySegs];
+    void *dst[kCopySegs];
+    unsigned long long bytes[kCopySegs]; // multiples of 4
+    int n;
+};
+
+// Host <-> device transfer as a kernel: every segment is swept grid-stride, 16 bytes per lane where source, destination and
+// length allow it, 4 bytes otherwise.  One side of every segment is mapped pinned host memory: the accesses go over the link.
+__global__ void __launch_bounds__(256) ps_copy_segments(CopySegs cs)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < cs.n; ++k) {
+        const size_t bytes = cs.bytes[k];
+        if ((((size_t)cs.src[k] | (size_t)cs.dst[k] | bytes) & 15) == 0) {
+            const uint4 *__restrict__ s = (const uint4 *)cs.src[k];
+            uint4 *__restrict__ d = (uint4 *)cs.dst[k];
+            for (size_t i = t0; i < bytes / 16; i += stride) d[i] = s[i];
+        } else {
+            const uint32_t *__restrict__ s = (const uint32_t *)cs.src[k];
+            uint32_t *__restrict__ d = (uint32_t *)cs.dst[k];
+            for (size_t i = t0; i < bytes / 4; i += stride) d[i] = s[i];
+        }
+    }
+}
+
+} // namespace psdev
+
+struct AsyncLane {
+    PsContext *ctx = nullptr;
+    Buf meta;                 // device: int32 [2 * B] pair list, then [ringFrames] row counts
+    int32_t *hmeta = nullptr; // pinned mirror of it
+    Buf res;                  // device: [matches B x cap x 16][mask B x cap][pose B x 64][stats B x 40][numMatches B x 4]
+    uint8_t *hres = nullptr;  // pinned mirror of it
+    uint8_t *hstage = nullptr; // pinned staging of frames that arrive one at a time / in pageable memory:
+                               // [B x cap x 32 descriptors][B x cap x 12 points]; allocated when first needed
+    int32_t *hmetaDev = nullptr; // device view of the pinned meta block (hipHostGetDevicePointer)
+    hipEvent_t evIn = nullptr, evDone = nullptr; // behind the chunk's uploads / behind its download
+    int state = 0;            // 0 free, 1 chunk in flight, 2 results handed to the caller
+    long long firstPair = 0;
+    int pairs = 0;
+    int epoch = 0;
+};
+
+struct PsVoAsync {
+    int B = 0, lanes = 0, ringFrames = 0;
+    PsRansacParams prm{};
+    PsRansacConfig cfg{};
+    float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool haveK = false;
+    Buf ringDesc, ringPts;
+    std::vector<int32_t> nkRing; // row counts of the ring's slots (host-authoritative; every chunk uploads a snapshot)
+    hipStream_t copyStream = nullptr;
+    std::vector<AsyncLane> lane;
+    size_t offMask = 0, offPose = 0, offStats = 0, offNum = 0, resBytes = 0;
+    int head = 0, tail = 0, inFlight = 0; // oldest chunk in flight, next lane to submit to
+    int held = -1;                        // lane whose result view the caller holds
+    int ringPos = 0;                      // slot the next frame goes to
+    int prevPos = -1;                     // slot of the stream's latest frame (-1: the next frame has no predecessor)
+    long long pairCounter = 0;
+    int epoch = 0;
+    int staged = 0;                       // frames collected in lane[tail].hstage by push_async
+    std::vector<int32_t> stagedNk;
+    int cursor = 0;                       // ps_vo_stream_pop: next pair of the held view
+    PsHostPairResults view{};
+    double dbgT[3] = {0, 0, 0};        // PUTSLAM_HIP_STREAM_DEBUG=1: host seconds inside the uploads' / the batched call's /
+    long long dbgN = 0;                   // the downloads' submission, printed when the pipeline is released
+};
+
+namespace {
+
+using psdev::CopySegs;
+using psdev::ps_copy_segments;
+
+int async_fail(PsVoStream *s, int code, const char *what, hipError_t e = hipSuccess) { return fail(s->ctx, code, what, e); }
+
+#define PSA_HIP(call)                                                      \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) return async_fail(s, PS_ERR_HIP, #call, e_); \
+    } while (0)
+
+void async_drain(PsVoAsync *a)
+{
+    if (a->copyStream) (void)hipStreamSynchronize(a->copyStream);
+    for (AsyncLane &l : a->lane)
+        if (l.ctx) (void)hipStreamSynchronize(l.ctx->stream);
+}
+
+void async_free(PsVoAsync *a)
+{
+    async_drain(a);
+    if (a->dbgN > 0 && std::getenv("PUTSLAM_HIP_STREAM_DEBUG"))
+        fprintf(stderr, "[ps stream] %lld chunks of <= %d frames on %d lanes: host us per chunk: upload %.1f, batched call %.1f, download %.1f\n",
+                a->dbgN, a->B, a->lanes, 1e6 * a->dbgT[0] / a->dbgN, 1e6 * a->dbgT[1] / a->dbgN, 1e6 * a->dbgT[2] / a->dbgN);
+    for (AsyncLane &l : a->lane) {
+        release(l.meta);
+        release(l.res);
+        if (l.hmeta) (void)hipHostFree(l.hmeta);
+        if (l.hres) (void)hipHostFree(l.hres);
+        if (l.hstage) (void)hipHostFree(l.hstage);
+        if (l.evIn) (void)hipEventDestroy(l.evIn);
+        if (l.evDone) (void)hipEventDestroy(l.evDone);
+        if (l.ctx) ps_context_destroy(l.ctx);
+    }
+    release(a->ringDesc);
+    release(a->ringPts);
+    if (a->copyStream) (void)hipStreamDestroy(a->copyStream);
+    delete a;
+}
+
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory: "invalid value", not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+int lane_stage(PsVoStream *s, AsyncLane &l)
+{
+    if (l.hstage) return PS_OK;
+    PsVoAsync *a = s->async;
+    PSA_HIP(hipHostMalloc((void **)&l.hstage, (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+    return PS_OK;
+}
+
+// One chunk: n frames (pinned host memory: desc n x cap x 32, pts n x cap x 3; row counts nk) -> ring -> lane[tail].  The
+// caller has checked that lane[tail] is free.
+int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
+{
+    PsVoAsync *a = s->async;
+    PsContext *ctx = s->ctx;
+    const size_t cap = (size_t)s->cap;
+    AsyncLane &l = a->lane[(size_t)a->tail];
+    PsContext *lc = l.ctx;
+    const int pos0 = (a->ringPos + n <= a->ringFrames) ? a->ringPos : 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
+                          a->copyStream));
+    PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
+                          a->copyStream));
+    PS_HIP(hipEventRecord(l.evIn, a->copyStream));
+    for (int i = 0; i < n; ++i) a->nkRing[(size_t)(pos0 + i)] = nk[i];
+    const int first = a->prevPos >= 0 ? 0 : 1; // the stream's first frame has no predecessor (matcher.cpp:17-64)
+    const int P = n - first;
+    const int prevPos = a->prevPos;
+    a->ringPos = pos0 + n;
+    a->prevPos = pos0 + n - 1;
+    if (P <= 0) {
+        // a lone first frame: nothing to run, no lane taken; its staging area (if it came through one) is reused by the
+        // next push, so the upload is waited for here
+        PS_HIP(hipStreamSynchronize(a->copyStream));
+        return PS_OK;
+    }
+    int32_t *pm = l.hmeta;
+    for (int i = first; i < n; ++i) { // query = previous frame, train = current (matcher.cpp:470-471)
+        pm[2 * (i - first)] = i == 0 ? prevPos : pos0 + i - 1;
+        pm[2 * (i - first) + 1] = pos0 + i;
+    }
+    memcpy(pm + 2 * (size_t)a->B, a->nkRing.data(), (size_t)a->ringFrames * sizeof(int32_t));
+    CopySegs up{};
+    up.src[0] = l.hmetaDev;
+    up.dst[0] = l.meta.p;
+    up.bytes[0] = ((unsigned long long)2 * a->B + a->ringFrames) * sizeof(int32_t);
+    up.n = 1;
+    hipLaunchKernelGGL(ps_copy_segments, dim3(1), dim3(256), 0, lc->stream, up); // (a few KB: beside the previous chunk's kernels)
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipStreamWaitEvent(lc->stream, l.evIn, 0));
+    const double t1 = now();
+    PsFrameSet fs;
+    fs.desc = (const uint8_t *)a->ringDesc.p;
+    fs.pts = (const float *)a->ringPts.p;
+    fs.nkpts = (const int32_t *)l.meta.p + 2 * (size_t)a->B;
+    fs.numFrames = a->ringFrames;
+    fs.maxKpts = s->cap;
+    uint8_t *dres = (uint8_t *)l.res.p;
+    PsPairResults out;
+    out.matches = (PsDMatch *)dres;
+    out.inlierMask = dres + a->offMask;
+    out.pose = (float *)(dres + a->offPose);
+    out.stats = (PsRansacStats *)(dres + a->offStats);
+    out.numMatches = (int32_t *)(dres + a->offNum);
+    PsRansacConfig c2 = a->cfg;
+    c2.seed = a->cfg.seed + (uint64_t)a->pairCounter;
+    int rc = ps_vo_pairs_device(lc, &a->prm, &c2, a->haveK ? a->K : nullptr, &fs, (const int32_t *)l.meta.p, P, &out);
+    if (rc != PS_OK) {
+        ctx->err = std::string("pipelined chunk: ") + lc->err;
+        (void)hipStreamSynchronize(lc->stream);
+        return rc;
+    }
+    const double t2 = now();
+    if (P == a->B) {
+        PS_HIP(hipMemcpyAsync(l.hres, dres, a->resBytes, hipMemcpyDeviceToHost, lc->stream));
+    } else {
+        const size_t p = (size_t)P;
+        PS_HIP(hipMemcpyAsync(l.hres, dres, p * cap * sizeof(PsDMatch), hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offMask, dres + a->offMask, p * cap, hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offPose, dres + a->offPose, p * 64, hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offStats, dres + a->offStats, p * sizeof(PsRansacStats), hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offNum, dres + a->offNum, p * sizeof(int32_t), hipMemcpyDeviceToHost, lc->stream));
+    }
+    PS_HIP(hipEventRecord(l.evDone, lc->stream));
+    const double t3 = now();
+    if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DEBUG"))
+        if (v[0] == '2')
+            fprintf(stderr, "[chunk %lld lane %d P %d] uploads %.1f call %.1f download %.1f\n", a->dbgN, a->tail, P, 1e6 * (t1 - t0),
+                    1e6 * (t2 - t1), 1e6 * (t3 - t2));
+    a->dbgT[0] += t1 - t0;
+    a->dbgT[1] += t2 - t1;
+    a->dbgT[2] += t3 - t2;
+    a->dbgN++;
+    l.state = 1;
+    l.firstPair = a->pairCounter;
+    l.pairs = P;
+    l.epoch = a->epoch;
+    a->pairCounter += P;
+    a->tail = (a->tail + 1) % a->lanes;
+    a->inFlight++;
+    return PS_OK;
+}
+
+int async_submit_staged(PsVoStream *s)
+{
+    PsVoAsync *a = s->async;
+    if (a->staged == 0) return PS_OK;
+    AsyncLane &l = a->lane[(size_t)a->tail];
+    const size_t cap = (size_t)s->cap;
+    const int n = a->staged;
+    // (the staging area belongs to lane[tail], which push_async found free when it took the chunk's first frame)
+    int rc = async_submit(s, l.hstage, reinterpret_cast<const float *>(l.hstage + (size_t)a->B * cap * 32), a->stagedNk.data(), n);
+    if (rc == PS_OK) a->staged = 0;
+    return rc;
+}
+
+// device / pinned blocks, streams, events and lane contexts of a freshly configured pipeline
+int async_build(PsVoStream *s)
+{
+    PsVoAsync *a = s->async;
+    PsContext *ctx = s->ctx;
+    const size_t cap = (size_t)s->cap, B = (size_t)a->B;
+    a->offMask = B * cap * sizeof(PsDMatch);
+    a->offPose = a->offMask + ((B * cap + 63) & ~(size_t)63);
+    a->offStats = a->offPose + B * 64;
+    a->offNum = a->offStats + ((B * sizeof(PsRansacStats) + 63) & ~(size_t)63);
+    a->resBytes = a->offNum + B * sizeof(int32_t);
+    a->nkRing.assign((size_t)a->ringFrames, 0);
+    a->stagedNk.assign(B, 0);
+    PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
+    PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
+    PS_HIP(hipStreamCreateWithFlags(&a->copyStream, hipStreamNonBlocking));
+    a->lane.resize((size_t)a->lanes);
+    for (AsyncLane &l : a->lane) {
+        int rc = ps_context_create(ctx->device, &l.ctx);
+        if (rc != PS_OK) {
+            l.ctx = nullptr;
+            return fail(ctx, rc, "ps_vo_stream_configure_async: lane context");
+        }
+        for (const OptDesc &o : kOptions) l.ctx->*(o.field) = ctx->*(o.field); // the lanes run what the stream's context would
+        PS_ENSURE(l.meta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t));
+        PS_ENSURE(l.res, (a->resBytes + 15) & ~(size_t)15);
+        PS_HIP(hipHostMalloc((void **)&l.hmeta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t), hipHostMallocDefault));
+        PS_HIP(hipHostMalloc((void **)&l.hres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
+        PS_HIP(hipHostGetDevicePointer((void **)&l.hmetaDev, l.hmeta, 0));
+        PS_HIP(hipEventCreateWithFlags(&l.evIn, hipEventDisableTiming));
+        PS_HIP(hipEventCreateWithFlags(&l.evDone, hipEventDisableTiming));
+    }
+    return PS_OK;
+}
+
+void release_view(PsVoAsync *a)
+{
+    if (a->held >= 0) {
+        a->lane[(size_t)a->held].state = 0;
+        a->held = -1;
+    }
+    a->cursor = 0;
+    memset(&a->view, 0, sizeof a->view);
+}
+
+} // namespace
+
+static void async_release(PsVoStream *s)
+{
+    if (!s || !s->async) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    async_free(s->async);
+    s->async = nullptr;
+}
+
+static int async_reset(PsVoStream *s)
+{
+    PsVoAsync *a = s->async;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    if (a->staged > 0) {
+        if (a->lane[(size_t)a->tail].state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_reset: a partly filled chunk is waiting for a free lane (pop first)");
+        rc = async_submit_staged(s);
+        if (rc) return rc;
+    }
+    a->prevPos = -1;
+    a->pairCounter = 0;
+    a->epoch++;
+    return PS_OK;
+}
+
+extern "C" {
+
+int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                                 int chunkFrames, int lanes)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    PsContext *ctx = s->ctx;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!params || !cfg) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: null params/config");
+    if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming calls");
+    if (chunkFrames == 0) chunkFrames = 128;
+    if (lanes == 0) lanes = 4;
+    if (chunkFrames < 1 || chunkFrames > 1024 || lanes < 2 || lanes > 8)
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: chunkFrames 1..1024, lanes 2..8");
+    {
+        // the parameters are checked here, not at the first chunk: a plan on the stream's own context
+        Plan pl;
+        rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
+        if (rc) return rc;
+    }
+    if (s->async) { // re-configuration: drain, drop what has not been popped
+        async_free(s->async);
+        s->async = nullptr;
+    }
+    PsVoAsync *a = new PsVoAsync();
+    s->async = a;
+    a->B = chunkFrames;
+    a->lanes = lanes;
+    a->ringFrames = (lanes + 2) * chunkFrames;
+    a->prm = *params;
+    a->cfg = *cfg;
+    a->cfg.sampleIdx = nullptr;
+    a->haveK = K != nullptr;
+    if (K) memcpy(a->K, K, sizeof a->K);
+    rc = async_build(s);
+    if (rc != PS_OK) { // (the error text stays in the stream's context)
+        const std::string why = ctx->err;
+        async_free(a);
+        s->async = nullptr;
+        ctx->err = why;
+    }
+    return rc;
+}
+
+int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep, const float *pts, int n)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    PsVoAsync *a = s->async;
+    if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_async: call ps_vo_stream_configure_async first");
+    if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES)
+        return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_async: bad argument");
+    AsyncLane &l = a->lane[(size_t)a->tail];
+    if (l.state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_async: no free lane (pop results first)");
+    rc = lane_stage(s, l);
+    if (rc) return rc;
+    const size_t cap = (size_t)s->cap;
+    uint8_t *hd = l.hstage + (size_t)a->staged * cap * 32;
+    uint8_t *hp = l.hstage + (size_t)a->B * cap * 32 + (size_t)a->staged * cap * 12;
+    if (descStep == PS_DESC_BYTES) {
+        if (n > 0) memcpy(hd, desc, (size_t)n * 32);
+    } else {
+        for (int i = 0; i < n; ++i) memcpy(hd + (size_t)i * 32, desc + (size_t)i * descStep, 32);
+    }
+    if (n > 0) memcpy(hp, pts, (size_t)n * 12);
+    a->stagedNk[(size_t)a->staged] = n;
+    a->staged++;
+    if (a->staged == a->B) return async_submit_staged(s);
+    return PS_OK;
+}
+
+int ps_vo_stream_flush(PsVoStream *s)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    PsVoAsync *a = s->async;
+    if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_flush: call ps_vo_stream_configure_async first");
+    if (a->staged == 0) return PS_OK;
+    if (a->lane[(size_t)a->tail].state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_flush: no free lane (pop results first)");
+    return async_submit_staged(s);
+}
+
+int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nkpts, int numFrames)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    PsVoAsync *a = s->async;
+    if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many: call ps_vo_stream_configure_async first");
+    if (numFrames < 0 || (numFrames > 0 && (!desc || !pts || !nkpts)))
+        return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many: bad argument");
+    for (int i = 0; i < numFrames; ++i)
+        if (nkpts[i] < 0 || nkpts[i] > s->cap) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many: row count out of range");
+    if (numFrames == 0) return PS_OK;
+    // lanes needed: one for the frames push_async has staged, one per chunk of these frames -- all or nothing
+    const int chunks = (numFrames + a->B - 1) / a->B;
+    const int need = chunks + (a->staged > 0 ? 1 : 0);
+    int freeLanes = 0;
+    for (int i = 0; i < a->lanes && a->lane[(size_t)((a->tail + i) % a->lanes)].state == 0; ++i) ++freeLanes;
+    if (need > freeLanes)
+        return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough free lanes for these frames (pop results first, or push fewer)");
+    rc = async_submit_staged(s);
+    if (rc) return rc;
+    const size_t cap = (size_t)s->cap;
+    // pinned frames are uploaded in place; pageable ones go through the lane's pinned staging area first
+    const bool inPlace = is_pinned_host(desc) && is_pinned_host(pts);
+    for (int f0 = 0; f0 < numFrames; f0 += a->B) {
+        const int n = numFrames - f0 < a->B ? numFrames - f0 : a->B;
+        const uint8_t *d = desc + (size_t)f0 * cap * 32;
+        const float *p = pts + (size_t)f0 * cap * 3;
+        if (!inPlace) {
+            AsyncLane &l = a->lane[(size_t)a->tail];
+            rc = lane_stage(s, l);
+            if (rc) return rc;
+            memcpy(l.hstage, d, (size_t)n * cap * 32);
+            memcpy(l.hstage + (size_t)a->B * cap * 32, p, (size_t)n * cap * 12);
+            d = l.hstage;
+            p = reinterpret_cast<const float *>(l.hstage + (size_t)a->B * cap * 32);
+        }
+        rc = async_submit(s, d, p, nkpts + f0, n);
+        if (rc) return rc;
+    }
+    return PS_OK;
+}
+
+int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    PsVoAsync *a = s->async;
+    if (!a || !out) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop_many: bad argument / stream not configured");
+    release_view(a);
+    memset(out, 0, sizeof *out);
+    out->maxKpts = s->cap;
+    if (a->inFlight == 0) return PS_OK;
+    AsyncLane &l = a->lane[(size_t)a->head];
+    if (wait) {
+        PSA_HIP(hipEventSynchronize(l.evDone));
+    } else {
+        hipError_t q = hipEventQuery(l.evDone);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return PS_OK;
+        }
+        if (q != hipSuccess) return async_fail(s, PS_ERR_HIP, "hipEventQuery", q);
+    }
+    out->matches = (const PsDMatch *)l.hres;
+    out->inlierMask = l.hres + a->offMask;
+    out->pose = (const float *)(l.hres + a->offPose);
+    out->stats = (const PsRansacStats *)(l.hres + a->offStats);
+    out->numMatches = (const int32_t *)(l.hres + a->offNum);
+    out->firstPair = l.firstPair;
+    out->count = l.pairs;
+    out->epoch = l.epoch;
+    l.state = 2;
+    a->held = a->head;
+    a->head = (a->head + 1) % a->lanes;
+    a->inFlight--;
+    a->view = *out;
+    return PS_OK;
+}
+
+int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose,
+                     PsRansacStats *stats)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    PsVoAsync *a = s->async;
+    if (!a || !nmatches || !pose) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: bad argument / stream not configured");
+    *nmatches = -1;
+    if (a->held < 0 || a->cursor >= a->view.count) {
+        PsHostPairResults v;
+        // (a frame that waits in a partly filled chunk is not submitted by a pop: ps_vo_stream_flush does that)
+        int rc = ps_vo_stream_pop_many(s, wait, &v);
+        if (rc) return rc;
+        if (v.count == 0) return PS_OK;
+    }
+    const PsHostPairResults &v = a->view;
+    const size_t i = (size_t)a->cursor++, cap = (size_t)s->cap;
+    const int nm = v.numMatches[i];
+    memcpy(pose, v.pose + i * 16, 16 * sizeof(float));
+    if (stats) *stats = v.stats[i];
+    if (nm > 0) {
+        if (!matches || !inlierMask) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: null output");
+        memcpy(matches, v.matches + i * cap, (size_t)nm * sizeof(PsDMatch));
+        memcpy(inlierMask, v.inlierMask + i * cap, (size_t)nm);
+    }
+    *nmatches = nm;
+    return PS_OK;
+}
+
+int ps_vo_stream_pending(const PsVoStream *s)
+{
+    if (!s || !s->async) return PS_ERR_BAD_ARG;
+    const PsVoAsync *a = s->async;
+    int n = 0;
+    for (const AsyncLane &l : a->lane)
+        if (l.state == 1) n += l.pairs;
+    if (a->held >= 0) n += a->view.count - a->cursor;
+    if (a->staged > 0) n += a->staged - (a->prevPos >= 0 ? 0 : 1);
+    return n;
+}
+
+void *ps_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void ps_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+} // extern "C"

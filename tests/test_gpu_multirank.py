@@ -162,3 +162,22 @@ def test_bench_rccl_branch_with_a_world_of_one(tmp_path, streams):
     assert got.shape == want.shape == (1, 13, 18)
     assert got.tobytes() == want.tobytes()
     assert np.abs(got[0, :, :16]).sum() > 0 and (got[0, :, 17] > 0).all()      # real records: poses and match counts
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the way the driver starts the one-GPU bench -- must not exit with
+    rc 2 (round 4) but start the two ranks itself (fresh child processes, the launcher never touches the GPU) and pass rank 0's
+    JSON line through.  Here both ranks share the one GPU over gloo; on a node they are one per GPU over RCCL."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = _env(PUTSLAM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=0)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    multi = tmp_path / "self.npy"
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--dump-records", str(multi)] + ARGS, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["pairs_per_step"] == 26 and j["value"] > 0
+    got = np.load(multi)
+    assert got.shape == (2, 13, 18) and got[0].tobytes() != got[1].tobytes()

@@ -1,0 +1,229 @@
+"""Pipelined streaming (ps_vo_stream_configure_async / push_async / push_many / flush / pop_many / pop) vs the oracle.
+
+The call shape is the reference's: one frame at a time, the previous frame kept as state (src/Matcher/matcher.cpp:452-516 in the
+loop of src/PUTSLAM/PUTSLAM.cpp:677-740).  Whatever the chunking, the results must be the bytes of ONE batched call over the
+sequence (pair k draws from seed + k), i.e. the oracle's vo_pairs."""
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, EUCLIDEAN_ERROR, REPROJECTION_ERROR, TUM_FR1_K,
+                              default_ransac_params, make_config)
+
+pytestmark = pytest.mark.gpu
+
+STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
+               "accepted", "bestInlierRatio", "pointInlierRatio")
+
+
+def _check_block(blk, c, lo):
+    """Block of popped results == the oracle's pairs [lo, lo + count)."""
+    for i in range(blk["count"]):
+        p = lo + i
+        n = int(c["numMatches"][p])
+        assert int(blk["numMatches"][i]) == n, p
+        assert blk["matches"][i, :n].tobytes() == c["matches"][p, :n].tobytes(), p
+        assert np.array_equal(blk["inlierMask"][i, :n], c["inlierMask"][p, :n]), p
+        assert blk["pose"][i].tobytes() == c["pose"][p].tobytes(), p
+        for f in STAT_FIELDS:
+            a, b = blk["stats"][i][f], c["stats"][p][f]
+            assert a == b or (np.isnan(a) and np.isnan(b)), (p, f, a, b)
+
+
+def _drain(st, c, got, wait=True):
+    while True:
+        blk = st.pop_many(wait=wait)
+        if blk is None:
+            return got
+        assert blk["first_pair"] == got, (blk["first_pair"], got)      # in order, nothing skipped
+        _check_block(blk, c, got)
+        got += blk["count"]
+
+
+@pytest.fixture(scope="module")
+def seq64(oracle):
+    seq = synth.make_sequence(64, 600, config=3, index=505)
+    out = {}
+    for name, mode, est, H in (("e1", REPROJECTION_ERROR, EST_FIXED, 1024), ("e0", EUCLIDEAN_ERROR, EST_RANSAC, 487)):
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(est, H, seed=0x5EED)
+        out[name] = (prm, cfg, oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=8))
+    return seq, out
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+@pytest.mark.parametrize("regime", ["e1", "e0"])
+def test_streamed_sequence_equals_batch_and_oracle(ctx, seq64, chunk, regime):
+    """a 64-frame sequence streamed in chunks of 1, 7 and 64 frames -- pinned frames handed over in
+    place -- gives the bytes of the batched call (= the oracle's)."""
+    from putslam_amd import api
+    seq, runs = seq64
+    prm, cfg, c = runs[regime]
+    F, cap = seq["desc"].shape[:2]
+    hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
+    hd.array[:] = seq["desc"]
+    hp.array[:] = seq["pts"]
+    st = api.VoStream(ctx, cap)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=3)
+    got = 0
+    f = 0
+    while f < F:
+        n = min(F - f, 2 * chunk)                          # two chunks per call: both the split and the lane accounting
+        if st.push_many(hd.array[f:f + n], hp.array[f:f + n], seq["nkpts"][f:f + n]):
+            f += n
+        else:
+            got = _drain(st, c, got, wait=False)           # PS_ERR_BUSY: make room
+            blk = st.pop_many(wait=True)
+            if blk is not None:
+                assert blk["first_pair"] == got
+                _check_block(blk, c, got)
+                got += blk["count"]
+    got = _drain(st, c, got)
+    assert got == F - 1 and st.pending() == 0
+    st.close()
+    hd.close()
+    hp.close()
+
+
+def test_frame_by_frame_push_async_and_pop(ctx, seq64):
+    """The reference's own shape: one frame per call in, one result per call out (with a lag), pageable host memory."""
+    from putslam_amd import api
+    seq, runs = seq64
+    prm, cfg, c = runs["e0"]
+    F, cap = seq["desc"].shape[:2]
+    st = api.VoStream(ctx, cap)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=5, lanes=2)
+    got = 0
+
+    def take(wait):
+        nonlocal got
+        r = st.pop(wait=wait)
+        if r is None:
+            return False
+        n = int(c["numMatches"][got])
+        assert r["matches"].tobytes() == c["matches"][got, :n].tobytes(), got
+        assert np.array_equal(r["mask"], c["inlierMask"][got, :n]) and r["pose"].T.reshape(-1).tobytes() == c["pose"][got].tobytes(), got
+        got += 1
+        return True
+
+    for f in range(F):
+        while not st.push_async(seq["desc"][f], seq["pts"][f]):
+            assert take(True)
+        take(False)
+    while not st.flush():
+        assert take(True)
+    while take(True):
+        pass
+    assert got == F - 1 and st.pending() == 0
+    st.close()
+
+
+def test_ragged_frames_reset_and_pageable_input(ctx, oracle):
+    """Ragged row counts incl. an empty and a one-keypoint frame, pageable input (staged through pinned buffers), a reset in
+    the middle (the next frame has no predecessor, numbering restarts, `epoch` advances), a partly filled chunk flushed."""
+    from putslam_amd import api
+    seq = synth.make_sequence(20, 500, config=3, index=71)
+    nk = np.array([500, 499, 500, 0, 500, 1, 500, 320, 500, 500, 500, 450, 500, 500, 2, 500, 500, 500, 17, 500], np.int32)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_USAC, 700, seed=31337)
+    first, second = slice(0, 11), slice(11, 20)
+    cs = []
+    for sl in (first, second):
+        F = sl.stop - sl.start
+        pairs = np.stack([np.arange(F - 1), np.arange(1, F)], axis=1).astype(np.int32)
+        cs.append(oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"][sl], seq["pts"][sl], nk[sl], pairs, threads=4))
+    st = api.VoStream(ctx, 500)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=4, lanes=4)
+    assert st.push_many(seq["desc"][0:8], seq["pts"][0:8], nk[0:8])           # two chunks
+    for f in range(8, 11):                                                     # three staged frames ...
+        assert st.push_async(seq["desc"][f][: nk[f]], seq["pts"][f][: nk[f]])
+    assert st.pending() == 10
+    assert st.reset()                                                          # ... submitted by the reset
+    assert st.push_many(seq["desc"][11:12], seq["pts"][11:12], nk[11:12])      # a lone first frame: no pair, no lane
+    blocks = []
+    while True:
+        b = st.pop_many(wait=True)
+        if b is None:
+            break
+        blocks.append(b)
+    assert [b["count"] for b in blocks] == [3, 4, 3] and [b["epoch"] for b in blocks] == [0, 0, 0]
+    lo = 0
+    for b in blocks:
+        assert b["first_pair"] == lo
+        _check_block(b, cs[0], lo)
+        lo += b["count"]
+    assert st.push_many(seq["desc"][12:20], seq["pts"][12:20], nk[12:20])
+    lo = 0
+    while True:
+        b = st.pop_many(wait=True)
+        if b is None:
+            break
+        assert b["epoch"] == 1 and b["first_pair"] == lo
+        _check_block(b, cs[1], lo)
+        lo += b["count"]
+    assert lo == 8
+    st.close()
+
+
+def test_flow_control_and_errors(ctx):
+    from putslam_amd import api
+    seq = synth.make_sequence(13, 300, config=3, index=3)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=1)
+    st = api.VoStream(ctx, 300)
+    with pytest.raises(api.PsError):                                           # not configured yet
+        st.push_async(seq["desc"][0], seq["pts"][0])
+    with pytest.raises(api.PsError):
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=2000, lanes=3)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=3, lanes=2)
+    with pytest.raises(api.PsError):                                           # the synchronous push is refused on a pipelined stream
+        st.push(prm, cfg, TUM_FR1_K, seq["desc"][0], seq["pts"][0])
+    assert st.push_many(seq["desc"][0:6], seq["pts"][0:6], seq["nkpts"][0:6])  # both lanes taken
+    assert not st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])    # PS_ERR_BUSY, nothing consumed
+    assert not st.push_async(seq["desc"][6], seq["pts"][6])
+    assert st.pending() == 5
+    a = st.pop_many(wait=True)
+    assert a["count"] == 2 and a["first_pair"] == 0
+    assert not st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])    # the view of lane 0 is still held
+    b = st.pop_many(wait=True)                                                 # gives lane 0 back
+    assert b["count"] == 3 and b["first_pair"] == 2
+    assert st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])
+    assert not st.push_many(seq["desc"][9:12], seq["pts"][9:12], seq["nkpts"][9:12])  # lane 1's view is held now
+    c = st.pop_many(wait=True)
+    assert c["count"] == 3 and c["first_pair"] == 5
+    assert st.pop_many(wait=True) is None and st.pop_many(wait=False) is None
+    # re-configuration drains and starts over; a bad row count is refused
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=4, lanes=2)
+    with pytest.raises(api.PsError):
+        st.push_many(seq["desc"][0:2], seq["pts"][0:2], np.array([300, 301], np.int32))
+    assert st.push_many(seq["desc"][0:4], seq["pts"][0:4], seq["nkpts"][0:4])
+    d = st.pop_many(wait=True)
+    assert d["count"] == 3 and d["first_pair"] == 0 and d["epoch"] == 0
+    st.close()
+
+
+def test_throughput_chunks_match_the_batched_call_on_the_bench_shape(ctx):
+    """A 130-frame, 2000-keypoint sequence (the bench's frame size) in chunks of 64: the pipelined results against the batched
+    call's own bytes (the oracle takes too long at this size; the batched call is compared with it elsewhere)."""
+    from putslam_amd import api
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(130, 2000, config=3, index=9090)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=0xB0B0)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, pb)
+    ref = pb.download()
+    ref = dict(ref, matches=ref["matches"], numMatches=ref["numMatches"])
+    F, cap = seq["desc"].shape[:2]
+    hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
+    hd.array[:] = seq["desc"]
+    hp.array[:] = seq["pts"]
+    st = api.VoStream(ctx, cap)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=64, lanes=4)
+    assert st.push_many(hd.array, hp.array, seq["nkpts"])                      # 3 chunks: 64 + 64 + 2 frames
+    got = _drain(st, ref, 0)
+    assert got == F - 1
+    st.close()
+    hd.close()
+    hp.close()

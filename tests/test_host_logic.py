@@ -144,3 +144,36 @@ def test_gather_world2_gloo():
         inc = blk[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
         traj = sharding.compose_trajectory(inc)
         assert traj.shape == (4, 4, 4) and np.all(np.isfinite(traj))
+
+
+def test_bench_launcher_sets_the_rank_environment_and_returns_the_worst_exit_code(tmp_path):
+    """bench.py --gpus N started plainly becomes the launcher (bench.spawn_ranks): N child processes with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rank 0's stdout passed through, the worst exit code returned.  The children here are a stand-in
+    script (no GPU in this container): what is under test is the launcher, which itself never imports torch."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "bench.py"
+    src = open(os.path.join(root, "bench.py")).read()
+    # the launcher half of bench.py verbatim, its main() replaced by a child that reports its environment
+    head = src[:src.index("def main():")]
+    fake.write_text(head + textwrap.dedent('''
+        def main():
+            args = parse()
+            if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+                assert "torch" not in sys.modules
+                sys.exit(spawn_ranks(args))
+            r = int(os.environ["RANK"])
+            print("rank", r, os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
+            sys.exit(3 if (r == 1 and args.steps == 99) else 0)
+        if __name__ == "__main__":
+            main()
+    '''))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    ok = subprocess.run([sys.executable, str(fake), "--gpus", "4", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    lines = ok.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].split()[:5] == ["rank", "0", "0", "4", "127.0.0.1"]      # only rank 0's stdout comes through
+    bad = subprocess.run([sys.executable, str(fake), "--gpus", "2", "--steps", "99"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 3
