@@ -4,14 +4,18 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -
 CSRC := putslam_amd/csrc
 LIB := putslam_amd/libputslam_hip.so
 DROPIN := putslam_amd/libputslam_dropin.so
+SHARD := putslam_amd/libputslam_shard.so
 
-all: $(LIB) $(DROPIN) oracle
+all: $(LIB) $(DROPIN) $(SHARD) oracle
 
 $(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_device_math.h $(CSRC)/ps_stream_async.h include/putslam_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
 
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I$(CSRC)/dropin $< -o $@ -Lputslam_amd -lputslam_hip '-Wl,-rpath,$$ORIGIN'
+
+$(SHARD): $(CSRC)/ps_shard.hip include/putslam_shard.h include/putslam_hip.h $(LIB)
+	$(HIPCC) --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -shared -Iinclude $< -o $@ -Lputslam_amd -lputslam_hip -L/opt/rocm/lib -lrccl '-Wl,-rpath,$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle
@@ -26,7 +30,7 @@ bench: all
 	python bench.py
 
 clean:
-	rm -f $(LIB) $(DROPIN) tests/cpp/test_dropin tests/cpp/test_reference_shaped
+	rm -f $(LIB) $(DROPIN) $(SHARD) tests/cpp/test_dropin tests/cpp/test_reference_shaped demos/cpp/demo_matching demos/cpp/demo_sequences_multi_gpu
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle test-cpu test-gpu bench clean

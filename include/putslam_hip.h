@@ -117,6 +117,11 @@ void ps_context_destroy(PsContext *ctx);
  * One context still serves one caller thread at a time; concurrent chains use one context each. */
 int ps_context_set_stream(PsContext *ctx, void *hipStream);
 int ps_context_synchronize(PsContext *ctx);
+/* The hipStream_t the context's calls are queued on (its private stream unless ps_context_set_stream chose another) and the
+ * device it was created for: what a host needs to order its own kernels, copies or collectives with the context's work
+ * (include/putslam_shard.h queues its RCCL calls there). */
+void *ps_context_stream(PsContext *ctx);
+int ps_context_device(const PsContext *ctx);
 /* Kernel variants kept side by side for A/B measurements and as tested twins (results are identical):
  *   "matcher": 1 = FP4 matrix-core sweep ps_hamming_mfma, 0 = integer VALU sweep ps_hamming_nn, 2 = by batch size
  *              (default: the matrix-core form, one launch more, from about five 2000-keypoint pairs per call on)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PUTSLAM_HIP_LIB") or os.path.join(_HERE, "libputslam_
 # every symbol include/putslam_hip.h declares
 EXPORTED = [
     "ps_context_create", "ps_context_destroy", "ps_context_set_stream", "ps_context_synchronize",
+    "ps_context_stream", "ps_context_device",
     "ps_context_set_option", "ps_context_get_option",
     "ps_last_error", "ps_abi_version", "ps_device_arch",
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
@@ -102,6 +103,9 @@ def load_path(path):
     L.ps_context_destroy.restype = None
     L.ps_context_set_stream.argtypes = [vp, vp]
     L.ps_context_synchronize.argtypes = [vp]
+    L.ps_context_stream.argtypes = [vp]
+    L.ps_context_stream.restype = vp
+    L.ps_context_device.argtypes = [vp]
     L.ps_context_set_option.argtypes = [vp, C.c_char_p, i32]
     L.ps_context_get_option.argtypes = [vp, C.c_char_p]
     L.ps_debug_score_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -321,8 +321,13 @@ struct FrameMatcher::Fused {
     PsContext *ctx = nullptr;
     PsVoStream *stream = nullptr;
     int cap = 0;
+    PsVoStream *pipe = nullptr; // the pipelined form's stream (enqueueFrame / dequeueResult)
+    int pipeCap = 0;
+    std::vector<cv::DMatch> pm;
+    std::vector<uint8_t> pmask;
     ~Fused()
     {
+        if (pipe) ps_vo_stream_destroy(pipe);
         if (stream) ps_vo_stream_destroy(stream);
         if (ctx) ps_context_destroy(ctx);
     }
@@ -407,6 +412,124 @@ bool FrameMatcher::fusedMatchCall(const cv::Mat &descriptors, const std::vector<
     // (unique inlier train indices / unique matched train indices, 0/0 = NaN like the reference's set sizes)
     pointInlierRatio = st.pointInlierRatio;
     return true;
+}
+
+// ---- pipelined form of runVO -------------------------------------------------------------------
+void FrameMatcher::setPipeline(int chunkFrames, int lanes)
+{
+    pipeChunk_ = chunkFrames;
+    pipeLanes_ = lanes;
+    resetPipeline();
+}
+
+void FrameMatcher::resetPipeline()
+{
+    if (fused_ && fused_->pipe) {
+        ps_vo_stream_destroy(fused_->pipe); // (drains; results not dequeued are dropped)
+        fused_->pipe = nullptr;
+    }
+    pipeFirst_ = true;
+}
+
+bool FrameMatcher::enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
+{
+    const int n = (int)features3D.size();
+    if (n > PS_MAX_KPTS || (n > 0 && (descriptors.cols != PS_DESC_BYTES || descriptors.rows != n))) return false;
+    if (!fused_) fused_.reset(new Fused());
+    Fused &f = *fused_;
+    if (!f.ctx) {
+        int dev = 0;
+        if (const char *e = std::getenv("PUTSLAM_HIP_DEVICE")) dev = std::atoi(e);
+        if (ps_context_create(dev, &f.ctx) != PS_OK) {
+            f.ctx = nullptr;
+            return false;
+        }
+    }
+    if (!f.pipe) {
+        // the pipeline's frame capacity is fixed when it is built: room for a quarter more keypoints than the first frame has
+        f.pipeCap = std::min(PS_MAX_KPTS, std::max(2048, n + n / 4));
+        if (ps_vo_stream_create(f.ctx, f.pipeCap, &f.pipe) != PS_OK) {
+            f.pipe = nullptr;
+            return false;
+        }
+        matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // matcher.cpp:491-492
+        RANSAC::parameters rp = matcherParameters.RANSACParams;
+        rp.iterationCount = ransacIterations(0.20); // RANSAC.cpp:30
+        const PsRansacParams prm = toPs(rp);
+        int a = ransacIterations(0.20), b = ransacIterations(rp.minimalInlierRatioThreshold);
+        int H = std::max(1, std::min(a > b ? a : b, PS_MAX_HYPOTHESES));
+        PsRansacConfig cfg;
+        cfg.estimator = PS_EST_RANSAC;
+        cfg.numHypotheses = H;
+        // pair k of the pipeline draws from seed + k: runVO's seeding (seed_ + frameCounter, the counter starting at 0 with the
+        // initial frame)
+        cfg.seed = seeded_ ? seed_ : (uint64_t)std::time(nullptr); // RANSAC.cpp:13
+        cfg.sampleIdx = nullptr;
+        float K[9];
+        bool haveK;
+        cameraToK(matcherParameters.cameraMatrixMat, K, haveK);
+        if (ps_vo_stream_configure_async(f.pipe, &prm, &cfg, haveK ? K : nullptr, pipeChunk_, pipeLanes_) != PS_OK) {
+            std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
+            ps_vo_stream_destroy(f.pipe);
+            f.pipe = nullptr;
+            return false;
+        }
+        f.pm.resize((size_t)f.pipeCap);
+        f.pmask.resize((size_t)f.pipeCap);
+        pipeFirst_ = true;
+    }
+    if (n > f.pipeCap) return false;
+    int rc = ps_vo_stream_push_async(f.pipe, descriptors.data, n > 0 ? (size_t)descriptors.step : (size_t)PS_DESC_BYTES,
+                                     reinterpret_cast<const float *>(features3D.data()), n);
+    if (rc == PS_ERR_BUSY) return false;
+    if (rc != PS_OK) {
+        std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
+        return false;
+    }
+    if (pipeFirst_) {
+        frameCounter = 0; // detectInitFeatures, matcher.cpp:17-64
+        pipeFirst_ = false;
+    } else {
+        ++frameCounter;
+    }
+    features3D.swap(prevFeatures3D); // matcher.cpp:506-513: the enqueued frame is the previous one for whatever comes next
+    prevDescriptors = descriptors;
+    fusedSynced_ = false;
+    return true;
+}
+
+bool FrameMatcher::flushFrames()
+{
+    if (!fused_ || !fused_->pipe) return true;
+    return ps_vo_stream_flush(fused_->pipe) == PS_OK;
+}
+
+int FrameMatcher::dequeueResult(Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
+                                double &pointInlierRatio, bool wait)
+{
+    if (!fused_ || !fused_->pipe) return 0;
+    Fused &f = *fused_;
+    Eigen::Matrix4f pose = Eigen::Matrix4f::Identity();
+    PsRansacStats st;
+    int nm = -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = ps_vo_stream_pop(f.pipe, wait ? 1 : 0, reinterpret_cast<PsDMatch *>(f.pm.data()), &nm, f.pmask.data(), pose.data(), &st);
+        if (rc != PS_OK) {
+            std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
+            return -1;
+        }
+        if (nm >= 0 || !wait) break;
+        // nothing in flight: frames may still wait in a partly filled chunk
+        if (ps_vo_stream_pending(f.pipe) <= 0 || ps_vo_stream_flush(f.pipe) != PS_OK) break;
+    }
+    if (nm < 0) return 0;
+    inlierMatches.clear();
+    inlierMatches.reserve((size_t)st.numInliers);
+    for (int i = 0; i < nm; ++i)
+        if (f.pmask[(size_t)i]) inlierMatches.push_back(f.pm[(size_t)i]);
+    estimatedTransformation = pose;
+    pointInlierRatio = st.pointInlierRatio;
+    return 1;
 }
 
 double FrameMatcher::match(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D, Eigen::Matrix4f &estimatedTransformation,

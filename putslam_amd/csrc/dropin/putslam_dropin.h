@@ -220,6 +220,22 @@ class FrameMatcher {
                     std::vector<Eigen::Vector3f> &currentPoseFeatures3D, const std::vector<int> &currentPoseOctaves,
                     const std::vector<double> &currentPoseDetDists, Eigen::Matrix4f &estimatedTransformation,
                     std::vector<cv::DMatch> &inlierMatches, int computationNumber = 1);
+    // ---- pipelined form of runVO (ps_vo_stream_push_async / ps_vo_stream_pop, include/putslam_hip.h): the same call shape --
+    // one frame per call, the previous frame kept as state (matcher.cpp:452-516) -- with the result returned with a LAG, so that
+    // uploads, kernels and downloads of consecutive frames overlap (BASELINE configs[2]: a sequence streamed through the matcher).
+    // Results are those runVO returns for the same frames in the same order (pair k draws from seed + k either way).
+    //   setPipeline    frames per submitted chunk (1 = lowest latency) and chunks in flight; before the first enqueueFrame
+    //   enqueueFrame   the first frame after construction / resetPipeline is the initial one (detectInitFeatures); returns false
+    //                  when the pipeline is full: dequeue results first
+    //   dequeueResult  1 = the next frame's result (in frame order), 0 = none ready (wait = false) or none pending,
+    //                  -1 = error; a partly filled chunk is submitted when a waiting call finds nothing in flight
+    //   flushFrames    submits a partly filled chunk now
+    void setPipeline(int chunkFrames, int lanes);
+    bool enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D);
+    int dequeueResult(Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches, double &pointInlierRatio,
+                      bool wait = true);
+    bool flushFrames();
+    void resetPipeline();
     int getNumberOfFeatures() const { return (int)prevFeatures3D.size(); }
     featureSet getFeatures() // matcher.cpp:980-989
     {
@@ -247,6 +263,8 @@ class FrameMatcher {
     struct Fused;
     std::unique_ptr<Fused> fused_;
     bool fusedSynced_ = false; // the resident frame is prevDescriptors / prevFeatures3D
+    int pipeChunk_ = 32, pipeLanes_ = 4;
+    bool pipeFirst_ = true;    // the next enqueued frame has no predecessor
     bool fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
                         Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
                         double &pointInlierRatio);

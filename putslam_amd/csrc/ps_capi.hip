@@ -1219,6 +1219,9 @@ int ps_context_set_stream(PsContext *ctx, void *s)
     return PS_OK;
 }
 
+void *ps_context_stream(PsContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int ps_context_device(const PsContext *ctx) { return ctx ? ctx->device : (int)PS_ERR_BAD_ARG; }
+
 int ps_context_set_option(PsContext *ctx, const char *name, int value)
 {
     if (!ctx || !name) return PS_ERR_BAD_ARG;

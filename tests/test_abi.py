@@ -27,6 +27,27 @@ def test_header_symbols_exported():
         assert n in names, f"{n} bound in Python but not declared in the header"
 
 
+def test_shard_header_symbols_exported():
+    """include/putslam_shard.h (sharding for C / C++ hosts over RCCL): every declared entry point is exported by
+    libputslam_shard.so, which loads here without a GPU (its calls fail with PS_ERR_NO_DEVICE)."""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "putslam_shard.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(ps_shard_[a-zA-Z0-9_]+)\s*\(", src)))
+    assert len(names) >= 12
+    so = os.path.join(ROOT, "putslam_amd", "libputslam_shard.so")
+    if not os.path.exists(so):
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_shard()
+    L = ctypes.CDLL(so)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/putslam_shard.h but not exported by libputslam_shard.so"
+    import torch
+    if not torch.cuda.is_available():
+        g = ctypes.c_void_p()
+        assert L.ps_shard_group_create(None, 1, ctypes.byref(g)) == -2 and not g.value    # PS_ERR_NO_DEVICE, no CPU fallback
+
+
 def test_struct_layout_matches_library():
     from putslam_amd import _lib
     L = _lib.load()

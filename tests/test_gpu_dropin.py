@@ -68,6 +68,24 @@ def test_cpp_demo_matching_sequence(tmp_path):
     assert "39 increments accepted, 0 rejected" in p.stdout
 
 
+@pytest.mark.parametrize("chunk", [1, 7, 32])
+def test_cpp_demo_matching_pipelined_writes_the_same_trajectory(tmp_path, chunk):
+    """FrameMatcher::enqueueFrame / dequeueResult (ps_vo_stream_push_async / ps_vo_stream_pop: results with a lag) against one
+    synchronous runVO per frame: the TUM trajectory files are identical, whatever the chunk size."""
+    exe = os.path.join(ROOT, "demos", "cpp", "demo_matching")
+    if not os.path.exists(exe):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_dropin()
+    a, b = tmp_path / "sync.txt", tmp_path / "pipe.txt"
+    p = subprocess.run([exe, "45", "1200", str(a)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    q = subprocess.run([exe, "45", "1200", str(b), "--pipelined", str(chunk)], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout + q.stderr
+    assert "44 increments accepted, 0 rejected" in q.stdout
+    assert a.read_text() == b.read_text() and len(a.read_text().strip().split("\n")) == 45
+
+
 def test_reference_shaped_plugin_links_and_matches_oracle(oracle, tmp_path):
     """tests/cpp/test_reference_shaped.cpp: a translation unit with classes named putslam::Matcher / ::MatcherOpenCV and
     the reference's factories (bodies as INTEGRATION.md section 2 prescribes) linked against the drop-in.  N3: the

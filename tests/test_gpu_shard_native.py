@@ -1,0 +1,75 @@
+"""include/putslam_shard.h: sharding over the GPUs of a node for C / C++ hosts (RCCL underneath), exercised with a world of
+one on the one-GPU box through demos/cpp/demo_sequences_multi_gpu -- a process without torch.  The exchanges are bench.py's:
+parameter block from rank 0 (ncclBroadcast), 72-byte per-pair records to rank 0 (ncclGather), where the reference's only
+sequential step composes the trajectory (reference src/PUTSLAM/PUTSLAM.cpp:735-740)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from putslam_amd import synth
+from putslam_amd._abi import EST_FIXED, EST_RANSAC, TUM_FR1_K, default_ransac_params, make_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "demos", "cpp", "demo_sequences_multi_gpu")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_dropin()
+    return EXE
+
+
+def _write_sequence(path, seq):
+    F, cap = seq["desc"].shape[:2]
+    with open(path, "wb") as f:
+        np.array([F, cap], np.int32).tofile(f)
+        np.ascontiguousarray(seq["nkpts"], np.int32).tofile(f)
+        np.ascontiguousarray(seq["desc"], np.uint8).tofile(f)
+        np.ascontiguousarray(seq["pts"], np.float32).tofile(f)
+
+
+@pytest.mark.parametrize("launch", ["one-process", "rank-per-process"])
+@pytest.mark.parametrize("estimator,est,H,ev", [("fixed", EST_FIXED, 768, 1), ("ransac", EST_RANSAC, 487, 0)])
+def test_native_gather_equals_python_batch_and_oracle(ctx, oracle, tmp_path, launch, estimator, est, H, ev):
+    """The records rank 0 gathers natively (ps_shard_broadcast_params -> ps_vo_pairs_device -> ps_shard_gather_records) are the
+    bytes sharding.pack_records makes of the oracle's results for the same sequence and seed."""
+    from putslam_amd import sharding
+    seq = synth.make_sequence(14, 700, config=3, index=4242)
+    _write_sequence(tmp_path / "seq0.bin", seq)
+    seed = 0xB0B0
+    dump = tmp_path / "records.bin"
+    cmd = [_exe(), "--sequence-prefix", str(tmp_path / "seq"), "--estimator", estimator, "--hyp", str(H), "--error-version", str(ev),
+           "--seed", str(seed), "--steps", "2", "--dump", str(dump), "--traj-prefix", str(tmp_path / "traj")]
+    cmd += ["--gpus", "1"] if launch == "one-process" else ["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "id.bin")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = np.fromfile(dump, np.float32).reshape(1, 13, sharding.RECORD_FLOATS)
+    prm = default_ransac_params(ev)
+    cfg, _ = make_config(est, H, seed=seed)                      # rank 0: seed + 0
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=4)
+    want = sharding.pack_records(c["pose"], c["stats"]["numInliers"], c["stats"]["numMatchesIn"]).numpy()
+    assert got[0].tobytes() == want.tobytes()
+    # the trajectory rank 0 composed from them (VOTrajectory, PUTSLAM.cpp:735-740,1006-1016) is sharding.compose_trajectory's
+    inc = want[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
+    traj = sharding.compose_trajectory(inc)
+    lines = open(tmp_path / "traj0.txt").read().strip().split("\n")
+    assert len(lines) == 14
+    for k, line in enumerate(lines):
+        assert line.split()[1:] == sharding.format_tum_line(0.0, traj[k]).split()[1:], k
+
+
+def test_native_demo_on_synthetic_sequences(tmp_path):
+    """The demo's own frames (known motion): exit code 0 = every rank's block arrived and every increment is within 5e-3 of
+    the ground truth."""
+    p = subprocess.run([_exe(), "--gpus", "1", "--frames", "30", "--kpts", "1200", "--estimator", "ransac", "--hyp", "487",
+                        "--error-version", "0", "--steps", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "29 of 29 increments accepted" in p.stdout and "records gathered over RCCL" in p.stdout
