@@ -416,8 +416,7 @@ def main():
             # staged form saves on THIS data is a measured figure, not a derived one
             legs.append(("E%d/%s/%d/prune0" % (args.error_version, args.estimator, args.hyp), args.error_version, est, args.hyp, 0))
             # the reference's other estimator at ITS cap (USAC_wrapper.cpp:66,70: 850 000 hypotheses at most): the schedules end
-            # after a handful of iterations; the batch is taken in slices of 210 pairs (48 B of parked model per pair and
-            # hypothesis), so `kernel_ms` is per SLICE here and `ms_per_step` the whole batch
+            # after a handful of iterations; one call (models are parked for the leading hypotheses of every pair only)
             legs.append(("E0/usac/850000", 0, EST_USAC, 850000, 1))
         for name, ev2, est2, hyp2, prune2 in legs:
             if args.preset == "stress" and est2 == EST_FIXED:
@@ -450,9 +449,8 @@ def main():
                                  "accepted_pairs": int(st2["accepted"].sum()), "staged_scoring": bool(prune2),
                                  "score_kernel": "fast" if c0.get_option("score") >= 1 else "exact"}
             if est2 == EST_USAC:
-                per_pair = hyp2 * 48
-                fit = max(1, (8 << 30) // per_pair)
-                other_modes[name]["slices"] = int(-(-P // fit)) if P * per_pair > (8 << 30) else 1
+                other_modes[name]["arena_mib"] = c0.get_option("arena_mib")
+                other_modes[name]["model_slots_per_pair"] = c0.get_option("last_model_slots")
             if name == "E0/ransac/487" and S > 1:
                 # the reference's own regime submitted like the timed region: S chains on S streams, steps pipelined
                 def chains_step():

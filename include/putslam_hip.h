@@ -159,6 +159,9 @@ int ps_context_device(const PsContext *ctx);
  *   1 .. 16), "reorder_margin" (matches past the miss budget where stage 1 ends), "reorder_c2div", "reorder_gran" (cut
  *   granularity, a power of two 2 .. 64).  "last_staged_pairs" / "last_reordered_pairs" (read only): pairs of the last
  *   scoring step if it was staged / reordered, else 0.
+ *   "model_room_mib": room for the staged scoring's parked models (48 bytes per pair and leading hypothesis); 0 (default) =
+ *              256 MiB under the adaptive schedules, 2 GiB under the fixed one.  Hypotheses without a slot are swept in one
+ *              piece by stage 1 and rebuilt by kernel 4 if one of them wins: identical outputs, tests force it small.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.
@@ -265,8 +268,10 @@ typedef struct PsPairResults {
 /* pairs: DEVICE array of P (prevFrame, curFrame) index pairs, int32 x 2 each.
  * Hypothesis h of pair p draws from the seeded stream with seed cfg->seed + p
  * (cfg->sampleIdx must be NULL). Asynchronous on the context's stream.
- * A batch whose parked models (48 bytes per pair and hypothesis) would exceed 8 GiB -- more than 210 pairs under USAC's
- * cap of 850 000 -- is taken in slices of pairs, queued one behind the other; the results are those of one call. */
+ * Scratch: counts take 4 bytes per pair and hypothesis of cfg->numHypotheses (1.7 GB for 499 pairs under USAC's cap of
+ * 850 000, USAC_wrapper.cpp:70; touched only up to each pair's trip limit); the staged scoring's parked models take 48 bytes
+ * per pair and LEADING hypothesis, 256 MB at most under the adaptive schedules (2 GiB under the fixed one): a hypothesis
+ * beyond the slots is swept in one piece and, should it win, rebuilt (options "arena_mib", "last_model_slots", read only). */
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);
@@ -396,8 +401,7 @@ int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations
 int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8);
 /* Staged scoring: hypotheses of every pair that survived stage 1 (out[0..P)) and stage 2 (out[P..2P)) of the last call
  * that was scored in stages: zeros if the LAST scoring step of the context was not staged, PS_ERR_BAD_ARG if P is not that
- * step's number of pairs (the counters are laid out with it).  A batch that ps_vo_pairs_device took in slices leaves the
- * LAST slice's step behind (option "last_staged_pairs" says how many pairs that was). */
+ * step's number of pairs (the counters are laid out with it; option "last_staged_pairs" says how many pairs that was). */
 int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out);
 /* Staged scoring with the reordered match record: perm[P][cap] = for every pair, the match (index into its depth-valid
  * matches) at each position of the order stages 1+ swept; front[P] = leading positions whose matches every voting hypothesis

@@ -102,6 +102,7 @@ struct PsContext {
     int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
     int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
     int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
+    int modelRoomMiB = 0; // option "model_room_mib": room for the staged scoring's parked models (0 = 256 MiB adaptive / 2 GiB fixed)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (options "reorder_top" / "reorder_margin" / "reorder_c2div")
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
@@ -111,6 +112,7 @@ struct PsContext {
     // what the LAST scoring step left in the staged-scoring buffers (ps_debug_stage_survivors / ps_debug_stage_order):
     // pairs and capacity the survivor counters / the order were laid out with, 0 = that step was not staged / not reordered
     int stagedP = 0, stagedCap = 0, reorderedP = 0;
+    int lastModelH = 0; // hypotheses per pair with a parked-model slot in the last scoring step (0: nothing parked)
     // "Nothing to gain" policy of the staged scoring (option "bail", Euclidean metrics, batched calls): ps_stage_reorder counts
     // the pairs it replayed and those whose prefix leaves nothing to abandon (stage 1 sweeps every match: hopeless data, no
     // pair accepted); kernel 4 forwards the two counters to mapped host memory.  While the last observation says "most pairs",
@@ -153,7 +155,9 @@ int fail(PsContext *c, int code, const char *what, hipError_t e = hipSuccess)
 int ensure(PsContext *ctx, Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return PS_OK;
-    size_t want = bytes + bytes / 4 + 256;
+    // (a quarter more than asked for, 16 MiB at most: the large blocks -- counts and parked models under a long cap -- grow in
+    // steps of the batch size, not by doubling)
+    size_t want = bytes + (bytes / 4 < ((size_t)16 << 20) ? bytes / 4 : ((size_t)16 << 20)) + 256;
     if (b.p) {
         // The old block may still be referenced by work queued on the stream.
         hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -401,6 +405,7 @@ struct Plan {
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
     bool bailWatch = false; // this staged call feeds the "nothing to gain" policy (PsContext::bailHost)
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
+    int lastStage = 0;  // staged scoring: 1 = ONE stage after the prefix (adaptive schedules without reordering), else kStages
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -574,7 +579,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     // the Euclidean ones: it pays from about 48 / 16 pairs of H = 4096 on, profiles/r03p/small_batches.txt)
     // (adaptive schedules: the trip limit the prefix leaves cuts most of the work whatever the batch size)
     const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
-    pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom && mbytes <= ((size_t)8 << 30);
+    pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom;
     pl.bailWatch = false;
     const bool willReorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
     if (adaptive && pl.prune && willReorder && ctx->bail != 0 && with_euclid_fast(ctx, pl.mode)) {
@@ -613,8 +618,24 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     pl.pa.zeroH = pl.prune ? pl.prefix : H;
     pl.pa.zeroStride = H;
     pl.ma.models = nullptr;
+    pl.ma.modelH = H;
+    // adaptive schedules without reordering: ONE stage after the prefix (all matches, hypotheses below the trip limit only)
+    pl.lastStage = (pl.sa.estimator != PS_EST_FIXED && !willReorder && ctx->singleRest != 0) ? 1 : kStages;
+    if (pl.prune) {
+        // Parked models in proportion to the work, not to the cap: under a long cap (USAC's 850 000, USAC_wrapper.cpp:70) the
+        // schedules end after a handful of iterations (USAC.h:944-971), and 48 bytes per pair and cap entry would be 20 GB for
+        // 499 pairs.  Only the leading hypotheses get a slot (256 MB under the adaptive schedules, 2 GiB under the fixed one,
+        // whose stages do read the models back); a hypothesis beyond is swept in one piece by stage 1 and, if it wins, rebuilt
+        // by kernel 4.
+        const size_t room = ctx->modelRoomMiB > 0 ? ((size_t)ctx->modelRoomMiB << 20)
+                                                  : (pl.sa.estimator == PS_EST_FIXED ? ((size_t)2 << 30) : ((size_t)256 << 20));
+        if (mbytes > room) {
+            long long fit = (long long)(room / ((size_t)P * 12 * sizeof(float))) & ~(long long)(kBlock - 1);
+            pl.ma.modelH = (int)(fit < kPrefixFixed ? kPrefixFixed : fit);
+        }
+    }
     if ((P <= kWidePairs && mbytes <= ((size_t)64 << 20)) || pl.prune) {
-        PS_ENSURE(ctx->models, mbytes);
+        PS_ENSURE(ctx->models, (size_t)P * pl.ma.modelH * 12 * sizeof(float));
         pl.ma.models = (float *)ctx->models.p;
     }
     // Complete scoring with the match range split over msplit work-groups repeats the sample -> SVD chain in every part (16
@@ -649,8 +670,10 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
         pl.pa.skipE = !(fastRep && !firstBig);
     }
     if (pl.prune) {
-        PS_ENSURE(ctx->survA, (size_t)P * H * sizeof(int32_t));
-        PS_ENSURE(ctx->survB, (size_t)P * H * sizeof(int32_t));
+        if (pl.lastStage > 1) { // (only hypotheses with a model slot are ever listed)
+            PS_ENSURE(ctx->survA, (size_t)P * pl.ma.modelH * sizeof(int32_t));
+            PS_ENSURE(ctx->survB, (size_t)P * pl.ma.modelH * sizeof(int32_t));
+        }
         PS_ENSURE(ctx->survN, (size_t)2 * P * sizeof(int32_t));
         if (pl.genSplit) PS_ENSURE(ctx->validMask, (size_t)P * ((pl.prefix + 63) / 64) * sizeof(unsigned long long));
         pl.reorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
@@ -664,6 +687,7 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
         pl.pa.zeroSurvA = (int32_t *)ctx->survN.p;       // cleared by kernel 2, one counter per pair and stage
         pl.pa.zeroSurvB = (int32_t *)ctx->survN.p + P;
     }
+    ctx->lastModelH = pl.ma.models ? pl.ma.modelH : 0;
     ctx->stagedP = pl.prune ? P : 0;
     ctx->stagedCap = pl.prune ? cap : 0;
     ctx->reorderedP = (pl.prune && pl.reorder) ? P : 0;
@@ -692,7 +716,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // between the launches.  stage_args(i) describes launch i.
     // stages 2+: work-groups per pair (they loop over longer lists; after the reordered stage 1 few hypotheses are left)
     auto list_groups = [&](int stage) {
-        const int all = (pl.H - pl.prefix + kBlock - 1) / kBlock;
+        const int listed = (pl.H < pl.ma.modelH ? pl.H : pl.ma.modelH) - pl.prefix; // hypotheses that can be on a survivor list
+        const int all = ((listed > 0 ? listed : 1) + kBlock - 1) / kBlock;
         // (stage 3 by default: one looping group per eight possible ones -- 1 for H = 4096, where 21 of 3840 hypotheses per
         // pair are left, 48 for the stress configuration's H = 100 000, which one group swept in 4.3 ms instead of 1.0)
         const int auto3 = all / 8 > 1 ? all / 8 : 1;
@@ -711,8 +736,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     // stage 1's one-direction pre-test on the far-off front of the reordered record: the reprojection metrics (ps_score_fast.h)
     const bool usePretest = pl.reorder && ctx->pretest != 0 &&
                             (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || pl.mode == PS_REPROJECTION_ERROR);
-    // adaptive schedules without reordering: ONE stage after the prefix (all matches, hypotheses below the trip limit only)
-    const int lastStage = (pl.sa.estimator != PS_EST_FIXED && !pl.reorder && ctx->singleRest != 0) ? 1 : kStages;
+    const int lastStage = pl.lastStage;
     // Stage 1 of an adaptive schedule with a long cap (USAC's 850 000 = 3320 blocks of 256 hypotheses per pair, of which the
     // trip limit leaves a handful): one work-group per block is hundreds of thousands of work-groups that look at the limit and
     // leave -- 0.9 ms per 210 pairs.  From 64 blocks per pair on a fixed number of work-groups per pair walks the blocks and
@@ -737,6 +761,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         if (stage >= 1 && pl.reorder) st.perm = (const int32_t *)ctx->permBuf.p;
         if (stage >= 1 && pl.reorder) st.prefInfo = (const int32_t *)ctx->prefInfo.p;
         if (stage == 1 && usePretest) st.frontRec = (const float2 *)ctx->frontRec.p;
+        st.listStride = pl.ma.modelH;
         st.loopGroups = stage == 1 ? loopGroups : 0;
         st.single = lastStage == 1 ? 1 : 0;
         st.margin = ctx->reorderMargin;
@@ -1101,6 +1126,7 @@ const OptDesc kOptions[] = {
     {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64"},
     {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64"},
     {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
+    {"model_room_mib", "MODEL_ROOM_MIB", &PsContext::modelRoomMiB, 0, 65536, "model_room_mib: 0 (default) .. 65536 MiB for the staged scoring's parked models"},
 };
 const OptDesc *find_option(const char *name)
 {
@@ -1250,6 +1276,17 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
     if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
     if (strcmp(name, "last_staged_pairs") == 0) return ctx->stagedP;       // pairs of the last scoring step if it was staged, else 0
     if (strcmp(name, "hopeless") == 0) return ctx->hopeless;               // the "nothing to gain" policy's current state
+    if (strcmp(name, "arena_mib") == 0) {                                  // device memory the context's scratch arena holds, MiB
+        const Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models,
+                            &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec,
+                            &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid, &ctx->cmax,
+                            &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk, &ctx->sMatches,
+                            &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats, &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
+        size_t sum = 0;
+        for (const Buf *b : all) sum += b->cap;
+        return (int)((sum + (((size_t)1 << 20) - 1)) >> 20);
+    }
+    if (strcmp(name, "last_model_slots") == 0) return ctx->lastModelH;     // hypotheses per pair with a parked-model slot, last scoring step
     if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
     const OptDesc *o = find_option(name);
     return o ? ctx->*(o->field) : (int)PS_ERR_BAD_ARG;
@@ -1873,42 +1910,15 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     Plan pl;
     rc = make_plan(ctx, params, cfg, K, cap, cap, pl);
     if (rc) return rc;
-    // The staged scoring parks one model per pair and hypothesis (48 bytes) and is refused above 8 GiB of them: a batch of
-    // 499 pairs under USAC's cap of 850 000 would then score every hypothesis of every pair completely -- hours instead of
-    // milliseconds, although the schedules end after a handful of iterations.  Such a batch is taken in slices whose models
-    // fit (pairs are independent: slice s starts at pair `first`, its sample streams at seed + first as in one call).
-    {
-        const size_t perPair = (size_t)pl.H * 12 * sizeof(float);
-        const size_t room = (size_t)8 << 30;
-        const long long fit = (long long)(room / (perPair ? perPair : 1));
-        if ((size_t)P * perPair > room && fit >= 1 && ctx->prune != 0 && pl.H > kPrefixFixed) {
-            const int slice = (int)(fit < P ? fit : P);
-            for (int first = 0; first < P; first += slice) {
-                const int n = P - first < slice ? P - first : slice;
-                PsRansacConfig c2 = *cfg;
-                c2.seed = cfg->seed + (uint64_t)first;
-                PsPairResults o2 = *out;
-                o2.matches = out->matches + (size_t)first * cap;
-                o2.numMatches = out->numMatches + first;
-                o2.inlierMask = out->inlierMask + (size_t)first * cap;
-                o2.pose = out->pose + (size_t)first * 16;
-                o2.stats = out->stats + first;
-                rc = ps_vo_pairs_device(ctx, params, &c2, K, frames, pairs + 2 * (size_t)first, n, &o2);
-                if (rc) return rc;
-            }
-            return PS_OK;
-        }
-    }
     if (ctx->timing) {
         ctx->curCall = (int)(ctx->timedCalls % kTimingRing);
         ctx->slotMask[ctx->curCall] = 0;
         ctx->timedCalls++;
     }
-    rc = prepare_score(ctx, pl, P, cap, false, true);
-    if (rc) return rc;
     // This call returns with its work still queued.  Whatever happens after the first launch -- success or an error half
     // way (an allocation failure for a later block, a launch failure) -- the end of what WAS queued is marked for a
     // later ps_context_set_stream: the new stream must not touch the shared arena before that work has finished.
+    // (prepare_score below may already queue a clearing: the guard stands before it)
     struct Handoff {
         PsContext *c;
         ~Handoff()
@@ -1924,6 +1934,8 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
                 (void)hipStreamSynchronize(c->stream);
         }
     } handoffGuard{ctx};
+    rc = prepare_score(ctx, pl, P, cap, false, true);
+    if (rc) return rc;
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);

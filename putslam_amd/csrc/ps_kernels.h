@@ -526,9 +526,12 @@ struct ModelArgs {
     uint64_t seed;
     const uint32_t *raw;     // optional explicit draws, H x 3 (device)
     const uint64_t *seedDev; // optional: the seed lives in device memory (captured graphs replay with a new seed)
-    float *models;           // optional [P][H][12]: kernel 3 parks every hypothesis model here and kernel 4 reads the
+    float *models;           // optional [P][modelH][12]: kernel 3 parks hypothesis models here and kernel 4 reads the
                              // winner's instead of repeating its sample -> Umeyama -> Jacobi-SVD chain (small batches:
                              // the chain is ~10 us of latency on the critical path of a single frame pair)
+    int modelH;              // hypotheses per pair that have a slot: [0, modelH).  Under a long cap (USAC's 850 000) only the
+                             // leading ones are parked -- the schedules end long before -- and a hypothesis beyond is swept in
+                             // one piece by stage 1 and, should it win, rebuilt by kernel 4 (the rare path)
 };
 
 PS_D void store_model(const ModelArgs &ma, size_t slot, const Rigid &m)
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(kBlock, 6) void ps_ransac_score(const float4 *__res
     bool valid = false;
     if (h < H) {
         valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
-        if (ma.models && by == 0) store_model(ma, (size_t)p * H + h, mdl);
+        if (ma.models && by == 0 && h < ma.modelH) store_model(ma, (size_t)p * ma.modelH + h, mdl);
         if (MODE == PS_REPROJECTION_ERROR || MODE == PS_EUCLIDEAN_AND_REPROJECTION_ERROR)
             inverse_rigid_general(mdl, inv);
     }
@@ -1240,8 +1243,8 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
     set_identity(inv);
     int kin = 0;
     if (run && bestIdx >= 0) {
-        if (ma.models)
-            load_model(ma, (size_t)p * a.H + bestIdx, mdl); // parked by kernel 3 (an invalid sample parks the identity)
+        if (ma.models && bestIdx < ma.modelH)
+            load_model(ma, (size_t)p * ma.modelH + bestIdx, mdl); // parked by kernel 3 (an invalid sample parks the identity)
         else
             gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)bestIdx, mdl);
         if (needInv) inverse_rigid_general(mdl, inv);

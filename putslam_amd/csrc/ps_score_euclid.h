@@ -124,6 +124,9 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)
                      st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
+        // a block with hypotheses that have no model slot (ModelArgs::modelH: long caps) is swept in one piece: nothing of it
+        // is parked or listed
+        if (!LIST && ma.models != nullptr && st.hBase + ((int)bx + 1) * kBlock > ma.modelH) m1 = M;
         mStageEnd = m1;
         if (m0 >= m1) return true; // an earlier stage finished the pair's matches
         if (!LIST) {
@@ -142,7 +145,7 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
             slot = tid - part * cover;
             const int i = (int)bx * cover + slot;
             hEnd = 0x7FFFFFFF;
-            h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
+            h = i < n ? st.listIn[(size_t)p * st.listStride + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
             // this wavefront's part of the stage's match range (whole blocks of 64 matches; a part may be empty)
             const int parts = kBlock / cover;
             const int plen = ((m1 - m0 + parts * 64 - 1) / (parts * 64)) * 64;
@@ -176,20 +179,21 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     bool valid = false;
     if (LIST) {
         if (h < hEnd) {
-            load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
+            load_model(ma, (size_t)p * ma.modelH + h, mdl); // parked by stage 1 (only valid samples survive it; h < modelH: a
+                                                            // hypothesis beyond is swept completely by stage 1 and never listed)
             valid = true;
         }
     } else if (KIND == 0 && st.validMask != nullptr && !st.genOnly) {
         // stage 0, second launch: models and validity read back (ps_score_fast.h)
         const unsigned long long vm = uniform64(st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)]);
         valid = h < hEnd && lane_in(vm);
-        if (h < hEnd) load_model(ma, (size_t)p * H + h, mdl);
+        if (h < hEnd) load_model(ma, (size_t)p * ma.modelH + h, mdl); // (launches of this form have a slot for every hypothesis)
     } else {
         if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H); // (ps_score_fast.h)
-            if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+            if (hs < hEnd && hs < ma.modelH) store_model(ma, (size_t)p * ma.modelH + hs, mdl);
         }
         if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
             const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
@@ -341,7 +345,7 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
         const bool alive = mine && valid && total + (M - mStageEnd) > best0;
-        if (!LIST && ma.models && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
+        if (!LIST && ma.models && h < ma.modelH && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -349,9 +353,9 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
                 for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tidE];
                 md.t[i] = s_mdl[9 + i][tidE];
             }
-            store_model(ma, (size_t)p * H + h, md);
+            store_model(ma, (size_t)p * ma.modelH + h, md);
         }
-        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
+        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, st.listStride);
         return false;
     }
     h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);

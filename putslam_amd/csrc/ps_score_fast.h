@@ -185,7 +185,8 @@ struct StageArgs {
     int stage;                 // 0 = the hypotheses [hBase, hBase + hCount) completely (the plain launch: [0, H)); 1 .. kStages
                                // = pruned stages
     int hBase, hCount;         // stage 0 / 1: the hypothesis range of this launch
-    const int32_t *listIn;     // stage >= 2: survivors of the previous stage, [P][H] hypothesis indices ...
+    int listStride;            // entries per pair of the survivor lists (= hypotheses with a model slot: only those are listed)
+    const int32_t *listIn;     // stage >= 2: survivors of the previous stage, [P][listStride] hypothesis indices ...
     const int32_t *countIn;    //             ... and how many per pair
     int32_t *listOut;          // stage < kStages: where this stage's survivors go
     int32_t *countOut;
@@ -321,7 +322,7 @@ PS_D void stage_prefix(const int32_t *__restrict__ cnts, int nPrefix, const Sele
 }
 
 // Appends the hypotheses of the lanes with `alive` to the next stage's list of pair p (one atomic per wavefront).
-PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t *__restrict__ countOut, int p, int H)
+PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t *__restrict__ countOut, int p, int stride)
 {
     const unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
     if (am == 0ull) return;
@@ -329,7 +330,7 @@ PS_D void stage_append(bool alive, int h, int32_t *__restrict__ listOut, int32_t
     int base = 0;
     if (lane == __builtin_ctzll(am)) base = atomicAdd(&countOut[p], __popcll(am));
     base = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
-    if (alive) listOut[(size_t)p * H + base + lanes_below(am)] = h;
+    if (alive) listOut[(size_t)p * stride + base + lanes_below(am)] = h;
 }
 
 // The hypothesis of a lane, derived AGAIN at the end of a staged launch from values that cost no vector register in between
@@ -342,7 +343,7 @@ PS_D int stage_hypothesis_again(bool list, const StageArgs &st, int base, int sl
     asm volatile("" : "+s"(base));
     if (!list) return st.hBase + base + slot;
     const int i = base + slot;
-    return i < st.countIn[p] ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF;
+    return i < st.countIn[p] ? st.listIn[(size_t)p * st.listStride + i] : 0x7FFFFFFF;
 }
 
 // Stages 2+: hypotheses one pass of a work-group takes from the survivor list.  After the reordered stage 1 the lists are
@@ -416,6 +417,9 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         stage_prefix(cout, st.hBase, sa, M, s_pref, best0, hLimit, // (stage >= 1: hBase = size of the prefix)
                      st.prefInfo != nullptr ? st.prefInfo + 4 * p : nullptr);
         stage_range(st, M, best0, m0, m1);
+        // a block with hypotheses that have no model slot (ModelArgs::modelH: long caps) is swept in one piece: nothing of it
+        // is parked or listed
+        if (!LIST && ma.models != nullptr && st.hBase + ((int)bx + 1) * kBlock > ma.modelH) m1 = M;
         mStageEnd = m1;
         if (m0 >= m1) return true; // an earlier stage finished the pair's matches
         if (!LIST) {
@@ -433,7 +437,7 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
             slot = tid - part * cover;
             const int i = (int)bx * cover + slot;
             hEnd = 0x7FFFFFFF;
-            h = i < n ? st.listIn[(size_t)p * H + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
+            h = i < n ? st.listIn[(size_t)p * st.listStride + i] : 0x7FFFFFFF; // (h >= hEnd: idle lane)
             // this wavefront's part of the stage's match range (whole blocks of 64 matches; a part may be empty)
             const int parts = kBlock / cover;
             const int plen = ((m1 - m0 + parts * 64 - 1) / (parts * 64)) * 64;
@@ -453,7 +457,8 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
     bool valid = false;
     if (LIST) {
         if (h < hEnd) {
-            load_model(ma, (size_t)p * H + h, mdl); // parked by stage 1 (only valid samples survive it)
+            load_model(ma, (size_t)p * ma.modelH + h, mdl); // parked by stage 1 (only valid samples survive it; h < modelH: a
+                                                            // hypothesis beyond is swept completely by stage 1 and never listed)
             valid = true;
         }
     } else if (KIND == 0 && st.validMask != nullptr && !st.genOnly) {
@@ -461,13 +466,13 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         // each of which would otherwise repeat the sample -> SVD chain: 63 % of stage 0's instructions with four parts)
         const unsigned long long vm = uniform64(st.validMask[(size_t)p * ((st.hCount + 63) >> 6) + (bx * (kBlock / 64) + wv)]);
         valid = h < hEnd && lane_in(vm);
-        if (h < hEnd) load_model(ma, (size_t)p * H + h, mdl);
+        if (h < hEnd) load_model(ma, (size_t)p * ma.modelH + h, mdl); // (launches of this form have a slot for every hypothesis)
     } else {
         if (h < hEnd) valid = gen_model(recA, recB, rbase, (uint32_t)M, ma, base_seed(ma) + (uint64_t)p, (uint32_t)h, mdl);
         // (stage 1 parks only the models of its survivors, at the end: the abandoned majority is never read again)
         if (ma.models && by == 0 && !pruned) {
             const int hs = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
-            if (hs < hEnd) store_model(ma, (size_t)p * H + hs, mdl);
+            if (hs < hEnd && hs < ma.modelH) store_model(ma, (size_t)p * ma.modelH + hs, mdl);
         }
         if (KIND == 0 && st.genOnly) { // stage 0, first launch: models and validity only
             const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
@@ -774,7 +779,7 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
         if (mine) cout[h] = total;
         // still able to become a record?  (count so far + matches left > best count of the earlier hypotheses)
         const bool alive = mine && valid && total + (M - mStageEnd) > best0;
-        if (!LIST && ma.models && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
+        if (!LIST && ma.models && h < ma.modelH && (alive || (mine && mStageEnd >= M))) { // survivors (or: this stage was the whole sweep)
             Rigid md;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -782,9 +787,9 @@ PS_D bool score_fast_pass(const float4 *__restrict__ recA, const float4 *__restr
                 for (int j = 0; j < 3; ++j) md.R[i][j] = s_mdl[3 * i + j][tidE];
                 md.t[i] = s_mdl[9 + i][tidE];
             }
-            store_model(ma, (size_t)p * H + h, md);
+            store_model(ma, (size_t)p * ma.modelH + h, md);
         }
-        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, H);
+        if (st.stage < kStages && mStageEnd < M) stage_append(alive, h, st.listOut, st.countOut, p, st.listStride);
         return false;
     }
     h = stage_hypothesis_again(false, st, (int)bx * kBlock, tid, p, H);
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void ps_stage_reorder(const float4 *__restr
     // the voters' models and inverses, one thread each, side by side (one global round trip instead of one per voter)
     if (tid < nTop) {
         Rigid mdl, inv;
-        load_model(ma, (size_t)p * H + s_top[1 + tid], mdl); // parked by stage 0
+        load_model(ma, (size_t)p * ma.modelH + s_top[1 + tid], mdl); // parked by stage 0
         inverse_rigid_general(mdl, inv);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

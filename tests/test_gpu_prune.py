@@ -114,6 +114,8 @@ def test_prune_ties_and_late_records(oracle):
             full = _run(seq, prm, cfg, 0)
             _same(pruned, full, P)
             _same(_run(seq, prm, cfg, 1, reorder=0), full, P)
+            # 256 model slots per pair: the late winner has none and is rebuilt by kernel 4 (ModelArgs::modelH)
+            _same(_run(seq, prm, cfg, 1, model_room_mib=1), full, P)
 
 
 def test_reordered_record_is_a_permutation_with_the_rejected_matches_in_front(oracle):
@@ -153,6 +155,9 @@ TWINS = [
     dict(reorder_top=1), dict(reorder_top=16, reorder_margin=1), dict(reorder_margin=300, reorder_c2div=1),
     dict(reorder_c2div=64, reorder_gran=2), dict(reorder_gran=8, pretest=0),
     dict(msplit=3), dict(msplit=32, gensplit=0),
+    # parked models in proportion to the work (round 5): with room for 1 MiB of them only the leading few hundred hypotheses of
+    # every pair have a slot, the others are swept in one piece by stage 1 and rebuilt by kernel 4 when one of them wins
+    dict(model_room_mib=1), dict(model_room_mib=1, gensplit=0, pretest=0),
 ]
 TWIN_CASES = [  # (errorVersion, estimator, H, frames, kpts, inlier_frac, noise)
     (EUCLIDEAN_ERROR, EST_FIXED, 4096, 24, 700, 0.70, 0.004),
@@ -185,7 +190,7 @@ def test_option_names_and_ranges():
     c = api.Context(0)
     for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "reorder", "qsplit", "msplit", "gensplit",
                  "singlerest", "pretest", "bail", "list_r3", "list_g2", "list_g3", "prefix", "reorder_top", "reorder_margin",
-                 "reorder_c2div", "reorder_gran", "stamps"):
+                 "reorder_c2div", "reorder_gran", "stamps", "model_room_mib"):
         v = c.get_option(name)
         c.set_option(name, v)   # every default is a legal value
     for name, bad in (("prefix", 100), ("prefix", 320), ("reorder_gran", 12), ("reorder_gran", 1), ("list_r3", 0),
@@ -351,11 +356,11 @@ def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
     c.close()
 
 
-def test_batch_under_the_reference_usac_cap_is_taken_in_slices(oracle):
-    """USAC's cap of 850 000 with more pairs than the staged scoring can park models for (48 bytes per pair and hypothesis,
-    8 GiB at most: 210 pairs): ps_vo_pairs_device takes the batch in slices -- complete scoring of 212 x 850 000 hypotheses
-    would run for minutes, the staged slices finish in milliseconds.  Pairs on both sides of the slice boundary equal the
-    oracle (their sample streams are seeded with seed + pair index of the WHOLE batch)."""
+def test_batch_under_the_reference_usac_cap_in_one_call(oracle):
+    """USAC's cap of 850 000 (USAC_wrapper.cpp:70) with 212 pairs: round 4 parked one model per pair and cap entry (48 bytes:
+    8.6 GB here) and took such a batch in slices.  Models are parked in proportion to the work now -- the leading hypotheses of
+    every pair get a slot, a later one is swept in one piece and rebuilt if it wins -- so the batch is ONE staged call whose
+    arena stays small; every pair equals the oracle (sample streams seeded with seed + pair index)."""
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     seq = synth.make_sequence(213, 260, config=3, index=41, inlier_frac=0.6, noise=0.004)
     prm = default_ransac_params(EUCLIDEAN_ERROR)
@@ -365,7 +370,10 @@ def test_batch_under_the_reference_usac_cap_is_taken_in_slices(oracle):
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
     run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
     g = pb.download()
-    assert c.get_option("last_staged_pairs") == len(seq["pairs"]) - 210   # the last slice, staged
+    assert c.get_option("last_staged_pairs") == len(seq["pairs"])           # one call, staged
+    slots = c.get_option("last_model_slots")
+    assert 256 <= slots < 850000 and slots * 212 * 48 <= (256 << 20)         # models: 256 MB at most, not 8.6 GB
+    assert c.get_option("arena_mib") < 1100                                  # counts (4 B x 212 x 850 000 = 721 MB) + models + records
     c.close()
     P = len(seq["pairs"])
     assert P == 212
