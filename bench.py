@@ -699,7 +699,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     h2d, d2h = _link_rate(torch, dev)
     out = {}
 
-    def run(chunk, lanes, steps, check):
+    def run(chunk, lanes, steps, check, warm_s=0.4):
         st = api.VoStream(c0, cap)
         st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
         lat, sub_t = [], {}
@@ -715,7 +715,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                 lat.append(now - sub_t.pop(key))
             state["pairs"] += b["count"]
             state["inl"] += int(b["stats"]["numInliers"].sum())          # the consumer reads what came back
-            if check and b["epoch"] == check:
+            if check and b["epoch"] == state.get("check_epoch"):
                 lo = b["first_pair"]
                 if b["pose"].tobytes() != res["pose"][lo:lo + b["count"]].tobytes():
                     state["bad"] += 1
@@ -741,12 +741,15 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                 else:
                     take(True)
 
-        for _ in range(3):
-            one_step()
+        tw = time.perf_counter()
+        while state["step"] < 3 or time.perf_counter() - tw < warm_s:   # (an un-warmed pipeline runs at half its rate:
+            one_step()                                                   # profiles/r05a/stream_sweep.txt, first rows)
         while take(True):
             pass
+        warm_steps = state["step"]
         lat.clear()
         pairs0 = state["pairs"]
+        state["check_epoch"] = warm_steps + steps            # the last timed step (epoch = resets before the block's frames)
         t0 = time.perf_counter()
         for _ in range(steps):
             one_step()
@@ -767,7 +770,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         return leg
 
     steps = max(10, min(40, 2 * args.steps))
-    main = run(args.stream_chunk, args.stream_lanes, steps, check=3 + steps)    # the last step's poses against the batched call's
+    main = run(args.stream_chunk, args.stream_lanes, steps, check=1)             # the last step's poses against the batched call's
     main["roofline"] = {"bound": "pcie", "achieved": main["h2d_GBps"], "peak": PCIE_GEN5_X16_GBS, "unit": "GB/s",
                         "frac": main["h2d_GBps"] / PCIE_GEN5_X16_GBS, "measured_link_h2d_GBps": h2d,
                         "measured_link_d2h_GBps": d2h, "frac_of_measured": main["h2d_GBps"] / h2d,
@@ -781,7 +784,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     out["streamed/chunk250"] = run(250, args.stream_lanes, steps, check=0)
     small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
     out["streamed/chunk32"] = small
-    one = run(1, args.stream_lanes, 3, check=0)
+    one = run(1, args.stream_lanes, 3, check=0, warm_s=0.1)
     out["streamed/chunk1"] = one
     hd.close()
     hp.close()

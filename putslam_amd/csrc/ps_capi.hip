@@ -744,8 +744,10 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
     const int blocks1 = (pl.H - pl.prefix + kBlock - 1) / kBlock;
     int loopGroups = 0;
     if (pl.prune && pl.sa.estimator != PS_EST_FIXED && blocks1 > 64) {
-        loopGroups = (2048 + P - 1) / P;
-        loopGroups = loopGroups < 64 ? 64 : loopGroups;
+        // (64 per pair at the least until round 5: 32 000 work-groups per 499 pairs that read the limit and leave, a third of the
+        // scoring step under USAC's cap; 4096 in all still fill the chip when the limits do stay at the cap)
+        loopGroups = (4096 + P - 1) / P;
+        loopGroups = loopGroups < 4 ? 4 : loopGroups;
         loopGroups = loopGroups > blocks1 ? blocks1 : loopGroups;
     }
     auto stage_args = [&](int stage) {

@@ -126,7 +126,10 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
         stage_range(st, M, best0, m0, m1);
         // a block with hypotheses that have no model slot (ModelArgs::modelH: long caps) is swept in one piece: nothing of it
         // is parked or listed
-        if (!LIST && ma.models != nullptr && st.hBase + ((int)bx + 1) * kBlock > ma.modelH) m1 = M;
+        {
+            const int blockEnd = st.hBase + ((int)bx + 1) * kBlock;
+            if (!LIST && ma.models != nullptr && (blockEnd < hEnd ? blockEnd : hEnd) > ma.modelH) m1 = M;
+        }
         mStageEnd = m1;
         if (m0 >= m1) return true; // an earlier stage finished the pair's matches
         if (!LIST) {
