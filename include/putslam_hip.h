@@ -147,10 +147,12 @@ int ps_context_device(const PsContext *ctx);
  *              fixed schedule only (under the adaptive ones the trip limit usually ends the scoring before the stages
  *              start and the launch would buy nothing)  (PUTSLAM_HIP_REORDER=0|1|2).
  *   "bail":    1 (default) = "nothing to gain" handling of the staged scoring for the Euclidean metrics: a pair whose prefix
- *              leaves a miss budget so large that the first stage sweeps every match anyway skips the reorder vote, and while
- *              most pairs of the last observed batched call were such pairs the context scores the next batched calls
- *              completely, probing with the staged form every 16th call (identical outputs either way; "hopeless", read
- *              only, is the policy's state).  0 = always the staged form.
+ *              leaves a miss budget so large that the first stage sweeps every match anyway skips the reorder vote, and -- fixed
+ *              schedule only -- while most pairs of the last observed batched call OF THE SAME KIND (metric, schedule, H,
+ *              batch-size class, frame capacity, frame set; eight kinds are tracked) were such pairs, the next calls of that
+ *              kind are scored completely, probing with the staged form every 16th call (identical outputs either way;
+ *              "hopeless", read only, is the state of the last call's kind).  Adaptive schedules always keep the staged form.
+ *              0 = always the staged form.  Setting the option (to either value) forgets what was observed.
  *   the staged scoring's twins and tuning knobs, each also PUTSLAM_HIP_<NAME> at context creation (tests run every one of
  *   them next to the default, tests/test_gpu_prune.py): "gensplit" (1: stage 0 as two launches, models then sweep),
  *   "singlerest" (1: one stage after the prefix under the adaptive schedules), "pretest" (1: stage 1's one-direction
@@ -380,6 +382,9 @@ int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches);
 int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                            const float *K, const float *prev, int nprev, const float *cur, int ncur,
                            const PsDMatch *matches, int m, int32_t *counts, int *numScored);
+/* Words of the context's keys block that are not all-ones once its queued work has drained; must be 0 after any sequence of
+ * calls (the matcher's query splits merge with atomicMin on a block kernel 2 leaves all-ones: no clearing launch per call). */
+int ps_debug_keys_clean(PsContext *ctx, uint64_t *bad);
 /* Device-side trip limit after a best model with c inliers out of M, for c = 1..M:
  * min(H, iterations(minRatio), iterations(float(c)/float(M))) for PS_EST_RANSAC (RANSAC.cpp:450-461),
  * min(H, updateStandardStopping(c, M, 3)) for PS_EST_USAC (USAC.h:944-971). */

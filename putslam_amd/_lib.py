@@ -25,7 +25,7 @@ EXPORTED = [
     "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
-    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_fastdiv", "ps_debug_mathcheck", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stage_order", "ps_debug_stamps",
+    "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_keys_clean", "ps_debug_fastdiv", "ps_debug_mathcheck", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stage_order", "ps_debug_stamps",
     "ps_abi_sizeof_dmatch", "ps_abi_sizeof_params", "ps_abi_sizeof_config", "ps_abi_sizeof_stats",
     "ps_abi_sizeof_frameset", "ps_abi_sizeof_results", "ps_abi_sizeof_host_results",
 ]
@@ -122,6 +122,7 @@ def load_path(path):
                                     vp, i32, vp, vp, C.POINTER(i32), vp, vp]
     L.ps_debug_ransac_counts.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, i32, vp,
                                          i32, vp, i32, vp, C.POINTER(i32)]
+    L.ps_debug_keys_clean.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ps_debug_limits.argtypes = [vp, i32, C.c_double, i32, i32, vp]
     L.ps_debug_fastdiv.argtypes = [vp, C.c_uint64, i32, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ps_debug_mathcheck.argtypes = [vp, i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

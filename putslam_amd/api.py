@@ -164,6 +164,12 @@ class Context:
                                                  matches.shape[0], _p(counts), C.byref(n)))
         return counts[: n.value].copy()
 
+    def debug_keys_clean(self):
+        """Words of the keys block that are not all-ones at rest (ps_debug_keys_clean): must be 0."""
+        bad = C.c_uint64(0)
+        self._chk(self._L.ps_debug_keys_clean(self._h, C.byref(bad)))
+        return int(bad.value)
+
     def debug_limits(self, estimator, min_ratio, H, M):
         out = np.zeros(M, np.int32)
         self._chk(self._L.ps_debug_limits(self._h, int(estimator), float(min_ratio), int(H), int(M), _p(out)))

@@ -113,17 +113,31 @@ struct PsContext {
     // pairs and capacity the survivor counters / the order were laid out with, 0 = that step was not staged / not reordered
     int stagedP = 0, stagedCap = 0, reorderedP = 0;
     int lastModelH = 0; // hypotheses per pair with a parked-model slot in the last scoring step (0: nothing parked)
-    // "Nothing to gain" policy of the staged scoring (option "bail", Euclidean metrics, batched calls): ps_stage_reorder counts
-    // the pairs it replayed and those whose prefix leaves nothing to abandon (stage 1 sweeps every match: hopeless data, no
-    // pair accepted); kernel 4 forwards the two counters to mapped host memory.  While the last observation says "most pairs",
-    // the next calls score completely -- one launch, what the staged form costs on such data is its extra launches, 14 - 19 %
-    // (profiles/r03p/data_sweep.txt) -- and every 16th call probes with the staged form again.  Results are bit-identical
-    // either way; the observation arrives asynchronously, so the switch lags the data by a call or two.
-    Buf bailCnt;                  // device: {pairs replayed, pairs with nothing to gain}, monotonic
-    unsigned *bailHost = nullptr; // mapped host mirror [2]
+    // "Nothing to gain" policy of the staged scoring (option "bail", Euclidean metrics, fixed schedule, batched calls):
+    // ps_stage_reorder counts the pairs it replayed and those whose prefix leaves nothing to abandon (stage 1 sweeps every match:
+    // hopeless data, no pair accepted); kernel 4 forwards the two counters to mapped host memory.  While the last observation
+    // says "most pairs", the next calls OF THE SAME KIND score completely -- one launch, what the staged form costs on such data
+    // is its extra launches, 14 - 19 % (profiles/r03p/data_sweep.txt) -- and every 16th call probes with the staged form again.
+    // Results are bit-identical either way; the observation arrives asynchronously, so the switch lags the data by a call or two.
+    // The state is kept per KIND of call -- (errorVersion, estimator, H, batch-size class, frame capacity, frame set) --, eight
+    // kinds at a time: a context that alternates a mostly failing batch (loop-closure candidates) with good VO batches keeps
+    // the staged form for the good ones (round 4 kept ONE flag per context: ADVICE round 4).  Adaptive schedules never drop the
+    // staged form: under a long cap complete scoring is the minutes-long path.
+    struct BailKind {
+        int mode = -1, estimator = 0, H = 0, pclass = 0, cap = 0;
+        const void *frames = nullptr;
+        unsigned seen[2] = {0, 0};
+        int hopeless = 0, calls = 0;
+        unsigned long long used = 0; // (least recently used slot is recycled)
+    };
+    static constexpr int kBailKinds = 8;
+    BailKind bailKinds[kBailKinds];
+    unsigned long long bailClock = 0;
+    int bailSlot = -1;            // slot of the last call the policy looked at
+    Buf bailCnt;                  // device: [kBailKinds]{pairs replayed, pairs with nothing to gain}, monotonic per slot
+    unsigned *bailHost = nullptr; // mapped host mirror [kBailKinds][2]
     unsigned *bailHostDev = nullptr;
-    unsigned bailSeen[2] = {0, 0};
-    int hopeless = 0, hopelessCalls = 0;
+    int hopeless = 0;             // state of the last call's kind (option "hopeless", read only)
     // The keys block is all-ones at rest: kernel 2 puts kNoKey back into every entry it reads, so the matcher forms that merge
     // their query splits with atomicMin need no clearing launch in front of them (a single pair paid a memset launch and its
     // gap for that on every call: 6 of 96 us).  keysCleanPtr / keysCleanBytes = the block and the leading bytes the invariant
@@ -404,6 +418,7 @@ struct Plan {
     bool reorder = false; // staged scoring: stages 1+ sweep the reordered hot record (ps_stage_reorder)
     bool prune = false; // staged scoring: hypotheses [0, prefix) completely (msplit applies to it), the rest in pruned stages
     bool bailWatch = false; // this staged call feeds the "nothing to gain" policy (PsContext::bailHost)
+    int bailSlot = 0;       // ... for this kind of call (PsContext::bailKinds)
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
     int lastStage = 0;  // staged scoring: 1 = ONE stage after the prefix (adaptive schedules without reordering), else kStages
 };
@@ -562,7 +577,7 @@ unsigned big_limit(int mode) { return mode == PS_REPROJECTION_ERROR ? 1536u : 12
 
 // complete = true: every hypothesis is scored completely whatever the batch size (ps_debug_ransac_counts returns the counts
 // themselves: the staged scoring leaves lower bounds for abandoned hypotheses)
-int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false, bool adaptive = false)
+int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false, bool adaptive = false, const void *dataKey = nullptr)
 {
     const int H = pl.H;
     PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
@@ -581,32 +596,57 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
     pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom;
     pl.bailWatch = false;
+    pl.bailSlot = 0;
     const bool willReorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
-    if (adaptive && pl.prune && willReorder && ctx->bail != 0 && with_euclid_fast(ctx, pl.mode)) {
+    if (adaptive && pl.prune && willReorder && ctx->bail != 0 && with_euclid_fast(ctx, pl.mode) && pl.sa.estimator == PS_EST_FIXED) {
         if (!ctx->bailHost) {
-            if (hipHostMalloc((void **)&ctx->bailHost, 2 * sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
+            const size_t nb = (size_t)PsContext::kBailKinds * 2 * sizeof(unsigned);
+            if (hipHostMalloc((void **)&ctx->bailHost, nb, hipHostMallocMapped) == hipSuccess &&
                 hipHostGetDevicePointer((void **)&ctx->bailHostDev, ctx->bailHost, 0) == hipSuccess) {
-                ctx->bailHost[0] = ctx->bailHost[1] = 0;
-                if (ensure(ctx, ctx->bailCnt, 2 * sizeof(unsigned)) == PS_OK)
-                    (void)hipMemsetAsync(ctx->bailCnt.p, 0, 2 * sizeof(unsigned), ctx->stream);
+                memset(ctx->bailHost, 0, nb);
+                if (ensure(ctx, ctx->bailCnt, nb) == PS_OK) (void)hipMemsetAsync(ctx->bailCnt.p, 0, nb, ctx->stream);
             } else {
                 (void)hipGetLastError();
                 ctx->bailHostDev = nullptr; // (no mapped memory here: the policy stays off)
             }
         }
         if (ctx->bailHostDev && ctx->bailCnt.p) {
-            const unsigned s0 = ((volatile unsigned *)ctx->bailHost)[0], s1 = ((volatile unsigned *)ctx->bailHost)[1];
-            if (s0 != ctx->bailSeen[0]) { // a new observation has landed
-                const unsigned d0 = s0 - ctx->bailSeen[0], d1 = s1 - ctx->bailSeen[1];
-                const int was = ctx->hopeless;
-                ctx->hopeless = (2ull * d1 > d0) ? 1 : 0;
-                if (ctx->hopeless != was) ctx->hopelessCalls = 0;
-                ctx->bailSeen[0] = s0;
-                ctx->bailSeen[1] = s1;
+            // the kind of this call: its own slot (a new kind takes the least recently used one and starts from "staged")
+            int pclass = 0;
+            for (int q = P; q > 1; q >>= 1) ++pclass;
+            int slot = -1, lru = 0;
+            for (int i = 0; i < PsContext::kBailKinds; ++i) {
+                const PsContext::BailKind &b = ctx->bailKinds[i];
+                if (b.mode == pl.mode && b.estimator == pl.sa.estimator && b.H == H && b.pclass == pclass && b.cap == cap && b.frames == dataKey) slot = i;
+                if (b.used < ctx->bailKinds[lru].used) lru = i;
             }
-            if (ctx->hopeless && (++ctx->hopelessCalls & 15) != 0)
+            if (slot < 0) {
+                slot = lru;
+                PsContext::BailKind &b = ctx->bailKinds[slot];
+                b.mode = pl.mode; b.estimator = pl.sa.estimator; b.H = H; b.pclass = pclass; b.cap = cap; b.frames = dataKey;
+                b.hopeless = 0;
+                b.calls = 0;
+                // (the slot's counters are monotonic: what its previous kind left there is simply "seen")
+                b.seen[0] = ((volatile unsigned *)ctx->bailHost)[2 * slot];
+                b.seen[1] = ((volatile unsigned *)ctx->bailHost)[2 * slot + 1];
+            }
+            PsContext::BailKind &b = ctx->bailKinds[slot];
+            b.used = ++ctx->bailClock;
+            const unsigned s0 = ((volatile unsigned *)ctx->bailHost)[2 * slot], s1 = ((volatile unsigned *)ctx->bailHost)[2 * slot + 1];
+            if (s0 != b.seen[0]) { // a new observation of this kind has landed
+                const unsigned d0 = s0 - b.seen[0], d1 = s1 - b.seen[1];
+                const int was = b.hopeless;
+                b.hopeless = (2ull * d1 > d0) ? 1 : 0;
+                if (b.hopeless != was) b.calls = 0;
+                b.seen[0] = s0;
+                b.seen[1] = s1;
+            }
+            if (b.hopeless && (++b.calls & 15) != 0)
                 pl.prune = false; // complete scoring while nothing can be abandoned; every 16th call looks again
             pl.bailWatch = pl.prune;
+            pl.bailSlot = slot;
+            ctx->bailSlot = slot;
+            ctx->hopeless = b.hopeless;
         }
     }
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
@@ -784,7 +824,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                                pl.minRun, (const int32_t *)ctx->counts.p, (float2 *)ctx->recF2.p,                       \
                                (int32_t *)ctx->permBuf.p, (int32_t *)ctx->prefInfo.p,                            \
                                usePretest ? (float2 *)ctx->frontRec.p : (float2 *)nullptr,                             \
-                               pl.bailWatch ? (unsigned *)ctx->bailCnt.p : (unsigned *)nullptr);                       \
+                               pl.bailWatch ? (unsigned *)ctx->bailCnt.p + 2 * pl.bailSlot : (unsigned *)nullptr);     \
     } while (0)
     // stage 0 as two launches: models + validity, then the sweep reading them back
     auto stage0_args = [&](bool gen) {
@@ -939,8 +979,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                        (const int4 *)ctx->recD.p, (const int32_t *)ctx->mvalid.p, (const int32_t *)ctx->counts.p,
                        dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
                        dMask, dStats, ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr,
-                       (pl.bailWatch && pl.reorder) ? (const unsigned *)ctx->bailCnt.p : (const unsigned *)nullptr,
-                       (pl.bailWatch && pl.reorder) ? ctx->bailHostDev : (unsigned *)nullptr);
+                       (pl.bailWatch && pl.reorder) ? (const unsigned *)ctx->bailCnt.p + 2 * pl.bailSlot : (const unsigned *)nullptr,
+                       (pl.bailWatch && pl.reorder) ? ctx->bailHostDev + 2 * pl.bailSlot : (unsigned *)nullptr);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;
@@ -1155,7 +1195,11 @@ int parse_option_text(const OptDesc &o, const char *v)
         if (strcmp(v, "mfma") == 0) return 1;
         if (strcmp(v, "auto") == 0) return 2;
     }
-    return std::atoi(v);
+    // (a number, all of it: "mfma" for an option that takes no such word, or a typo, is not 0 -- it is ignored)
+    char *end = nullptr;
+    const long x = std::strtol(v, &end, 10);
+    if (end == v || *end != '\0' || x < INT_MIN || x > INT_MAX) return INT_MIN;
+    return (int)x;
 }
 
 } // namespace
@@ -1268,6 +1312,11 @@ int ps_context_set_option(PsContext *ctx, const char *name, int value)
     if (!o) return fail(ctx, PS_ERR_BAD_ARG, "unknown option");
     if (!option_value_ok(*o, value)) return fail(ctx, PS_ERR_BAD_ARG, o->what);
     ctx->*(o->field) = value;
+    if (strcmp(name, "bail") == 0) { // (setting the option also forgets what the policy has observed: every kind starts staged)
+        for (PsContext::BailKind &b : ctx->bailKinds) b = PsContext::BailKind();
+        ctx->hopeless = 0;
+        ctx->bailSlot = -1;
+    }
     return PS_OK;
 }
 
@@ -1682,6 +1731,29 @@ int ps_debug_stamps(PsContext *ctx, uint64_t *out16)
     return PS_OK;
 }
 
+// Diagnostic: how many words of the context's keys block are not all-ones once the queued work has drained (the matcher forms
+// that merge their query splits with atomicMin rely on kernel 2 putting kNoKey back into every entry it read; see
+// PsContext::keysCleanPtr).  *bad must come back 0 after any sequence of calls, failed ones included.
+int ps_debug_keys_clean(PsContext *ctx, uint64_t *bad)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!bad) return PS_ERR_BAD_ARG;
+    *bad = 0;
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->keys.p || ctx->keysCleanPtr != ctx->keys.p || ctx->keysCleanBytes == 0) return PS_OK; // nothing is claimed to be clean
+    PS_ENSURE(ctx->sMisc2, 16);
+    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(ps_count_not_ones, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->keys.p,
+                       ctx->keysCleanBytes / sizeof(uint32_t), (unsigned long long *)ctx->sMisc2.p);
+    PS_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    PS_HIP(hipMemcpyAsync(&h, ctx->sMisc2.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PS_HIP(hipStreamSynchronize(ctx->stream));
+    *bad = h;
+    return PS_OK;
+}
+
 // Diagnostic: device-side trip limits for every inlier count 1..M (see ps_limits_table).
 int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M, int32_t *out)
 {
@@ -1936,8 +2008,14 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
                 (void)hipStreamSynchronize(c->stream);
         }
     } handoffGuard{ctx};
-    rc = prepare_score(ctx, pl, P, cap, false, true);
+    rc = prepare_score(ctx, pl, P, cap, false, true, frames->desc);
     if (rc) return rc;
+    // Complete scoring of a batch under a long cap is the reference's own worst case times P (850 000 iterations over every
+    // match, USAC_wrapper.cpp:70): minutes of GPU time behind an asynchronous call.  It is refused; the staged scoring (option
+    // "prune", the default) takes the same batch in milliseconds whenever the schedules end early.
+    if (!pl.prune && (double)P * (double)pl.H * (double)cap > 2.0e14)
+        return fail(ctx, PS_ERR_UNSUPPORTED, "complete scoring of this batch (pairs x hypotheses x matches > 2e14) would run for minutes: "
+                                             "leave the staged scoring on (option \"prune\") or pass fewer pairs per call");
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);

@@ -1995,6 +1995,14 @@ __global__ __launch_bounds__(kBlock) void ps_mathcheck(int mode, uint64_t seed, 
 // libm evaluation (RANSAC.cpp:457-461, USAC.h:944-971) for every (count, M).
 // (the limit functions search their table as a wavefront with uniform arguments, as the replays call them: the wave takes
 // its 64 counts one after the other)
+// Diagnostic: words of the keys block that are not kNoKey (the matcher's atomicMin merge relies on an all-ones block at rest).
+__global__ void ps_count_not_ones(const uint32_t *__restrict__ keys, size_t n, unsigned long long *__restrict__ bad)
+{
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += keys[i] != kNoKey;
+    if (c) atomicAdd(bad, c);
+}
+
 __global__ void ps_limits_table(SelectArgs a, int M, int32_t *__restrict__ out)
 {
     const int c0 = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) + 1; // the wave's first count

@@ -133,6 +133,9 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
             pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
             run_pairs(ctxs[pr], prm, cfg, TUM_FR1_K, fs, pb)
             outs[pr] = pb.download()
+            if hasattr(ctxs[pr], "debug_keys_clean") and it % 8 == 0:
+                # the matcher's atomicMin merge starts from an all-ones keys block that kernel 2 restores (no clearing launch)
+                assert ctxs[pr].debug_keys_clean() == 0, ("keys block not all-ones at rest", it, pr)
         a = outs[1]
         P = len(seq["pairs"])
         why = []   # what differs, for the log: (against what, pair, field)

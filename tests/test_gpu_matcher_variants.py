@@ -158,3 +158,51 @@ def test_keys_block_is_all_ones_at_rest(oracle):
                     assert int(got["numMatches"][p]) == len(m) and got["matches"][p][:len(m)].tobytes() == m.tobytes(), (rnd, p)
     finally:
         c.close()
+
+
+def test_keys_block_is_all_ones_at_rest_across_shapes_variants_and_failed_calls():
+    """the matcher forms that merge their query splits with atomicMin take no clearing launch -- the keys block
+    is all-ones at rest because kernel 2 puts kNoKey back into every entry it read.  One context alternating batch sizes,
+    frame capacities, ragged row counts, both matchers, query splits, streamed pushes and a failed call: after each of them
+    ps_debug_keys_clean finds no other word, and results stay those of a fresh context."""
+    from putslam_amd import api, synth
+    from putslam_amd._abi import EST_RANSAC, EUCLIDEAN_ERROR, TUM_FR1_K, default_ransac_params, make_config
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    c = api.Context(0)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=5)
+    rng = np.random.default_rng(3)
+    shapes = [(2, 300), (9, 1200), (3, 2000), (30, 257), (2, 4100), (12, 640), (2, 31)]
+    for it in range(14):
+        frames, kpts = shapes[it % len(shapes)]
+        seq = synth.make_sequence(frames, kpts, config=3, index=900 + it)
+        if it % 3 == 1:
+            seq["nkpts"][:] = rng.integers(0, kpts + 1, frames)
+        c.set_option("matcher", int(rng.integers(0, 3)))
+        c.set_option("qsplit", int(rng.choice([0, 0, 1, 2, 5, 16])))
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        assert c.debug_keys_clean() == 0, it
+        ref = api.Context(0)
+        pb2 = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(ref, prm, cfg, TUM_FR1_K, fs, pb2)
+        r = pb2.download()
+        ref.close()
+        assert np.array_equal(g["numMatches"], r["numMatches"]) and g["matches"].tobytes() == r["matches"].tobytes(), it
+        if it % 4 == 2:   # a host-pointer call and a streamed push in between
+            a, b = synth.make_pair(int(rng.integers(50, 3000)), config=2, index=it)
+            c.match_hamming256(a["desc"], b["desc"])
+            assert c.debug_keys_clean() == 0
+            st = api.VoStream(c, 700)
+            for f in range(4):
+                st.push(prm, cfg, TUM_FR1_K, seq["desc"][f % frames][:min(kpts, 700)], seq["pts"][f % frames][:min(kpts, 700)])
+            st.close()
+            assert c.debug_keys_clean() == 0
+        if it % 5 == 4:   # a failed call (bad hypothesis count) must leave the invariant alone
+            badcfg, _ = make_config(EST_RANSAC, 0, seed=1)
+            with pytest.raises(api.PsError):
+                run_pairs(c, prm, badcfg, TUM_FR1_K, fs, pb)
+            assert c.debug_keys_clean() == 0
+    c.close()

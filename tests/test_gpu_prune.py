@@ -356,6 +356,46 @@ def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
     c.close()
 
 
+def test_nothing_to_gain_policy_is_kept_per_kind_of_call(oracle):
+    """one context alternating a mostly failing batch (loop-closure candidates) with a good VO batch.  The
+    policy's state belongs to the kind of call (metric, schedule, H, batch-size class, frame set): the good batches stay staged
+    on every call, the bad ones go to complete scoring; an adaptive schedule never leaves the staged form; setting the option
+    resets what was observed."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    bad = synth.make_sequence(41, 500, config=9, index=15, inlier_frac=0.12, noise=0.02)
+    good = synth.make_sequence(41, 500, config=9, index=70, inlier_frac=0.7, noise=0.004)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_FIXED, 4096, seed=11)
+    c = api.Context(0)
+    sets = {}
+    for name, seq in (("bad", bad), ("good", good)):       # two frame sets that stay resident: two kinds of call
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        sets[name] = (seq, fs, PairBatchDevice(seq["pairs"], fs.max_kpts), _run(seq, prm, cfg, 0))
+
+    def call(name, cfg_=cfg):
+        seq, fs, pb, ref = sets[name]
+        run_pairs(c, prm, cfg_, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        if cfg_ is cfg:
+            _same(g, ref, len(seq["pairs"]))
+        return c.get_option("last_staged_pairs") > 0
+
+    staged = {"bad": [], "good": []}
+    for i in range(24):
+        for name in ("bad", "good"):
+            staged[name].append(call(name))
+    assert all(staged["good"])                                   # never dragged into complete scoring by its neighbour
+    assert staged["bad"][0] and sum(staged["bad"]) <= 4          # first call + the periodic probe
+    c.set_option("bail", 1)                                      # forgets the observations
+    assert call("bad") and c.get_option("hopeless") == 0
+    # an adaptive schedule with reordering forced on: the policy does not apply, always staged (long caps: complete scoring
+    # would run for minutes)
+    c.set_option("reorder", 1)
+    cfg_u, _ = make_config(EST_USAC, 3000, seed=11)
+    assert all(call("bad", cfg_u) for _ in range(5))
+    c.close()
+
+
 def test_batch_under_the_reference_usac_cap_in_one_call(oracle):
     """USAC's cap of 850 000 (USAC_wrapper.cpp:70) with 212 pairs: round 4 parked one model per pair and cap entry (48 bytes:
     8.6 GB here) and took such a batch in slices.  Models are parked in proportion to the work now -- the leading hypotheses of
