@@ -138,8 +138,11 @@ int ps_context_device(const PsContext *ctx);
  *              hypothesis that cannot become a record of the sequential selection any more (count so far + matches left
  *              <= best count of the earlier ones, RANSAC.cpp:438-455) is abandoned, and hypotheses beyond the adaptive
  *              trip limit (RANSAC.cpp:450-453) are never started; all outputs are unchanged, only the scratch counts of
- *              abandoned hypotheses are lower bounds.  0 = every hypothesis is scored completely
- *              (PUTSLAM_HIP_PRUNE=0|1).  The diagnostic ps_debug_ransac_counts always scores completely.
+ *              abandoned hypotheses are lower bounds.  "Large" is decided by a cost model: pairs x (ceil(H / 256) - 1) x
+ *              maxKpts against base + perRow x maxKpts, per metric family and schedule (the staged form costs six or seven
+ *              dependent launches and pays them back with the evaluations it abandons).  2 = the staged form whenever the
+ *              kernels have it (H > 256), whatever the batch size; 0 = every hypothesis is scored completely
+ *              (PUTSLAM_HIP_PRUNE=0|1|2).  The diagnostic ps_debug_ransac_counts always scores completely.
  *   "reorder": the stages after the first sweep a copy of the pair's match record in which the matches the best hypotheses
  *              so far reject come first (written by a launch of its own between the stages): whatever is not better than
  *              those hypotheses rejects nearly all of them too and is abandoned a few matches later.  Counts are sums over

@@ -29,6 +29,13 @@ struct Buf {
 };
 
 constexpr int kWidePairs = 16; // batches of at most this many pairs run kernel 2 with 1024-thread work-groups
+// where the staged scoring takes over from complete scoring (prepare_score): batch size in work units = pairs x
+// (ceil(H / 256) - 1) x frame capacity, threshold = base + perRow x frame capacity (profiles/r05c/staged_crossover.txt)
+struct StagedFrom {
+    double base, perRow;
+};
+constexpr StagedFrom kStagedFromEuclidFixed = {7.8e5, 250.0}, kStagedFromReprojFixed = {1.3e6, 500.0},
+                     kStagedFromEuclidAdaptive = {6.0e4, 0.0}, kStagedFromReprojAdaptive = {4.5e4, 0.0};
 constexpr int kMaxTimed = 8;   // kernels timed per call
 constexpr int kTimingRing = 128; // calls kept (HIP events on the launch stream around every kernel)
 
@@ -593,8 +600,18 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     // (the staged form is six or seven dependent launches, 0.23 ms at the least with the reprojection kernels and 0.08 ms with
     // the Euclidean ones: it pays from about 48 / 16 pairs of H = 4096 on, profiles/r03p/small_batches.txt)
     // (adaptive schedules: the trip limit the prefix leaves cuts most of the work whatever the batch size)
-    const long long stagedFrom = (with_euclid_fast(ctx, pl.mode) || pl.sa.estimator != PS_EST_FIXED) ? 256 : 768;
-    pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (long long)P * (hb - 1) >= stagedFrom;
+    // Cost model (round 5): the staged form trades six or seven dependent launches for the evaluations it abandons, and an
+    // evaluation's worth of work is a (hypothesis, match) pair -- so the batch is sized in work-groups of 256 hypotheses beyond the
+    // first one x rows of the frame capacity (matches <= keypoints), and the crossover is where (1 - share of evaluations left)
+    // of that pays for the launches: base + perRow x capacity, fitted on profiles/r05c/staged_crossover.txt over 500 ... 4000
+    // keypoints x H = 1024 ... 16384 (rounds 3 - 4 counted work-groups only, with constants from 2000 keypoints that DESIGN
+    // section 8 knew to be 2 - 14 % off on either side; adaptive schedules gain from far smaller batches than they were given).
+    // Option "prune" = 2 takes the staged form whenever the kernels have it (tests; A/B).
+    const double units = (double)P * (double)(hb - 1) * (double)cap;
+    const StagedFrom sf = with_euclid_fast(ctx, pl.mode) ? (pl.sa.estimator == PS_EST_FIXED ? kStagedFromEuclidFixed : kStagedFromEuclidAdaptive)
+                                                         : (pl.sa.estimator == PS_EST_FIXED ? kStagedFromReprojFixed : kStagedFromReprojAdaptive);
+    const double stagedFrom = sf.base + sf.perRow * (double)cap;
+    pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (ctx->prune == 2 || units >= stagedFrom);
     pl.bailWatch = false;
     pl.bailSlot = 0;
     const bool willReorder = ctx->reorder == 1 || (ctx->reorder == 2 && pl.sa.estimator == PS_EST_FIXED);
@@ -1150,7 +1167,7 @@ const OptDesc kOptions[] = {
     {"matcher_fused", "MATCHER_FUSED", &PsContext::matcherFused, 0, 1, "matcher_fused: 0 or 1"},
     {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
     {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
-    {"prune", "PRUNE", &PsContext::prune, 0, 1, "prune: 0 or 1"},
+    {"prune", "PRUNE", &PsContext::prune, 0, 2, "prune: 0 (complete scoring), 1 (staged from the cost model's batch size on) or 2 (staged whenever possible)"},
     {"reorder", "REORDER", &PsContext::reorder, 0, 2, "reorder: 0, 1 or 2"},
     {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024"},
     {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024"},

@@ -95,7 +95,7 @@ def run_batch(iters, seed, verbose=True, modes=(0, 1, 2, 4), oracle_pairs=3):
     ctxs = {}
     for pr in (1, 2, 0):   # 1: staged, reordered match record; 2: staged, original order; 0: complete
         ctxs[pr] = api.Context(0)
-        ctxs[pr].set_option("prune", 1 if pr else 0)
+        ctxs[pr].set_option("prune", 2 if pr else 0)   # (2: staged whatever the batch size; the default asks the cost model)
         ctxs[pr].set_option("reorder", 1 if pr == 1 else 0)
     for it in range(iters):
         mode = int(rng.choice(list(modes)))

@@ -21,7 +21,7 @@ STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierC
 def _run(seq, prm, cfg, prune, reorder=1, **options):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     c = api.Context(0)
-    c.set_option("prune", prune)
+    c.set_option("prune", 2 if prune else 0)   # 2 = the staged form whatever the batch size (the default, 1, asks the cost model)
     c.set_option("reorder", reorder)   # 1 = also under the adaptive schedules (the default reorders the fixed one only)
     assert c.get_option("reorder") == reorder
     for name, value in options.items():   # the staged scoring's twins and tuning knobs (ps_context_set_option)
@@ -130,6 +130,7 @@ def test_reordered_record_is_a_permutation_with_the_rejected_matches_in_front(or
         prm = default_ransac_params(mode)
         cfg, _ = make_config(EST_FIXED, 4096, seed=5)
         c = api.Context(0)
+        c.set_option("prune", 2)
         fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
         pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
         run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
@@ -194,7 +195,7 @@ def test_option_names_and_ranges():
         v = c.get_option(name)
         c.set_option(name, v)   # every default is a legal value
     for name, bad in (("prefix", 100), ("prefix", 320), ("reorder_gran", 12), ("reorder_gran", 1), ("list_r3", 0),
-                      ("reorder_top", 17), ("prune", 2), ("no_such_option", 0)):
+                      ("reorder_top", 17), ("prune", 3), ("no_such_option", 0)):
         with pytest.raises(api.PsError):
             c.set_option(name, bad)
     c.close()
@@ -222,6 +223,7 @@ def test_host_entry_with_staged_scoring_two_calls_one_context(oracle, mode, est,
     K = TUM_FR1_K
     staged, full = api.Context(0), api.Context(0)
     staged.set_option("reorder", 1)
+    staged.set_option("prune", 2)
     full.set_option("prune", 0)
     for rep, (x, y, seed) in enumerate(((a, b, 5), (a2, b2, 6), (a, b, 5), (a2, b2, 7))):
         cfg, _ = make_config(est, H, seed=seed)
@@ -246,6 +248,7 @@ def test_debug_counts_are_complete_counts_whatever_the_size(oracle):
     m = oracle.match_hamming256(a["desc"], b["desc"])
     c = api.Context(0)
     c.set_option("reorder", 1)
+    c.set_option("prune", 2)
     c.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)          # a staged call first
     cg = c.debug_ransac_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
     cc, _ = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
@@ -266,6 +269,7 @@ def test_stream_push_with_staged_scoring(oracle, mode, est, H):
     prm.minimalInlierRatioThreshold = 0.05
     c = api.Context(0)
     c.set_option("reorder", 1)
+    c.set_option("prune", 2)
     vs = api.VoStream(c, 300)
     for f in range(7):
         cfg, _ = make_config(est, H, seed=100 + f)
@@ -294,6 +298,7 @@ def test_stage_diagnostics_reject_another_batch_shape():
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     seq = synth.make_sequence(30, 400, config=3, index=61, inlier_frac=0.7, noise=0.004)
     c = api.Context(0)
+    c.set_option("prune", 2)
     prm = default_ransac_params(EUCLIDEAN_ERROR)
     cfg, _ = make_config(EST_FIXED, 4096, seed=3)
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
@@ -320,6 +325,7 @@ def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
     prm = default_ransac_params(EUCLIDEAN_ERROR)
     cfg, _ = make_config(EST_FIXED, 4096, seed=11)
     c = api.Context(0)
+    c.set_option("prune", 2)
 
     def call(seq):
         fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
@@ -346,6 +352,7 @@ def test_nothing_to_gain_policy_switches_to_complete_scoring_and_probes(oracle):
     c.set_option("bail", 0)
     c2 = api.Context(0)
     c2.set_option("bail", 0)
+    c2.set_option("prune", 2)
     c.close()
     c, staged = c2, []
     for i in range(6):
@@ -367,6 +374,7 @@ def test_nothing_to_gain_policy_is_kept_per_kind_of_call(oracle):
     prm = default_ransac_params(EUCLIDEAN_ERROR)
     cfg, _ = make_config(EST_FIXED, 4096, seed=11)
     c = api.Context(0)
+    c.set_option("prune", 2)
     sets = {}
     for name, seq in (("bad", bad), ("good", good)):       # two frame sets that stay resident: two kinds of call
         fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
@@ -427,3 +435,30 @@ def test_batch_under_the_reference_usac_cap_in_one_call(oracle):
         for f in STAT_FIELDS:
             x, y = g["stats"][p][f], cp["stats"][0][f]
             assert x == y or (np.isnan(x) and np.isnan(y)), (p, f, x, y)
+
+
+@pytest.mark.parametrize("mode,est,H,kpts,below,above", [
+    # threshold = base + perRow x capacity in units of pairs x (ceil(H / 256) - 1) x capacity (ps_capi.hip: kStagedFrom*)
+    (EUCLIDEAN_ERROR, EST_FIXED, 4096, 500, 100, 140),       # 7.8e5 + 250 x 500 = 9.05e5: 121 pairs
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 230, 270),    # 1.3e6 + 500 x 400 = 1.5e6: 250 pairs
+    (EUCLIDEAN_ERROR, EST_RANSAC, 1157, 300, 40, 60),        # 6.0e4: 50 pairs (hb - 1 = 4)
+    (REPROJECTION_ERROR, EST_USAC, 3000, 300, 10, 18),       # 4.5e4: 14 pairs (hb - 1 = 11)
+])
+def test_cost_model_picks_the_form_by_batch_size_and_both_forms_agree(mode, est, H, kpts, below, above):
+    """Round 5: the default (option prune = 1) takes the staged form from the cost model's batch size on -- pairs x work-groups of
+    hypotheses x frame capacity against base + perRow x capacity (profiles/r05c/staged_crossover.txt) -- and complete scoring
+    below it.  Just below and just above the point: the form taken is the predicted one and the outputs are those of the other
+    form (selection rule RANSAC.cpp:438-455 untouched either way)."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    prm = default_ransac_params(mode, lc=(H == 1157))
+    cfg, _ = make_config(est, H, seed=5150)
+    for P, expect_staged in ((below, False), (above, True)):
+        seq = synth.make_sequence(P + 1, kpts, config=3, index=8800 + P, inlier_frac=0.6, noise=0.005)
+        c = api.Context(0)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        assert (c.get_option("last_staged_pairs") > 0) == expect_staged, (P, c.get_option("last_staged_pairs"))
+        c.close()
+        _same(g, _run(seq, prm, cfg, 0 if expect_staged else 1), P)

@@ -58,7 +58,7 @@ def test_staged_batch_is_deterministic_under_contention(rig, mode, est, H, reord
 
     def submit(prune, join=True):
         for c in ctxs:
-            c.set_option("prune", prune)
+            c.set_option("prune", 2 if prune else 0)   # (2: the staged form whatever the cost model says of this batch size)
             c.set_option("reorder", reorder)
         pb = PairBatchDevice(seq["pairs"], fs.max_kpts)   # fresh zeroed outputs: a missing write shows too
         run_pairs_split(ctxs, streams, prm, est, H, 4242, TUM_FR1_K, fs, pb, join=join)
