@@ -109,6 +109,8 @@ struct PsContext {
     int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
     int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
     int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
+    int streamCopyKernels = 1; // option "stream_copy_kernels": ps_vo_stream_push moves its frame in / results out with a copy
+                               // kernel over mapped pinned memory (1) or with hipMemcpyAsync (0: rounds 1 - 4)
     int modelRoomMiB = 0; // option "model_room_mib": room for the staged scoring's parked models (0 = 256 MiB adaptive / 2 GiB fixed)
     int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (options "reorder_top" / "reorder_margin" / "reorder_c2div")
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
@@ -1185,6 +1187,7 @@ const OptDesc kOptions[] = {
     {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64"},
     {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64"},
     {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
+    {"stream_copy_kernels", "STREAM_COPY_KERNELS", &PsContext::streamCopyKernels, 0, 1, "stream_copy_kernels: 0 (hipMemcpyAsync) or 1 (copy kernels over mapped pinned memory)"},
     {"model_room_mib", "MODEL_ROOM_MIB", &PsContext::modelRoomMiB, 0, 65536, "model_room_mib: 0 (default) .. 65536 MiB for the staged scoring's parked models"},
 };
 const OptDesc *find_option(const char *name)
@@ -2056,6 +2059,7 @@ struct PsVoStream {
     Buf res;
     uint8_t *hres = nullptr;   // pinned
     uint8_t *hin = nullptr;    // pinned staging of the incoming frame: [cap x 32 B][cap x 12 B][4 x i32]
+    uint8_t *hresDev = nullptr, *hinDev = nullptr; // their device views (hipHostGetDevicePointer): the copy kernels' side
     size_t offPose = 0, offNum = 0, offMatches = 0, offMask = 0, resBytes = 0;
     // A push is launch-bound (three copies in, four kernels, one copy out): once the scratch
     // arena has been sized by an ordinary push with the same parameters the sequence is captured into one hipGraph
@@ -2097,10 +2101,14 @@ int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
     PS_ENSURE(s->desc, 2 * cap * 32);
     PS_ENSURE(s->pts, 2 * cap * 12);
     PS_ENSURE(s->meta, 8 * sizeof(int32_t));
-    PS_ENSURE(s->res, s->resBytes);
-    PS_HIP(hipHostMalloc((void **)&s->hres, s->resBytes, hipHostMallocDefault));
+    PS_ENSURE(s->res, (s->resBytes + 3) & ~(size_t)3);
+    PS_HIP(hipHostMalloc((void **)&s->hres, (s->resBytes + 3) & ~(size_t)3, hipHostMallocDefault));
     PS_HIP(hipHostMalloc((void **)&s->hin, cap * 44 + 32, hipHostMallocDefault));
     memset(s->hin, 0, cap * 44 + 32); // rows beyond a frame's count are copied by the captured graph, never read
+    if (hipHostGetDevicePointer((void **)&s->hresDev, s->hres, 0) != hipSuccess || hipHostGetDevicePointer((void **)&s->hinDev, s->hin, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->hresDev = s->hinDev = nullptr; // (no device view: the pushes use hipMemcpyAsync)
+    }
     PS_HIP(hipMemsetAsync(s->meta.p, 0, 8 * sizeof(int32_t), ctx->stream));
     if (const char *v = std::getenv("PUTSLAM_HIP_NO_GRAPH")) s->graphsEnabled = std::atoi(v) == 0;
     return PS_OK;
@@ -2182,7 +2190,31 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         s->nkSlot[slot] = n;
         s->frames++;
     };
+    // Frame in / results out as ONE kernel each over the mapped pinned staging blocks (ps_copy_segments) instead of three and one
+    // hipMemcpyAsync: a copy of this size is a node of its own with 5 - 8 us of latency in the captured graph, the kernel reads
+    // the 88 KB of a 2000-keypoint frame over the link in 4 (option "stream_copy_kernels" = 0: the copies of rounds 1 - 4).
+    const bool copyKernels = ctx->streamCopyKernels != 0 && s->hinDev != nullptr && s->hresDev != nullptr;
     auto copy_in = [&](size_t rows) -> int {
+        if (copyKernels) {
+            CopySegs up{};
+            int k = 0;
+            if (rows > 0) {
+                up.src[k] = s->hinDev;
+                up.dst[k] = (uint8_t *)s->desc.p + (size_t)slot * cap * 32;
+                up.bytes[k++] = rows * 32;
+                up.src[k] = s->hinDev + cap * 32;
+                up.dst[k] = (uint8_t *)s->pts.p + (size_t)slot * cap * 12;
+                up.bytes[k++] = rows * 12;
+            }
+            up.src[k] = s->hinDev + cap * 44;
+            up.dst[k] = s->meta.p;
+            up.bytes[k++] = 6 * sizeof(int32_t);
+            up.n = k;
+            const unsigned groups = (unsigned)((rows * 32 / 16 + 255) / 256);
+            hipLaunchKernelGGL(ps_copy_segments, dim3(groups < 1 ? 1 : (groups > 64 ? 64 : groups)), dim3(256), 0, ctx->stream, up);
+            PS_HIP(hipGetLastError());
+            return PS_OK;
+        }
         if (rows > 0) {
             PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, rows * 32, hipMemcpyHostToDevice,
                                   ctx->stream));
@@ -2227,6 +2259,17 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
                              (const int32_t *)(dres + s->offNum), s->cap, (float *)(dres + s->offPose), dres + s->offMask,
                              (PsRansacStats *)dres, 2);
         if (r) return r;
+        if (copyKernels) {
+            CopySegs down{};
+            down.src[0] = dres;
+            down.dst[0] = s->hresDev;
+            down.bytes[0] = (s->resBytes + 3) & ~(size_t)3;
+            down.n = 1;
+            const unsigned groups = (unsigned)((s->resBytes / 16 + 255) / 256);
+            hipLaunchKernelGGL(ps_copy_segments, dim3(groups < 1 ? 1 : (groups > 32 ? 32 : groups)), dim3(256), 0, ctx->stream, down);
+            PS_HIP(hipGetLastError());
+            return PS_OK;
+        }
         PS_HIP(hipMemcpyAsync(s->hres, dres, s->resBytes, hipMemcpyDeviceToHost, ctx->stream));
         return PS_OK;
     };

@@ -1995,6 +1995,37 @@ __global__ __launch_bounds__(kBlock) void ps_mathcheck(int mode, uint64_t seed, 
 // libm evaluation (RANSAC.cpp:457-461, USAC.h:944-971) for every (count, M).
 // (the limit functions search their table as a wavefront with uniform arguments, as the replays call them: the wave takes
 // its 64 counts one after the other)
+// ------------------------------------------------------------------------------------------
+// Host <-> device transfers as a kernel over mapped pinned host memory (the streaming entry points: ps_vo_stream_push's frame in /
+// results out, the pipelined form's meta block).
+constexpr int kCopySegs = 5;
+struct CopySegs {
+    const void *src[kCopySegs];
+    void *dst[kCopySegs];
+    unsigned long long bytes[kCopySegs]; // multiples of 4
+    int n;
+};
+
+// Host <-> device transfer as a kernel: every segment is swept grid-stride, 16 bytes per lane where source, destination and
+// length allow it, 4 bytes otherwise.  One side of every segment is mapped pinned host memory: the accesses go over the link.
+__global__ void __launch_bounds__(256) ps_copy_segments(CopySegs cs)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < cs.n; ++k) {
+        const size_t bytes = cs.bytes[k];
+        if ((((size_t)cs.src[k] | (size_t)cs.dst[k] | bytes) & 15) == 0) {
+            const uint4 *__restrict__ s = (const uint4 *)cs.src[k];
+            uint4 *__restrict__ d = (uint4 *)cs.dst[k];
+            for (size_t i = t0; i < bytes / 16; i += stride) d[i] = s[i];
+        } else {
+            const uint32_t *__restrict__ s = (const uint32_t *)cs.src[k];
+            uint32_t *__restrict__ d = (uint32_t *)cs.dst[k];
+            for (size_t i = t0; i < bytes / 4; i += stride) d[i] = s[i];
+        }
+    }
+}
+
+
 // Diagnostic: words of the keys block that are not kNoKey (the matcher's atomicMin merge relies on an all-ones block at rest).
 __global__ void ps_count_not_ones(const uint32_t *__restrict__ keys, size_t n, unsigned long long *__restrict__ bad)
 {

@@ -30,37 +30,6 @@
 //   * results are those of ONE ps_vo_pairs_device call over the whole sequence: pair k draws from cfg->seed + k.
 #pragma once
 
-namespace psdev {
-
-constexpr int kCopySegs = 5;
-struct CopySegs {
-    const void *src[kCopySegs];
-    void *dst[kCopySegs];
-    unsigned long long bytes[kCopySegs]; // multiples of 4
-    int n;
-};
-
-// Host <-> device transfer as a kernel: every segment is swept grid-stride, 16 bytes per lane where source, destination and
-// length allow it, 4 bytes otherwise.  One side of every segment is mapped pinned host memory: the accesses go over the link.
-__global__ void __launch_bounds__(256) ps_copy_segments(CopySegs cs)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int k = 0; k < cs.n; ++k) {
-        const size_t bytes = cs.bytes[k];
-        if ((((size_t)cs.src[k] | (size_t)cs.dst[k] | bytes) & 15) == 0) {
-            const uint4 *__restrict__ s = (const uint4 *)cs.src[k];
-            uint4 *__restrict__ d = (uint4 *)cs.dst[k];
-            for (size_t i = t0; i < bytes / 16; i += stride) d[i] = s[i];
-        } else {
-            const uint32_t *__restrict__ s = (const uint32_t *)cs.src[k];
-            uint32_t *__restrict__ d = (uint32_t *)cs.dst[k];
-            for (size_t i = t0; i < bytes / 4; i += stride) d[i] = s[i];
-        }
-    }
-}
-
-} // namespace psdev
-
 struct AsyncLane {
     PsContext *ctx = nullptr;
     Buf meta;                 // device: int32 [2 * B] pair list, then [ringFrames] row counts
