@@ -39,7 +39,7 @@ struct AsyncLane {
     uint8_t *hstage = nullptr; // pinned staging of frames that arrive one at a time / in pageable memory:
                                // [B x cap x 32 descriptors][B x cap x 12 points]; allocated when first needed
     int32_t *hmetaDev = nullptr; // device view of the pinned meta block (hipHostGetDevicePointer)
-    hipEvent_t evIn = nullptr, evDone = nullptr; // behind the chunk's uploads / behind its download
+    hipEvent_t evIn = nullptr, evRun = nullptr, evDone = nullptr; // behind the chunk's uploads / its kernels / its download
     int state = 0;            // 0 free, 1 chunk in flight, 2 results handed to the caller
     long long firstPair = 0;
     int pairs = 0;
@@ -54,7 +54,8 @@ struct PsVoAsync {
     bool haveK = false;
     Buf ringDesc, ringPts;
     std::vector<int32_t> nkRing; // row counts of the ring's slots (host-authoritative; every chunk uploads a snapshot)
-    hipStream_t copyStream = nullptr;
+    hipStream_t copyStream = nullptr;    // uploads
+    hipStream_t copyOutStream = nullptr; // downloads
     std::vector<AsyncLane> lane;
     size_t offMask = 0, offPose = 0, offStats = 0, offNum = 0, resBytes = 0;
     int head = 0, tail = 0, inFlight = 0; // oldest chunk in flight, next lane to submit to
@@ -65,6 +66,7 @@ struct PsVoAsync {
     int epoch = 0;
     int staged = 0;                       // frames collected in lane[tail].hstage by push_async
     std::vector<int32_t> stagedNk;
+    bool downloadsOnLane = false;         // PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=1: the first form (A/B)
     int cursor = 0;                       // ps_vo_stream_pop: next pair of the held view
     PsHostPairResults view{};
     double dbgT[3] = {0, 0, 0};        // PUTSLAM_HIP_STREAM_DEBUG=1: host seconds inside the uploads' / the batched call's /
@@ -89,6 +91,7 @@ void async_drain(PsVoAsync *a)
     if (a->copyStream) (void)hipStreamSynchronize(a->copyStream);
     for (AsyncLane &l : a->lane)
         if (l.ctx) (void)hipStreamSynchronize(l.ctx->stream);
+    if (a->copyOutStream) (void)hipStreamSynchronize(a->copyOutStream);
 }
 
 void async_free(PsVoAsync *a)
@@ -104,12 +107,14 @@ void async_free(PsVoAsync *a)
         if (l.hres) (void)hipHostFree(l.hres);
         if (l.hstage) (void)hipHostFree(l.hstage);
         if (l.evIn) (void)hipEventDestroy(l.evIn);
+        if (l.evRun) (void)hipEventDestroy(l.evRun);
         if (l.evDone) (void)hipEventDestroy(l.evDone);
         if (l.ctx) ps_context_destroy(l.ctx);
     }
     release(a->ringDesc);
     release(a->ringPts);
     if (a->copyStream) (void)hipStreamDestroy(a->copyStream);
+    if (a->copyOutStream) (void)hipStreamDestroy(a->copyOutStream);
     delete a;
 }
 
@@ -198,17 +203,26 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
         return rc;
     }
     const double t2 = now();
+    // The download goes out on a stream of its own, behind an event: queued on the lane's stream (behind its kernels) the
+    // runtime made it a blit kernel, whose writes over the link slowed the other lanes' kernels (29 % of the time a blit was
+    // running and every kernel beside it took 2 - 3 x its time, profiles/r05d/stream_trace); a stream that carries only copies
+    // gets an SDMA engine, like the uploads.
+    hipStream_t ds = a->downloadsOnLane ? lc->stream : a->copyOutStream;
+    if (!a->downloadsOnLane) {
+        PS_HIP(hipEventRecord(l.evRun, lc->stream));
+        PS_HIP(hipStreamWaitEvent(ds, l.evRun, 0));
+    }
     if (P == a->B) {
-        PS_HIP(hipMemcpyAsync(l.hres, dres, a->resBytes, hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres, dres, a->resBytes, hipMemcpyDeviceToHost, ds));
     } else {
         const size_t p = (size_t)P;
-        PS_HIP(hipMemcpyAsync(l.hres, dres, p * cap * sizeof(PsDMatch), hipMemcpyDeviceToHost, lc->stream));
-        PS_HIP(hipMemcpyAsync(l.hres + a->offMask, dres + a->offMask, p * cap, hipMemcpyDeviceToHost, lc->stream));
-        PS_HIP(hipMemcpyAsync(l.hres + a->offPose, dres + a->offPose, p * 64, hipMemcpyDeviceToHost, lc->stream));
-        PS_HIP(hipMemcpyAsync(l.hres + a->offStats, dres + a->offStats, p * sizeof(PsRansacStats), hipMemcpyDeviceToHost, lc->stream));
-        PS_HIP(hipMemcpyAsync(l.hres + a->offNum, dres + a->offNum, p * sizeof(int32_t), hipMemcpyDeviceToHost, lc->stream));
+        PS_HIP(hipMemcpyAsync(l.hres, dres, p * cap * sizeof(PsDMatch), hipMemcpyDeviceToHost, ds));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offMask, dres + a->offMask, p * cap, hipMemcpyDeviceToHost, ds));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offPose, dres + a->offPose, p * 64, hipMemcpyDeviceToHost, ds));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offStats, dres + a->offStats, p * sizeof(PsRansacStats), hipMemcpyDeviceToHost, ds));
+        PS_HIP(hipMemcpyAsync(l.hres + a->offNum, dres + a->offNum, p * sizeof(int32_t), hipMemcpyDeviceToHost, ds));
     }
-    PS_HIP(hipEventRecord(l.evDone, lc->stream));
+    PS_HIP(hipEventRecord(l.evDone, ds));
     const double t3 = now();
     if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DEBUG"))
         if (v[0] == '2')
@@ -257,6 +271,8 @@ int async_build(PsVoStream *s)
     PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
     PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
     PS_HIP(hipStreamCreateWithFlags(&a->copyStream, hipStreamNonBlocking));
+    PS_HIP(hipStreamCreateWithFlags(&a->copyOutStream, hipStreamNonBlocking));
+    if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE")) a->downloadsOnLane = std::atoi(v) != 0;
     a->lane.resize((size_t)a->lanes);
     for (AsyncLane &l : a->lane) {
         int rc = ps_context_create(ctx->device, &l.ctx);
@@ -271,6 +287,7 @@ int async_build(PsVoStream *s)
         PS_HIP(hipHostMalloc((void **)&l.hres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hmetaDev, l.hmeta, 0));
         PS_HIP(hipEventCreateWithFlags(&l.evIn, hipEventDisableTiming));
+        PS_HIP(hipEventCreateWithFlags(&l.evRun, hipEventDisableTiming));
         PS_HIP(hipEventCreateWithFlags(&l.evDone, hipEventDisableTiming));
     }
     return PS_OK;
