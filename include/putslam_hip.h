@@ -310,6 +310,11 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * another's scoring sweep), and its results come back in one download into pinned host memory.  chunkFrames = 1 is the
  * lowest-latency setting, 64..256 the throughput setting; ps_vo_stream_push stays the synchronous per-frame form.
  *
+ * Hardware queues: every lane, the upload stream and the download stream want a hardware queue of their own; the HIP runtime
+ * gives a process GPU_MAX_HW_QUEUES of them (default 4) and lets streams share beyond that, which serialises what shares.  Set
+ * GPU_MAX_HW_QUEUES = 16 in the environment before the first HIP call (bench.py does); with fewer than lanes + 6 the downloads
+ * are queued on the lanes' own streams instead of a stream of their own (results identical, 10 - 20 % slower).
+ *
  * Pair k of the stream (frames k, k+1 counted from the last reset; frame k is the query = previous frame) draws its
  * hypotheses from the seeded stream cfg->seed + k: the results are byte for byte those of ONE ps_vo_pairs_device call
  * over the whole sequence with the same cfg, whatever the chunking.

@@ -14,7 +14,7 @@ TAG=${1:-r02}
 ARGS=${2:-"--streams 1 --steps 20 --warmup 20 --warm-seconds 0 --repeats 1 --no-other-modes --no-cpu-baseline"}
 # bench.py sets this with os.environ.setdefault, but under rocprofv3 the profiler's preloaded library may initialise the
 # HIP runtime before Python runs: export it here so that profiled and un-profiled runs use the same queue count
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -66,7 +66,9 @@ struct PsVoAsync {
     int epoch = 0;
     int staged = 0;                       // frames collected in lane[tail].hstage by push_async
     std::vector<int32_t> stagedNk;
-    bool downloadsOnLane = false;         // PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=1: the first form (A/B)
+    bool downloadsOnLane = false;         // downloads queued on the lane's own stream instead of the copy-out stream: when the
+                                          // process has few hardware queues (GPU_MAX_HW_QUEUES < lanes + 6), or forced either
+                                          // way by PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=0|1
     int cursor = 0;                       // ps_vo_stream_pop: next pair of the held view
     PsHostPairResults view{};
     double dbgT[3] = {0, 0, 0};        // PUTSLAM_HIP_STREAM_DEBUG=1: host seconds inside the uploads' / the batched call's /
@@ -272,6 +274,15 @@ int async_build(PsVoStream *s)
     PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
     PS_HIP(hipStreamCreateWithFlags(&a->copyStream, hipStreamNonBlocking));
     PS_HIP(hipStreamCreateWithFlags(&a->copyOutStream, hipStreamNonBlocking));
+    // A stream of its own for the downloads pays only when it also gets a hardware queue of its own: with the runtime's
+    // default of four queues (or eight shared with the host's other streams) it lands on a lane's or the upload stream's queue
+    // and serialises with it -- 130 k instead of 390 k frame-pairs/s in bench.py's process (profiles/r05f/hw_queues.txt).  The
+    // runtime has no query for the number of queues; the environment variable that sets it is read instead.
+    {
+        int queues = 4; // (ROCclr's default)
+        if (const char *q = std::getenv("GPU_MAX_HW_QUEUES")) queues = std::atoi(q);
+        a->downloadsOnLane = queues < a->lanes + 6;
+    }
     if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE")) a->downloadsOnLane = std::atoi(v) != 0;
     a->lane.resize((size_t)a->lanes);
     for (AsyncLane &l : a->lane) {

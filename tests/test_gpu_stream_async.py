@@ -227,3 +227,18 @@ def test_throughput_chunks_match_the_batched_call_on_the_bench_shape(ctx):
     st.close()
     hd.close()
     hp.close()
+
+
+def test_both_download_forms_in_a_process_with_sixteen_hardware_queues():
+    """The downloads go out on a stream of their own when the process has hardware queues to spare (GPU_MAX_HW_QUEUES >= lanes
+    + 6, what bench.py sets) and on the lanes' own streams otherwise (this test process: the runtime's default of four).  The
+    sequence tests above again in a fresh process with sixteen queues, once per form."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    for on_lane in ("0", "1"):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="16", PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=on_lane)
+        p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                            "streamed_sequence or ragged or frame_by_frame"], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
