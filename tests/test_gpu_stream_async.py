@@ -242,3 +242,121 @@ def test_both_download_forms_in_a_process_with_sixteen_hardware_queues():
         p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                             "streamed_sequence or ragged or frame_by_frame"], env=env, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def fuzz_stream(iters, seed, verbose=False):
+    """Random sequences (ragged row counts, empty frames), schedules, metrics, chunk sizes, lane counts, push forms (in-place
+    pinned / pageable / one frame at a time), resets and partial flushes through the pipelined stream, against ONE batched call
+    per epoch on a second context.  Returns the number of configurations with a difference."""
+    from putslam_amd import api
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    rng = np.random.default_rng(seed)
+    ctx, ref_ctx = api.Context(0), api.Context(0)
+    bad = 0
+    for it in range(iters):
+        F = int(rng.integers(2, 60))
+        cap = int(rng.choice([64, 200, 333, 700]))
+        seq = synth.make_sequence(F, cap, config=3, index=int(rng.integers(0, 2 ** 31)), inlier_frac=float(rng.uniform(0.1, 0.9)),
+                                  noise=float(10 ** rng.uniform(-3.5, -1.8)))
+        nk = seq["nkpts"].copy()
+        if rng.random() < 0.5:
+            for f in rng.integers(0, F, max(1, F // 5)):
+                nk[f] = int(rng.integers(0, cap + 1))
+        mode = int(rng.choice([0, 1, 2, 4]))
+        est, H = [(EST_RANSAC, 487), (EST_USAC, int(rng.integers(300, 3000))), (EST_FIXED, int(rng.integers(257, 3000)))][int(rng.integers(0, 3))]
+        prm = default_ransac_params(mode)
+        cfg, _ = make_config(est, H, seed=int(rng.integers(0, 2 ** 40)))
+        chunk, lanes = int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64])), int(rng.integers(2, 7))
+        form = int(rng.integers(0, 3))           # 0 pinned push_many, 1 pageable push_many, 2 push_async
+        cut = int(rng.integers(1, F)) if (F > 3 and rng.random() < 0.4) else None      # a reset in front of frame `cut`
+        epochs = [(0, F)] if cut is None else [(0, cut), (cut, F)]
+        refs = []
+        for lo, hi in epochs:
+            n = hi - lo
+            pairs = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1).astype(np.int32).reshape(-1, 2)
+            if n < 2:
+                refs.append(None)
+                continue
+            fs = FrameSetDevice(seq["desc"][lo:hi], seq["pts"][lo:hi], nk[lo:hi])
+            pb = PairBatchDevice(pairs, fs.max_kpts)
+            run_pairs(ref_ctx, prm, cfg, TUM_FR1_K, fs, pb)
+            refs.append(pb.download())
+        hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
+        hd.array[:] = seq["desc"]
+        hp.array[:] = seq["pts"]
+        st = api.VoStream(ctx, cap)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        got = [0 for _ in epochs]
+        ok = True
+
+        def take(wait):
+            nonlocal ok
+            b = st.pop_many(wait=wait)
+            if b is None:
+                return False
+            e = b["epoch"]
+            ref = refs[e]
+            try:
+                assert b["first_pair"] == got[e]
+                _check_block(b, ref, got[e])
+            except AssertionError as ex:
+                ok = False
+                if verbose:
+                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, form=form, cut=cut), repr(ex)[:300])
+            got[e] += b["count"]
+            return True
+
+        f = 0
+        did_reset = False
+        while f < F:
+            if cut is not None and f == cut and not did_reset:
+                while not st.reset():
+                    take(True)
+                did_reset = True
+            stop = cut if (cut is not None and f < cut) else F
+            n = int(min(stop - f, rng.integers(1, 2 * chunk + 2)))
+            if form == 2:
+                pushed = st.push_async(seq["desc"][f][: nk[f]], seq["pts"][f][: nk[f]])
+                n = 1
+            elif form == 1:
+                pushed = st.push_many(seq["desc"][f:f + n], seq["pts"][f:f + n], nk[f:f + n])
+            else:
+                pushed = st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n])
+            if pushed:
+                f += n
+                if rng.random() < 0.3:
+                    take(False)
+                if form == 2 and rng.random() < 0.1:
+                    while not st.flush():
+                        take(True)
+            else:
+                take(True)
+        while not st.flush():
+            take(True)
+        while take(True):
+            pass
+        want = [0 if r is None else len(r["numMatches"]) for r in refs]
+        if got != want or st.pending() != 0:
+            ok = False
+            if verbose:
+                print("MISMATCH counts", it, got, want, st.pending())
+        st.close()
+        hd.close()
+        hp.close()
+        bad += 0 if ok else 1
+    ctx.close()
+    ref_ctx.close()
+    return bad
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_stream_slice(seed):
+    assert fuzz_stream(20, 7000 + seed, verbose=True) == 0
+
+
+if __name__ == "__main__":
+    import sys
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    b = fuzz_stream(n, seed, verbose=True)
+    print(f"stream fuzz done: {n} configurations, {b} mismatches")
+    sys.exit(1 if b else 0)
