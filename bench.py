@@ -701,9 +701,9 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     h2d, d2h = _link_rate(torch, dev)
     out = {}
 
-    def run(chunk, lanes, steps, check, warm_s=0.4):
+    def run(chunk, lanes, steps, check, warm_s=0.4, results=0):
         st = api.VoStream(c0, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=results)
         lat, sub_t = [], {}
         state = {"pairs": 0, "inl": 0, "bad": 0, "step": 0}
 
@@ -750,7 +750,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
             pass
         warm_steps = state["step"]
         lat.clear()
-        pairs0 = state["pairs"]
+        pairs0, inl0 = state["pairs"], state["inl"]
         state["check_epoch"] = warm_steps + steps            # the last timed step (epoch = resets before the block's frames)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -763,7 +763,10 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         lat_ms = np.array(sorted(lat)) * 1e3
         leg = {"pairs_per_s": done / el, "ms_per_step": el / steps * 1e3, "steps": steps, "pairs": done,
                "chunk_frames": chunk, "lanes": lanes,
-               "h2d_GBps": steps * F * cap * 44 / el / 1e9, "d2h_GBps": done * (cap * 17 + 108) / el / 1e9,
+               "results": ["full", "inliers", "poses"][results],
+               "h2d_GBps": steps * F * cap * 44 / el / 1e9,
+               "d2h_GBps": (done * (cap * 17 + 108) if results == 0 else
+                            (state["inl"] - inl0) * 16 + done * 108 if results == 1 else done * 108) / el / 1e9,
                "chunk_latency_ms": ({"p50": float(lat_ms[len(lat_ms) // 2]), "p95": float(lat_ms[int(len(lat_ms) * 0.95)]),
                                      "max": float(lat_ms[-1]), "n": int(len(lat_ms)),
                                      "what": "push_many call of the chunk -> its results readable on the host"} if len(lat_ms) else None)}
@@ -783,6 +786,10 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                         "chunks of %d frames on %d lanes), every pair's matches / mask / pose / stats downloaded (pop_many); same "
                         "parameters as the timed workload" % (F, args.stream_chunk, args.stream_lanes))
     out["streamed"] = main
+    # what Matcher::match itself returns -- estimatedTransformation + inlierMatches (matcher.cpp:452-516) -- instead of every
+    # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block
+    out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
+    out["streamed/poses"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=2)   # (a host that only composes the trajectory)
     out["streamed/chunk250"] = run(250, args.stream_lanes, steps, check=0)
     small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
     out["streamed/chunk32"] = small

@@ -336,22 +336,35 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   (valid until the next pop_many / pop / configure / destroy of this stream).  wait = 0: out->count = 0 if that chunk
  *   has not finished (or nothing is in flight); wait = 1: blocks until it has.
  * ps_vo_stream_pop: the same, one pair at a time, copied out (matches / inlierMask: capacity maxKpts; *nmatches = -1 and
- *   PS_OK when nothing is ready / in flight).
+ *   PS_OK when nothing is ready / in flight).  PS_RESULTS_INLIERS: *nmatches = number of inliers, matches = the inlier
+ *   matches, inlierMask all ones; PS_RESULTS_POSES: *nmatches = 0, pose and stats only.
  * ps_vo_stream_reset on a pipelined stream: the next frame has no predecessor (Matcher::detectInitFeatures) and pair
  *   numbering restarts at 0; a partly filled chunk is submitted first (PS_ERR_BUSY if that is not possible); chunks in
  *   flight are unaffected and keep their numbering (`epoch` tells them apart). */
+/* What a chunk's download carries (ps_vo_stream_set_result_mode, before ps_vo_stream_configure_async):
+ *   PS_RESULTS_FULL     every cross-check match + the inlier mask + pose + stats (34 KB per 2000-keypoint pair);
+ *   PS_RESULTS_INLIERS  what Matcher::match hands back (matcher.cpp:452-516: estimatedTransformation, inlierMatches): the
+ *                       inlier matches of every pair in input order -- the first stats[i].numInliers entries of
+ *                       matches[i * maxKpts ...] -- + pose + stats; inlierMask is NULL (12 KB per pair);
+ *   PS_RESULTS_POSES    pose + stats only; matches and inlierMask are NULL (108 bytes per pair: a host that only composes
+ *                       the trajectory, PUTSLAM.cpp:735-740).
+ * numMatches is the number of cross-check matches in every mode.  Modes 1 and 2 are written by a kernel straight into the
+ * lane's pinned block (no copy engine, no blit kernel beside the other lanes' launches). */
+typedef enum PsStreamResults { PS_RESULTS_FULL = 0, PS_RESULTS_INLIERS = 1, PS_RESULTS_POSES = 2 } PsStreamResults;
+
 typedef struct PsHostPairResults {
-    const PsDMatch *matches;      /* count x maxKpts */
+    const PsDMatch *matches;      /* count x maxKpts (PS_RESULTS_INLIERS: the inlier matches first; PS_RESULTS_POSES: NULL) */
     const int32_t *numMatches;    /* count */
-    const uint8_t *inlierMask;    /* count x maxKpts */
+    const uint8_t *inlierMask;    /* count x maxKpts (NULL unless PS_RESULTS_FULL) */
     const float *pose;            /* count x 16, column-major */
     const PsRansacStats *stats;   /* count */
     int64_t firstPair;            /* number of the first pair of the block since the reset it belongs to */
     int32_t count;                /* pairs in this block; 0 = nothing ready */
     int32_t maxKpts;
     int32_t epoch;                /* resets of the stream before this block's frames */
-    int32_t reserved;
+    int32_t resultMode;           /* PsStreamResults the block was written with */
 } PsHostPairResults;
+int ps_vo_stream_set_result_mode(PsVoStream *s, int mode /* PsStreamResults; takes effect at the next configure_async */);
 int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
                                  int chunkFrames, int lanes);
 int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep, const float *pts, int n);

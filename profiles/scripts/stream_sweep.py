@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--kpts", type=int, default=2000)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warm", type=float, default=0.5, help="seconds of untimed steps before every row")
+    ap.add_argument("--results", type=int, default=0, help="0 = everything, 1 = inlier matches + pose + stats, 2 = pose + stats")
     ap.add_argument("--grid", default="125x4,125x6,125x8,166x4,166x6,250x4,250x6,64x8,32x8")
     a = ap.parse_args()
     from putslam_amd import api, synth
@@ -40,7 +41,7 @@ def main():
     for item in a.grid.split(","):
         chunk, lanes = (int(v) for v in item.split("x"))
         st = api.VoStream(ctx, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=a.results)
         done = [0]
 
         def take(wait):

@@ -63,7 +63,7 @@ class PsPairResults(C.Structure):
 class PsHostPairResults(C.Structure):
     _fields_ = [("matches", C.c_void_p), ("numMatches", C.c_void_p), ("inlierMask", C.c_void_p),
                 ("pose", C.c_void_p), ("stats", C.c_void_p), ("firstPair", C.c_int64), ("count", C.c_int32),
-                ("maxKpts", C.c_int32), ("epoch", C.c_int32), ("reserved", C.c_int32)]
+                ("maxKpts", C.c_int32), ("epoch", C.c_int32), ("resultMode", C.c_int32)]
 
 
 PS_ERR_BUSY = -6

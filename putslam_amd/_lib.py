@@ -21,7 +21,7 @@ EXPORTED = [
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
-    "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
+    "ps_vo_stream_set_result_mode", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
     "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
@@ -141,6 +141,7 @@ def load_path(path):
     L.ps_vo_stream_push.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, vp, sz, vp, i32, vp,
                                     C.POINTER(i32), vp, vp, vp]
     L.ps_vo_stream_configure_async.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, i32, i32]
+    L.ps_vo_stream_set_result_mode.argtypes = [vp, i32]
     L.ps_vo_stream_push_async.argtypes = [vp, vp, sz, vp, i32]
     L.ps_vo_stream_push_many.argtypes = [vp, vp, vp, vp, i32]
     L.ps_vo_stream_flush.argtypes = [vp]

@@ -313,8 +313,10 @@ class VoStream:
                     pose=pose.reshape(4, 4).T.copy(), stats=stats[0].copy())
 
     # ---- pipelined form (ps_vo_stream_configure_async ...): results come back with a lag, in pair order ----
-    def configure_async(self, params, cfg, K, chunk_frames=0, lanes=0):
+    def configure_async(self, params, cfg, K, chunk_frames=0, lanes=0, results=0):
+        """results: 0 = everything (PS_RESULTS_FULL), 1 = inlier matches + pose + stats, 2 = pose + stats."""
         K = None if K is None else np.ascontiguousarray(K, np.float32)
+        self._ctx._chk(self._ctx._L.ps_vo_stream_set_result_mode(self._h, int(results)))
         self._ctx._chk(self._ctx._L.ps_vo_stream_configure_async(self._h, C.byref(params), C.byref(cfg), _p(K),
                                                                  int(chunk_frames), int(lanes)))
 
@@ -365,10 +367,10 @@ class VoStream:
             a = np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype).reshape(shape)
             return a.copy() if copy else a
 
-        return dict(first_pair=int(v.firstPair), epoch=int(v.epoch), count=n,
-                    matches=arr(v.matches, n * cap * 16, DMATCH_DTYPE, (n, cap)),
+        return dict(first_pair=int(v.firstPair), epoch=int(v.epoch), count=n, result_mode=int(v.resultMode),
+                    matches=arr(v.matches, n * cap * 16, DMATCH_DTYPE, (n, cap)) if v.matches else None,
                     numMatches=arr(v.numMatches, n * 4, np.int32, (n,)),
-                    inlierMask=arr(v.inlierMask, n * cap, np.uint8, (n, cap)),
+                    inlierMask=arr(v.inlierMask, n * cap, np.uint8, (n, cap)) if v.inlierMask else None,
                     pose=arr(v.pose, n * 64, np.float32, (n, 16)),
                     stats=arr(v.stats, n * STATS_DTYPE.itemsize, STATS_DTYPE, (n,)))
 

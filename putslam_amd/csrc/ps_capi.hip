@@ -2079,6 +2079,7 @@ struct PsVoStream {
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
     struct PsVoAsync *async = nullptr; // the pipelined form's state (ps_stream_async.h); null = synchronous stream
+    int asyncResultMode = 0;           // PsStreamResults of the next ps_vo_stream_configure_async
 };
 static void async_release(PsVoStream *s); // (ps_stream_async.h)
 static int async_reset(PsVoStream *s);

@@ -38,7 +38,8 @@ struct AsyncLane {
     uint8_t *hres = nullptr;  // pinned mirror of it
     uint8_t *hstage = nullptr; // pinned staging of frames that arrive one at a time / in pageable memory:
                                // [B x cap x 32 descriptors][B x cap x 12 points]; allocated when first needed
-    int32_t *hmetaDev = nullptr; // device view of the pinned meta block (hipHostGetDevicePointer)
+    int32_t *hmetaDev = nullptr; // device views of the pinned blocks (hipHostGetDevicePointer)
+    uint8_t *hresDev = nullptr;
     hipEvent_t evIn = nullptr, evRun = nullptr, evDone = nullptr; // behind the chunk's uploads / its kernels / its download
     int state = 0;            // 0 free, 1 chunk in flight, 2 results handed to the caller
     long long firstPair = 0;
@@ -66,6 +67,7 @@ struct PsVoAsync {
     int epoch = 0;
     int staged = 0;                       // frames collected in lane[tail].hstage by push_async
     std::vector<int32_t> stagedNk;
+    int resultMode = 0;                   // PsStreamResults
     bool downloadsOnLane = false;         // downloads queued on the lane's own stream instead of the copy-out stream: when the
                                           // process has few hardware queues (GPU_MAX_HW_QUEUES < lanes + 6), or forced either
                                           // way by PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=0|1
@@ -79,6 +81,7 @@ namespace {
 
 using psdev::CopySegs;
 using psdev::ps_copy_segments;
+using psdev::ps_pack_results_to_host;
 
 int async_fail(PsVoStream *s, int code, const char *what, hipError_t e = hipSuccess) { return fail(s->ctx, code, what, e); }
 
@@ -209,12 +212,22 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
     // runtime made it a blit kernel, whose writes over the link slowed the other lanes' kernels (29 % of the time a blit was
     // running and every kernel beside it took 2 - 3 x its time, profiles/r05d/stream_trace); a stream that carries only copies
     // gets an SDMA engine, like the uploads.
-    hipStream_t ds = a->downloadsOnLane ? lc->stream : a->copyOutStream;
-    if (!a->downloadsOnLane) {
+    hipStream_t ds = (a->downloadsOnLane || a->resultMode != PS_RESULTS_FULL) ? lc->stream : a->copyOutStream;
+    if (a->resultMode != PS_RESULTS_FULL) {
+        // inliers / poses only: a kernel writes just those into the mapped pinned block, behind kernel 4 on the lane's stream
+        hipLaunchKernelGGL(ps_pack_results_to_host, dim3((unsigned)P), dim3(kBlock), 0, lc->stream, (const PsDMatch *)dres,
+                           (const int32_t *)(dres + a->offNum), (const uint8_t *)(dres + a->offMask), (const float *)(dres + a->offPose),
+                           (const PsRansacStats *)(dres + a->offStats), s->cap, a->resultMode, (PsDMatch *)l.hresDev,
+                           (float *)(l.hresDev + a->offPose), (PsRansacStats *)(l.hresDev + a->offStats),
+                           (int32_t *)(l.hresDev + a->offNum));
+        PS_HIP(hipGetLastError());
+    } else if (!a->downloadsOnLane) {
         PS_HIP(hipEventRecord(l.evRun, lc->stream));
         PS_HIP(hipStreamWaitEvent(ds, l.evRun, 0));
     }
-    if (P == a->B) {
+    if (a->resultMode != PS_RESULTS_FULL) {
+        // (written by ps_pack_results_to_host above)
+    } else if (P == a->B) {
         PS_HIP(hipMemcpyAsync(l.hres, dres, a->resBytes, hipMemcpyDeviceToHost, ds));
     } else {
         const size_t p = (size_t)P;
@@ -297,6 +310,7 @@ int async_build(PsVoStream *s)
         PS_HIP(hipHostMalloc((void **)&l.hmeta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t), hipHostMallocDefault));
         PS_HIP(hipHostMalloc((void **)&l.hres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hmetaDev, l.hmeta, 0));
+        PS_HIP(hipHostGetDevicePointer((void **)&l.hresDev, l.hres, 0));
         PS_HIP(hipEventCreateWithFlags(&l.evIn, hipEventDisableTiming));
         PS_HIP(hipEventCreateWithFlags(&l.evRun, hipEventDisableTiming));
         PS_HIP(hipEventCreateWithFlags(&l.evDone, hipEventDisableTiming));
@@ -375,6 +389,7 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     a->cfg.sampleIdx = nullptr;
     a->haveK = K != nullptr;
     if (K) memcpy(a->K, K, sizeof a->K);
+    a->resultMode = s->asyncResultMode;
     rc = async_build(s);
     if (rc != PS_OK) { // (the error text stays in the stream's context)
         const std::string why = ctx->err;
@@ -383,6 +398,14 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
         ctx->err = why;
     }
     return rc;
+}
+
+int ps_vo_stream_set_result_mode(PsVoStream *s, int mode)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    if (mode < PS_RESULTS_FULL || mode > PS_RESULTS_POSES) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_set_result_mode: 0 (full), 1 (inliers) or 2 (poses)");
+    s->asyncResultMode = mode;
+    return PS_OK;
 }
 
 int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep, const float *pts, int n)
@@ -490,8 +513,9 @@ int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out)
         }
         if (q != hipSuccess) return async_fail(s, PS_ERR_HIP, "hipEventQuery", q);
     }
-    out->matches = (const PsDMatch *)l.hres;
-    out->inlierMask = l.hres + a->offMask;
+    out->matches = a->resultMode == PS_RESULTS_POSES ? nullptr : (const PsDMatch *)l.hres;
+    out->inlierMask = a->resultMode == PS_RESULTS_FULL ? l.hres + a->offMask : nullptr;
+    out->resultMode = a->resultMode;
     out->pose = (const float *)(l.hres + a->offPose);
     out->stats = (const PsRansacStats *)(l.hres + a->offStats);
     out->numMatches = (const int32_t *)(l.hres + a->offNum);
@@ -522,13 +546,18 @@ int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, 
     }
     const PsHostPairResults &v = a->view;
     const size_t i = (size_t)a->cursor++, cap = (size_t)s->cap;
-    const int nm = v.numMatches[i];
+    int nm = v.numMatches[i];
+    if (a->resultMode == PS_RESULTS_INLIERS) nm = v.stats[i].numInliers; // the inlier matches only, as Matcher::match returns them
+    if (a->resultMode == PS_RESULTS_POSES) nm = 0;
     memcpy(pose, v.pose + i * 16, 16 * sizeof(float));
     if (stats) *stats = v.stats[i];
     if (nm > 0) {
         if (!matches || !inlierMask) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: null output");
         memcpy(matches, v.matches + i * cap, (size_t)nm * sizeof(PsDMatch));
-        memcpy(inlierMask, v.inlierMask + i * cap, (size_t)nm);
+        if (a->resultMode == PS_RESULTS_FULL)
+            memcpy(inlierMask, v.inlierMask + i * cap, (size_t)nm);
+        else
+            memset(inlierMask, 1, (size_t)nm);
     }
     *nmatches = nm;
     return PS_OK;

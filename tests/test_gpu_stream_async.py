@@ -17,13 +17,23 @@ STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierC
 
 
 def _check_block(blk, c, lo):
-    """Block of popped results == the oracle's pairs [lo, lo + count)."""
+    """Block of popped results == the oracle's pairs [lo, lo + count) (in the block's result mode: everything / the inlier
+    matches in input order / pose and stats only)."""
+    mode = blk.get("result_mode", 0)
     for i in range(blk["count"]):
         p = lo + i
         n = int(c["numMatches"][p])
         assert int(blk["numMatches"][i]) == n, p
-        assert blk["matches"][i, :n].tobytes() == c["matches"][p, :n].tobytes(), p
-        assert np.array_equal(blk["inlierMask"][i, :n], c["inlierMask"][p, :n]), p
+        if mode == 0:
+            assert blk["matches"][i, :n].tobytes() == c["matches"][p, :n].tobytes(), p
+            assert np.array_equal(blk["inlierMask"][i, :n], c["inlierMask"][p, :n]), p
+        elif mode == 1:
+            inl = c["matches"][p, :n][c["inlierMask"][p, :n] != 0]      # what Matcher::match returns: inlierMatches, in order
+            assert len(inl) == int(c["stats"][p]["numInliers"])
+            assert blk["matches"][i, :len(inl)].tobytes() == inl.tobytes(), p
+            assert blk["inlierMask"] is None
+        else:
+            assert blk["matches"] is None and blk["inlierMask"] is None
         assert blk["pose"][i].tobytes() == c["pose"][p].tobytes(), p
         for f in STAT_FIELDS:
             a, b = blk["stats"][i][f], c["stats"][p][f]
@@ -83,6 +93,47 @@ def test_streamed_sequence_equals_batch_and_oracle(ctx, seq64, chunk, regime):
     st.close()
     hd.close()
     hp.close()
+
+
+@pytest.mark.parametrize("results", [1, 2])
+@pytest.mark.parametrize("regime", ["e1", "e0"])
+def test_compact_result_modes(ctx, seq64, regime, results):
+    """PS_RESULTS_INLIERS (what Matcher::match hands back: the inlier matches in input order + pose) and PS_RESULTS_POSES: a
+    kernel writes just those into the pinned block; block views and the one-pair pop against the oracle."""
+    from putslam_amd import api
+    seq, runs = seq64
+    prm, cfg, c = runs[regime]
+    F, cap = seq["desc"].shape[:2]
+    st = api.VoStream(ctx, cap)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=9, lanes=3, results=results)
+    got, f = 0, 0
+    while f < 40:
+        n = min(40 - f, 9)
+        if st.push_many(seq["desc"][f:f + n], seq["pts"][f:f + n], seq["nkpts"][f:f + n]):
+            f += n
+        else:
+            got = _drain(st, c, got, wait=True)
+    got = _drain(st, c, got)
+    assert got == 39
+    for f in range(40, F):                                  # the rest one frame at a time, popped one pair at a time
+        while not st.push_async(seq["desc"][f], seq["pts"][f]):
+            r = st.pop(wait=True)
+            assert r is not None
+            inl = c["matches"][got, :int(c["numMatches"][got])][c["inlierMask"][got, :int(c["numMatches"][got])] != 0]
+            assert (r["matches"].tobytes() == inl.tobytes() and r["mask"].all()) if results == 1 else len(r["matches"]) == 0
+            assert r["pose"].T.reshape(-1).tobytes() == c["pose"][got].tobytes()
+            got += 1
+    while not st.flush():
+        assert st.pop(wait=True) is not None
+        got += 1
+    while True:
+        r = st.pop(wait=True)
+        if r is None:
+            break
+        assert r["pose"].T.reshape(-1).tobytes() == c["pose"][got].tobytes() and r["stats"]["numInliers"] == c["stats"][got]["numInliers"]
+        got += 1
+    assert got == F - 1
+    st.close()
 
 
 def test_frame_by_frame_push_async_and_pop(ctx, seq64):
@@ -285,7 +336,7 @@ def fuzz_stream(iters, seed, verbose=False):
         hd.array[:] = seq["desc"]
         hp.array[:] = seq["pts"]
         st = api.VoStream(ctx, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=int(rng.integers(0, 3)))
         got = [0 for _ in epochs]
         ok = True
 
