@@ -468,6 +468,8 @@ bool FrameMatcher::enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f
         float K[9];
         bool haveK;
         cameraToK(matcherParameters.cameraMatrixMat, K, haveK);
+        // what comes back per frame is what Matcher::match returns: the inlier matches in input order + the pose (matcher.cpp:452-516)
+        ps_vo_stream_set_result_mode(f.pipe, PS_RESULTS_INLIERS);
         if (ps_vo_stream_configure_async(f.pipe, &prm, &cfg, haveK ? K : nullptr, pipeChunk_, pipeLanes_) != PS_OK) {
             std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
             ps_vo_stream_destroy(f.pipe);
@@ -523,10 +525,7 @@ int FrameMatcher::dequeueResult(Eigen::Matrix4f &estimatedTransformation, std::v
         if (ps_vo_stream_pending(f.pipe) <= 0 || ps_vo_stream_flush(f.pipe) != PS_OK) break;
     }
     if (nm < 0) return 0;
-    inlierMatches.clear();
-    inlierMatches.reserve((size_t)st.numInliers);
-    for (int i = 0; i < nm; ++i)
-        if (f.pmask[(size_t)i]) inlierMatches.push_back(f.pm[(size_t)i]);
+    inlierMatches.assign(f.pm.begin(), f.pm.begin() + nm); // (PS_RESULTS_INLIERS: the popped matches ARE the inliers)
     estimatedTransformation = pose;
     pointInlierRatio = st.pointInlierRatio;
     return 1;
