@@ -208,10 +208,11 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
         return rc;
     }
     const double t2 = now();
-    // The download goes out on a stream of its own, behind an event: queued on the lane's stream (behind its kernels) the
-    // runtime made it a blit kernel, whose writes over the link slowed the other lanes' kernels (29 % of the time a blit was
-    // running and every kernel beside it took 2 - 3 x its time, profiles/r05d/stream_trace); a stream that carries only copies
-    // gets an SDMA engine, like the uploads.
+    // The download goes out on a stream of its own, behind an event, when the process has hardware queues to spare (async_build):
+    // this runtime executes a device -> host hipMemcpyAsync as a blit kernel whatever stream it is queued on
+    // (profiles/r05e/timeline_tail.txt), and on the lane's own stream that kernel sat between the lane's launches (29 % of the
+    // time one was running, profiles/r05d); on the copy-out stream it overlaps the lane's NEXT chunk instead: + 11 ... 18 % with
+    // six lanes.
     hipStream_t ds = (a->downloadsOnLane || a->resultMode != PS_RESULTS_FULL) ? lc->stream : a->copyOutStream;
     if (a->resultMode != PS_RESULTS_FULL) {
         // inliers / poses only: a kernel writes just those into the mapped pinned block, behind kernel 4 on the lane's stream

@@ -1,5 +1,6 @@
-/* The public header must be plain C (C99): this file is compiled with gcc -std=c99 -pedantic by tests/test_abi.py. */
+/* The public headers must be plain C (C99): this file is compiled with gcc -std=c99 -pedantic by tests/test_abi.py. */
 #include "putslam_hip.h"
+#include "putslam_shard.h"
 
 int abi_check(void)
 {
@@ -9,6 +10,10 @@ int abi_check(void)
     PsRansacStats s;
     PsFrameSet f = {0, 0, 0, 0, 0};
     PsPairResults r = {0, 0, 0, 0, 0};
-    (void)m; (void)p; (void)c; (void)s; (void)f; (void)r;
-    return (int)sizeof(PsDMatch) + PS_ABI_VERSION + PS_DESC_BYTES;
+    PsHostPairResults h;
+    PsShardRunParams sp;
+    PsStreamResults mode = PS_RESULTS_INLIERS;
+    int64_t lo, hi;
+    (void)m; (void)p; (void)c; (void)s; (void)f; (void)r; (void)h; (void)sp; (void)mode; (void)lo; (void)hi;
+    return (int)sizeof(PsDMatch) + PS_ABI_VERSION + PS_DESC_BYTES + PS_SHARD_RECORD_FLOATS + (int)PS_ERR_BUSY;
 }
