@@ -3,8 +3,9 @@
 for the hot path only (BASELINE configs[2]): stream a synthetic TUM-style sequence, per frame pair
 performMatching -> RANSAC -> refit on the GPU, compose VO_k = VO_{k-1} * inc_k with the 0.1 m gate
 (PUTSLAM.cpp:735-740) and write the trajectory in Freiburg format `timestamp tx ty tz qx qy qz qw`
-(PUTSLAM.cpp:1006-1016).  Prints the absolute trajectory error against the generator's ground truth
-(the reference evaluates the same file with scripts/evaluate_ate.py).
+(PUTSLAM.cpp:1006-1016).  Prints the raw position error against the generator's ground truth and, with --groundtruth FILE,
+writes the ground truth in the same format and scores the trajectory file the way the reference's scripts/evaluate_ate.py
+and evaluate_rpe.py do (putslam_amd/tum_eval.py).
 """
 import argparse
 import os
@@ -21,6 +22,7 @@ def main(argv=None):
     ap.add_argument("--kpts", type=int, default=2000)
     ap.add_argument("--error-version", type=int, default=0)
     ap.add_argument("--out", default="VO_trajectory.res")
+    ap.add_argument("--groundtruth", default=None, help="write the generator's ground truth here and print the TUM ATE / RPE")
     a = ap.parse_args(argv)
     from putslam_amd import api, sharding, synth
     from putslam_amd._abi import EST_RANSAC, TUM_FR1_K, default_ransac_params, make_config
@@ -43,6 +45,15 @@ def main(argv=None):
     ratio = res["stats"]["pointInlierRatio"]
     print(f"{a.frames} frames, {len(inc)} pairs: mean inlier ratio {np.nanmean(ratio):.3f}, "
           f"accepted {int(res['stats']['accepted'].sum())}, ATE rmse {ate * 100:.2f} cm -> {a.out}")
+    if a.groundtruth:
+        from putslam_amd import tum_eval
+        sharding.write_tum_trajectory(a.groundtruth, stamps, gt)
+        ev = tum_eval.evaluate_files(a.groundtruth, a.out)
+        print(f"TUM protocol: ATE rmse {ev['ate']['rmse'] * 100:.2f} cm over {ev['ate']['pairs']} poses, "
+              f"RPE {ev['rpe_per_second']['translation']['rmse'] * 100:.2f} cm/s "
+              f"{np.degrees(ev['rpe_per_second']['rotation']['rmse']):.3f} deg/s, "
+              f"{ev['rpe_per_frame']['translation']['rmse'] * 1000:.2f} mm/frame")
+        return traj, gt, ate, ev
     return traj, gt, ate
 
 

@@ -26,6 +26,19 @@ def test_demo_matching_trajectory(ctx, tmp_path):
     assert ate < 0.02                                       # 39 increments of <= 5 cm each, 4 mm point noise
 
 
+def test_demo_matching_scored_with_the_tum_protocol(ctx, tmp_path):
+    """The trajectory file the path writes, scored as the reference scores its runs (scripts/evaluate_ate.py / evaluate_rpe.py;
+    putslam_amd/tum_eval.py restates them, tests/test_tum_eval.py pins it to the reference's scripts)."""
+    from demos import demo_matching
+    out, gtf = tmp_path / "VO_trajectory.res", tmp_path / "groundtruth.txt"
+    traj, gt, ate, ev = demo_matching.main(["--frames", "60", "--kpts", "1000", "--out", str(out), "--groundtruth", str(gtf)])
+    assert ev["ate"]["pairs"] == 60
+    assert ev["ate"]["rmse"] <= ate + 1e-4 and ev["ate"]["rmse"] < 0.02      # aligned error never exceeds the raw one
+    assert ev["rpe_per_frame"]["pairs"] == 58 and ev["rpe_per_frame"]["translation"]["rmse"] < 0.005
+    assert ev["rpe_per_second"]["pairs"] >= 28 and ev["rpe_per_second"]["translation"]["rmse"] < 0.02
+    assert ev["rpe_per_second"]["rotation"]["rmse"] < np.radians(0.5)
+
+
 def test_demo_usac(ctx):
     from demos import demo_usac
     out, gt = demo_usac.main([])
