@@ -30,7 +30,7 @@ bench: all
 	python bench.py
 
 clean:
-	rm -f $(LIB) $(DROPIN) $(SHARD) tests/cpp/test_dropin tests/cpp/test_reference_shaped demos/cpp/demo_matching demos/cpp/demo_sequences_multi_gpu
+	rm -f $(LIB) $(DROPIN) $(SHARD) tests/cpp/test_dropin tests/cpp/test_reference_shaped demos/cpp/demo_matching demos/cpp/demo_sequences_multi_gpu demos/cpp/demo_latency
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle test-cpu test-gpu bench clean

@@ -129,6 +129,7 @@ def parse():
                          "regions start on a chip at its steady clock")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the errorVersion-0 legs after the timed regions")
     ap.add_argument("--no-streamed", action="store_true", help="skip the streamed legs (frames from pinned host memory)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (demos/cpp/demo_latency)")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] legs (5000 keypoints, H = 100 000)")
     ap.add_argument("--stream-chunk", type=int, default=125, help="frames per chunk of the streamed leg")
     ap.add_argument("--stream-lanes", type=int, default=6, help="lanes of the streamed leg: chunks in flight + the one being read")
@@ -480,6 +481,13 @@ def main():
             other_modes.update(stress_legs(args, api, c0, chains[0], dev))
         except Exception as e:
             other_modes["stress"] = {"error": repr(e)}
+    if other_modes is not None and args.preset is None and not args.no_latency:
+        # ---- BASELINE configs[1]: what ONE call costs a C / C++ host (demos/cpp/demo_latency: the C ABI timed with std::chrono
+        # in a child process of its own -- no Python, no torch, no second stream)
+        try:
+            other_modes["latency"] = latency_leg()
+        except Exception as e:
+            other_modes["latency"] = {"error": repr(e)}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
@@ -797,6 +805,28 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     out["streamed/chunk1"] = one
     hd.close()
     hp.close()
+    return out
+
+
+def latency_leg(kpts=2000, calls=600):
+    """One 2000-keypoint pair in the reference's own regime (errorVersion 0, <= 487 iterations) through the C ABI, as a C++
+    host sees it: (a) device-resident pair, call + synchronize; (b) the same call back to back (the GPU side of the chain);
+    (c) ps_vo_stream_push, host frame in / results out (Matcher::match's call shape, matcher.cpp:452-516)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "demos", "cpp", "demo_latency")
+    if not os.path.exists(exe):
+        return {"error": "demos/cpp/demo_latency is not built (__graft_entry__.build())"}
+    p = subprocess.run([exe, str(kpts), "0", str(calls)], capture_output=True, text=True, timeout=120)
+    out = {"workload": "BASELINE configs[1]: one pair, %d keypoints, errorVersion 0, RANSAC <= 487, C ABI timed from C++" % kpts,
+           "rc": p.returncode}
+    for key, tag in (("pair_call_and_sync_us", r"\(a\)"), ("pair_back_to_back_us", r"\(b\)"), ("pushed_frame_us", r"\(c\)")):
+        m = re.search(tag + r"[^\n]*?(?:median|:) ([0-9.]+) us", p.stdout)
+        out[key] = float(m.group(1)) if m else None
+    m = re.search(r"\(a\)[^\n]*host time inside the call ([0-9.]+)", p.stdout)
+    out["pair_host_time_in_call_us"] = float(m.group(1)) if m else None
+    if out["pushed_frame_us"]:
+        out["pushed_frames_per_s"] = 1e6 / out["pushed_frame_us"]
     return out
 
 

@@ -2078,6 +2078,11 @@ struct PsVoStream {
     } key{};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     long long graphLaunches = 0;
+    // PUTSLAM_HIP_PUSH_TIMING=1: host-side phases of the synchronous push, printed to stderr when the stream is destroyed
+    // (staging copy | plan + tables + key | submission | wait for the GPU | results out), microseconds per push
+    bool pushTiming = false;
+    double pushPhase[5] = {0, 0, 0, 0, 0};
+    long long pushTimed = 0;
     struct PsVoAsync *async = nullptr; // the pipelined form's state (ps_stream_async.h); null = synchronous stream
     int asyncResultMode = 0;           // PsStreamResults of the next ps_vo_stream_configure_async
 };
@@ -2092,6 +2097,7 @@ int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
     PsVoStream *s = new PsVoStream();
     s->ctx = ctx;
     s->cap = maxKpts;
+    if (const char *v = std::getenv("PUTSLAM_HIP_PUSH_TIMING")) s->pushTiming = std::strtol(v, nullptr, 10) != 0;
     *out = s;
     const size_t cap = (size_t)maxKpts;
     s->offPose = sizeof(PsRansacStats);
@@ -2122,6 +2128,10 @@ void ps_vo_stream_destroy(PsVoStream *s)
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    if (s->pushTiming && s->pushTimed > 0)
+        fprintf(stderr, "[putslam_hip] %lld replayed pushes, host phases in us: staging copy %.1f | plan, tables, key %.1f | submission %.1f | "
+                        "wait for the GPU %.1f | results out %.1f\n", s->pushTimed, s->pushPhase[0] / s->pushTimed, s->pushPhase[1] / s->pushTimed,
+                s->pushPhase[2] / s->pushTimed, s->pushPhase[3] / s->pushTimed, s->pushPhase[4] / s->pushTimed);
     async_release(s);
     for (hipGraphExec_t &g : s->gexec)
         if (g) {
@@ -2169,6 +2179,9 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     const int slot = first ? 0 : 1 - s->curSlot;
     const int prevSlot = s->curSlot;
     const size_t cap = (size_t)s->cap;
+    using PushClock = std::chrono::steady_clock;
+    PushClock::time_point tp[6];
+    if (s->pushTiming) tp[0] = PushClock::now();
     // incoming frame -> pinned staging -> HBM (asynchronous; the staging area is free again after the
     // synchronisation that ends the previous push)
     uint8_t *hd = s->hin;
@@ -2184,6 +2197,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     hm[2] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
     hm[3] = slot;
     memcpy(&hm[4], &cfg->seed, sizeof(uint64_t));
+    if (s->pushTiming) tp[1] = PushClock::now();
     // The stream's state (curSlot, frames) is committed only when the push has succeeded: after a failed push
     // (bad parameters, a HIP error) the resident frame is still the previous one and the next push matches against it.
     auto commit = [&]() {
@@ -2307,6 +2321,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
             }
     }
     bool launched = false;
+    if (s->pushTiming) tp[2] = PushClock::now();
     if (s->graphsEnabled && sameKey) {
         if (!s->gexec[slot]) {
             hipGraph_t graph = nullptr;
@@ -2339,7 +2354,9 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         memcpy(&s->key, &key, sizeof key); // (bytewise, padding included: the key is compared with memcmp)
         s->warm = true;
     }
+    if (s->pushTiming) tp[3] = PushClock::now();
     PS_HIP(hipStreamSynchronize(ctx->stream));
+    if (s->pushTiming) tp[4] = PushClock::now();
     commit();
     int32_t nm = 0;
     memcpy(&nm, s->hres + s->offNum, sizeof nm);
@@ -2350,6 +2367,11 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
         memcpy(inlierMask, s->hres + s->offMask, (size_t)nm);
     }
     *nmatches = nm;
+    if (s->pushTiming && launched) {
+        tp[5] = PushClock::now();
+        for (int i = 0; i < 5; ++i) s->pushPhase[i] += std::chrono::duration<double, std::micro>(tp[i + 1] - tp[i]).count();
+        s->pushTimed++;
+    }
     return PS_OK;
 }
 

@@ -39,6 +39,22 @@ def test_demo_matching_scored_with_the_tum_protocol(ctx, tmp_path):
     assert ev["rpe_per_second"]["rotation"]["rmse"] < np.radians(0.5)
 
 
+def test_cpp_demo_latency_runs_through_the_c_abi(ctx):
+    """demos/cpp/demo_latency: single-pair call + synchronize, back-to-back calls and ps_vo_stream_push timed from C++ (the
+    figures bench.py's `other_modes["latency"]` reports); here: it runs, every increment is accepted, the figures parse."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "demos", "cpp", "demo_latency")
+    if not os.path.exists(exe):
+        pytest.fail("demos/cpp/demo_latency is not built (__graft_entry__.build())")
+    p = subprocess.run([exe, "1000", "0", "200"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    us = [float(x) for x in re.findall(r"(?:median|300:) ([0-9.]+) us", p.stdout)]
+    assert len(us) == 3 and all(5.0 < v < 2000.0 for v in us), p.stdout
+    assert us[1] <= us[0]                                    # the chain alone is never slower than call + synchronize
+
+
 def test_demo_usac(ctx):
     from demos import demo_usac
     out, gt = demo_usac.main([])
