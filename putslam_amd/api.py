@@ -283,7 +283,7 @@ class VoStream:
         ctx._chk(ctx._L.ps_vo_stream_create(ctx._h, self._cap, C.byref(h)))
         self._h = h
         # push()'s output block, allocated once with its pointers (four arrays and five pointer objects per call were a
-        # quarter of a pushed frame's 0.097 ms; the C call itself takes 0.072, demos/cpp/demo_latency)
+        # quarter of a pushed frame's 0.097 ms; the C call itself takes 0.07 - 0.08, demos/cpp/demo_latency)
         self._matches = np.zeros(max(self._cap, 1), DMATCH_DTYPE)
         self._mask = np.zeros(max(self._cap, 1), np.uint8)
         self._pose = np.zeros(16, np.float32)
