@@ -156,22 +156,24 @@ int ps_context_device(const PsContext *ctx);
  *              kind are scored completely, probing with the staged form every 16th call (identical outputs either way;
  *              "hopeless", read only, is the state of the last call's kind).  Adaptive schedules always keep the staged form.
  *              0 = always the staged form.  Setting the option (to either value) forgets what was observed.
- *   the staged scoring's twins and tuning knobs, each also PUTSLAM_HIP_<NAME> at context creation (tests run every one of
- *   them next to the default, tests/test_gpu_prune.py): "gensplit" (1: stage 0 as two launches, models then sweep),
- *   "singlerest" (1: one stage after the prefix under the adaptive schedules), "pretest" (1: stage 1's one-direction
- *   pre-test on the far-off front), "prefix" (0 = default, or 64 / 128 / 192 / 256 hypotheses of stage 0, fixed schedule),
- *   "list_g2" / "list_g3" / "list_r3" (work-groups per pair of stages 2 / 3, range split of stage 3), "reorder_top" (voters,
- *   1 .. 16), "reorder_margin" (matches past the miss budget where stage 1 ends), "reorder_c2div", "reorder_gran" (cut
- *   granularity, a power of two 2 .. 64).  "last_staged_pairs" / "last_reordered_pairs" (read only): pairs of the last
- *   scoring step if it was staged / reordered, else 0.
+ *   "last_staged_pairs" / "last_reordered_pairs" (read only): pairs of the last scoring step if it was staged / reordered,
+ *              else 0.
  *   "model_room_mib": room for the staged scoring's parked models (48 bytes per pair and leading hypothesis); 0 (default) =
  *              256 MiB under the adaptive schedules, 2 GiB under the fixed one.  Hypotheses without a slot are swept in one
  *              piece by stage 1 and rebuilt by kernel 4 if one of them wins: identical outputs, tests force it small.
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.
- *   "qsplit" / "msplit": work-groups the query range of kernel 1 / the match range of kernel 3 is split over
- *              (0 = automatic; PUTSLAM_HIP_QSPLIT / PUTSLAM_HIP_MSPLIT).
+ * Eleven options in all are the surface: "matcher", "matcher_fused", "score", "prune", "reorder", "bail", "model_room_mib",
+ * "stream_copy_kernels", "score_stats", "stamps" and the read-only ones.
+ * NOT part of it -- launch-shape and tuning knobs of the sweeps and of the staged scoring, every value of which gives the same
+ * results; they exist for the parity tests (tests/test_gpu_prune.py runs every one next to the default) and for A/B
+ * measurements, answer only to the name "debug.<knob>" (and PUTSLAM_HIP_<KNOB> at context creation) and may change between
+ * versions: qsplit / msplit (work-groups the query range of kernel 1 / the match range of kernel 3 is split over, 0 =
+ * automatic), gensplit (stage 0 as two launches, models then sweep), singlerest (one stage after the prefix under the adaptive
+ * schedules), pretest (stage 1's one-direction pre-test), prefix (64 / 128 / 192 / 256 hypotheses of stage 0), list_g2 /
+ * list_g3 / list_r3 (work-groups per pair of stages 2 / 3, range split of stage 3), reorder_top (voters), reorder_margin,
+ * reorder_c2div, reorder_gran (where the stages' ranges are cut).
  * ps_context_get_option returns the value or a negative PsStatus. */
 int ps_context_set_option(PsContext *ctx, const char *name, int value);
 int ps_context_get_option(const PsContext *ctx, const char *name);

@@ -1163,6 +1163,8 @@ struct OptDesc {
     int PsContext::*field;
     int lo, hi;            // accepted range
     const char *what;      // error text
+    bool shape = false;    // a launch-shape / tuning knob of the staged scoring and the sweeps: every value gives the same results;
+                           // kept for the parity tests and A/B measurements, addressed as "debug.<name>" (not part of the surface)
 };
 const OptDesc kOptions[] = {
     {"matcher", "MATCHER", &PsContext::matcher, 0, 2, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)"},
@@ -1171,29 +1173,31 @@ const OptDesc kOptions[] = {
     {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
     {"prune", "PRUNE", &PsContext::prune, 0, 2, "prune: 0 (complete scoring), 1 (staged from the cost model's batch size on) or 2 (staged whenever possible)"},
     {"reorder", "REORDER", &PsContext::reorder, 0, 2, "reorder: 0, 1 or 2"},
-    {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024"},
-    {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024"},
+    {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024", true},
+    {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024", true},
     // staged scoring (ps_score_fast.h): the twins of its launch forms ...
-    {"gensplit", "GENSPLIT", &PsContext::genSplit, 0, 1, "gensplit: 0 (stage 0 as one launch) or 1 (models, then the sweep)"},
-    {"singlerest", "SINGLEREST", &PsContext::singleRest, 0, 1, "singlerest: 0 (three stages) or 1 (one stage after the prefix, adaptive schedules)"},
-    {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)"},
+    {"gensplit", "GENSPLIT", &PsContext::genSplit, 0, 1, "gensplit: 0 (stage 0 as one launch) or 1 (models, then the sweep)", true},
+    {"singlerest", "SINGLEREST", &PsContext::singleRest, 0, 1, "singlerest: 0 (three stages) or 1 (one stage after the prefix, adaptive schedules)", true},
+    {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)", true},
     // ... and its tuning knobs
-    {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over"},
-    {"list_g2", "LISTG2", &PsContext::listGroups2, 0, 64, "list_g2: 0 (automatic) .. 64 work-groups per pair of stage 2"},
-    {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3"},
-    {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)"},
-    {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kReorderTopMax, "reorder_top: 1 .. 16 voters"},
-    {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches"},
-    {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64"},
-    {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64"},
+    {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over", true},
+    {"list_g2", "LISTG2", &PsContext::listGroups2, 0, 64, "list_g2: 0 (automatic) .. 64 work-groups per pair of stage 2", true},
+    {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3", true},
+    {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)", true},
+    {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kReorderTopMax, "reorder_top: 1 .. 16 voters", true},
+    {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches", true},
+    {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64", true},
+    {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64", true},
     {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
     {"stream_copy_kernels", "STREAM_COPY_KERNELS", &PsContext::streamCopyKernels, 0, 1, "stream_copy_kernels: 0 (hipMemcpyAsync) or 1 (copy kernels over mapped pinned memory)"},
     {"model_room_mib", "MODEL_ROOM_MIB", &PsContext::modelRoomMiB, 0, 65536, "model_room_mib: 0 (default) .. 65536 MiB for the staged scoring's parked models"},
 };
 const OptDesc *find_option(const char *name)
 {
+    const bool dbg = strncmp(name, "debug.", 6) == 0;
+    if (dbg) name += 6;
     for (const OptDesc &o : kOptions)
-        if (strcmp(name, o.name) == 0) return &o;
+        if (o.shape == dbg && strcmp(name, o.name) == 0) return &o;
     return nullptr;
 }
 // value checks beyond the range

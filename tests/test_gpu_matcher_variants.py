@@ -75,11 +75,11 @@ def test_variant_ties_across_query_tiles(vctx, oracle, qsplit):
     base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
     q = base[rng.integers(0, 40, 1500)]                      # 1500 queries drawn from 40 distinct rows: many exact ties
     t = base[rng.integers(0, 40, 1300)] ^ np.packbits(rng.random((1300, 256)) < 0.02, axis=1)
-    vctx.set_option("qsplit", qsplit)
+    vctx.set_option("debug.qsplit", qsplit)
     try:
         g = vctx.match_hamming256(q, t)
     finally:
-        vctx.set_option("qsplit", 0)
+        vctx.set_option("debug.qsplit", 0)
     assert g.tobytes() == oracle.match_hamming256(q, t).tobytes()
 
 
@@ -139,7 +139,7 @@ def test_keys_block_is_all_ones_at_rest(oracle):
         for rnd, ((kind, fused, qsplit), (nq, nt)) in enumerate(zip(forms, sizes)):
             c.set_option("matcher", kind)
             c.set_option("matcher_fused", fused)
-            c.set_option("qsplit", qsplit)
+            c.set_option("debug.qsplit", qsplit)
             q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
             t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
             k = min(nq, nt) // 2
@@ -179,7 +179,7 @@ def test_keys_block_is_all_ones_at_rest_across_shapes_variants_and_failed_calls(
         if it % 3 == 1:
             seq["nkpts"][:] = rng.integers(0, kpts + 1, frames)
         c.set_option("matcher", int(rng.integers(0, 3)))
-        c.set_option("qsplit", int(rng.choice([0, 0, 1, 2, 5, 16])))
+        c.set_option("debug.qsplit", int(rng.choice([0, 0, 1, 2, 5, 16])))
         fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
         pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
         run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)

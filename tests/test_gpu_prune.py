@@ -14,6 +14,9 @@ from putslam_amd._abi import (ADAPTIVE_ERROR, EST_FIXED, EST_RANSAC, EST_USAC, E
 
 pytestmark = pytest.mark.gpu
 
+# launch-shape / tuning knobs: every value gives the same results; addressed as "debug.<name>" (include/putslam_hip.h)
+SHAPE_KNOBS = ("qsplit", "msplit", "gensplit", "singlerest", "pretest", "list_r3", "list_g2", "list_g3", "prefix", "reorder_top",
+               "reorder_margin", "reorder_c2div", "reorder_gran")
 STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
                "accepted", "bestInlierRatio", "pointInlierRatio")
 
@@ -24,7 +27,8 @@ def _run(seq, prm, cfg, prune, reorder=1, **options):
     c.set_option("prune", 2 if prune else 0)   # 2 = the staged form whatever the batch size (the default, 1, asks the cost model)
     c.set_option("reorder", reorder)   # 1 = also under the adaptive schedules (the default reorders the fixed one only)
     assert c.get_option("reorder") == reorder
-    for name, value in options.items():   # the staged scoring's twins and tuning knobs (ps_context_set_option)
+    for name, value in options.items():   # the staged scoring's twins and launch-shape knobs ("debug.<name>", ps_context_set_option)
+        name = "debug." + name if name in SHAPE_KNOBS else name
         c.set_option(name, value)
         assert c.get_option(name) == value
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
@@ -189,13 +193,13 @@ def test_staged_twins_equal_complete(twin, case):
 
 def test_option_names_and_ranges():
     c = api.Context(0)
-    for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "reorder", "qsplit", "msplit", "gensplit",
-                 "singlerest", "pretest", "bail", "list_r3", "list_g2", "list_g3", "prefix", "reorder_top", "reorder_margin",
-                 "reorder_c2div", "reorder_gran", "stamps", "model_room_mib"):
+    for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "reorder", "bail", "stamps", "stream_copy_kernels",
+                 "model_room_mib") + tuple("debug." + k for k in SHAPE_KNOBS):
         v = c.get_option(name)
         c.set_option(name, v)   # every default is a legal value
-    for name, bad in (("prefix", 100), ("prefix", 320), ("reorder_gran", 12), ("reorder_gran", 1), ("list_r3", 0),
-                      ("reorder_top", 17), ("prune", 3), ("no_such_option", 0)):
+    for name, bad in (("debug.prefix", 100), ("debug.prefix", 320), ("debug.reorder_gran", 12), ("debug.reorder_gran", 1),
+                      ("debug.list_r3", 0), ("debug.reorder_top", 17), ("prune", 3), ("no_such_option", 0),
+                      ("list_r3", 4), ("msplit", 0), ("debug.prune", 1)):   # (the two families do not answer to each other's names)
         with pytest.raises(api.PsError):
             c.set_option(name, bad)
     c.close()

@@ -101,11 +101,11 @@ def test_euclid_odd_and_tiny_match_counts(fctx, ectx, oracle, mode, n):
     prm.minimalNumberOfMatches = 3
     cfg, _ = make_config(EST_FIXED, 700, seed=n)
     for msplit in (0, 1, 3, 32):
-        fctx.set_option("msplit", msplit)
-        ectx.set_option("msplit", msplit)
+        fctx.set_option("debug.msplit", msplit)
+        ectx.set_option("debug.msplit", msplit)
         _counts(fctx, ectx, oracle, prm, cfg, TUM_FR1_K, prev, cur, m)
-    fctx.set_option("msplit", 0)
-    ectx.set_option("msplit", 0)
+    fctx.set_option("debug.msplit", 0)
+    ectx.set_option("debug.msplit", 0)
 
 
 @pytest.mark.parametrize("mode", MODES)
