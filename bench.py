@@ -132,7 +132,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (demos/cpp/demo_latency)")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] legs (5000 keypoints, H = 100 000)")
     ap.add_argument("--stream-chunk", type=int, default=125, help="frames per chunk of the streamed leg")
-    ap.add_argument("--stream-lanes", type=int, default=6, help="lanes of the streamed leg: chunks in flight + the one being read")
+    ap.add_argument("--stream-lanes", type=int, default=3, help="lanes of the streamed leg: launch chains that run side by side (the library's stream_ahead places queue more chunks behind them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()

@@ -165,7 +165,8 @@ int ps_context_device(const PsContext *ctx);
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.
  * Eleven options in all are the surface: "matcher", "matcher_fused", "score", "prune", "reorder", "bail", "model_room_mib",
- * "stream_copy_kernels", "score_stats", "stamps" and the read-only ones.
+ * "stream_copy_kernels", "stream_ahead" (places of the pipelined stream beyond one per lane, see below), "score_stats", "stamps",
+ * and the read-only ones.
  * NOT part of it -- launch-shape and tuning knobs of the sweeps and of the staged scoring, every value of which gives the same
  * results; they exist for the parity tests (tests/test_gpu_prune.py runs every one next to the default) and for A/B
  * measurements, answer only to the name "debug.<knob>" (and PUTSLAM_HIP_<KNOB> at context creation) and may change between
@@ -308,8 +309,9 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * of inside the push, so that uploads, kernels and downloads of consecutive frames overlap.  Frames are collected into
  * chunks of `chunkFrames`; a full chunk is uploaded on a copy stream into a ring of frames resident in HBM (the last
  * frame of the previous chunk is still there: no halo is sent twice), runs as ONE batched call (ps_vo_pairs_device's
- * launches) on one of `lanes` private contexts (stream + scratch arena each, so that one chunk's Hamming sweep runs beside
- * another's scoring sweep), and its results come back in one download into pinned host memory.  chunkFrames = 1 is the
+ * launches) on one of `lanes` private contexts in turn (stream + scratch arena each, so that one chunk's Hamming sweep runs
+ * beside another's scoring sweep; a lane's stream may hold further chunks queued behind the running one), and its results come
+ * back in one download into pinned host memory.  chunkFrames = 1 is the
  * lowest-latency setting, 64..256 the throughput setting; ps_vo_stream_push stays the synchronous per-frame form.
  *
  * Hardware queues: every lane, the upload stream and the download stream want a hardware queue of their own; the HIP runtime
@@ -322,7 +324,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * over the whole sequence with the same cfg, whatever the chunking.
  *
  * ps_vo_stream_configure_async: parameters of the pipelined form, fixed until the next configure (which drains).  chunkFrames
- *   1..1024 (0 = 128), lanes 2..8 (0 = 4).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
+ *   1..1024 (0 = 128), lanes 2..8 (0 = 3).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
  * ps_vo_stream_push_async: ONE frame (host pointers, rows of descStep bytes) is copied into the pinned staging area of
  *   the chunk being collected; the chunk is submitted when it is full.  Returns at once.
  * ps_vo_stream_push_many: numFrames frames laid out like a PsFrameSet on the HOST (desc numFrames x maxKpts x 32 B,
@@ -331,9 +333,13 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   stay untouched until the results of their frames have been popped; pageable memory is staged through pinned buffers.
  *   Frames staged by push_async before are submitted first, as a chunk of their own.
  * ps_vo_stream_flush: submits a partly filled chunk.
- * Flow control: a chunk needs a free lane.  A lane is busy from the submission of its chunk until the view of its results
- *   has been given back, i.e. until the pop_many / pop call AFTER the one that returned them.  push_async / push_many /
- *   flush return PS_ERR_BUSY -- and take nothing -- when they would have to submit and no lane is free: pop first.
+ * Flow control: a chunk needs a PLACE (a meta block, device and pinned result blocks, events); there are lanes + `ahead` of
+ *   them (context option "stream_ahead", 0 .. 8, default 3, read by configure_async).  An accepted chunk is uploaded and
+ *   launched at once, on the next lane in turn -- behind that lane's running chunk if it has one --, so a lane never waits for
+ *   the host between chunks.  A place is busy from the launch of its chunk until pop_many has returned its results (the pinned
+ *   block they lie in changes hands: the place goes on with a spare one while the caller reads).  push_async (at the first frame of a chunk) / push_many return
+ *   PS_ERR_BUSY -- and take nothing -- when there is no place: pop first.  (Pinned frames handed to push_many are read in
+ *   place: untouched until their results have been popped, as before.)
  * ps_vo_stream_pop_many: results of the oldest chunk in flight, as HOST pointers into that lane's pinned result block
  *   (valid until the next pop_many / pop / configure / destroy of this stream).  wait = 0: out->count = 0 if that chunk
  *   has not finished (or nothing is in flight); wait = 1: blocks until it has.
@@ -341,8 +347,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   PS_OK when nothing is ready / in flight).  PS_RESULTS_INLIERS: *nmatches = number of inliers, matches = the inlier
  *   matches, inlierMask all ones; PS_RESULTS_POSES: *nmatches = 0, pose and stats only.
  * ps_vo_stream_reset on a pipelined stream: the next frame has no predecessor (Matcher::detectInitFeatures) and pair
- *   numbering restarts at 0; a partly filled chunk is submitted first (PS_ERR_BUSY if that is not possible); chunks in
- *   flight are unaffected and keep their numbering (`epoch` tells them apart). */
+ *   numbering restarts at 0; a partly filled chunk is submitted first (its place was reserved by its first frame); chunks in
+ *   flight or waiting are unaffected and keep their numbering (`epoch` tells them apart). */
 /* What a chunk's download carries (ps_vo_stream_set_result_mode, before ps_vo_stream_configure_async):
  *   PS_RESULTS_FULL     every cross-check match + the inlier mask + pose + stats (34 KB per 2000-keypoint pair);
  *   PS_RESULTS_INLIERS  what Matcher::match hands back (matcher.cpp:452-516: estimatedTransformation, inlierMatches): the

@@ -39,7 +39,11 @@ def main():
     cfg, _ = make_config(est, a.hyp, seed=0xB0B0)
     ctx = api.Context(0)
     for item in a.grid.split(","):
+        ahead = 2                                   # "125x4a0": chunk x lanes, upload-ahead depth (option stream_ahead)
+        if "a" in item:
+            item, ahead = item.split("a")[0], int(item.split("a")[1])
         chunk, lanes = (int(v) for v in item.split("x"))
+        ctx.set_option("stream_ahead", ahead)
         st = api.VoStream(ctx, cap)
         st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=a.results)
         done = [0]
@@ -76,7 +80,7 @@ def main():
         while take(True):
             pass
         el = time.perf_counter() - t0
-        print(f"chunk {chunk:4d} lanes {lanes}: {(done[0] - d0) / el:10.0f} pairs/s  {el / a.steps * 1e3:7.3f} ms/step  "
+        print(f"chunk {chunk:4d} lanes {lanes} ahead {ahead}: {(done[0] - d0) / el:10.0f} pairs/s  {el / a.steps * 1e3:7.3f} ms/step  "
               f"H2D {a.steps * F * cap * 44 / el / 1e9:5.1f} GB/s", flush=True)
         st.close()
 

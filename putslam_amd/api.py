@@ -334,7 +334,7 @@ class VoStream:
         return True
 
     def push_async(self, desc, pts):
-        """One frame (matcher.cpp:452-516's call shape); False = no free lane, pop first."""
+        """One frame (matcher.cpp:452-516's call shape); False = no room (every lane busy and the upload-ahead queue full), pop first."""
         desc = np.ascontiguousarray(desc, np.uint8)
         pts = np.ascontiguousarray(pts, np.float32)
         return self._rc(self._ctx._L.ps_vo_stream_push_async(self._h, _p(desc), 32, _p(pts), desc.shape[0]))

@@ -17,12 +17,18 @@
 //     (profiles/microbench/h2d_kernel.hip) but slow the kernels they run beside by 3 - 10 x (profiles/r05b/stream_trace: their
 //     outstanding host reads fill the L2's request queues); SDMA transfers do not.
 //
-//   * ring: (lanes + 2) x chunkFrames frame slots.  A chunk's frames are contiguous in it (a chunk that would not fit before
-//     the end starts at slot 0 again); the frame before the chunk's first one is still resident, so pair (previous chunk's
-//     last frame, this chunk's first frame) needs no second upload.  The chunks in flight read at most the
-//     (lanes - 1) x chunkFrames + 1 slots written last, a jump to slot 0 skips fewer than chunkFrames, the new chunk writes
-//     at most chunkFrames: no slot that is still read is overwritten, with no device-side wait.
-//   * lane = a private PsContext (stream + scratch arena) + device / pinned result blocks + a small meta block (the chunk's
+//   * places: a chunk needs a place (meta block, device + pinned result blocks, events), not a lane: there are lanes + `ahead`
+//     of them (option "stream_ahead", default 3), and chunk k is LAUNCHED at once on lane k % lanes -- behind that lane's running
+//     chunk if it has one.  With one place per lane a lane idled from the end of its chunk's last kernel through the download,
+//     the host's pop, the next chunk's upload and the copy-stream -> lane dependency (300 - 500 us of a chunk's ~ 800,
+//     profiles/r05h/timeline_ahead0.txt); now its next chunk's launches are already in its stream.
+//   * ring: (lanes + ahead + 2) x chunkFrames frame slots.  A chunk's frames are contiguous in it (a chunk that would not fit
+//     before the end starts at slot 0 again); the frame before the chunk's first one is still resident, so pair (previous
+//     chunk's last frame, this chunk's first frame) needs no second upload.  The chunks alive (running or queued on a lane) read at most the
+//     (lanes + ahead - 1) x chunkFrames + 1 slots written last, a jump to slot 0 skips fewer than chunkFrames, the new chunk
+//     writes at most chunkFrames: no slot that is still read is overwritten, with no device-side wait.
+//   * lane = a private PsContext (stream + scratch arena) + device / pinned result blocks (the pinned one changes hands at the
+//     pop: the caller reads it until the next pop, the lane continues with the spare one) + a small meta block (the chunk's
 //     pair list and a snapshot of the ring's row counts, one upload).  Consecutive chunks go to consecutive lanes, so one
 //     chunk's matrix-core Hamming sweep runs beside another's vector scoring sweep, as bench.py's sub-batch chains do.
 //   * per chunk: 2 uploads, the meta kernel, the batched call's launches, 1 download (5 for a partly filled chunk); uploads are
@@ -30,25 +36,44 @@
 //   * results are those of ONE ps_vo_pairs_device call over the whole sequence: pair k draws from cfg->seed + k.
 #pragma once
 
+// One chunk's place in the pipeline: meta block, device and pinned result blocks, events.  There are lanes + ahead of them; a
+// chunk takes the next one and runs on the next LANE (a private PsContext: stream + scratch arena) in turn, so each lane's
+// stream can hold a chunk that runs and further ones queued behind it.
 struct AsyncLane {
-    PsContext *ctx = nullptr;
+    PsContext *ctx = nullptr; // the lane context this place's chunk was launched on (not owned)
     Buf meta;                 // device: int32 [2 * B] pair list, then [ringFrames] row counts
     int32_t *hmeta = nullptr; // pinned mirror of it
     Buf res;                  // device: [matches B x cap x 16][mask B x cap][pose B x 64][stats B x 40][numMatches B x 4]
     uint8_t *hres = nullptr;  // pinned mirror of it
-    uint8_t *hstage = nullptr; // pinned staging of frames that arrive one at a time / in pageable memory:
-                               // [B x cap x 32 descriptors][B x cap x 12 points]; allocated when first needed
     int32_t *hmetaDev = nullptr; // device views of the pinned blocks (hipHostGetDevicePointer)
     uint8_t *hresDev = nullptr;
-    hipEvent_t evIn = nullptr, evRun = nullptr, evDone = nullptr; // behind the chunk's uploads / its kernels / its download
-    int state = 0;            // 0 free, 1 chunk in flight, 2 results handed to the caller
+    hipEvent_t evRun = nullptr, evDone = nullptr; // behind the chunk's kernels / its download
+    int state = 0;            // 0 free, 1 chunk in flight
     long long firstPair = 0;
     int pairs = 0;
     int epoch = 0;
 };
 
+// A chunk whose frames are in the ring (or on their way: `up` is recorded behind its uploads), about to be launched.
+struct AsyncChunk {
+    int pos0 = 0, n = 0;       // ring slots [pos0, pos0 + n)
+    int first = 0;             // 1: the chunk's first frame has no predecessor (the stream's first frame, or after a reset)
+    int prevPos = -1;          // slot of the frame before the chunk's first one
+    long long firstPair = 0;   // index of its first pair in the stream (-> seed)
+    int epoch = 0;
+    hipEvent_t up = nullptr;   // (owned by PsVoAsync::upEv)
+};
+
 struct PsVoAsync {
     int B = 0, lanes = 0, ringFrames = 0;
+    int ahead = 0;                        // places beyond one per lane: chunks queued on the lanes' streams behind the running ones
+    std::vector<PsContext *> laneCtx;     // the lanes (owned)
+    long long launchSeq = 0;              // chunks launched so far (chunk k runs on lane k % lanes)
+    std::vector<hipEvent_t> upEv;         // lanes + ahead + 1 events, one per chunk alive, by chunk number
+    std::vector<uint8_t *> stagePool;     // lanes + ahead + 1 pinned staging areas for frames that arrive one at a time / in
+                                          // pageable memory: [B x cap x 32 descriptors][B x cap x 12 points], by chunk number;
+                                          // allocated when first needed
+    long long chunkSeq = 0;               // chunks uploaded so far
     PsRansacParams prm{};
     PsRansacConfig cfg{};
     float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -57,15 +82,19 @@ struct PsVoAsync {
     std::vector<int32_t> nkRing; // row counts of the ring's slots (host-authoritative; every chunk uploads a snapshot)
     hipStream_t copyStream = nullptr;    // uploads
     hipStream_t copyOutStream = nullptr; // downloads
-    std::vector<AsyncLane> lane;
+    std::vector<AsyncLane> lane;         // the lanes + ahead places, taken in ring order
     size_t offMask = 0, offPose = 0, offStats = 0, offNum = 0, resBytes = 0;
     int head = 0, tail = 0, inFlight = 0; // oldest chunk in flight, next lane to submit to
-    int held = -1;                        // lane whose result view the caller holds
+    // The block a pop hands to the caller changes hands instead of keeping its lane busy: the lane takes the spare pinned block
+    // and is free at once (round 5's first form held the lane until the NEXT pop: of four lanes three computed).  Pops are in
+    // order and a view lives until the next pop, so one block is held at any time.
+    uint8_t *spareHres = nullptr, *spareHresDev = nullptr; // free pinned result block (+ its device view)
+    uint8_t *heldHres = nullptr, *heldHresDev = nullptr;   // the block the caller's view points into (null: no view)
     int ringPos = 0;                      // slot the next frame goes to
     int prevPos = -1;                     // slot of the stream's latest frame (-1: the next frame has no predecessor)
     long long pairCounter = 0;
     int epoch = 0;
-    int staged = 0;                       // frames collected in lane[tail].hstage by push_async
+    int staged = 0;                       // frames collected in the next chunk's staging area by push_async
     std::vector<int32_t> stagedNk;
     int resultMode = 0;                   // PsStreamResults
     bool downloadsOnLane = false;         // downloads queued on the lane's own stream instead of the copy-out stream: when the
@@ -94,8 +123,8 @@ int async_fail(PsVoStream *s, int code, const char *what, hipError_t e = hipSucc
 void async_drain(PsVoAsync *a)
 {
     if (a->copyStream) (void)hipStreamSynchronize(a->copyStream);
-    for (AsyncLane &l : a->lane)
-        if (l.ctx) (void)hipStreamSynchronize(l.ctx->stream);
+    for (PsContext *c : a->laneCtx)
+        if (c) (void)hipStreamSynchronize(c->stream);
     if (a->copyOutStream) (void)hipStreamSynchronize(a->copyOutStream);
 }
 
@@ -103,19 +132,24 @@ void async_free(PsVoAsync *a)
 {
     async_drain(a);
     if (a->dbgN > 0 && std::getenv("PUTSLAM_HIP_STREAM_DEBUG"))
-        fprintf(stderr, "[ps stream] %lld chunks of <= %d frames on %d lanes: host us per chunk: upload %.1f, batched call %.1f, download %.1f\n",
-                a->dbgN, a->B, a->lanes, 1e6 * a->dbgT[0] / a->dbgN, 1e6 * a->dbgT[1] / a->dbgN, 1e6 * a->dbgT[2] / a->dbgN);
+        fprintf(stderr, "[ps stream] %lld chunks of <= %d frames on %d lanes (+ %d ahead): host us per chunk: upload %.1f, batched call %.1f, download %.1f\n",
+                a->dbgN, a->B, a->lanes, a->ahead, 1e6 * a->dbgT[0] / a->dbgN, 1e6 * a->dbgT[1] / a->dbgN, 1e6 * a->dbgT[2] / a->dbgN);
     for (AsyncLane &l : a->lane) {
         release(l.meta);
         release(l.res);
         if (l.hmeta) (void)hipHostFree(l.hmeta);
         if (l.hres) (void)hipHostFree(l.hres);
-        if (l.hstage) (void)hipHostFree(l.hstage);
-        if (l.evIn) (void)hipEventDestroy(l.evIn);
         if (l.evRun) (void)hipEventDestroy(l.evRun);
         if (l.evDone) (void)hipEventDestroy(l.evDone);
-        if (l.ctx) ps_context_destroy(l.ctx);
     }
+    for (PsContext *c : a->laneCtx)
+        if (c) ps_context_destroy(c);
+    if (a->spareHres) (void)hipHostFree(a->spareHres);
+    if (a->heldHres) (void)hipHostFree(a->heldHres);
+    for (hipEvent_t e : a->upEv)
+        if (e) (void)hipEventDestroy(e);
+    for (uint8_t *h : a->stagePool)
+        if (h) (void)hipHostFree(h);
     release(a->ringDesc);
     release(a->ringPts);
     if (a->copyStream) (void)hipStreamDestroy(a->copyStream);
@@ -134,48 +168,48 @@ bool is_pinned_host(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
-int lane_stage(PsVoStream *s, AsyncLane &l)
+// chunks that can be accepted now: the free places (they are taken in ring order: free ones are contiguous from `tail`)
+int async_room(const PsVoAsync *a)
 {
-    if (l.hstage) return PS_OK;
+    const int S = (int)a->lane.size();
+    int freePlaces = 0;
+    for (int i = 0; i < S && a->lane[(size_t)((a->tail + i) % S)].state == 0; ++i) ++freePlaces;
+    return freePlaces;
+}
+
+// the pinned staging area of the chunk that will be uploaded next (chunk number chunkSeq): a chunk's area is used again
+// lanes + ahead + 1 chunks later, and a chunk is only accepted while fewer than lanes + ahead chunks are alive (async_room) --
+// by then the earlier user of the area has been popped, so its upload is long done
+int stage_area(PsVoStream *s, uint8_t **out)
+{
     PsVoAsync *a = s->async;
-    PSA_HIP(hipHostMalloc((void **)&l.hstage, (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+    uint8_t *&h = a->stagePool[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
+    if (!h) PSA_HIP(hipHostMalloc((void **)&h, (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+    *out = h;
     return PS_OK;
 }
 
-// One chunk: n frames (pinned host memory: desc n x cap x 32, pts n x cap x 3; row counts nk) -> ring -> lane[tail].  The
-// caller has checked that lane[tail] is free.
-int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
+// One chunk on lane[tail] (free, checked by the caller): meta block, the batched call's launches behind the chunk's uploads,
+// the download.
+int async_launch(PsVoStream *s, const AsyncChunk &c)
 {
     PsVoAsync *a = s->async;
     PsContext *ctx = s->ctx;
     const size_t cap = (size_t)s->cap;
     AsyncLane &l = a->lane[(size_t)a->tail];
-    PsContext *lc = l.ctx;
-    const int pos0 = (a->ringPos + n <= a->ringFrames) ? a->ringPos : 0;
+    // consecutive chunks on consecutive lanes; a lane's stream orders the chunks it is given (its scratch arena is theirs in turn)
+    PsContext *lc = l.ctx = a->laneCtx[(size_t)(a->launchSeq % (long long)a->lanes)];
+    a->launchSeq++;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
-                          a->copyStream));
-    PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
-                          a->copyStream));
-    PS_HIP(hipEventRecord(l.evIn, a->copyStream));
-    for (int i = 0; i < n; ++i) a->nkRing[(size_t)(pos0 + i)] = nk[i];
-    const int first = a->prevPos >= 0 ? 0 : 1; // the stream's first frame has no predecessor (matcher.cpp:17-64)
-    const int P = n - first;
-    const int prevPos = a->prevPos;
-    a->ringPos = pos0 + n;
-    a->prevPos = pos0 + n - 1;
-    if (P <= 0) {
-        // a lone first frame: nothing to run, no lane taken; its staging area (if it came through one) is reused by the
-        // next push, so the upload is waited for here
-        PS_HIP(hipStreamSynchronize(a->copyStream));
-        return PS_OK;
-    }
+    const double t1 = now();
+    const int P = c.n - c.first;
     int32_t *pm = l.hmeta;
-    for (int i = first; i < n; ++i) { // query = previous frame, train = current (matcher.cpp:470-471)
-        pm[2 * (i - first)] = i == 0 ? prevPos : pos0 + i - 1;
-        pm[2 * (i - first) + 1] = pos0 + i;
+    for (int i = c.first; i < c.n; ++i) { // query = previous frame, train = current (matcher.cpp:470-471)
+        pm[2 * (i - c.first)] = i == 0 ? c.prevPos : c.pos0 + i - 1;
+        pm[2 * (i - c.first) + 1] = c.pos0 + i;
     }
+    // (a snapshot of the ring's row counts as they are NOW: it may already hold those of later chunks, never other values for
+    // the slots this chunk reads -- those are not written again while it is alive)
     memcpy(pm + 2 * (size_t)a->B, a->nkRing.data(), (size_t)a->ringFrames * sizeof(int32_t));
     CopySegs up{};
     up.src[0] = l.hmetaDev;
@@ -184,8 +218,7 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
     up.n = 1;
     hipLaunchKernelGGL(ps_copy_segments, dim3(1), dim3(256), 0, lc->stream, up); // (a few KB: beside the previous chunk's kernels)
     PS_HIP(hipGetLastError());
-    PS_HIP(hipStreamWaitEvent(lc->stream, l.evIn, 0));
-    const double t1 = now();
+    PS_HIP(hipStreamWaitEvent(lc->stream, c.up, 0));
     PsFrameSet fs;
     fs.desc = (const uint8_t *)a->ringDesc.p;
     fs.pts = (const float *)a->ringPts.p;
@@ -200,7 +233,7 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
     out.stats = (PsRansacStats *)(dres + a->offStats);
     out.numMatches = (int32_t *)(dres + a->offNum);
     PsRansacConfig c2 = a->cfg;
-    c2.seed = a->cfg.seed + (uint64_t)a->pairCounter;
+    c2.seed = a->cfg.seed + (uint64_t)c.firstPair;
     int rc = ps_vo_pairs_device(lc, &a->prm, &c2, a->haveK ? a->K : nullptr, &fs, (const int32_t *)l.meta.p, P, &out);
     if (rc != PS_OK) {
         ctx->err = std::string("pipelined chunk: ") + lc->err;
@@ -242,33 +275,77 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
     const double t3 = now();
     if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DEBUG"))
         if (v[0] == '2')
-            fprintf(stderr, "[chunk %lld lane %d P %d] uploads %.1f call %.1f download %.1f\n", a->dbgN, a->tail, P, 1e6 * (t1 - t0),
-                    1e6 * (t2 - t1), 1e6 * (t3 - t2));
-    a->dbgT[0] += t1 - t0;
+            fprintf(stderr, "[chunk at pair %lld lane %d P %d] call %.1f download %.1f\n", c.firstPair, a->tail, P, 1e6 * (t2 - t1),
+                    1e6 * (t3 - t2));
     a->dbgT[1] += t2 - t1;
     a->dbgT[2] += t3 - t2;
     a->dbgN++;
     l.state = 1;
-    l.firstPair = a->pairCounter;
+    l.firstPair = c.firstPair;
     l.pairs = P;
-    l.epoch = a->epoch;
-    a->pairCounter += P;
-    a->tail = (a->tail + 1) % a->lanes;
+    l.epoch = c.epoch;
+    a->tail = (a->tail + 1) % (int)a->lane.size();
     a->inFlight++;
     return PS_OK;
+}
+
+// One chunk: n frames (pinned host memory: desc n x cap x 32, pts n x cap x 3; row counts nk) -> ring -> the next place, launched
+// on the next lane's stream.  The caller has checked async_room().
+int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
+{
+    PsVoAsync *a = s->async;
+    PsContext *ctx = s->ctx;
+    const size_t cap = (size_t)s->cap;
+    const int pos0 = (a->ringPos + n <= a->ringFrames) ? a->ringPos : 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    hipEvent_t ev = a->upEv[(size_t)(a->chunkSeq % (long long)a->upEv.size())];
+    a->chunkSeq++;
+    // (PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD=1, a diagnostic: after the first 64 chunks the uploads are skipped and the chunks run on
+    // whatever frames the ring holds -- results are then meaningless; it tells what the pipeline does when the link costs nothing)
+    static const bool diagNoUpload = std::getenv("PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD") != nullptr;
+    if (!(diagNoUpload && a->chunkSeq > 64)) {
+        PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
+                              a->copyStream));
+        PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
+                              a->copyStream));
+    }
+    PS_HIP(hipEventRecord(ev, a->copyStream));
+    for (int i = 0; i < n; ++i) a->nkRing[(size_t)(pos0 + i)] = nk[i];
+    AsyncChunk c;
+    c.pos0 = pos0;
+    c.n = n;
+    c.first = a->prevPos >= 0 ? 0 : 1; // the stream's first frame has no predecessor (matcher.cpp:17-64)
+    c.prevPos = a->prevPos;
+    c.firstPair = a->pairCounter;
+    c.epoch = a->epoch;
+    c.up = ev;
+    const int P = n - c.first;
+    a->ringPos = pos0 + n;
+    a->prevPos = pos0 + n - 1;
+    a->dbgT[0] += now() - t0;
+    if (P <= 0) {
+        // a lone first frame: nothing to run, no lane taken; its staging area (if it came through one) is reused by the
+        // next push, so the upload is waited for here
+        PS_HIP(hipStreamSynchronize(a->copyStream));
+        return PS_OK;
+    }
+    a->pairCounter += P;
+    return async_launch(s, c);
 }
 
 int async_submit_staged(PsVoStream *s)
 {
     PsVoAsync *a = s->async;
     if (a->staged == 0) return PS_OK;
-    AsyncLane &l = a->lane[(size_t)a->tail];
     const size_t cap = (size_t)s->cap;
     const int n = a->staged;
-    // (the staging area belongs to lane[tail], which push_async found free when it took the chunk's first frame)
-    int rc = async_submit(s, l.hstage, reinterpret_cast<const float *>(l.hstage + (size_t)a->B * cap * 32), a->stagedNk.data(), n);
-    if (rc == PS_OK) a->staged = 0;
-    return rc;
+    // (the staging area is the one push_async has been filling: that of chunk number chunkSeq)
+    uint8_t *h = nullptr;
+    int rc = stage_area(s, &h);
+    if (rc) return rc;
+    a->staged = 0; // (whatever happens below, these frames are not submitted a second time)
+    return async_submit(s, h, reinterpret_cast<const float *>(h + (size_t)a->B * cap * 32), a->stagedNk.data(), n);
 }
 
 // device / pinned blocks, streams, events and lane contexts of a freshly configured pipeline
@@ -284,6 +361,9 @@ int async_build(PsVoStream *s)
     a->resBytes = a->offNum + B * sizeof(int32_t);
     a->nkRing.assign((size_t)a->ringFrames, 0);
     a->stagedNk.assign(B, 0);
+    a->upEv.assign((size_t)(a->lanes + a->ahead + 1), nullptr);
+    a->stagePool.assign((size_t)(a->lanes + a->ahead + 1), nullptr);
+    for (hipEvent_t &e : a->upEv) PS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
     PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
     PS_HIP(hipStreamCreateWithFlags(&a->copyStream, hipStreamNonBlocking));
@@ -298,21 +378,25 @@ int async_build(PsVoStream *s)
         a->downloadsOnLane = queues < a->lanes + 6;
     }
     if (const char *v = std::getenv("PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE")) a->downloadsOnLane = std::atoi(v) != 0;
-    a->lane.resize((size_t)a->lanes);
-    for (AsyncLane &l : a->lane) {
-        int rc = ps_context_create(ctx->device, &l.ctx);
+    PS_HIP(hipHostMalloc((void **)&a->spareHres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
+    PS_HIP(hipHostGetDevicePointer((void **)&a->spareHresDev, a->spareHres, 0));
+    a->laneCtx.assign((size_t)a->lanes, nullptr);
+    for (PsContext *&c : a->laneCtx) {
+        int rc = ps_context_create(ctx->device, &c);
         if (rc != PS_OK) {
-            l.ctx = nullptr;
+            c = nullptr;
             return fail(ctx, rc, "ps_vo_stream_configure_async: lane context");
         }
-        for (const OptDesc &o : kOptions) l.ctx->*(o.field) = ctx->*(o.field); // the lanes run what the stream's context would
+        for (const OptDesc &o : kOptions) c->*(o.field) = ctx->*(o.field); // the lanes run what the stream's context would
+    }
+    a->lane.resize((size_t)(a->lanes + a->ahead));
+    for (AsyncLane &l : a->lane) {
         PS_ENSURE(l.meta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t));
         PS_ENSURE(l.res, (a->resBytes + 15) & ~(size_t)15);
         PS_HIP(hipHostMalloc((void **)&l.hmeta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t), hipHostMallocDefault));
         PS_HIP(hipHostMalloc((void **)&l.hres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hmetaDev, l.hmeta, 0));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hresDev, l.hres, 0));
-        PS_HIP(hipEventCreateWithFlags(&l.evIn, hipEventDisableTiming));
         PS_HIP(hipEventCreateWithFlags(&l.evRun, hipEventDisableTiming));
         PS_HIP(hipEventCreateWithFlags(&l.evDone, hipEventDisableTiming));
     }
@@ -321,9 +405,10 @@ int async_build(PsVoStream *s)
 
 void release_view(PsVoAsync *a)
 {
-    if (a->held >= 0) {
-        a->lane[(size_t)a->held].state = 0;
-        a->held = -1;
+    if (a->heldHres) { // the block goes back to being the spare one
+        a->spareHres = a->heldHres;
+        a->spareHresDev = a->heldHresDev;
+        a->heldHres = a->heldHresDev = nullptr;
     }
     a->cursor = 0;
     memset(&a->view, 0, sizeof a->view);
@@ -344,8 +429,7 @@ static int async_reset(PsVoStream *s)
     PsVoAsync *a = s->async;
     int rc = bind(s->ctx);
     if (rc) return rc;
-    if (a->staged > 0) {
-        if (a->lane[(size_t)a->tail].state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_reset: a partly filled chunk is waiting for a free lane (pop first)");
+    if (a->staged > 0) { // (its place was reserved when push_async took the chunk's first frame)
         rc = async_submit_staged(s);
         if (rc) return rc;
     }
@@ -367,7 +451,7 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     if (!params || !cfg) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: null params/config");
     if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming calls");
     if (chunkFrames == 0) chunkFrames = 128;
-    if (lanes == 0) lanes = 4;
+    if (lanes == 0) lanes = 3;
     if (chunkFrames < 1 || chunkFrames > 1024 || lanes < 2 || lanes > 8)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: chunkFrames 1..1024, lanes 2..8");
     {
@@ -384,7 +468,8 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     s->async = a;
     a->B = chunkFrames;
     a->lanes = lanes;
-    a->ringFrames = (lanes + 2) * chunkFrames;
+    a->ahead = ctx->streamAhead;
+    a->ringFrames = (lanes + a->ahead + 2) * chunkFrames;
     a->prm = *params;
     a->cfg = *cfg;
     a->cfg.sampleIdx = nullptr;
@@ -418,13 +503,14 @@ int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep,
     if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_async: call ps_vo_stream_configure_async first");
     if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES)
         return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_async: bad argument");
-    AsyncLane &l = a->lane[(size_t)a->tail];
-    if (l.state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_async: no free lane (pop results first)");
-    rc = lane_stage(s, l);
+    // (the first frame of a chunk reserves the chunk's place; the later ones ride on it)
+    if (a->staged == 0 && async_room(a) < 1) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_async: no room (pop results first)");
+    uint8_t *h = nullptr;
+    rc = stage_area(s, &h);
     if (rc) return rc;
     const size_t cap = (size_t)s->cap;
-    uint8_t *hd = l.hstage + (size_t)a->staged * cap * 32;
-    uint8_t *hp = l.hstage + (size_t)a->B * cap * 32 + (size_t)a->staged * cap * 12;
+    uint8_t *hd = h + (size_t)a->staged * cap * 32;
+    uint8_t *hp = h + (size_t)a->B * cap * 32 + (size_t)a->staged * cap * 12;
     if (descStep == PS_DESC_BYTES) {
         if (n > 0) memcpy(hd, desc, (size_t)n * 32);
     } else {
@@ -444,9 +530,7 @@ int ps_vo_stream_flush(PsVoStream *s)
     if (rc) return rc;
     PsVoAsync *a = s->async;
     if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_flush: call ps_vo_stream_configure_async first");
-    if (a->staged == 0) return PS_OK;
-    if (a->lane[(size_t)a->tail].state != 0) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_flush: no free lane (pop results first)");
-    return async_submit_staged(s);
+    return async_submit_staged(s); // (the partly filled chunk's place was reserved by its first frame)
 }
 
 int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nkpts, int numFrames)
@@ -461,13 +545,11 @@ int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts,
     for (int i = 0; i < numFrames; ++i)
         if (nkpts[i] < 0 || nkpts[i] > s->cap) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many: row count out of range");
     if (numFrames == 0) return PS_OK;
-    // lanes needed: one for the frames push_async has staged, one per chunk of these frames -- all or nothing
+    // places needed: one for the frames push_async has staged, one per chunk of these frames -- all or nothing
     const int chunks = (numFrames + a->B - 1) / a->B;
     const int need = chunks + (a->staged > 0 ? 1 : 0);
-    int freeLanes = 0;
-    for (int i = 0; i < a->lanes && a->lane[(size_t)((a->tail + i) % a->lanes)].state == 0; ++i) ++freeLanes;
-    if (need > freeLanes)
-        return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough free lanes for these frames (pop results first, or push fewer)");
+    if (need > async_room(a))
+        return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough room for these frames (pop results first, or push fewer)");
     rc = async_submit_staged(s);
     if (rc) return rc;
     const size_t cap = (size_t)s->cap;
@@ -478,13 +560,13 @@ int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts,
         const uint8_t *d = desc + (size_t)f0 * cap * 32;
         const float *p = pts + (size_t)f0 * cap * 3;
         if (!inPlace) {
-            AsyncLane &l = a->lane[(size_t)a->tail];
-            rc = lane_stage(s, l);
+            uint8_t *h = nullptr;
+            rc = stage_area(s, &h);
             if (rc) return rc;
-            memcpy(l.hstage, d, (size_t)n * cap * 32);
-            memcpy(l.hstage + (size_t)a->B * cap * 32, p, (size_t)n * cap * 12);
-            d = l.hstage;
-            p = reinterpret_cast<const float *>(l.hstage + (size_t)a->B * cap * 32);
+            memcpy(h, d, (size_t)n * cap * 32);
+            memcpy(h + (size_t)a->B * cap * 32, p, (size_t)n * cap * 12);
+            d = h;
+            p = reinterpret_cast<const float *>(h + (size_t)a->B * cap * 32);
         }
         rc = async_submit(s, d, p, nkpts + f0, n);
         if (rc) return rc;
@@ -514,18 +596,24 @@ int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out)
         }
         if (q != hipSuccess) return async_fail(s, PS_ERR_HIP, "hipEventQuery", q);
     }
-    out->matches = a->resultMode == PS_RESULTS_POSES ? nullptr : (const PsDMatch *)l.hres;
-    out->inlierMask = a->resultMode == PS_RESULTS_FULL ? l.hres + a->offMask : nullptr;
+    // the lane's block becomes the held one, the spare one the lane's: the lane is free now
+    uint8_t *blk = l.hres;
+    a->heldHres = l.hres;
+    a->heldHresDev = l.hresDev;
+    l.hres = a->spareHres;
+    l.hresDev = a->spareHresDev;
+    a->spareHres = a->spareHresDev = nullptr;
+    out->matches = a->resultMode == PS_RESULTS_POSES ? nullptr : (const PsDMatch *)blk;
+    out->inlierMask = a->resultMode == PS_RESULTS_FULL ? blk + a->offMask : nullptr;
     out->resultMode = a->resultMode;
-    out->pose = (const float *)(l.hres + a->offPose);
-    out->stats = (const PsRansacStats *)(l.hres + a->offStats);
-    out->numMatches = (const int32_t *)(l.hres + a->offNum);
+    out->pose = (const float *)(blk + a->offPose);
+    out->stats = (const PsRansacStats *)(blk + a->offStats);
+    out->numMatches = (const int32_t *)(blk + a->offNum);
     out->firstPair = l.firstPair;
     out->count = l.pairs;
     out->epoch = l.epoch;
-    l.state = 2;
-    a->held = a->head;
-    a->head = (a->head + 1) % a->lanes;
+    l.state = 0;
+    a->head = (a->head + 1) % (int)a->lane.size();
     a->inFlight--;
     a->view = *out;
     return PS_OK;
@@ -538,7 +626,7 @@ int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, 
     PsVoAsync *a = s->async;
     if (!a || !nmatches || !pose) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: bad argument / stream not configured");
     *nmatches = -1;
-    if (a->held < 0 || a->cursor >= a->view.count) {
+    if (!a->heldHres || a->cursor >= a->view.count) {
         PsHostPairResults v;
         // (a frame that waits in a partly filled chunk is not submitted by a pop: ps_vo_stream_flush does that)
         int rc = ps_vo_stream_pop_many(s, wait, &v);
@@ -571,7 +659,7 @@ int ps_vo_stream_pending(const PsVoStream *s)
     int n = 0;
     for (const AsyncLane &l : a->lane)
         if (l.state == 1) n += l.pairs;
-    if (a->held >= 0) n += a->view.count - a->cursor;
+    if (a->heldHres) n += a->view.count - a->cursor;
     if (a->staged > 0) n += a->staged - (a->prevPos >= 0 ? 0 : 1);
     return n;
 }

@@ -226,6 +226,7 @@ def test_flow_control_and_errors(ctx):
         st.push_async(seq["desc"][0], seq["pts"][0])
     with pytest.raises(api.PsError):
         st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=2000, lanes=3)
+    ctx.set_option("stream_ahead", 0)                                          # no upload-ahead: a chunk needs a free lane
     st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=3, lanes=2)
     with pytest.raises(api.PsError):                                           # the synchronous push is refused on a pipelined stream
         st.push(prm, cfg, TUM_FR1_K, seq["desc"][0], seq["pts"][0])
@@ -235,13 +236,18 @@ def test_flow_control_and_errors(ctx):
     assert st.pending() == 5
     a = st.pop_many(wait=True)
     assert a["count"] == 2 and a["first_pair"] == 0
-    assert not st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])    # the view of lane 0 is still held
-    b = st.pop_many(wait=True)                                                 # gives lane 0 back
-    assert b["count"] == 3 and b["first_pair"] == 2
-    assert st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])
-    assert not st.push_many(seq["desc"][9:12], seq["pts"][9:12], seq["nkpts"][9:12])  # lane 1's view is held now
+    keep = {k: np.array(a[k]) for k in ("pose", "numMatches")}                 # (copies of what the view shows now)
+    assert st.push_many(seq["desc"][6:9], seq["pts"][6:9], seq["nkpts"][6:9])  # lane 0 is free again: the popped block changed hands
+    assert not st.push_many(seq["desc"][9:12], seq["pts"][9:12], seq["nkpts"][9:12])  # both lanes busy
+    v = st.pop_many(wait=True, copy=False)                                     # a view (no copy): valid until the next pop
+    assert v["count"] == 3 and v["first_pair"] == 2
+    assert st.push_many(seq["desc"][9:12], seq["pts"][9:12], seq["nkpts"][9:12])   # ... while lane 1 already runs the next chunk
+    pose_v = np.array(v["pose"])
     c = st.pop_many(wait=True)
     assert c["count"] == 3 and c["first_pair"] == 5
+    d = st.pop_many(wait=True)
+    assert d["count"] == 3 and d["first_pair"] == 8
+    assert np.array_equal(keep["pose"], a["pose"]) and pose_v.shape == (3, 16)
     assert st.pop_many(wait=True) is None and st.pop_many(wait=False) is None
     # re-configuration drains and starts over; a bad row count is refused
     st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=4, lanes=2)
@@ -251,6 +257,53 @@ def test_flow_control_and_errors(ctx):
     d = st.pop_many(wait=True)
     assert d["count"] == 3 and d["first_pair"] == 0 and d["epoch"] == 0
     st.close()
+    ctx.set_option("stream_ahead", 3)
+
+
+def test_upload_ahead_accepts_chunks_beyond_the_lanes_and_keeps_the_bytes(ctx, oracle):
+    """Option "stream_ahead" (default 3): a chunk needs a place, and there are lanes + ahead of them -- the chunks beyond one per
+    lane are queued on the lanes' streams behind the running ones.  The results are those of the batched call whatever the
+    depth."""
+    from putslam_amd import api
+    seq = synth.make_sequence(31, 300, config=3, index=5)
+    prm = default_ransac_params(EUCLIDEAN_ERROR)
+    cfg, _ = make_config(EST_RANSAC, 487, seed=11)
+    ref = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=8)
+    for ahead in (2, 4, 1):
+        ctx.set_option("stream_ahead", ahead)
+        st = api.VoStream(ctx, 300)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=3, lanes=2)
+        f, chunks = 0, 0
+        while st.push_many(seq["desc"][f:f + 3], seq["pts"][f:f + 3], seq["nkpts"][f:f + 3]):
+            f, chunks = f + 3, chunks + 1
+        assert chunks == 2 + ahead                                             # lanes + ahead places, then PS_ERR_BUSY
+        assert not st.push_async(seq["desc"][f], seq["pts"][f])
+        assert st.pending() == f - 1
+        got = []
+        b = st.pop_many(wait=True)                                             # the oldest chunk: its place is free again
+        got.append(b)
+        assert st.push_many(seq["desc"][f:f + 3], seq["pts"][f:f + 3], seq["nkpts"][f:f + 3])   # so one place is free again
+        assert not st.push_many(seq["desc"][f + 3:f + 6], seq["pts"][f + 3:f + 6], seq["nkpts"][f + 3:f + 6])
+        f += 3
+        while f < 31:                                                          # the rest of the sequence, popping when there is no room
+            n = min(3, 31 - f)
+            if st.push_many(seq["desc"][f:f + n], seq["pts"][f:f + n], seq["nkpts"][f:f + n]):
+                f += n
+            else:
+                got.append(st.pop_many(wait=True))
+        while True:
+            b = st.pop_many(wait=True)
+            if b is None:
+                break
+            got.append(b)
+        done = 0
+        for b in got:
+            assert b["first_pair"] == done
+            _check_block(b, ref, done)
+            done += b["count"]
+        assert done == 30 and st.pending() == 0
+        st.close()
+    ctx.set_option("stream_ahead", 3)
 
 
 def test_throughput_chunks_match_the_batched_call_on_the_bench_shape(ctx):
@@ -335,6 +388,8 @@ def fuzz_stream(iters, seed, verbose=False):
         hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
         hd.array[:] = seq["desc"]
         hp.array[:] = seq["pts"]
+        ahead = int(rng.integers(0, 9))
+        ctx.set_option("stream_ahead", ahead)      # chunks accepted and uploaded while every lane is busy (read by configure_async)
         st = api.VoStream(ctx, cap)
         st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=int(rng.integers(0, 3)))
         got = [0 for _ in epochs]
@@ -353,7 +408,7 @@ def fuzz_stream(iters, seed, verbose=False):
             except AssertionError as ex:
                 ok = False
                 if verbose:
-                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, form=form, cut=cut), repr(ex)[:300])
+                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, ahead=ahead, form=form, cut=cut), repr(ex)[:300])
             got[e] += b["count"]
             return True
 
