@@ -132,7 +132,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (demos/cpp/demo_latency)")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] legs (5000 keypoints, H = 100 000)")
     ap.add_argument("--stream-chunk", type=int, default=125, help="frames per chunk of the streamed leg")
-    ap.add_argument("--stream-lanes", type=int, default=3, help="lanes of the streamed leg: launch chains that run side by side (the library's stream_ahead places queue more chunks behind them)")
+    ap.add_argument("--stream-lanes", type=int, default=0, help="lanes of the streamed leg: launch chains that run side by side (the library's stream_ahead places queue more chunks behind them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
@@ -693,6 +693,14 @@ def _link_rate(torch, dev, mb=64, reps=8):
     return out
 
 
+def _stream_shape(chunk, lanes):
+    """(lanes, places beyond one per lane) ps_vo_stream_configure_async uses for `lanes` = 0 and option stream_ahead = -1 (the
+    defaults): six places in all; three launch chains from 192 frames per chunk on, six below."""
+    if lanes == 0:
+        lanes = 3 if chunk >= 192 else 6
+    return lanes, max(0, 6 - lanes)
+
+
 def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     """The timed workload with the frames STREAMED from the host (reference call shape: one frame after the other, previous
     frame kept as state, src/Matcher/matcher.cpp:452-516 in the loop of src/PUTSLAM/PUTSLAM.cpp:677-740): every step uploads
@@ -770,7 +778,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         st.close()
         lat_ms = np.array(sorted(lat)) * 1e3
         leg = {"pairs_per_s": done / el, "ms_per_step": el / steps * 1e3, "steps": steps, "pairs": done,
-               "chunk_frames": chunk, "lanes": lanes,
+               "chunk_frames": chunk, "lanes": _stream_shape(chunk, lanes)[0], "places": sum(_stream_shape(chunk, lanes)),
                "results": ["full", "inliers", "poses"][results],
                "h2d_GBps": steps * F * cap * 44 / el / 1e9,
                "d2h_GBps": (done * (cap * 17 + 108) if results == 0 else
@@ -792,7 +800,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                                 "and downloads of consecutive chunks overlap"}
     main["workload"] = ("BASELINE configs[2] as written: %d frames streamed from pinned host memory per step (ps_vo_stream_push_many, "
                         "chunks of %d frames on %d lanes), every pair's matches / mask / pose / stats downloaded (pop_many); same "
-                        "parameters as the timed workload" % (F, args.stream_chunk, args.stream_lanes))
+                        "parameters as the timed workload" % (F, args.stream_chunk, _stream_shape(args.stream_chunk, args.stream_lanes)[0]))
     out["streamed"] = main
     # what Matcher::match itself returns -- estimatedTransformation + inlierMatches (matcher.cpp:452-516) -- instead of every
     # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block

@@ -324,7 +324,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * over the whole sequence with the same cfg, whatever the chunking.
  *
  * ps_vo_stream_configure_async: parameters of the pipelined form, fixed until the next configure (which drains).  chunkFrames
- *   1..1024 (0 = 128), lanes 2..8 (0 = 3).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
+ *   1..1024 (0 = 128), lanes 2..8 (0 = 6, or 3 from 192 frames per chunk on).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
  * ps_vo_stream_push_async: ONE frame (host pointers, rows of descStep bytes) is copied into the pinned staging area of
  *   the chunk being collected; the chunk is submitted when it is full.  Returns at once.
  * ps_vo_stream_push_many: numFrames frames laid out like a PsFrameSet on the HOST (desc numFrames x maxKpts x 32 B,
@@ -334,7 +334,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   Frames staged by push_async before are submitted first, as a chunk of their own.
  * ps_vo_stream_flush: submits a partly filled chunk.
  * Flow control: a chunk needs a PLACE (a meta block, device and pinned result blocks, events); there are lanes + `ahead` of
- *   them (context option "stream_ahead", 0 .. 8, default 3, read by configure_async).  An accepted chunk is uploaded and
+ *   them (context option "stream_ahead", 0 .. 8, or -1 = six places in all, the default; read by configure_async).  An accepted chunk is uploaded and
  *   launched at once, on the next lane in turn -- behind that lane's running chunk if it has one --, so a lane never waits for
  *   the host between chunks.  A place is busy from the launch of its chunk until pop_many has returned its results (the pinned
  *   block they lie in changes hands: the place goes on with a spare one while the caller reads).  push_async (at the first frame of a chunk) / push_many return

@@ -18,7 +18,7 @@
 //     outstanding host reads fill the L2's request queues); SDMA transfers do not.
 //
 //   * places: a chunk needs a place (meta block, device + pinned result blocks, events), not a lane: there are lanes + `ahead`
-//     of them (option "stream_ahead", default 3), and chunk k is LAUNCHED at once on lane k % lanes -- behind that lane's running
+//     of them (option "stream_ahead"; default: six places in all), and chunk k is LAUNCHED at once on lane k % lanes -- behind that lane's running
 //     chunk if it has one.  With one place per lane a lane idled from the end of its chunk's last kernel through the download,
 //     the host's pop, the next chunk's upload and the copy-stream -> lane dependency (300 - 500 us of a chunk's ~ 800,
 //     profiles/r05h/timeline_ahead0.txt); now its next chunk's launches are already in its stream.
@@ -246,18 +246,20 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     // (profiles/r05e/timeline_tail.txt), and on the lane's own stream that kernel sat between the lane's launches (29 % of the
     // time one was running, profiles/r05d); on the copy-out stream it overlaps the lane's NEXT chunk instead: + 11 ... 18 % with
     // six lanes.
-    hipStream_t ds = (a->downloadsOnLane || a->resultMode != PS_RESULTS_FULL) ? lc->stream : a->copyOutStream;
+    hipStream_t ds = a->downloadsOnLane ? lc->stream : a->copyOutStream;
+    if (!a->downloadsOnLane) {
+        PS_HIP(hipEventRecord(l.evRun, lc->stream));
+        PS_HIP(hipStreamWaitEvent(ds, l.evRun, 0));
+    }
     if (a->resultMode != PS_RESULTS_FULL) {
-        // inliers / poses only: a kernel writes just those into the mapped pinned block, behind kernel 4 on the lane's stream
-        hipLaunchKernelGGL(ps_pack_results_to_host, dim3((unsigned)P), dim3(kBlock), 0, lc->stream, (const PsDMatch *)dres,
+        // inliers / poses only: a kernel writes just those into the mapped pinned block, behind kernel 4 (on the download stream
+        // too: on the lane's own stream the lane's next chunk waited behind its writes over the link)
+        hipLaunchKernelGGL(ps_pack_results_to_host, dim3((unsigned)P), dim3(kBlock), 0, ds, (const PsDMatch *)dres,
                            (const int32_t *)(dres + a->offNum), (const uint8_t *)(dres + a->offMask), (const float *)(dres + a->offPose),
                            (const PsRansacStats *)(dres + a->offStats), s->cap, a->resultMode, (PsDMatch *)l.hresDev,
                            (float *)(l.hresDev + a->offPose), (PsRansacStats *)(l.hresDev + a->offStats),
                            (int32_t *)(l.hresDev + a->offNum));
         PS_HIP(hipGetLastError());
-    } else if (!a->downloadsOnLane) {
-        PS_HIP(hipEventRecord(l.evRun, lc->stream));
-        PS_HIP(hipStreamWaitEvent(ds, l.evRun, 0));
     }
     if (a->resultMode != PS_RESULTS_FULL) {
         // (written by ps_pack_results_to_host above)
@@ -451,7 +453,9 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     if (!params || !cfg) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: null params/config");
     if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming calls");
     if (chunkFrames == 0) chunkFrames = 128;
-    if (lanes == 0) lanes = 3;
+    // (measured, profiles/r05h/stream_ab_*.txt: six places in all; large chunks fill the chip by themselves and run best as three
+    // launch chains with three more chunks queued behind them, small ones as six chains)
+    if (lanes == 0) lanes = chunkFrames >= 192 ? 3 : 6;
     if (chunkFrames < 1 || chunkFrames > 1024 || lanes < 2 || lanes > 8)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: chunkFrames 1..1024, lanes 2..8");
     {
@@ -468,7 +472,7 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     s->async = a;
     a->B = chunkFrames;
     a->lanes = lanes;
-    a->ahead = ctx->streamAhead;
+    a->ahead = ctx->streamAhead >= 0 ? ctx->streamAhead : (lanes < 6 ? 6 - lanes : 0);
     a->ringFrames = (lanes + a->ahead + 2) * chunkFrames;
     a->prm = *params;
     a->cfg = *cfg;

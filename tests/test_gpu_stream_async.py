@@ -257,11 +257,11 @@ def test_flow_control_and_errors(ctx):
     d = st.pop_many(wait=True)
     assert d["count"] == 3 and d["first_pair"] == 0 and d["epoch"] == 0
     st.close()
-    ctx.set_option("stream_ahead", 3)
+    ctx.set_option("stream_ahead", -1)
 
 
 def test_upload_ahead_accepts_chunks_beyond_the_lanes_and_keeps_the_bytes(ctx, oracle):
-    """Option "stream_ahead" (default 3): a chunk needs a place, and there are lanes + ahead of them -- the chunks beyond one per
+    """Option "stream_ahead" (default -1: six places in all): a chunk needs a place, and there are lanes + ahead of them -- the chunks beyond one per
     lane are queued on the lanes' streams behind the running ones.  The results are those of the batched call whatever the
     depth."""
     from putslam_amd import api
@@ -303,7 +303,7 @@ def test_upload_ahead_accepts_chunks_beyond_the_lanes_and_keeps_the_bytes(ctx, o
             done += b["count"]
         assert done == 30 and st.pending() == 0
         st.close()
-    ctx.set_option("stream_ahead", 3)
+    ctx.set_option("stream_ahead", -1)
 
 
 def test_throughput_chunks_match_the_batched_call_on_the_bench_shape(ctx):
@@ -388,7 +388,7 @@ def fuzz_stream(iters, seed, verbose=False):
         hd, hp = api.PinnedBuffer((F, cap, 32), np.uint8), api.PinnedBuffer((F, cap, 3), np.float32)
         hd.array[:] = seq["desc"]
         hp.array[:] = seq["pts"]
-        ahead = int(rng.integers(0, 9))
+        ahead = int(rng.integers(-1, 9))
         ctx.set_option("stream_ahead", ahead)      # chunks accepted and uploaded while every lane is busy (read by configure_async)
         st = api.VoStream(ctx, cap)
         st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=int(rng.integers(0, 3)))
