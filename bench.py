@@ -186,7 +186,7 @@ def main():
     # The sub-batches of a step run on separate HIP streams; with the runtime's default of four hardware queues two
     # streams can end up sharing one (then they serialise).  More queues keep them apart (measured: no effect on two
     # streams, 105 k -> 117 k pairs/s on three).  Must be set before the HIP runtime initialises.
-    # (round 5: 16 -- the streamed legs run six lanes + an upload and a download stream beside the three chains' streams; with
+    # (round 5: 16 -- the streamed legs run up to six lanes + an upload and a download stream beside the three chains' streams; with
     # eight queues two of those shared one and the leg dropped from 390 k to 130 k pairs/s; the headline is the same either way)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
