@@ -168,6 +168,19 @@ def usac_stopping(inl, tot, s=3):
     return lib().po_usac_stopping(inl, tot, s)
 
 
+def usac_replay(valid, counts, H, M):
+    """(iterations, best count, best hypothesis) of the USAC loop over replayed per-hypothesis outcomes (po_usac_replay)."""
+    v = np.ascontiguousarray(valid, np.int32)
+    c = np.ascontiguousarray(counts, np.int32)
+    it, bc, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    lib().po_usac_replay(_p(v), _p(c), int(len(c)), int(H), int(M), C.byref(it), C.byref(bc), C.byref(b))
+    return int(it.value), int(bc.value), int(b.value)
+
+
+def draw31(seed, h, j):
+    return int(lib().po_draw31(C.c_uint64(seed), int(h), int(j)))
+
+
 def sample_triplet(cfg, h, M):
     idx = (C.c_int * 3)()
     lib().po_sample_triplet(C.byref(cfg), C.c_uint64(cfg.seed), int(h), int(M), idx)

@@ -1,8 +1,12 @@
 /* putslam_oracle.c -- CPU restatement of PUTSLAM's Matcher -> RANSAC/USAC -> Kabsch path.
  *
  * TEST INFRASTRUCTURE ONLY (checker + timed CPU baseline); see putslam_oracle.h.
- * PARITY UNPINNED: restates OpenCV 3.x / Eigen 3.3 published algorithms, neither library is
- * available to compile the reference here; checked against analytic KATs and float64 numpy.
+ * PARITY UNPINNED for everything that goes through OpenCV 3.x / Eigen 3.3 (the matcher, Umeyama / JacobiSVD, the inverse,
+ * the metrics: restated from the published algorithms -- neither library is available to compile the reference here --
+ * and checked against analytic KATs, float64 numpy and an independent emulation).
+ * PINNED to the reference's own code: row A11's stopping rule, main loop and sampler (po_usac_stopping, UsacLoop /
+ * po_usac_replay, po_sample_triplet's seeded rule) -- include/putslam/USAC/USAC.h compiles from its own sources and
+ * oracle/ref_usac drives it; its answers are tests/golden/ref_usac.npz (tests/test_ref_usac.py).
  *
  * Citations are file:line under the reference tree (LRMPUT/PUTSLAM).
  * Build: gcc -O3 -march=native -ffp-contract=off -fno-fast-math (no FMA contraction: the
@@ -421,7 +425,54 @@ unsigned po_usac_stopping(unsigned numInliers, unsigned totPoints, unsigned samp
     if (prob_good_model < DBL_EPSILON) return USAC_MAX_HYP;
     if (1 - prob_good_model < DBL_EPSILON) return 1;
     double nusample_s = log(1 - USAC_CONF) / log(1 - prob_good_model);
-    return (unsigned)ceil(nusample_s);
+    /* The reference returns (unsigned int) ceil(nusample_s): undefined from 2^32 on (good-model probabilities below 1.07e-9:
+     * three inliers among 1777 matches and more).  What the reference's code does there -- an SSE2 x86-64 build keeps the low
+     * 32 bits of the 64-bit conversion, a pseudo-random number -- is on file (tests/golden/ref_usac.npz, from the reference's
+     * USAC.h itself); the build returns the cap instead, here and on the device, whatever the compiler makes of the cast. */
+    const double c = ceil(nusample_s);
+    if (!(c < 4294967296.0)) return USAC_MAX_HYP;
+    return (unsigned)c;
+}
+
+/* The bookkeeping of USAC<T>::solve's main loop (USAC.h:299,326-329,409-414,498-509) under RANSAC_USAC's configuration
+ * (USAC_wrapper.cpp:62-100): hypotheses are counted when they start; a model that could not be generated is skipped (0
+ * solutions, USAC.h:376-379); a count STRICTLY above the best so far is stored and re-derives the stopping count. */
+typedef struct UsacLoop {
+    unsigned adaptive, hyp;
+    int bestCount, best;
+} UsacLoop;
+static void usac_loop_init(UsacLoop *l)
+{
+    l->adaptive = USAC_MAX_HYP;
+    l->hyp = 0;
+    l->bestCount = 0;
+    l->best = -1;
+}
+static int usac_loop_continues(const UsacLoop *l, int H) { return l->hyp < l->adaptive && l->hyp < USAC_MAX_HYP && (int)l->hyp < H; }
+static int usac_loop_next(UsacLoop *l) { return (int)l->hyp++; }
+static int usac_loop_result(UsacLoop *l, int i, int cnt, int M) /* 1: hypothesis i is the best so far */
+{
+    if (cnt <= l->bestCount) return 0;
+    l->bestCount = cnt;
+    l->best = i;
+    l->adaptive = po_usac_stopping((unsigned)cnt, (unsigned)M, 3);
+    return 1;
+}
+/* The loop over REPLAYED outcomes (valid[i] != 0: hypothesis i has a model, counts[i] its inlier count; hypotheses from n on have
+ * a model and count 0), at most H hypotheses: what the reference's solve() does with the same outcomes. */
+void po_usac_replay(const int32_t *valid, const int32_t *counts, int n, int H, int M, int32_t *iterations, int32_t *bestCount,
+                    int32_t *best)
+{
+    UsacLoop l;
+    usac_loop_init(&l);
+    while (usac_loop_continues(&l, H)) {
+        const int i = usac_loop_next(&l);
+        if (i < n && !valid[i]) continue;
+        usac_loop_result(&l, i, i < n ? counts[i] : 0, M);
+    }
+    *iterations = (int32_t)l.hyp;
+    *bestCount = l.bestCount;
+    *best = l.best;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -693,12 +744,12 @@ int po_ransac_rigid3d(const PsRansacParams *params, const PsRansacConfig *cfg, c
             st.accepted = 0;
         }
     } else {
-        /* USAC<T>::solve, USAC.h:326,409-414,498-509 with SAMP_UNIFORM / VERIF_STANDARD / LO_NONE */
-        unsigned adaptive = USAC_MAX_HYP;
-        unsigned hyp = 0;
-        while (hyp < adaptive && hyp < USAC_MAX_HYP && (int)hyp < H) {
-            int i = (int)hyp;
-            ++hyp;
+        /* USAC<T>::solve, USAC.h:326,409-414,498-509 with SAMP_UNIFORM / VERIF_STANDARD / LO_NONE: the loop's bookkeeping is
+         * UsacLoop (below), the same code po_usac_replay runs against the reference's own solve() (tests/test_ref_usac.py) */
+        UsacLoop lp;
+        usac_loop_init(&lp);
+        while (usac_loop_continues(&lp, H)) {
+            int i = usac_loop_next(&lp);
             ++iterationsRun;
             int idx[3];
             float T[16];
@@ -709,13 +760,12 @@ int po_ransac_rigid3d(const PsRansacParams *params, const PsRansacConfig *cfg, c
             }
             int cnt = score_all(mode, T, K, prev, cur, matches, valid, M, thrE, thrR, flags);
             if (hypCounts) hypCounts[i] = cnt;
-            if (cnt > bestCount) {
+            if (usac_loop_result(&lp, i, cnt, M)) {
                 bestCount = cnt;
                 memcpy(bestT, T, sizeof bestT);
                 memcpy(bestFlags, flags, (size_t)M);
                 st.bestHypothesis = i;
                 bestRatioF = (float)cnt / (float)M;
-                adaptive = po_usac_stopping((unsigned)bestCount, (unsigned)M, 3);
             }
         }
         int nfinal = 0;

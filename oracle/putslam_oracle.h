@@ -15,6 +15,9 @@
  * reference's call sites, and is checked against analytic known answers and a
  * float64 numpy SVD (tests/test_oracle_*.py).  Agreement with a real
  * OpenCV/Eigen build is a tolerance claim, not a bit claim.
+ * PINNED (the exception): the USAC template library include/putslam/USAC/USAC.h compiles from its own
+ * sources, so row A11's stopping rule, main loop and sampler are checked against the reference's code itself
+ * (oracle/ref_usac -> oracle/_ref/usac_harness -> tests/golden/ref_usac.npz, tests/test_ref_usac.py).
  *
  * POD types are shared with the public C ABI (include/putslam_hip.h).
  */
@@ -64,6 +67,8 @@ int po_ransac_iterations(double inlierRatio, double successProbability, int numb
 unsigned po_usac_stopping(unsigned numInliers, unsigned totPoints, unsigned sampleSize);
 
 /* The sample stream shared by oracle and device (replaces srand(time(0)) + rand()%M, RANSAC.cpp:13,180-205). */
+void po_usac_replay(const int32_t *valid, const int32_t *counts, int n, int H, int M, int32_t *iterations, int32_t *bestCount,
+                    int32_t *best);
 uint32_t po_draw31(uint64_t seed, uint32_t h, uint32_t j);
 void po_sample_triplet(const PsRansacConfig *cfg, uint64_t seed, int h, int M, int idx[3]);
 

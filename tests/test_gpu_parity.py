@@ -370,6 +370,30 @@ def test_usac_limit_table_long_schedules(ctx, oracle, H):
         assert np.array_equal(dev, ref), (M, [(int(i) + 1, int(dev[i]), int(ref[i])) for i in np.nonzero(dev != ref)[0][:5]])
 
 
+def test_usac_limit_table_equals_the_reference_code(ctx):
+    """The DEVICE's stop table against what the reference's own USAC.h answers (tests/golden/ref_usac.npz, made by
+    oracle/ref_usac from the reference's header): every inlier count of M = 59 ... 40 000 under the reference's cap.  Where the
+    reference's (unsigned) cast is undefined -- 57 of the (count, M) pairs on file, all with M >= 1777 -- the device gives the cap."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_usac.npz"))
+    q, want = G["stop_query"], G["stop_answer"]
+    H = 850000
+    undefined = 0
+    for M in (59, 133, 400, 487, 1000, 1700, 1776, 1777, 2000, 5000, 12000, 40000):
+        sel = (q[:, 1] == M) & (q[:, 0] >= 1)
+        assert sel.sum() == M and np.array_equal(q[sel, 0], np.arange(1, M + 1))
+        ref = np.minimum(want[sel], H)
+        dev = ctx.debug_limits(EST_USAC, 0.2, H, M).astype(np.int64)
+        c = np.arange(1, M + 1, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            p_good = c * (c - 1) * (c - 2) / (float(M) * (M - 1) * (M - 2))
+            undef = (p_good >= np.finfo(np.float64).eps) & (np.ceil(np.log(1 - 0.99) / np.log(1 - p_good)) >= 2.0 ** 32)
+        assert np.array_equal(dev[~undef], ref[~undef]), (M, np.nonzero((dev != ref) & ~undef)[0][:5])
+        assert np.all(dev[undef] == H)
+        undefined += int(undef.sum())
+    assert undefined == 56          # (57 pairs on file, one of them for M = 1778)
+
+
 # ---------------------------------------------------------------- A10 Kabsch (double)
 @pytest.mark.parametrize("n", [3, 100, 500, 4097, 16384, 16385, 100003, 5000000])  # > 16384: multi-wave reduction
 def test_kabsch_f64(ctx, oracle, n):

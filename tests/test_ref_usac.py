@@ -1,0 +1,81 @@
+"""The oracle's restatement of SURVEY 8a row A11 (RANSAC_USAC: stopping rule, main loop, sampler) against the REFERENCE'S OWN
+code: tests/golden/ref_usac.npz holds what include/putslam/USAC/USAC.h -- compiled where it lies under /root/reference into
+oracle/_ref/usac_harness, oracle/ref_usac/ -- answered (tests/golden/make_ref_usac_golden.py made it in the build container).
+This is the one part of the path whose reference code builds without OpenCV / Eigen: for it the oracle is PINNED."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from putslam_amd._abi import EST_USAC, make_config
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_usac.npz"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "usac_harness")
+
+
+def test_stopping_rule_equals_the_reference(oracle):
+    """updateStandardStopping (USAC.h:944-971): 148 123 (numInliers, totPoints) pairs -- every count of every M up to 400, of the
+    iteration table's M = 487, of 1000 ... 40 000 -- incl. the unsigned wrap of `numInliers - i` below three inliers.  The oracle
+    equals the reference's code everywhere the rule is DEFINED; where the quotient reaches 2^32 (57 of the pairs: three inliers
+    among 1777 matches and more) the reference's (unsigned) cast is undefined -- its SSE2 build keeps the low 32 bits of the
+    64-bit conversion, which the vectors record -- and the build returns the cap."""
+    q, want = G["stop_query"], G["stop_answer"]
+    got = np.array([oracle.usac_stopping(int(a), int(b), 3) for a, b in q], np.int64)
+    a, b = q[:, 0].astype(np.float64), q[:, 1].astype(np.float64)
+    with np.errstate(all="ignore"):
+        p = np.where(q[:, 0] >= 3, (a * (a - 1) * (a - 2)) / (b * (b - 1) * (b - 2)), 0.0)
+        quotient = np.ceil(np.log(1 - 0.99) / np.log(1 - p))
+    undefined = (p >= np.finfo(np.float64).eps) & (1 - p >= np.finfo(np.float64).eps) & ~(quotient < 2.0 ** 32)
+    assert undefined.sum() == 57 and q[undefined, 1].min() == 1777 and q[undefined, 0].max() == 41
+    bad = np.nonzero((got != want) & ~undefined)[0]
+    assert len(bad) == 0, [(tuple(q[i]), int(got[i]), int(want[i])) for i in bad[:5]]
+    assert np.all(got[undefined] == 850000)
+    # what the reference's code returns there: the low 32 bits of the quotient's 64-bit conversion
+    assert np.array_equal(want[undefined], quotient[undefined].astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    assert want.min() == 1 and len(np.unique(want)) > 10000
+
+
+def test_main_loop_equals_the_reference(oracle):
+    """USAC<T>::solve() (USAC.h:296-520) under RANSAC_USAC's configuration (USAC_wrapper.cpp:62-100) over 600 replayed outcome
+    sequences: iterations made, best count, the hypothesis stored last == the oracle's loop (the code po_ransac's USAC branch runs)."""
+    off = 0
+    seen_long = 0
+    for M, n, (ok, hyp, best, stored) in zip(G["solve_M"], G["solve_n"], G["solve_answer"]):
+        valid, counts = G["solve_valid"][off:off + n], G["solve_counts"][off:off + n]
+        off += n
+        it, bc, b = oracle.usac_replay(valid, counts, 850000, int(M))
+        assert ok == 1 and (it, bc, b) == (int(hyp), int(best), int(stored)), (int(M), int(n), (it, bc, b), (hyp, best, stored))
+        seen_long += hyp > 100000
+    assert off == len(G["solve_counts"]) and seen_long > 20        # (schedules that run to six figures are in the set)
+
+
+def test_sampler_equals_the_reference(oracle):
+    """generateUniformRandomSample (USAC.h:562-579: rand() % dataSize, redraw on a repeat) fed the build's draw stream
+    po_draw31(seed, hypothesis, draw) == po_sample_triplet's seeded stream, down to M = 3 where nearly every sample redraws."""
+    for (seed, M, H), want in zip(G["sample_query"], G["sample_answer"]):
+        cfg, _ = make_config(EST_USAC, int(H), seed=int(seed))
+        got = np.array([oracle.sample_triplet(cfg, h, int(M)) for h in range(int(H))], np.int32)
+        assert np.array_equal(got, want), (int(seed), int(M))
+        assert all(len(set(r)) == 3 for r in got.tolist())
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/usac_harness is built where /root/reference exists")
+def test_live_harness_agrees_on_fresh_cases(oracle):
+    """Where the harness binary is present (the build container): new random cases, answered by the reference's code now."""
+    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
+    # (counts from 50 up for the larger M: below, the reference's cast is undefined -- test_stopping_rule_equals_the_reference)
+    q = [(int(c), int(M)) for M in rng.integers(3, 30000, 40) for c in rng.integers(50 if M > 1700 else 0, M + 1, 60)]
+    p = subprocess.run([HARNESS], input="stop %d\n" % len(q) + "".join("%d %d\n" % t for t in q), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0
+    want = [int(x) for x in p.stdout.split()]
+    assert [oracle.usac_stopping(a, b, 3) for a, b in q] == want
+    for _ in range(20):
+        M, n = int(rng.integers(8, 2000)), int(rng.integers(1, 2000))
+        counts = np.minimum(rng.integers(0, max(4, M // 3), n) * (rng.random(n) < 0.1) + rng.integers(0, 5, n), M).astype(np.int32)
+        valid = (rng.random(n) > 0.05).astype(np.int32)
+        p = subprocess.run([HARNESS], input="solve %d %d\n" % (M, n) + "".join("%d %d\n" % t for t in zip(valid, counts)),
+                           capture_output=True, text=True, timeout=300)
+        ok, hyp, best, stored = (int(x) for x in p.stdout.split())
+        assert (hyp, best, stored) == oracle.usac_replay(valid, counts, 850000, M)
