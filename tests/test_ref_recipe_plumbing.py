@@ -112,4 +112,5 @@ def test_recipe_roundtrip_through_collect_and_golden_checks(oracle, tmp_path, mo
     tgr.test_ref_bfmatcher(oracle)
     tgr.test_ref_ransac(oracle)
     # nothing was written into the repository's own golden directory
-    assert not [f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.startswith("ref_")]
+    # (ref_usac.npz is the one reference-made fixture that exists: tests/golden/make_ref_usac_golden.py)
+    assert [f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.startswith("ref_")] == ["ref_usac.npz"]
