@@ -372,9 +372,12 @@ PS_D bool score_euclid_pass(const float4 *__restrict__ recA, const float4 *__res
     return false;
 }
 
-// (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast; LOOP: stage 1 of an adaptive schedule with a long cap, same place)
+// (kind 2: five wavefronts per SIMD, see ps_ransac_score_fast; LOOP: stage 1 of an adaptive schedule with a long cap, same place.
+// Kind 0 -- the plain launch and stage 0 -- asks for seven: at eight the register allocator spilled 34 scalar registers into
+// vector lanes and left a 20-byte private segment behind that no instruction touched; at seven: 8 spills, no
+// private segment, the same times within 1 % in every regime, profiles/r05i/ab_seven_waves.txt)
 template <int MODE, int KIND = 0, bool LOOP = false>
-__global__ __launch_bounds__(kBlock, (KIND == 2 || LOOP) ? 5 : 8) void ps_ransac_score_euclid(
+__global__ __launch_bounds__(kBlock, (KIND == 2 || LOOP) ? 5 : (KIND == 0 ? 7 : 8)) void ps_ransac_score_euclid(
     const float4 *__restrict__ recA, const float4 *__restrict__ recB, const float2 *__restrict__ recG,
     const int32_t *__restrict__ mvalid, const float2 *__restrict__ pairBound, ModelArgs ma, ScoreConsts k,
     EuclidConsts ec, SelectArgs sa, StageArgs st, int H, int cap, int minRun, int msplit, int32_t *__restrict__ counts,

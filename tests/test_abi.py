@@ -148,3 +148,12 @@ def test_device_code_has_no_scratch_or_flat_instructions(tmp_path):
             bad.append((kernel, ins[0]))
     assert kernels >= 30, "disassembly found no kernels"
     assert not bad, sorted(set(bad))[:10]
+    # ... and no kernel declares a private segment (a launch with one pays the scratch set-up even if nothing reads it: round 4's
+    # ps_ransac_score_euclid<0 / 4> carried 20 unused bytes)
+    readelf = os.path.join(llvm, "llvm-readelf")
+    if os.path.exists(readelf):
+        notes = subprocess.check_output([readelf, "--notes", co], text=True)
+        names = re.findall(r"\.name:\s+(\S+)", notes)
+        sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+        assert len(sizes) >= 30 and len(sizes) <= len(names)
+        assert all(v == 0 for v in sizes), [v for v in sizes if v]
