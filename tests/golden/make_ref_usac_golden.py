@@ -71,6 +71,27 @@ def main():
             sa.append(np.array([[int(x) for x in l.split()] for l in lines[:H]], np.int32))
     out["sample_query"] = np.array(sq, np.uint64)
     out["sample_answer"] = np.stack(sa)
+    # ---- end to end: the oracle's own per-hypothesis counts of synthetic frame pairs, replayed through the reference's solve()
+    from oracle import oracle_py as po
+    from putslam_amd import synth
+    from putslam_amd._abi import EST_USAC, TUM_FR1_K, default_ransac_params, make_config
+    e2e_q, e2e_a = [], []
+    for n, index, frac, mode in ((300, 1, 0.7, 0), (600, 2, 0.4, 0), (600, 3, 0.15, 1), (1000, 4, 0.08, 0), (1500, 5, 0.04, 1),
+                                 (2000, 6, 0.6, 2), (2000, 7, 0.03, 0), (800, 8, 0.25, 4), (64, 9, 0.5, 0), (2000, 10, 0.0, 0)):
+        a, b = synth.make_pair(n, config=2, index=index, inlier_frac=frac)
+        m = po.match_hamming256(a["desc"], b["desc"])
+        prm = default_ransac_params(mode)
+        H = 6000
+        cfg, _ = make_config(EST_USAC, H, seed=1000 + index)
+        counts, M = po.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+        if M < 8:
+            continue
+        lines = run("solve %d %d\n" % (M, H) + "".join("1 %d\n" % c for c in counts))
+        ok, hyp, best, stored = (int(x) for x in lines[0].split())
+        e2e_q.append((n, index, int(frac * 1000), mode, H, M, int(np.asarray(counts, np.int64).sum())))
+        e2e_a.append((ok, hyp, best, stored))
+    out["e2e_query"] = np.array(e2e_q, np.int64)
+    out["e2e_answer"] = np.array(e2e_a, np.int64)
     np.savez_compressed(os.path.join(HERE, "ref_usac.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_usac.npz"), {k: v.shape for k, v in out.items()})
 

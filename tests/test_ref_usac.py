@@ -61,6 +61,24 @@ def test_sampler_equals_the_reference(oracle):
         assert all(len(set(r)) == 3 for r in got.tolist())
 
 
+def test_end_to_end_usac_runs_equal_the_reference_loop(oracle):
+    """Ten synthetic frame pairs (70 % ... 0 % inliers, all four metrics): the oracle's own per-hypothesis counts were replayed
+    through the reference's solve() when the vectors were made; po_ransac's USAC run over the same pairs must report the
+    iterations, the best count and the best hypothesis the reference's loop reported (capped at the H handed to the oracle)."""
+    from putslam_amd import synth
+    from putslam_amd._abi import TUM_FR1_K, default_ransac_params
+    for (n, index, frac1000, mode, H, M, csum), (ok, hyp, best, stored) in zip(G["e2e_query"], G["e2e_answer"]):
+        a, b = synth.make_pair(int(n), config=2, index=int(index), inlier_frac=frac1000 / 1000.0)
+        m = oracle.match_hamming256(a["desc"], b["desc"])
+        prm = default_ransac_params(int(mode))
+        cfg, _ = make_config(EST_USAC, int(H), seed=1000 + int(index))
+        counts, M2 = oracle.hypothesis_counts(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)
+        assert M2 == M and int(np.asarray(counts, np.int64).sum()) == csum       # the outcomes the reference's loop was fed
+        st = oracle.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)["stats"]
+        assert ok == 1 and int(st["iterationsRun"]) == min(int(hyp), int(H)), (int(index), int(st["iterationsRun"]), int(hyp))
+        assert int(st["bestInlierCount"]) == best and int(st["bestHypothesis"]) == stored, (int(index), st, best, stored)
+
+
 @pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/usac_harness is built where /root/reference exists")
 def test_live_harness_agrees_on_fresh_cases(oracle):
     """Where the harness binary is present (the build container): new random cases, answered by the reference's code now."""
