@@ -394,6 +394,22 @@ def test_usac_limit_table_equals_the_reference_code(ctx):
     assert undefined == 56          # (57 pairs on file, one of them for M = 1778)
 
 
+def test_usac_runs_equal_the_reference_loop(ctx):
+    """The DEVICE's USAC runs over ten synthetic pairs against what the reference's own solve() reported for the same outcome
+    sequences (tests/golden/ref_usac.npz, e2e section: oracle counts replayed through include/putslam/USAC/USAC.h)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_usac.npz"))
+    for (n, index, frac1000, mode, H, M, csum), (ok, hyp, best, stored) in zip(G["e2e_query"], G["e2e_answer"]):
+        a, b = synth.make_pair(int(n), config=2, index=int(index), inlier_frac=frac1000 / 1000.0)
+        m = ctx.match_hamming256(a["desc"], b["desc"])
+        prm = default_ransac_params(int(mode))
+        cfg, _ = make_config(EST_USAC, int(H), seed=1000 + int(index))
+        st = ctx.ransac_rigid3d(prm, cfg, TUM_FR1_K, a["pts"], b["pts"], m)["stats"]
+        assert int(st["numMatchesValid"]) == M
+        assert int(st["iterationsRun"]) == min(int(hyp), int(H)), (int(index), int(st["iterationsRun"]), int(hyp))
+        assert int(st["bestInlierCount"]) == best and int(st["bestHypothesis"]) == stored, (int(index), st, best, stored)
+
+
 # ---------------------------------------------------------------- A10 Kabsch (double)
 @pytest.mark.parametrize("n", [3, 100, 500, 4097, 16384, 16385, 100003, 5000000])  # > 16384: multi-wave reduction
 def test_kabsch_f64(ctx, oracle, n):
