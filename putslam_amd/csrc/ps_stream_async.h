@@ -303,10 +303,14 @@ int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int
     const double t0 = now();
     hipEvent_t ev = a->upEv[(size_t)(a->chunkSeq % (long long)a->upEv.size())];
     a->chunkSeq++;
-    // (PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD=1, a diagnostic: after the first 64 chunks the uploads are skipped and the chunks run on
-    // whatever frames the ring holds -- results are then meaningless; it tells what the pipeline does when the link costs nothing)
+    // (a build with -DPS_STREAM_DIAG and PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD=1 skips the uploads after the first 64 chunks -- the chunks
+    // then run on whatever frames the ring holds and the results are meaningless; it told what the pipeline does when the link
+    // costs nothing, profiles/r05h/stream_limits.txt.  The shipped library does not contain it.)
+#ifdef PS_STREAM_DIAG
     static const bool diagNoUpload = std::getenv("PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD") != nullptr;
-    if (!(diagNoUpload && a->chunkSeq > 64)) {
+    if (!(diagNoUpload && a->chunkSeq > 64))
+#endif
+    {
         PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
                               a->copyStream));
         PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
