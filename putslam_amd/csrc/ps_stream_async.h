@@ -4,10 +4,10 @@
 //
 // Call shape served: reference src/Matcher/matcher.cpp:452-516 (one frame per call, the previous frame kept as state) in the
 // loop of src/PUTSLAM/PUTSLAM.cpp:677-740.  The synchronous ps_vo_stream_push pays a copy in, four kernels, a copy out and a
-// synchronisation per frame (0.1 ms: 10 k frames/s); here frames are collected into chunks, each chunk is one batched call
+// synchronisation per frame (0.08 ms: 12.5 k frames/s); here frames are collected into chunks, each chunk is one batched call
 // (ps_vo_pairs_device's launches) on one of several lanes, and the results are returned with a lag:
 //
-//   host frames --(copy stream: SDMA uploads)--> ring of frames in HBM --(lane i: kernels 1-4, download)--> pinned result block i --> pop
+//   host frames --(copy stream: SDMA uploads)--> ring of frames in HBM --(lane k % lanes: kernels 1-4)--(download stream)--> pinned block --> pop
 //
 //   * the copy stream carries ONLY the two large uploads of every chunk (descriptors, points), which the runtime gives to an
 //     SDMA engine: back to back they keep the link at 48 GB/s of its 55.  The chunk's small meta block (pair list, row counts)
@@ -27,10 +27,10 @@
 //     chunk's last frame, this chunk's first frame) needs no second upload.  The chunks alive (running or queued on a lane) read at most the
 //     (lanes + ahead - 1) x chunkFrames + 1 slots written last, a jump to slot 0 skips fewer than chunkFrames, the new chunk
 //     writes at most chunkFrames: no slot that is still read is overwritten, with no device-side wait.
-//   * lane = a private PsContext (stream + scratch arena) + device / pinned result blocks (the pinned one changes hands at the
-//     pop: the caller reads it until the next pop, the lane continues with the spare one) + a small meta block (the chunk's
-//     pair list and a snapshot of the ring's row counts, one upload).  Consecutive chunks go to consecutive lanes, so one
-//     chunk's matrix-core Hamming sweep runs beside another's vector scoring sweep, as bench.py's sub-batch chains do.
+//   * lane = a private PsContext (stream + scratch arena).  Consecutive chunks go to consecutive lanes, so one chunk's matrix-core
+//     Hamming sweep runs beside another's vector scoring sweep, as bench.py's sub-batch chains do.  The pinned result block of a
+//     place changes hands at the pop: the caller reads it until the next pop, the place continues with the spare one -- so a
+//     place is free the moment its results are popped.
 //   * per chunk: 2 uploads, the meta kernel, the batched call's launches, 1 download (5 for a partly filled chunk); uploads are
 //     in stream order, so the halo frame needs no event of its own.
 //   * results are those of ONE ps_vo_pairs_device call over the whole sequence: pair k draws from cfg->seed + k.
