@@ -33,7 +33,10 @@ After the timed regions (never part of `value`) rank 0 of a single-GPU run adds 
   * `other_modes`: the same sequence as ONE launch chain in the regimes every shipped reference config runs --
     errorVersion 0 with H = 4096 fixed, and errorVersion 0 with the reference's own adaptive <= 487-iteration schedule
     (RANSAC.cpp:30,450-453) -- `ms_per_step`, `pairs_per_s` and the kernels' own durations; the timed workload with the
-    staged scoring off; USAC at the reference's cap of 850 000 hypotheses;
+    staged scoring off; USAC at the reference's cap of 850 000 hypotheses; `streamed*` (BASELINE configs[2] as written: frames
+    uploaded from pinned host memory, results downloaded, ps_vo_stream_push_many / pop_many); `stress/E0`, `stress/E1`
+    (configs[4]); `.../inliers40`, `.../inliers90` (the timed step on data with other shares of true correspondences);
+    `latency` (configs[1] through the C ABI, demos/cpp/demo_latency);
   * `cpu_baseline`: the oracle on the same workload on all host cores, 5 passes, median, with the SIMD popcount
     matcher (OpenCV's normHamming is vectorised; the scalar-popcnt figure is kept as `scalar_matcher_value`)
     (+ the reference's own <= 487-iteration schedule as `cpu_reference_schedule`).
