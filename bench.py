@@ -15,7 +15,8 @@ pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypothes
 thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
 72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
 
-Submission: the step's pairs go out as --streams sub-batch chains (default 3), one HIP stream and one
+Submission: the step's pairs go out as --streams sub-batch chains (default 2; three read 1.3 % less with the runtime's 16
+hardware queues, profiles/r05k/chains_ab.txt), one HIP stream and one
 context each.  With --join end (default) the chains are ordered only within their own stream, so
 consecutive steps pipeline into each other (one chain's matrix-core Hamming sweep runs beside another's vector
 scoring sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
@@ -27,7 +28,7 @@ all of them.
 After the timed regions (never part of `value`) rank 0 of a single-GPU run adds short legs:
   * a single-chain leg -- the same step as ONE launch chain on one stream, HIP events around every kernel: the
     kernels' own durations.  `kernel_ms`, `roofline`, `kernel_bounds`, `single_chain` come from it (the timed region's
-    per-launch figures, measured while three chains share the CUs, are kept as `timed_region_kernel_ms`);
+    per-launch figures, measured while the chains share the CUs, are kept as `timed_region_kernel_ms`);
   * one pass with the fast scoring kernel's statistics on (`score_parked_frac`; `score_evals_frac` = share of the
     complete hypotheses x matches sweep the staged scoring still evaluates, 1.0 without it);
   * `other_modes`: the same sequence as ONE launch chain in the regimes every shipped reference config runs --
@@ -106,7 +107,7 @@ def parse():
     ap.add_argument("--preset", default=None, choices=["demoMatching", "sequence", "stress"],
                     help="BASELINE configs: demoMatching = configs[1] (one pair per step), sequence = configs[2] "
                          "(default), stress = configs[4] (5000 kpts, H = 100000, 8 pairs per step)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="sub-batch chains of the step, one HIP stream and one context (scratch arena) each; with "
                          "--join end they run freely, so one chain's popcount sweep overlaps another's scoring sweep")
     ap.add_argument("--join", default="end", choices=["step", "end"],
@@ -190,7 +191,7 @@ def main():
     # The sub-batches of a step run on separate HIP streams; with the runtime's default of four hardware queues two
     # streams can end up sharing one (then they serialise).  More queues keep them apart (measured: no effect on two
     # streams, 105 k -> 117 k pairs/s on three).  Must be set before the HIP runtime initialises.
-    # (round 5: 16 -- the streamed legs run up to six lanes + an upload and a download stream beside the three chains' streams; with
+    # (round 5: 16 -- the streamed legs run up to six lanes + an upload and a download stream beside the chains' streams; with
     # eight queues two of those shared one and the leg dropped from 390 k to 130 k pairs/s; the headline is the same either way)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
