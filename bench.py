@@ -117,6 +117,7 @@ def parse():
                     help="with --streams 2: fraction of the pairs on stream 0.  Unequal halves keep the two chains out of step -- one "
                          "runs its matrix-core Hamming sweep while the other is in its vector scoring sweep -- where equal ones march in "
                          "lockstep: 0.45 reads 557 - 561 k, 0.5 541 - 549 k (profiles/r05k/chains_ab.txt)")
+    ap.add_argument("--cuts", default=None, help="explicit cut points of the chains as fractions of the pairs, comma separated (streams - 1 values)")
     ap.add_argument("--dump-records", default=None,
                     help="test hook: write the per-pair records rank 0 holds after the last step (numpy .npy)")
     ap.add_argument("--as-rank", type=int, default=None,
@@ -272,6 +273,9 @@ def main():
     bounds = [P * i // S for i in range(S + 1)]
     if S == 2:
         bounds = [0, int(P * args.split), P]
+    if args.cuts:                                          # (experiments: explicit cut points, e.g. --streams 3 --cuts 0.3,0.63)
+        bounds = [0] + [int(P * float(c)) for c in args.cuts.split(",")] + [P]
+        assert len(bounds) == S + 1 and all(bounds[i] < bounds[i + 1] for i in range(S))
     # one non-default torch stream per sub-batch chain (the C ABI reads a NULL stream as "the context's private
     # stream", so the legacy default stream is never handed over)
     chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
