@@ -5,7 +5,7 @@
 #   3. --pmc WRITE_SIZE        : HBM write traffic (separate pass)
 # Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ afterwards.
 # The profiled command is the single launch chain (--streams 1): every kernel has the chip to itself, which is what
-# bench.py's `roofline` / `kernel_ms` (its single-chain leg) report; the default three-chain timing of `value` is in
+# bench.py's `roofline` / `kernel_ms` (its single-chain leg) report; the default (two chains out of step) timing of `value` is in
 # bench_default.json of the same directory.
 set -u
 TAG=${1:-r02}
