@@ -490,7 +490,7 @@ def main():
     if other_modes is not None and args.preset is None and not args.no_stress:
         # ---- BASELINE configs[4] under the driver's clock: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule
         try:
-            other_modes.update(stress_legs(args, api, c0, chains[0], dev))
+            other_modes.update(stress_legs(args, api, c0, chains[0], dev, ctxs, chains))
         except Exception as e:
             other_modes["stress"] = {"error": repr(e)}
     if other_modes is not None and args.preset is None and not args.no_data_legs:
@@ -901,7 +901,7 @@ def latency_leg(kpts=2000, calls=600):
     return out
 
 
-def stress_legs(args, api, c0, chain, dev):
+def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
     """BASELINE configs[4]: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule (RANSAC.cpp:87-150 with
     the adaptive stop disabled), both metrics, one launch chain, HIP events around every kernel."""
     import torch
@@ -949,6 +949,22 @@ def stress_legs(args, api, c0, chain, dev):
                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": P,
                          "avg_launch_ms": kms[dom], "traffic": None,
                          "whole_call_frac": bpp * P / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if ctxs is not None and len(ctxs) >= 2 and P >= 4:
+            # the same 8 pairs submitted like the timed region: two unequal chains (3 + 5 pairs) that are never joined
+            b2 = [0, max(1, int(P * 0.45)), P]
+
+            def chains_step():
+                run_pairs_split(ctxs[:2], chains[:2], prm, EST_FIXED, hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=b2, join=False)
+
+            for _ in range(3):
+                chains_step()
+            torch.cuda.synchronize(dev)
+            tc = time.perf_counter()
+            for _ in range(n):
+                chains_step()
+            torch.cuda.synchronize(dev)
+            cms = (time.perf_counter() - tc) / n * 1e3
+            out["stress/E%d" % ev]["chains"] = {"streams": 2, "bounds": b2, "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
     return out
 
 
