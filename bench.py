@@ -117,6 +117,11 @@ def parse():
                     help="with --streams 2: fraction of the pairs on stream 0.  Unequal halves keep the two chains out of step -- one "
                          "runs its matrix-core Hamming sweep while the other is in its vector scoring sweep -- where equal ones march in "
                          "lockstep: 0.45 reads 557 - 561 k, 0.5 541 - 549 k (profiles/r05k/chains_ab.txt)")
+    ap.add_argument("--submit", default="queue", choices=["queue", "python"],
+                    help="queue (default): every step is ONE ps_batch_queue_submit -- the library owns the chains (contexts + streams), "
+                         "splits the batch 45 %% / 55 %% and never joins them; python: rounds 3 - 5's submission, the sub-batches handed "
+                         "to --streams contexts from here (also taken for --cuts, --join step, another --split, --shard sequence)")
+    ap.add_argument("--no-native-legs", action="store_true", help="skip the C++ host legs (demos/cpp/demo_batch_queue, demo_sequences_multi_gpu)")
     ap.add_argument("--cuts", default=None, help="explicit cut points of the chains as fractions of the pairs, comma separated (streams - 1 values)")
     ap.add_argument("--dump-records", default=None,
                     help="test hook: write the per-pair records rank 0 holds after the last step (numpy .npy)")
@@ -232,12 +237,10 @@ def main():
 
     from putslam_amd import api, synth
     from putslam_amd._abi import (EST_FIXED, EST_RANSAC, EST_USAC, TUM_FR1_K, default_ransac_params, make_config)
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue, run_pairs_split
 
     est = {"fixed": EST_FIXED, "ransac": EST_RANSAC, "usac": EST_USAC}[args.estimator]
     S = max(1, args.streams)
-    ctxs = [api.Context(dev.index) for _ in range(S)]
-    ctx = ctxs[0]
     prm = default_ransac_params(args.error_version)
     vrank = rank if args.as_rank is None else args.as_rank   # which rank's sequence / seed this process works on
     cfg, _ = make_config(est, args.hyp, seed=0xB0B0 + vrank)
@@ -268,6 +271,19 @@ def main():
     P = len(seq["pairs"])
     if not shard_seq:
         Pmax = P
+    # The submission of the timed region: a PsBatchQueue of S chains (the library owns contexts and streams and splits every
+    # batch), unless an experiment asks for something the queue does not do.  (Batches of fewer than 20 pairs go to the queue's
+    # chains in turn, whole: a multi-rank run's per-chain record gathers want fixed bounds, so those keep the Python submission.)
+    use_queue = (args.submit == "queue" and not args.cuts and args.join == "end" and S <= 4 and (S != 2 or abs(args.split - 0.45) < 1e-9)
+                 and not shard_seq and (P >= 20 or S == 1 or not dist_on))
+    queue = None
+    if use_queue:
+        parent = api.Context(dev.index)          # the queue's parent: options' source, error texts
+        queue = api.BatchQueue(parent, S)
+        ctxs = queue.contexts
+    else:
+        ctxs = [api.Context(dev.index) for _ in range(S)]
+    ctx = ctxs[0]
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
     pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
     bounds = [P * i // S for i in range(S + 1)]
@@ -278,7 +294,11 @@ def main():
         assert len(bounds) == S + 1 and all(bounds[i] < bounds[i + 1] for i in range(S))
     # one non-default torch stream per sub-batch chain (the C ABI reads a NULL stream as "the context's private
     # stream", so the legacy default stream is never handed over)
-    chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    if use_queue:   # the chains' own streams, as torch sees them (record packing / gathers of a multi-rank run are queued on them)
+        chains = [torch.cuda.ExternalStream(c.stream_ptr, device=dev) for c in ctxs]
+        bounds = [0, P * 450 // 1000, P] if (S == 2 and P >= 20) else bounds
+    else:
+        chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
     join = args.join == "step"
     # gather blocks: chain i carries pairs [bounds[i], bounds[i+1]) of this rank; with --shard sequence the shards differ
     # by at most one pair and every rank pads its LAST chain's block to the size of the largest shard's
@@ -293,7 +313,10 @@ def main():
     def step():
         # S sub-batches of the step on S streams (device_batch.run_pairs_split); with --join end the chains are
         # ordered only within their own stream, so consecutive steps pipeline into each other
-        run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds, join=join)
+        if use_queue:
+            run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, pb)
+        else:
+            run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds, join=join)
         if dist_on:
             # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI -- one
             # gather per chain, queued behind that chain's kernels and issued asynchronously: it completes beside
@@ -508,6 +531,14 @@ def main():
             other_modes["latency"] = latency_leg()
         except Exception as e:
             other_modes["latency"] = {"error": repr(e)}
+    if other_modes is not None and args.preset is None and not args.no_native_legs:
+        # ---- what a C / C++ host that links the library gets on THIS workload: (a) a loop of ps_batch_queue_submit calls
+        # (demos/cpp/demo_batch_queue), (b) the sharding layer with a world of one (demos/cpp/demo_sequences_multi_gpu: a queue per
+        # member, asynchronous RCCL gather of the records) -- child processes of their own, GPU_MAX_HW_QUEUES unset in their environment
+        try:
+            other_modes.update(native_legs(args, seq, cfg))
+        except Exception as e:
+            other_modes["native"] = {"error": repr(e)}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
@@ -654,6 +685,7 @@ def main():
                 "backend": (dist.get_backend() if dist_on else None), "shard": args.shard,
                 "force_dist": bool(dist_on and world == 1),
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "split": (args.split if S == 2 and not shard_seq else None), "join": args.join,
+                "submit": ("ps_batch_queue_submit (the library's chains)" if use_queue else "python (sub-batches handed to the contexts from bench.py)"),
                 "matcher_kernel": matcher + ("-fused" if matcher_fused else ""), "score_kernel": score,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
@@ -685,12 +717,15 @@ def main():
                              "chains' kernels share the CUs (they sum to more than ms_per_step); kernel_ms / roofline / "
                              "kernel_bounds come from the single-chain leg (DESIGN.md section 5)"),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline(args, seq, prm, cfg, est))
-        print(json.dumps(out))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU figure beside the line, on rank 0's host cores -- after the closing barrier of a multi-rank run, so that no
+        # rank waits in a collective while rank 0 computes (its peers have left; their GPUs are idle, the cores are rank 0's)
+        if not args.no_cpu_baseline:
+            out.update(cpu_baseline(args, seq, prm, cfg, est))
+        print(json.dumps(out))
 
 
 PCIE_GEN5_X16_GBS = 63.0        # PCIe 5.0 x16, one direction, after 128b/130b encoding (the MI355X host link)
@@ -898,6 +933,63 @@ def latency_leg(kpts=2000, calls=600):
     out["pair_host_time_in_call_us"] = float(m.group(1)) if m else None
     if out["pushed_frame_us"]:
         out["pushed_frames_per_s"] = 1e6 / out["pushed_frame_us"]
+    return out
+
+
+def native_legs(args, seq, cfg):
+    """The timed workload through the C ABI from C++ hosts (no Python, no torch in those processes).  The sequence travels as a
+    file; the children's environment has no GPU_MAX_HW_QUEUES (the library's constructor sets its default)."""
+    import re
+    import subprocess
+    import tempfile
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    with tempfile.TemporaryDirectory(prefix="putslam_bench_") as td:
+        path = os.path.join(td, "seq0.bin")
+        F, cap = seq["desc"].shape[:2]
+        with open(path, "wb") as f:
+            np.array([F, cap], np.int32).tofile(f)
+            np.ascontiguousarray(seq["nkpts"], np.int32).tofile(f)
+            np.ascontiguousarray(seq["desc"], np.uint8).tofile(f)
+            np.ascontiguousarray(seq["pts"], np.float32).tofile(f)
+        common = ["--hyp", str(args.hyp), "--estimator", args.estimator, "--error-version", str(args.error_version)]
+        steps = str(max(10, args.steps))
+        exe = os.path.join(ROOT, "demos", "cpp", "demo_batch_queue")
+        if os.path.exists(exe):
+            for name, chains in (("batch_queue_cpp", 2), ("batch_queue_cpp/one_context", 1)):
+                p = subprocess.run([exe, "--sequence", path, "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--chains", str(chains)]
+                                   + common + (["--check"] if chains == 2 else []), capture_output=True, text=True, timeout=180, env=env)
+                m = re.search(r"batch_queue: chains (\d+), median ([0-9.]+) frame-pairs/s, min ([0-9.]+), max ([0-9.]+).*hw_queues_seen (\d+) \(GPU_MAX_HW_QUEUES=([^)]*)\)", p.stdout)
+                leg = {"rc": p.returncode, "what": ("demos/cpp/demo_batch_queue: a C++ loop of ps_batch_queue_submit calls over the timed workload's "
+                                                     "sequence, GPU_MAX_HW_QUEUES unset in its environment" if chains == 2 else
+                                                     "the same loop through ONE context (ps_vo_pairs_device)")}
+                if m:
+                    leg.update({"chains": int(m.group(1)), "pairs_per_s": float(m.group(2)), "pairs_per_s_min": float(m.group(3)),
+                                "pairs_per_s_max": float(m.group(4)), "hw_queues_seen": int(m.group(5)), "env_GPU_MAX_HW_QUEUES_after_load": m.group(6),
+                                "steps": int(steps), "regions": 5})
+                    if chains == 2:
+                        leg["equals_one_call"] = "check against one ps_vo_pairs_device call: equal" in p.stdout
+                else:
+                    leg["error"] = (p.stdout + p.stderr)[-400:]
+                out[name] = leg
+        else:
+            out["batch_queue_cpp"] = {"error": "demos/cpp/demo_batch_queue is not built (__graft_entry__.build())"}
+        exe = os.path.join(ROOT, "demos", "cpp", "demo_sequences_multi_gpu")
+        if os.path.exists(exe):
+            p = subprocess.run([exe, "--gpus", "1", "--sequence-prefix", os.path.join(td, "seq"), "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--warm-seconds", "1"]
+                               + common, capture_output=True, text=True, timeout=180, env=env)
+            m = re.search(r"median ([0-9.]+) frame-pairs/s in all, min ([0-9.]+), max ([0-9.]+)", p.stdout)
+            leg = {"rc": p.returncode, "what": "demos/cpp/demo_sequences_multi_gpu --gpus 1: include/putslam_shard.h with a world of one -- a batch queue per "
+                                               "member, records packed on the chains and gathered over RCCL asynchronously every step (ps_shard_gather_records_async), "
+                                               "trajectory composed on rank 0"}
+            if m:
+                leg.update({"pairs_per_s": float(m.group(1)), "pairs_per_s_min": float(m.group(2)), "pairs_per_s_max": float(m.group(3)),
+                            "steps": int(steps), "regions": 5})
+            else:
+                leg["error"] = (p.stdout + p.stderr)[-400:]
+            out["native_shard"] = leg
+        else:
+            out["native_shard"] = {"error": "demos/cpp/demo_sequences_multi_gpu is not built (RCCL missing?)"}
     return out
 
 

@@ -8,7 +8,10 @@
 //
 //   demo_sequences_multi_gpu [--gpus N] [--frames 500] [--kpts 2000] [--hyp 4096] [--estimator fixed|ransac|usac]
 //                            [--error-version 1] [--seed 45232] [--steps 5] [--sequence-prefix P] [--dump records.bin]
-//                            [--traj-prefix T]
+//                            [--traj-prefix T] [--repeats 1] [--warm-seconds 0] [--blocking]
+//   --blocking: rounds 1 - 5's host loop (one context per GPU, ps_shard_gather_records every step) instead of the default --
+//               a PsBatchQueue per GPU (two chains that are never joined) and ps_shard_gather_records_async, the records of
+//               step n read after step n + 1 has been submitted.
 //   --sequence-prefix P: rank r reads its frames from P<r>.bin (int32 frames, int32 cap, int32 nkpts[frames],
 //                        uint8 desc[frames][cap][32], float pts[frames][cap][3]) instead of generating them.
 //   --dump: rank 0 writes the gathered records, float32 [world][pairs][18], after the last step.
@@ -16,12 +19,14 @@
 // ground truth.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -130,7 +135,9 @@ int upload(const Sequence &s, int P, DeviceSide &d)
 
 int main(int argc, char **argv)
 {
-    int gpus = 0, frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 5, rank = -1, world = 0;
+    int gpus = 0, frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 5, rank = -1, world = 0, repeats = 1;
+    bool blocking = false;
+    double warmSeconds = 0.0;
     uint64_t seed = 0xB0B0;
     std::string estimator = "fixed", seqPrefix, dumpPath, trajPrefix, idFile;
     for (int i = 1; i < argc; ++i) {
@@ -144,6 +151,9 @@ int main(int argc, char **argv)
         else if (a == "--error-version") errorVersion = std::atoi(next());
         else if (a == "--seed") seed = std::strtoull(next(), nullptr, 0);
         else if (a == "--steps") steps = std::atoi(next());
+        else if (a == "--repeats") repeats = std::atoi(next());
+        else if (a == "--warm-seconds") warmSeconds = std::atof(next());
+        else if (a == "--blocking") blocking = true;
         else if (a == "--sequence-prefix") seqPrefix = next();
         else if (a == "--dump") dumpPath = next();
         else if (a == "--traj-prefix") trajPrefix = next();
@@ -244,41 +254,107 @@ int main(int argc, char **argv)
         dev[(size_t)i].device = ps_shard_device(g, i);
         if (upload(seq[(size_t)i], P, dev[(size_t)i])) return 2;
     }
+    // ---- the host loop: every step submits every member's batch (asynchronous: a PsBatchQueue of two chains per member, the
+    // members on their own host threads) and starts the gather of its records; the records of step n are waited for after
+    // step n + 1 has been submitted, so nothing ever drains a GPU (at most PS_SHARD_GATHERS_IN_FLIGHT gathers are outstanding)
+    std::vector<PsRansacConfig> cfgs((size_t)L);
+    std::vector<PsFrameSet> fsets((size_t)L);
+    std::vector<PsShardJob> jobs((size_t)L);
+    for (int i = 0; i < L; ++i) {
+        const PsShardRunParams &r = rp[(size_t)i];
+        PsRansacConfig &cfg = cfgs[(size_t)i];
+        cfg.estimator = r.estimator;
+        cfg.numHypotheses = r.numHypotheses;
+        cfg.seed = r.seed + (uint64_t)ps_shard_rank(g, i); // one sequence per GPU: bench.py's seeding
+        cfg.sampleIdx = nullptr;
+        PsFrameSet &fs = fsets[(size_t)i];
+        fs.desc = dev[(size_t)i].desc;
+        fs.pts = dev[(size_t)i].pts;
+        fs.nkpts = dev[(size_t)i].nk;
+        fs.numFrames = seq[(size_t)i].frames;
+        fs.maxKpts = seq[(size_t)i].cap;
+        PsShardJob &j = jobs[(size_t)i];
+        j.params = &r.params;
+        j.cfg = &cfg;
+        j.K = r.K;
+        j.frames = &fs;
+        j.pairs = dev[(size_t)i].pairs;
+        j.P = P;
+        j.out = &dev[(size_t)i].out;
+    }
     std::vector<float> records(driveRoot ? (size_t)W * P * PS_SHARD_RECORD_FLOATS : 0);
-    std::vector<PsPairResults> results((size_t)L);
-    for (int i = 0; i < L; ++i) results[(size_t)i] = dev[(size_t)i].out;
-
-    auto step = [&]() -> int {
-        for (int i = 0; i < L; ++i) { // asynchronous: every GPU works on its own sequence
-            const PsShardRunParams &r = rp[(size_t)i];
-            PsRansacConfig cfg;
-            cfg.estimator = r.estimator;
-            cfg.numHypotheses = r.numHypotheses;
-            cfg.seed = r.seed + (uint64_t)ps_shard_rank(g, i); // one sequence per GPU: bench.py's seeding
-            cfg.sampleIdx = nullptr;
-            PsFrameSet fs;
-            fs.desc = dev[(size_t)i].desc;
-            fs.pts = dev[(size_t)i].pts;
-            fs.nkpts = dev[(size_t)i].nk;
-            fs.numFrames = seq[(size_t)i].frames;
-            fs.maxKpts = seq[(size_t)i].cap;
-            PsContext *ctx = ps_shard_context(g, i);
-            int rc2 = ps_vo_pairs_device(ctx, &r.params, &cfg, r.K, &fs, dev[(size_t)i].pairs, P, &dev[(size_t)i].out);
-            if (rc2 != PS_OK) {
-                std::fprintf(stderr, "rank %d: %s\n", ps_shard_rank(g, i), ps_last_error(ctx));
-                return rc2;
-            }
+    int64_t inFlight = -1;
+    auto take = [&](int64_t t) -> int { // the records of gather t: complete, on the host
+        const float *rec = nullptr;
+        int rc2 = ps_shard_wait(g, t, &rec);
+        if (rc2 != PS_OK) {
+            std::fprintf(stderr, "wait: %s\n", ps_shard_last_error(g));
+            return rc2;
         }
-        // the path's only exchange: 72 bytes per pair to rank 0, queued behind each member's kernels
-        int rc2 = ps_shard_gather_records(g, results.data(), nullptr, P, driveRoot ? records.data() : nullptr, 0);
-        if (rc2 != PS_OK) std::fprintf(stderr, "gather: %s\n", ps_shard_last_error(g));
+        if (driveRoot && rec) std::memcpy(records.data(), rec, records.size() * sizeof(float)); // (the consumer reads what came back)
+        return PS_OK;
+    };
+    std::function<int()> step = [&]() -> int {
+        int rc2 = ps_shard_submit_all(g, jobs.data());
+        if (rc2 != PS_OK) {
+            std::fprintf(stderr, "submit: %s\n", ps_shard_last_error(g));
+            return rc2;
+        }
+        // the path's only exchange: 72 bytes per pair to rank 0, behind each chain's share of the batch
+        int64_t t = -1;
+        rc2 = ps_shard_gather_records_async(g, P, 0, &t);
+        if (rc2 != PS_OK) {
+            std::fprintf(stderr, "gather: %s\n", ps_shard_last_error(g));
+            return rc2;
+        }
+        if (inFlight >= 0 && (rc2 = take(inFlight)) != PS_OK) return rc2; // the previous step's records
+        inFlight = t;
+        return PS_OK;
+    };
+    auto drain = [&]() -> int {
+        int rc2 = inFlight >= 0 ? take(inFlight) : PS_OK;
+        inFlight = -1;
         return rc2;
     };
-    if (step() != PS_OK) return 2; // warm-up (code objects, stop tables, scratch arenas)
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int s = 0; s < steps; ++s)
+    if (step() != PS_OK || drain() != PS_OK) return 2; // warm-up (code objects, stop tables, scratch arenas)
+    if (blocking) {
+        // rounds 1 - 5's host loop, kept for comparison: one context per member, the blocking gather every step
+        std::vector<PsPairResults> results((size_t)L);
+        for (int i = 0; i < L; ++i) results[(size_t)i] = dev[(size_t)i].out;
+        step = [&, results]() -> int {
+            for (int i = 0; i < L; ++i) {
+                const PsShardJob &j = jobs[(size_t)i];
+                PsContext *ctx = ps_shard_context(g, i);
+                int rc2 = ps_vo_pairs_device(ctx, j.params, j.cfg, j.K, j.frames, j.pairs, j.P, j.out);
+                if (rc2 != PS_OK) {
+                    std::fprintf(stderr, "rank %d: %s\n", ps_shard_rank(g, i), ps_last_error(ctx));
+                    return rc2;
+                }
+            }
+            int rc2 = ps_shard_gather_records(g, results.data(), nullptr, P, driveRoot ? records.data() : nullptr, 0);
+            if (rc2 != PS_OK) std::fprintf(stderr, "gather: %s\n", ps_shard_last_error(g));
+            return rc2;
+        };
         if (step() != PS_OK) return 2;
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    using clk = std::chrono::steady_clock;
+    if (warmSeconds > 0) { // until the chip is at its steady clock, whole steps, outside the timed regions
+        const auto tw = clk::now();
+        while (std::chrono::duration<double>(clk::now() - tw).count() < warmSeconds)
+            for (int s2 = 0; s2 < 10; ++s2)
+                if (step() != PS_OK) return 2;
+        if (drain() != PS_OK) return 2;
+    }
+    std::vector<double> rates;
+    double sec = 0;
+    for (int r = 0; r < (repeats > 0 ? repeats : 1); ++r) {
+        const auto t0 = clk::now();
+        for (int s2 = 0; s2 < steps; ++s2)
+            if (step() != PS_OK) return 2;
+        if (drain() != PS_OK) return 2; // the region ends when the last step's records are on the host
+        sec = std::chrono::duration<double>(clk::now() - t0).count();
+        rates.push_back(steps > 0 ? (double)W * P * steps / sec : 0.0);
+    }
 
     int bad = 0;
     if (driveRoot) {
@@ -311,8 +387,11 @@ int main(int argc, char **argv)
             if (seqPrefix.empty() && rank < 0 && (accepted < P || worst > 5e-3)) ++bad;
             if (records[((size_t)r * P) * PS_SHARD_RECORD_FLOATS + 17] <= 0.0f) ++bad; // the rank's block never arrived
         }
-        std::printf("%d GPU(s) x %d pairs, %d steps: %.3f ms per step, %.0f frame-pairs/s in all (records gathered over RCCL every step)\n", W,
-                    P, steps, 1e3 * sec / (steps > 0 ? steps : 1), steps > 0 ? (double)W * P * steps / sec : 0.0);
+        std::sort(rates.begin(), rates.end());
+        std::printf("%d GPU(s) x %d pairs, %d steps x %d regions (%s): %.3f ms per step, median %.0f frame-pairs/s in all, min %.0f, max %.0f "
+                    "(records gathered over RCCL every step)\n",
+                    W, P, steps, (int)rates.size(), blocking ? "one chain per GPU, blocking gather" : "batch queue per GPU, asynchronous gather",
+                    1e3 * sec / (steps > 0 ? steps : 1), rates[rates.size() / 2], rates.front(), rates.back());
         if (!dumpPath.empty()) {
             FILE *f = std::fopen(dumpPath.c_str(), "wb");
             if (!f || std::fwrite(records.data(), 4, records.size(), f) != records.size()) ++bad;

@@ -280,13 +280,51 @@ typedef struct PsPairResults {
  * 850 000, USAC_wrapper.cpp:70; touched only up to each pair's trip limit); the staged scoring's parked models take 48 bytes
  * per pair and LEADING hypothesis, 256 MB at most under the adaptive schedules (2 GiB under the fixed one): a hypothesis
  * beyond the slots is swept in one piece and, should it win, rebuilt (options "arena_mib", "last_model_slots", read only).
- * Throughput: a host that loops over batches gets 16 % more by handing every batch over as TWO UNEQUAL sub-batches (45 % / 55 %
- * of the pairs; the second one's cfg->seed advanced by the first one's pair count: the results are those of the single call)
- * through two contexts on two streams that are never joined -- the chains stay out of step, one in its matrix-core Hamming
- * sweep while the other is in its vector scoring sweep (bench.py's default submission). */
+ * Throughput: a host that loops over batches gets up to 16 % more from a PsBatchQueue (below), which hands every batch over as
+ * two unequal sub-batches through two contexts on two streams that are never joined. */
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);
+
+/* ---- A2, for a host that loops over batches (the loop of src/PUTSLAM/PUTSLAM.cpp:677-740 around Matcher::match,
+ * src/Matcher/matcher.cpp:470-515): ps_vo_pairs_device through launch chains that are never joined.
+ * One context is one launch chain: a batch's matrix-core Hamming sweep, then its vector scoring stages, dependent launches with
+ * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = 2; 1 .. 4) on ctx's device, with ctx's
+ * options, and hands every batch over as unequal sub-batches -- two chains: 45 % / 55 % of the pairs -- so that the chains stay
+ * out of step, one in its Hamming sweep while the other scores: + 8 ... 16 % on batches of hundreds of pairs
+ * (profiles/r05k/chains_ab.txt).  Batches of fewer than 20 pairs go to the chains in turn, whole.  The chains are ordered only
+ * within themselves; nothing ever makes one wait for the other.
+ *   submit: arguments of ps_vo_pairs_device (device pointers); pair p draws from cfg->seed + p whatever chain it runs on, so the
+ *           outputs are byte for byte those of ONE ps_vo_pairs_device call.  Returns at once; *ticket (may be NULL) names the
+ *           batch.  Inputs and outputs must stay valid until the batch is complete.  Consecutive batches may use the same
+ *           output block (a chain's sub-batches are stream-ordered and the chains' slices are disjoint for equal P); reading
+ *           a batch's results needs its ticket waited for.  At most 64 batches are in flight: the 65th submit waits for the first.
+ *           If a chain's call fails the error is returned (text: ps_last_error of ctx), the ticket still stands for whatever
+ *           part of the batch was queued.
+ *   wait / query: the host blocks until / asks whether both chains are past that batch (query: 1 complete, 0 not yet).
+ *   wait_on_stream: the given hipStream_t waits for the batch instead (device-side; the host does not block): what a host
+ *           that post-processes on a stream of its own, or gathers results with a collective, queues behind a batch.
+ *   context(q, i): chain i's context -- for ps_context_stream (work to be queued behind that chain's share of a batch),
+ *           ps_context_enable_timing, options; not for calls of its own while batches are in flight.
+ *   last_split: bounds[0 .. chains] of the last submitted batch: pairs [bounds[i], bounds[i+1]) ran on chain i.
+ * Hardware queues: every chain wants one of its own.  The HIP runtime gives a process GPU_MAX_HW_QUEUES of them (default 4,
+ * shared with the host's other streams) and serialises streams that share one (two chains: 415 k instead of 560 k
+ * frame-pairs/s).  The library sets GPU_MAX_HW_QUEUES=16 when it is loaded if the variable is unset (a constructor, before
+ * the process' first HIP call for a program that links the library; a host that set the variable keeps its value).  Read-only
+ * option "hw_queues_seen" = the value found; ps_batch_queue_create leaves a warning in ps_last_error(ctx) when it is too
+ * small.  A process that initialises HIP before loading the library sets the variable itself (putslam_amd/_lib.py does). */
+typedef struct PsBatchQueue PsBatchQueue;
+int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out);
+void ps_batch_queue_destroy(PsBatchQueue *q);
+int ps_batch_queue_submit(PsBatchQueue *q, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                          const PsFrameSet *frames, const int32_t *pairs, int P, const PsPairResults *out, int64_t *ticket);
+int ps_batch_queue_wait(PsBatchQueue *q, int64_t ticket);
+int ps_batch_queue_query(PsBatchQueue *q, int64_t ticket);
+int ps_batch_queue_wait_on_stream(PsBatchQueue *q, int64_t ticket, void *hipStream);
+int ps_batch_queue_synchronize(PsBatchQueue *q);
+int ps_batch_queue_chains(const PsBatchQueue *q);
+PsContext *ps_batch_queue_context(PsBatchQueue *q, int chain);
+int ps_batch_queue_last_split(const PsBatchQueue *q, int32_t *bounds);
 
 /* ---- A2, streaming form: Matcher::match (src/Matcher/matcher.cpp:452-516) with the previous frame's
  * descriptors and 3-D points resident in HBM (the prevDescriptors / prevFeatures3D state, matcher.h:379-384).
@@ -319,8 +357,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * lowest-latency setting, 64..256 the throughput setting; ps_vo_stream_push stays the synchronous per-frame form.
  *
  * Hardware queues: every lane, the upload stream and the download stream want a hardware queue of their own; the HIP runtime
- * gives a process GPU_MAX_HW_QUEUES of them (default 4) and lets streams share beyond that, which serialises what shares.  Set
- * GPU_MAX_HW_QUEUES = 16 in the environment before the first HIP call (bench.py does); with fewer than lanes + 6 the downloads
+ * gives a process GPU_MAX_HW_QUEUES of them (default 4) and lets streams share beyond that, which serialises what shares.  The
+ * library sets GPU_MAX_HW_QUEUES = 16 itself when it is loaded and the variable is unset (see PsBatchQueue above); with fewer than lanes + 6 the downloads
  * are queued on the lanes' own streams instead of a stream of their own (results identical, 10 - 20 % slower).
  *
  * Pair k of the stream (frames k, k+1 counted from the last reset; frame k is the query = previous frame) draws its

@@ -8,6 +8,11 @@ import os
 
 from ._abi import PsDMatch, PsFrameSet, PsHostPairResults, PsPairResults, PsRansacConfig, PsRansacParams, PsRansacStats
 
+# Hardware queues: the library's launch chains (batch queue, pipelined stream) want one each, the HIP runtime reads
+# GPU_MAX_HW_QUEUES once, at its first call.  The library sets its default (16) from a constructor when it is loaded -- too late
+# in a Python process whose torch has already initialised HIP, so the default is also set here, at import (csrc/ps_env.cpp).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PUTSLAM_HIP_LIB: A/B hook of the profiling scripts (another build of the same library, e.g. a kernel variant)
 LIB_PATH = os.environ.get("PUTSLAM_HIP_LIB") or os.path.join(_HERE, "libputslam_hip.so")
@@ -19,7 +24,10 @@ EXPORTED = [
     "ps_context_set_option", "ps_context_get_option",
     "ps_last_error", "ps_abi_version", "ps_device_arch",
     "ps_match_hamming256", "ps_ransac_rigid3d", "ps_umeyama_f32", "ps_kabsch_f64",
-    "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
+    "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device",
+    "ps_batch_queue_create", "ps_batch_queue_destroy", "ps_batch_queue_submit", "ps_batch_queue_wait", "ps_batch_queue_query",
+    "ps_batch_queue_wait_on_stream", "ps_batch_queue_synchronize", "ps_batch_queue_chains", "ps_batch_queue_context",
+    "ps_batch_queue_last_split", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_vo_stream_set_result_mode", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
     "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
@@ -39,15 +47,13 @@ class HipLibraryMissing(RuntimeError):
 
 
 def _try_build():
-    """The .so is a build artefact (git-ignored): if it is absent but hipcc is here, compile it in-tree."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    src = os.path.join(_HERE, "csrc", "ps_capi.hip")
-    if not (os.path.exists(hipcc) and os.path.exists(src)):
+    """The .so is a build artefact (git-ignored): if it is absent but hipcc is here, compile it in-tree (_build.py)."""
+    from . import _build
+    if not (os.path.exists(_build.HIPCC) and os.path.exists(os.path.join(_build.CSRC, _build.DEVICE_TU))):
         return
     import subprocess
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-shared", src, "-o", LIB_PATH]
     try:
-        subprocess.check_call(cmd)
+        _build.build_hip()
     except (OSError, subprocess.CalledProcessError):
         pass
 
@@ -154,6 +160,19 @@ def load_path(path):
     L.ps_host_free.restype = None
     L.ps_vo_pairs_device.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp,
                                      C.POINTER(PsFrameSet), vp, i32, C.POINTER(PsPairResults)]
+    L.ps_batch_queue_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.ps_batch_queue_destroy.argtypes = [vp]
+    L.ps_batch_queue_destroy.restype = None
+    L.ps_batch_queue_submit.argtypes = [vp, C.POINTER(PsRansacParams), C.POINTER(PsRansacConfig), vp, C.POINTER(PsFrameSet), vp, i32,
+                                        C.POINTER(PsPairResults), C.POINTER(C.c_int64)]
+    L.ps_batch_queue_wait.argtypes = [vp, C.c_int64]
+    L.ps_batch_queue_query.argtypes = [vp, C.c_int64]
+    L.ps_batch_queue_wait_on_stream.argtypes = [vp, C.c_int64, vp]
+    L.ps_batch_queue_synchronize.argtypes = [vp]
+    L.ps_batch_queue_chains.argtypes = [vp]
+    L.ps_batch_queue_context.argtypes = [vp, i32]
+    L.ps_batch_queue_context.restype = vp
+    L.ps_batch_queue_last_split.argtypes = [vp, vp]
     L.ps_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
     L.ps_algorithmic_bytes.restype = C.c_uint64
     L.ps_kernel_names.restype = C.POINTER(C.c_char)

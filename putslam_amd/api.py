@@ -56,6 +56,11 @@ class Context:
     def set_stream(self, stream_ptr):
         self._chk(self._L.ps_context_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    @property
+    def stream_ptr(self):
+        """The hipStream_t the context's calls are queued on (ps_context_stream)."""
+        return int(self._L.ps_context_stream(self._h) or 0)
+
     def synchronize(self):
         self._chk(self._L.ps_context_synchronize(self._h))
 
@@ -271,6 +276,72 @@ class Context:
         res = PsPairResults(out.matches_ptr, out.num_matches_ptr, out.mask_ptr, out.pose_ptr, out.stats_ptr)
         self._chk(self._L.ps_vo_pairs_device(self._h, C.byref(params), C.byref(cfg), _p(K), C.byref(fs),
                                              C.c_void_p(pairs_dev_ptr), int(P), C.byref(res)))
+
+
+class _ChainContext(Context):
+    """A chain context of a BatchQueue: owned by the queue (never destroyed from here)."""
+
+    def __init__(self, L, handle):
+        self._L = L
+        self._h = C.c_void_p(handle)
+
+    def close(self):
+        self._h = None
+
+
+class BatchQueue:
+    """PsBatchQueue: ps_vo_pairs_device through launch chains that are never joined (two chains, 45 % / 55 % of every batch)."""
+
+    def __init__(self, ctx: Context, chains=0):
+        self._ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx._L.ps_batch_queue_create(ctx._h, int(chains), C.byref(h)))
+        self._h = h
+        self.chains = ctx._L.ps_batch_queue_chains(h)
+        self.contexts = [_ChainContext(ctx._L, ctx._L.ps_batch_queue_context(h, i)) for i in range(self.chains)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._ctx._L.ps_batch_queue_destroy(self._h)
+            self._h = None
+            for c in self.contexts:
+                c.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, params, cfg, K, frames: "DeviceFrames", pairs_dev_ptr, P, out: "DeviceResults"):
+        """Asynchronous; returns the batch's ticket."""
+        K = np.ascontiguousarray(K, np.float32)
+        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts)
+        res = PsPairResults(out.matches_ptr, out.num_matches_ptr, out.mask_ptr, out.pose_ptr, out.stats_ptr)
+        t = C.c_int64(-1)
+        self._ctx._chk(self._ctx._L.ps_batch_queue_submit(self._h, C.byref(params), C.byref(cfg), _p(K), C.byref(fs),
+                                                          C.c_void_p(pairs_dev_ptr), int(P), C.byref(res), C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket):
+        self._ctx._chk(self._ctx._L.ps_batch_queue_wait(self._h, int(ticket)))
+
+    def query(self, ticket):
+        r = self._ctx._L.ps_batch_queue_query(self._h, int(ticket))
+        if r < 0:
+            self._ctx._chk(r)
+        return bool(r)
+
+    def wait_on_stream(self, ticket, stream_ptr):
+        self._ctx._chk(self._ctx._L.ps_batch_queue_wait_on_stream(self._h, int(ticket), C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ctx._chk(self._ctx._L.ps_batch_queue_synchronize(self._h))
+
+    def last_split(self):
+        b = np.zeros(self.chains + 1, np.int32)
+        self._ctx._L.ps_batch_queue_last_split(self._h, b.ctypes.data)
+        return [int(x) for x in b]
 
 
 class VoStream:

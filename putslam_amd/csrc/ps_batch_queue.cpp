@@ -1,0 +1,299 @@
+// ps_batch_queue.cpp -- PsBatchQueue (include/putslam_hip.h): the submission pattern that gives a looping host the library's
+// full rate, inside the library.
+//
+// A host that hands batch after batch to ONE context gets one launch chain: the matrix-core Hamming sweep and the vector scoring
+// sweep of a batch run one after the other, and a chain's six or seven dependent launches leave the chip idle between them
+// (484 - 521 k frame-pairs/s on the 499-pair workload).  Two chains that are never joined -- every batch split 45 % / 55 %, each
+// part on its own context + stream -- stay out of step: one chain's Hamming sweep runs beside the other's scoring sweep
+// (560 k; profiles/r05k/chains_ab.txt).  Rounds 3 - 5 had this recipe in bench.py and as a paragraph of the header; a C / C++
+// host (the reference is one: the loop of src/PUTSLAM/PUTSLAM.cpp:677-740 around Matcher::match, src/Matcher/matcher.cpp:470-515)
+// could only rebuild it by hand.  Here it is three calls: create, submit, wait.
+//
+//   * chains are ordered only within themselves: submit never makes one chain wait for another, and a batch's completion is an
+//     event per chain, recorded behind the chain's last launch -- waited for by the host (ps_batch_queue_wait) or by a stream of
+//     the host's (ps_batch_queue_wait_on_stream), never by the other chain;
+//   * pair p of a batch keeps its hypothesis stream cfg->seed + p whatever chain it runs on: results are byte for byte those of
+//     one ps_vo_pairs_device call;
+//   * small batches (fewer than 20 pairs) are not worth splitting: they go to the chains in turn, whole -- consecutive batches
+//     then overlap the same way.
+// Host-only translation unit: everything here is queue bookkeeping around ps_vo_pairs_device.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ps_internal.h"
+
+namespace {
+
+constexpr int kMaxChains = 4;
+constexpr int kTickets = 64;      // batches that can be in flight; submit waits for the oldest when the ring is full
+constexpr int kSplitFromPairs = 20;
+
+struct Ticket {
+    long long seq = -1;              // batch number this slot holds (-1: never used)
+    bool used[kMaxChains] = {false, false, false, false};
+    hipEvent_t ev[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+} // namespace
+
+struct PsBatchQueue {
+    PsContext *parent = nullptr;     // options' source and the place error texts go to (not owned)
+    int device = 0;
+    int chains = 0;
+    int splitPermille = 450;         // two chains: share of the pairs on chain 0
+    PsContext *ctx[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+    Ticket ring[kTickets];
+    long long next = 0;              // number of the next batch
+    int32_t lastBounds[kMaxChains + 1] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int qfail(PsBatchQueue *q, int code, const std::string &what)
+{
+    if (q && q->parent) psi_set_error(q->parent, what.c_str());
+    return code;
+}
+
+int wait_slot(PsBatchQueue *q, Ticket &t)
+{
+    for (int i = 0; i < q->chains; ++i)
+        if (t.used[i]) {
+            hipError_t e = hipEventSynchronize(t.ev[i]);
+            if (e != hipSuccess) return qfail(q, PS_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+        }
+    return PS_OK;
+}
+
+// which pairs of a batch of P go to which chain: bounds[0 .. chains]
+void split(const PsBatchQueue *q, int P, long long seq, int32_t *bounds)
+{
+    const int C = q->chains;
+    if (C == 1) {
+        bounds[0] = 0;
+        bounds[1] = P;
+        return;
+    }
+    if (P < kSplitFromPairs) { // the whole batch on one chain, the chains in turn
+        const int c = (int)(seq % C);
+        for (int i = 0; i <= C; ++i) bounds[i] = i <= c ? 0 : P;
+        return;
+    }
+    if (C == 2) {
+        bounds[0] = 0;
+        bounds[1] = (int32_t)((long long)P * q->splitPermille / 1000);
+        bounds[2] = P;
+        return;
+    }
+    for (int i = 0; i <= C; ++i) bounds[i] = (int32_t)((long long)P * i / C);
+}
+
+} // namespace
+
+extern "C" {
+
+int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out)
+{
+    if (!out) return PS_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!ctx) return PS_ERR_BAD_ARG;
+    if (chains == 0) chains = 2;
+    if (chains < 1 || chains > kMaxChains) {
+        psi_set_error(ctx, "ps_batch_queue_create: chains 1 .. 4 (0 = 2)");
+        return PS_ERR_BAD_ARG;
+    }
+    PsBatchQueue *q = new PsBatchQueue();
+    q->parent = ctx;
+    q->device = ps_context_device(ctx);
+    q->chains = chains;
+    if (const char *v = std::getenv("PUTSLAM_HIP_QUEUE_SPLIT")) { // (A/B hook: share of chain 0 in permille)
+        const int x = std::atoi(v);
+        if (x >= 50 && x <= 950) q->splitPermille = x;
+    }
+    for (int i = 0; i < chains; ++i) {
+        int rc = ps_context_create(q->device, &q->ctx[i]);
+        if (rc != PS_OK) {
+            q->ctx[i] = nullptr;
+            ps_batch_queue_destroy(q);
+            psi_set_error(ctx, "ps_batch_queue_create: chain context");
+            return rc;
+        }
+        psi_copy_options(q->ctx[i], ctx);
+    }
+    if (hipSetDevice(q->device) != hipSuccess) {
+        ps_batch_queue_destroy(q);
+        psi_set_error(ctx, "ps_batch_queue_create: hipSetDevice");
+        return PS_ERR_HIP;
+    }
+    for (Ticket &t : q->ring)
+        for (int i = 0; i < chains; ++i)
+            if (hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming) != hipSuccess) {
+                t.ev[i] = nullptr;
+                ps_batch_queue_destroy(q);
+                psi_set_error(ctx, "ps_batch_queue_create: hipEventCreateWithFlags");
+                return PS_ERR_HIP;
+            }
+    // every chain wants a hardware queue of its own (ps_env.cpp): with fewer the chains share one and serialise -- results are
+    // the same, the rate is that of one chain or worse.  Not an error; the text is there for whoever asks.
+    if (chains > 1 && psi_hw_queues_seen() > 0 && psi_hw_queues_seen() < chains + 2) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg,
+                      "ps_batch_queue_create: GPU_MAX_HW_QUEUES=%d in the environment: %d chains want %d hardware queues (16 recommended); "
+                      "chains that share a queue run one after the other",
+                      psi_hw_queues_seen(), chains, chains + 2);
+        psi_set_error(ctx, msg);
+    }
+    *out = q;
+    return PS_OK;
+}
+
+void ps_batch_queue_destroy(PsBatchQueue *q)
+{
+    if (!q) return;
+    (void)hipSetDevice(q->device);
+    for (int i = 0; i < kMaxChains; ++i)
+        if (q->ctx[i]) (void)ps_context_synchronize(q->ctx[i]);
+    for (Ticket &t : q->ring)
+        for (hipEvent_t &e : t.ev)
+            if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < kMaxChains; ++i)
+        if (q->ctx[i]) ps_context_destroy(q->ctx[i]);
+    delete q;
+}
+
+int ps_batch_queue_chains(const PsBatchQueue *q) { return q ? q->chains : (int)PS_ERR_BAD_ARG; }
+
+PsContext *ps_batch_queue_context(PsBatchQueue *q, int chain)
+{
+    return (q && chain >= 0 && chain < q->chains) ? q->ctx[chain] : nullptr;
+}
+
+int ps_batch_queue_submit(PsBatchQueue *q, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
+                          const PsFrameSet *frames, const int32_t *pairs, int P, const PsPairResults *out, int64_t *ticket)
+{
+    if (!q) return PS_ERR_BAD_ARG;
+    if (ticket) *ticket = -1;
+    if (!params || !cfg || !frames || !out || P < 0 || (P > 0 && !pairs))
+        return qfail(q, PS_ERR_BAD_ARG, "ps_batch_queue_submit: bad argument");
+    if (cfg->sampleIdx) return qfail(q, PS_ERR_BAD_ARG, "ps_batch_queue_submit: explicit sample streams are per call, not per batch");
+    if (hipSetDevice(q->device) != hipSuccess) return qfail(q, PS_ERR_HIP, "ps_batch_queue_submit: hipSetDevice");
+    const long long seq = q->next;
+    Ticket &t = q->ring[seq % kTickets];
+    if (t.seq >= 0) { // flow control: the slot's previous batch (kTickets batches ago) has to be complete
+        int rc = wait_slot(q, t);
+        if (rc != PS_OK) return rc;
+    }
+    int32_t bounds[kMaxChains + 1];
+    split(q, P, seq, bounds);
+    const size_t cap = (size_t)frames->maxKpts;
+    bool used[kMaxChains] = {false, false, false, false};
+    int rcAll = PS_OK;
+    for (int i = 0; i < q->chains; ++i) {
+        const int lo = bounds[i], hi = bounds[i + 1];
+        if (hi <= lo) continue;
+        PsRansacConfig c2 = *cfg;
+        c2.seed = cfg->seed + (uint64_t)lo; // pair p draws from cfg->seed + p on whatever chain it runs
+        PsPairResults o2;
+        o2.matches = out->matches ? out->matches + (size_t)lo * cap : nullptr;
+        o2.numMatches = out->numMatches ? out->numMatches + lo : nullptr;
+        o2.inlierMask = out->inlierMask ? out->inlierMask + (size_t)lo * cap : nullptr;
+        o2.pose = out->pose ? out->pose + (size_t)lo * 16 : nullptr;
+        o2.stats = out->stats ? out->stats + lo : nullptr;
+        int rc = ps_vo_pairs_device(q->ctx[i], params, &c2, K, frames, pairs + 2 * (size_t)lo, hi - lo, &o2);
+        if (rc != PS_OK) {
+            // what was queued stays queued (the other chain's share of this batch may complete); the batch as a whole failed
+            rcAll = qfail(q, rc, std::string("ps_batch_queue_submit: chain ") + std::to_string(i) + ": " + ps_last_error(q->ctx[i]));
+            break;
+        }
+        if (hipEventRecord(t.ev[i], (hipStream_t)ps_context_stream(q->ctx[i])) != hipSuccess) {
+            (void)ps_context_synchronize(q->ctx[i]); // no event to wait on: drain the chain instead
+            continue;
+        }
+        used[i] = true;
+    }
+    // (the ticket exists even for a failed batch: waiting for it waits for whatever part of it was queued)
+    t.seq = seq;
+    for (int i = 0; i < kMaxChains; ++i) t.used[i] = used[i];
+    for (int i = 0; i <= q->chains; ++i) q->lastBounds[i] = bounds[i];
+    q->next = seq + 1;
+    if (ticket) *ticket = seq;
+    return rcAll;
+}
+
+int ps_batch_queue_last_split(const PsBatchQueue *q, int32_t *bounds)
+{
+    if (!q || !bounds) return PS_ERR_BAD_ARG;
+    for (int i = 0; i <= q->chains; ++i) bounds[i] = q->lastBounds[i];
+    return q->chains;
+}
+
+static Ticket *find_ticket(PsBatchQueue *q, int64_t ticket, int *rc)
+{
+    *rc = PS_OK;
+    if (ticket < 0 || ticket >= q->next) {
+        *rc = qfail(q, PS_ERR_BAD_ARG, "ps_batch_queue: no such ticket");
+        return nullptr;
+    }
+    Ticket &t = q->ring[ticket % kTickets];
+    if (t.seq != ticket) return nullptr; // older than the ring: complete (submit waited for it before reusing the slot)
+    return &t;
+}
+
+int ps_batch_queue_wait(PsBatchQueue *q, int64_t ticket)
+{
+    if (!q) return PS_ERR_BAD_ARG;
+    int rc;
+    Ticket *t = find_ticket(q, ticket, &rc);
+    if (!t) return rc;
+    return wait_slot(q, *t);
+}
+
+int ps_batch_queue_query(PsBatchQueue *q, int64_t ticket)
+{
+    if (!q) return PS_ERR_BAD_ARG;
+    int rc;
+    Ticket *t = find_ticket(q, ticket, &rc);
+    if (!t) return rc == PS_OK ? 1 : rc;
+    for (int i = 0; i < q->chains; ++i)
+        if (t->used[i]) {
+            hipError_t e = hipEventQuery(t->ev[i]);
+            if (e == hipErrorNotReady) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            if (e != hipSuccess) return qfail(q, PS_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        }
+    return 1;
+}
+
+int ps_batch_queue_wait_on_stream(PsBatchQueue *q, int64_t ticket, void *hipStream)
+{
+    if (!q) return PS_ERR_BAD_ARG;
+    int rc;
+    Ticket *t = find_ticket(q, ticket, &rc);
+    if (!t) return rc;
+    if (hipSetDevice(q->device) != hipSuccess) return qfail(q, PS_ERR_HIP, "ps_batch_queue_wait_on_stream: hipSetDevice");
+    for (int i = 0; i < q->chains; ++i)
+        if (t->used[i]) {
+            hipError_t e = hipStreamWaitEvent((hipStream_t)hipStream, t->ev[i], 0);
+            if (e != hipSuccess) return qfail(q, PS_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+        }
+    return PS_OK;
+}
+
+int ps_batch_queue_synchronize(PsBatchQueue *q)
+{
+    if (!q) return PS_ERR_BAD_ARG;
+    for (int i = 0; i < q->chains; ++i) {
+        int rc = ps_context_synchronize(q->ctx[i]);
+        if (rc != PS_OK) return qfail(q, rc, std::string("ps_batch_queue_synchronize: ") + ps_last_error(q->ctx[i]));
+    }
+    return PS_OK;
+}
+
+} // extern "C"

@@ -8,6 +8,7 @@
 #include "ps_matcher_mfma.h"
 #include "ps_score_fast.h"
 #include "ps_score_euclid.h"
+#include "ps_internal.h"
 
 #include <cfloat>
 #include <chrono>
@@ -1364,6 +1365,7 @@ int ps_context_get_option(const PsContext *ctx, const char *name)
         for (const Buf *b : all) sum += b->cap;
         return (int)((sum + (((size_t)1 << 20) - 1)) >> 20);
     }
+    if (strcmp(name, "hw_queues_seen") == 0) return psi_hw_queues_seen();   // GPU_MAX_HW_QUEUES when the library was loaded (ps_env.cpp)
     if (strcmp(name, "last_model_slots") == 0) return ctx->lastModelH;     // hypotheses per pair with a parked-model slot, last scoring step
     if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
     const OptDesc *o = find_option(name);
@@ -1379,6 +1381,18 @@ int ps_context_synchronize(PsContext *ctx)
 }
 
 const char *ps_last_error(const PsContext *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// (ps_internal.h: for the library's other translation units)
+void psi_set_error(PsContext *ctx, const char *what)
+{
+    if (ctx) ctx->err = what ? what : "";
+}
+
+void psi_copy_options(PsContext *dst, const PsContext *src)
+{
+    if (!dst || !src) return;
+    for (const OptDesc &o : kOptions) dst->*(o.field) = src->*(o.field);
+}
 const char *ps_device_arch(const PsContext *ctx) { return ctx ? ctx->arch : ""; }
 
 int ps_context_enable_timing(PsContext *ctx, int enable)

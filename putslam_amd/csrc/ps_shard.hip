@@ -2,14 +2,30 @@
 //
 // The exchanges are those of bench.py / putslam_amd/sharding.py: one broadcast of the run's parameter
 // block, one gather of 72-byte per-pair records to the rank that composes the trajectories (the reference's only sequential
-// step, src/PUTSLAM/PUTSLAM.cpp:735-740).  Collectives are queued on the members' own context streams, behind the kernels that
-// produce what they send.
+// step, src/PUTSLAM/PUTSLAM.cpp:735-740).
+//
+// Round 6: nothing on the data path joins.  Every member owns a PsBatchQueue (two launch chains) and a communication stream.
+// A batch's records are packed by a small kernel queued on each chain right behind that chain's share of the batch (so the
+// chain's next batch cannot overwrite a pose before it has been packed); the communication stream waits for the two packing
+// events, gathers, copies to pinned host memory on the root and records the ticket's event.  The chains never wait for the
+// communication stream: a record block is one of PS_SHARD_GATHERS_IN_FLIGHT, and it is the HOST that waits (in submit) when all
+// of them are outstanding.  Rounds 1 - 5 packed, gathered, copied and synchronised every member on the member's one chain,
+// every call, from one host thread.
+//
+// One process driving several GPUs: from two members on every member has a host thread of its own; a call that addresses all
+// members hands each thread its member's share and waits for all of them.  RCCL collectives are then issued one per thread on
+// that thread's communicator (no ncclGroupStart needed); with one member the calls run inline.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "putslam_shard.h"
@@ -18,15 +34,45 @@ static_assert(PS_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
 
 namespace {
 
+constexpr int kSlots = PS_SHARD_GATHERS_IN_FLIGHT;
+constexpr int kMaxChains = 4;
+constexpr int kProducers = kMaxChains + 1; // the queue's chains + the member's own context stream (the blocking form)
+
+struct Slot { // the buffers of one gather on one member
+    float *rec = nullptr;      // device: this member's packed records
+    size_t recCap = 0;         // floats
+    float *gathered = nullptr; // device, root only: [world][pairs][18]
+    size_t gatheredCap = 0;
+    float *host = nullptr;     // pinned, root only
+    size_t hostCap = 0;
+    hipEvent_t done = nullptr; // behind the gather and the copy to the host
+    bool pending = false;      // a gather has been queued on this slot and not waited for by the host
+    long long ticket = -1;
+    int pairsPerRank = 0;
+    bool isRoot = false;
+};
+
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has = false, quit = false;
+};
+
 struct Member {
     int device = 0, rank = 0;
     PsContext *ctx = nullptr;
+    PsBatchQueue *queue = nullptr; // created at the first submit (the options of ctx at that moment are its chains')
     ncclComm_t comm = nullptr;
-    float *rec = nullptr;      // device: this member's packed records
-    size_t recCap = 0;
-    float *gathered = nullptr; // device, root only: [world][pairs][18]
-    size_t gatheredCap = 0;
-    uint8_t *blob = nullptr;   // device: parameter block
+    hipStream_t commStream = nullptr;
+    uint8_t *blob = nullptr; // device: parameter block
+    Slot slot[kSlots];
+    hipEvent_t packed[kProducers] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool packedUsed[kProducers] = {false, false, false, false, false};
+    int lastP = 0;           // pairs packed for the next gather
+    std::string err;
+    Worker *worker = nullptr;
 };
 
 __global__ void ps_pack_records(const float *__restrict__ pose, const PsRansacStats *__restrict__ stats, int valid, int pairs,
@@ -50,6 +96,13 @@ struct PsShardGroup {
     int world = 0;
     std::vector<Member> m;
     std::string err;
+    long long nextGather = 0;
+    bool threaded = false;
+    // completion of a fan-out over the workers
+    std::mutex jm;
+    std::condition_variable jcv;
+    int remaining = 0;
+    std::vector<int> rcs;
 };
 
 namespace {
@@ -66,31 +119,255 @@ int sfail(PsShardGroup *g, int code, const char *what, const char *detail = null
     return code;
 }
 
+int mfail(Member &mb, int code, const char *what, const char *detail = nullptr)
+{
+    mb.err = what;
+    if (detail) {
+        mb.err += ": ";
+        mb.err += detail;
+    }
+    return code;
+}
+
 #define SH_HIP(call)                                                                  \
     do {                                                                              \
         hipError_t e_ = (call);                                                       \
         if (e_ != hipSuccess) return sfail(g, PS_ERR_HIP, #call, hipGetErrorString(e_)); \
     } while (0)
-#define SH_NCCL(call)                                                                   \
-    do {                                                                                \
-        ncclResult_t r_ = (call);                                                       \
-        if (r_ != ncclSuccess) return sfail(g, PS_ERR_HIP, #call, ncclGetErrorString(r_)); \
+#define MB_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) return mfail(mb, PS_ERR_HIP, #call, hipGetErrorString(e_)); \
+    } while (0)
+#define MB_NCCL(call)                                                                    \
+    do {                                                                                 \
+        ncclResult_t r_ = (call);                                                        \
+        if (r_ != ncclSuccess) return mfail(mb, PS_ERR_HIP, #call, ncclGetErrorString(r_)); \
     } while (0)
 
-int member_buffers(PsShardGroup *g, Member &mb)
+void worker_main(Member *mb)
 {
-    SH_HIP(hipSetDevice(mb.device));
-    SH_HIP(hipMalloc((void **)&mb.blob, sizeof(PsShardRunParams)));
+    (void)hipSetDevice(mb->device);
+    Worker &w = *mb->worker;
+    for (;;) {
+        std::function<int()> task;
+        {
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv.wait(lk, [&] { return w.has || w.quit; });
+            if (w.quit && !w.has) return;
+            task = std::move(w.task);
+            w.has = false;
+        }
+        task(); // (reports its result and its completion itself: for_members)
+    }
+}
+
+// fn(local) for every local member: on the members' own threads, side by side, when the group is threaded; inline otherwise.
+// Returns the first failing member's status; its text becomes the group's.
+int for_members(PsShardGroup *g, const std::function<int(int)> &fn)
+{
+    const int L = (int)g->m.size();
+    g->rcs.assign((size_t)L, PS_OK);
+    if (!g->threaded) {
+        for (int i = 0; i < L; ++i) {
+            (void)hipSetDevice(g->m[(size_t)i].device);
+            g->rcs[(size_t)i] = fn(i);
+        }
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(g->jm);
+            g->remaining = L;
+        }
+        for (int i = 0; i < L; ++i) {
+            Worker &w = *g->m[(size_t)i].worker;
+            {
+                std::lock_guard<std::mutex> lk(w.m);
+                w.task = [g, i, &fn]() {
+                    const int rc = fn(i);
+                    std::lock_guard<std::mutex> lk2(g->jm);
+                    g->rcs[(size_t)i] = rc;
+                    if (--g->remaining == 0) g->jcv.notify_all();
+                    return rc;
+                };
+                w.has = true;
+            }
+            w.cv.notify_one();
+        }
+        std::unique_lock<std::mutex> lk(g->jm);
+        g->jcv.wait(lk, [&] { return g->remaining == 0; });
+    }
+    for (int i = 0; i < L; ++i)
+        if (g->rcs[(size_t)i] != PS_OK) {
+            g->err = "rank " + std::to_string(g->m[(size_t)i].rank) + ": " + g->m[(size_t)i].err;
+            return g->rcs[(size_t)i];
+        }
     return PS_OK;
 }
 
-hipStream_t mstream(const Member &mb) { return (hipStream_t)ps_context_stream(mb.ctx); }
+int member_init(PsShardGroup *g, Member &mb)
+{
+    SH_HIP(hipSetDevice(mb.device));
+    int rc = ps_context_create(mb.device, &mb.ctx);
+    if (rc != PS_OK) return sfail(g, rc, "ps_context_create");
+    SH_HIP(hipMalloc((void **)&mb.blob, sizeof(PsShardRunParams)));
+    SH_HIP(hipStreamCreateWithFlags(&mb.commStream, hipStreamNonBlocking));
+    for (hipEvent_t &e : mb.packed) SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (Slot &s : mb.slot) SH_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    return PS_OK;
+}
+
+void start_workers(PsShardGroup *g)
+{
+    const char *force = std::getenv("PUTSLAM_SHARD_THREADS"); // (test hook: "1" = a thread even for a single member, "0" = never)
+    g->threaded = g->m.size() >= 2;
+    if (force) g->threaded = std::atoi(force) != 0;
+    if (!g->threaded) return;
+    for (Member &mb : g->m) {
+        mb.worker = new Worker();
+        mb.worker->th = std::thread(worker_main, &mb);
+    }
+}
 
 int find_root(const PsShardGroup *g, int root)
 {
     for (size_t i = 0; i < g->m.size(); ++i)
         if (g->m[i].rank == root) return (int)i;
     return -1;
+}
+
+int ensure_queue(Member &mb)
+{
+    if (mb.queue) return PS_OK;
+    int rc = ps_batch_queue_create(mb.ctx, 2, &mb.queue);
+    if (rc != PS_OK) return mfail(mb, rc, "ps_batch_queue_create", ps_last_error(mb.ctx));
+    return PS_OK;
+}
+
+// the host waits for the slot's previous gather before the slot's blocks are written again
+int slot_free(Member &mb, Slot &s)
+{
+    if (s.pending) {
+        MB_HIP(hipEventSynchronize(s.done));
+        s.pending = false;
+    }
+    return PS_OK;
+}
+
+// room for `floats` packed records in the slot; what is already packed there is kept (drains the member's producers first)
+int ensure_rec(Member &mb, Slot &s, size_t floats, bool keep)
+{
+    if (floats <= s.recCap) return PS_OK;
+    size_t want = floats * 2;
+    if (want < (size_t)1024 * PS_SHARD_RECORD_FLOATS) want = (size_t)1024 * PS_SHARD_RECORD_FLOATS;
+    float *nw = nullptr;
+    MB_HIP(hipMalloc((void **)&nw, want * sizeof(float)));
+    if (s.rec) {
+        // the old block may be the target of packing launches still queued: drain them
+        if (mb.queue && ps_batch_queue_synchronize(mb.queue) != PS_OK) return mfail(mb, PS_ERR_HIP, "ps_batch_queue_synchronize");
+        if (ps_context_synchronize(mb.ctx) != PS_OK) return mfail(mb, PS_ERR_HIP, "ps_context_synchronize");
+        MB_HIP(hipStreamSynchronize(mb.commStream));
+        if (keep && s.recCap) MB_HIP(hipMemcpy(nw, s.rec, s.recCap * sizeof(float), hipMemcpyDeviceToDevice));
+        (void)hipFree(s.rec);
+    }
+    s.rec = nw;
+    s.recCap = want;
+    return PS_OK;
+}
+
+int member_submit(PsShardGroup *g, Member &mb, const PsShardJob &job)
+{
+    for (bool &u : mb.packedUsed) u = false;
+    mb.lastP = 0;
+    if (job.P <= 0) return PS_OK;
+    if (!job.params || !job.cfg || !job.frames || !job.pairs || !job.out || !job.out->pose || !job.out->stats)
+        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_submit_all: bad job");
+    int rc = ensure_queue(mb);
+    if (rc != PS_OK) return rc;
+    Slot &s = mb.slot[g->nextGather % kSlots];
+    rc = slot_free(mb, s);
+    if (rc != PS_OK) return rc;
+    rc = ensure_rec(mb, s, (size_t)job.P * PS_SHARD_RECORD_FLOATS, false);
+    if (rc != PS_OK) return rc;
+    rc = ps_batch_queue_submit(mb.queue, job.params, job.cfg, job.K, job.frames, job.pairs, job.P, job.out, nullptr);
+    if (rc != PS_OK) return mfail(mb, rc, "ps_batch_queue_submit", ps_last_error(mb.ctx));
+    int32_t bounds[kMaxChains + 1];
+    const int C = ps_batch_queue_last_split(mb.queue, bounds);
+    for (int i = 0; i < C; ++i) {
+        const int lo = bounds[i], n = bounds[i + 1] - bounds[i];
+        if (n <= 0) continue;
+        hipStream_t st = (hipStream_t)ps_context_stream(ps_batch_queue_context(mb.queue, i));
+        // behind this chain's share of the batch, before the chain's next batch can overwrite a pose
+        hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, job.out->pose + (size_t)lo * 16,
+                           job.out->stats + lo, n, n, s.rec + (size_t)lo * PS_SHARD_RECORD_FLOATS);
+        MB_HIP(hipGetLastError());
+        MB_HIP(hipEventRecord(mb.packed[i], st));
+        mb.packedUsed[i] = true;
+    }
+    mb.lastP = job.P;
+    return PS_OK;
+}
+
+// the blocking form's producer: results a host wrote with ps_vo_pairs_device on the member's own context
+int member_pack_from_context(PsShardGroup *g, Member &mb, const PsPairResults &res, int valid, int pairsPerRank)
+{
+    for (bool &u : mb.packedUsed) u = false;
+    mb.lastP = 0;
+    if (valid < 0 || valid > pairsPerRank || !res.pose || !res.stats)
+        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records: bad results / validPairs");
+    Slot &s = mb.slot[g->nextGather % kSlots];
+    int rc = slot_free(mb, s);
+    if (rc != PS_OK) return rc;
+    rc = ensure_rec(mb, s, (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS, false);
+    if (rc != PS_OK) return rc;
+    hipStream_t st = (hipStream_t)ps_context_stream(mb.ctx);
+    hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((pairsPerRank + 255) / 256)), dim3(256), 0, st, res.pose, res.stats, valid,
+                       pairsPerRank, s.rec);
+    MB_HIP(hipGetLastError());
+    MB_HIP(hipEventRecord(mb.packed[kMaxChains], st));
+    mb.packedUsed[kMaxChains] = true;
+    mb.lastP = pairsPerRank; // (zero-filled by the kernel itself)
+    return PS_OK;
+}
+
+int member_gather(PsShardGroup *g, Member &mb, long long ticket, int pairsPerRank, int root)
+{
+    Slot &s = mb.slot[ticket % kSlots];
+    int rc = slot_free(mb, s); // (a gather with no submit since this slot's last use)
+    if (rc != PS_OK) return rc;
+    if (mb.lastP > pairsPerRank) return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: pairsPerRank is smaller than the member's batch");
+    const size_t recFloats = (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS;
+    for (int i = 0; i < kProducers; ++i)
+        if (mb.packedUsed[i]) MB_HIP(hipStreamWaitEvent(mb.commStream, mb.packed[i], 0));
+    rc = ensure_rec(mb, s, recFloats, true);
+    if (rc != PS_OK) return rc;
+    if (mb.lastP < pairsPerRank)
+        MB_HIP(hipMemsetAsync(s.rec + (size_t)mb.lastP * PS_SHARD_RECORD_FLOATS, 0, (size_t)(pairsPerRank - mb.lastP) * PS_SHARD_RECORD_FLOATS * sizeof(float),
+                              mb.commStream));
+    s.isRoot = mb.rank == root;
+    if (s.isRoot) {
+        const size_t all = recFloats * (size_t)g->world;
+        if (s.gatheredCap < all) {
+            MB_HIP(hipStreamSynchronize(mb.commStream));
+            if (s.gathered) (void)hipFree(s.gathered);
+            s.gathered = nullptr;
+            MB_HIP(hipMalloc((void **)&s.gathered, all * sizeof(float)));
+            s.gatheredCap = all;
+        }
+        if (s.hostCap < all) {
+            if (s.host) (void)hipHostFree(s.host);
+            s.host = nullptr;
+            MB_HIP(hipHostMalloc((void **)&s.host, all * sizeof(float), hipHostMallocDefault));
+            s.hostCap = all;
+        }
+    }
+    MB_NCCL(ncclGather(s.rec, s.isRoot ? s.gathered : nullptr, recFloats, ncclFloat, root, mb.comm, mb.commStream));
+    if (s.isRoot)
+        MB_HIP(hipMemcpyAsync(s.host, s.gathered, recFloats * (size_t)g->world * sizeof(float), hipMemcpyDeviceToHost, mb.commStream));
+    MB_HIP(hipEventRecord(s.done, mb.commStream));
+    s.pending = true;
+    s.ticket = ticket;
+    s.pairsPerRank = pairsPerRank;
+    return PS_OK;
 }
 
 } // namespace
@@ -124,13 +401,16 @@ int ps_shard_group_create(const int *devices, int numDevices, PsShardGroup **out
         mb.device = dev[(size_t)i];
         mb.rank = i;
         mb.comm = comms[(size_t)i];
-        int rc = ps_context_create(mb.device, &mb.ctx);
-        if (rc == PS_OK) rc = member_buffers(g, mb);
+    }
+    for (Member &mb : g->m) {
+        int rc = member_init(g, mb);
         if (rc != PS_OK) {
+            fprintf(stderr, "ps_shard_group_create: %s\n", g->err.c_str());
             ps_shard_group_destroy(g);
             return rc;
         }
     }
+    start_workers(g);
     *out = g;
     return PS_OK;
 }
@@ -167,12 +447,13 @@ int ps_shard_group_create_rank(int device, int rank, int worldSize, const uint8_
         delete g;
         return PS_ERR_HIP;
     }
-    int rc = ps_context_create(device, &mb.ctx);
-    if (rc == PS_OK) rc = member_buffers(g, mb);
+    int rc = member_init(g, mb);
     if (rc != PS_OK) {
+        fprintf(stderr, "ps_shard_group_create_rank: %s\n", g->err.c_str());
         ps_shard_group_destroy(g);
         return rc;
     }
+    start_workers(g);
     *out = g;
     return PS_OK;
 }
@@ -180,13 +461,34 @@ int ps_shard_group_create_rank(int device, int rank, int worldSize, const uint8_
 void ps_shard_group_destroy(PsShardGroup *g)
 {
     if (!g) return;
+    for (Member &mb : g->m)
+        if (mb.worker) {
+            {
+                std::lock_guard<std::mutex> lk(mb.worker->m);
+                mb.worker->quit = true;
+            }
+            mb.worker->cv.notify_one();
+            if (mb.worker->th.joinable()) mb.worker->th.join();
+            delete mb.worker;
+            mb.worker = nullptr;
+        }
     for (Member &mb : g->m) {
         (void)hipSetDevice(mb.device);
+        if (mb.queue) (void)ps_batch_queue_synchronize(mb.queue);
         if (mb.ctx) (void)ps_context_synchronize(mb.ctx);
+        if (mb.commStream) (void)hipStreamSynchronize(mb.commStream);
         if (mb.comm) (void)ncclCommDestroy(mb.comm);
-        if (mb.rec) (void)hipFree(mb.rec);
-        if (mb.gathered) (void)hipFree(mb.gathered);
+        for (Slot &s : mb.slot) {
+            if (s.rec) (void)hipFree(s.rec);
+            if (s.gathered) (void)hipFree(s.gathered);
+            if (s.host) (void)hipHostFree(s.host);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+        for (hipEvent_t e : mb.packed)
+            if (e) (void)hipEventDestroy(e);
         if (mb.blob) (void)hipFree(mb.blob);
+        if (mb.commStream) (void)hipStreamDestroy(mb.commStream);
+        if (mb.queue) ps_batch_queue_destroy(mb.queue);
         if (mb.ctx) ps_context_destroy(mb.ctx);
     }
     delete g;
@@ -207,6 +509,13 @@ PsContext *ps_shard_context(PsShardGroup *g, int local)
 {
     return (g && local >= 0 && local < (int)g->m.size()) ? g->m[(size_t)local].ctx : nullptr;
 }
+PsBatchQueue *ps_shard_queue(PsShardGroup *g, int local)
+{
+    if (!g || local < 0 || local >= (int)g->m.size()) return nullptr;
+    Member &mb = g->m[(size_t)local];
+    (void)hipSetDevice(mb.device);
+    return ensure_queue(mb) == PS_OK ? mb.queue : nullptr;
+}
 
 void ps_shard_range(int64_t total, int world, int rank, int64_t *lo, int64_t *hi)
 {
@@ -220,26 +529,47 @@ void ps_shard_range(int64_t total, int world, int rank, int64_t *lo, int64_t *hi
 int ps_shard_broadcast_params(PsShardGroup *g, PsShardRunParams *perLocal, int root)
 {
     if (!g || !perLocal || root < 0 || root >= g->world) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_broadcast_params: bad argument");
-    const int rl = find_root(g, root);
-    if (rl >= 0) {
-        Member &mb = g->m[(size_t)rl];
-        SH_HIP(hipSetDevice(mb.device));
-        SH_HIP(hipMemcpyAsync(mb.blob, &perLocal[rl], sizeof(PsShardRunParams), hipMemcpyHostToDevice, mstream(mb)));
-    }
-    SH_NCCL(ncclGroupStart());
+    return for_members(g, [g, perLocal, root](int i) -> int {
+        Member &mb = g->m[(size_t)i];
+        if (mb.rank == root) MB_HIP(hipMemcpyAsync(mb.blob, &perLocal[i], sizeof(PsShardRunParams), hipMemcpyHostToDevice, mb.commStream));
+        MB_NCCL(ncclBroadcast(mb.blob, mb.blob, sizeof(PsShardRunParams), ncclUint8, root, mb.comm, mb.commStream));
+        MB_HIP(hipMemcpyAsync(&perLocal[i], mb.blob, sizeof(PsShardRunParams), hipMemcpyDeviceToHost, mb.commStream));
+        MB_HIP(hipStreamSynchronize(mb.commStream));
+        return PS_OK;
+    });
+}
+
+int ps_shard_submit_all(PsShardGroup *g, const PsShardJob *jobs)
+{
+    if (!g || !jobs) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_submit_all: bad argument");
+    return for_members(g, [g, jobs](int i) -> int { return member_submit(g, g->m[(size_t)i], jobs[i]); });
+}
+
+int ps_shard_gather_records_async(PsShardGroup *g, int pairsPerRank, int root, int64_t *ticket)
+{
+    if (ticket) *ticket = -1;
+    if (!g || pairsPerRank < 1 || root < 0 || root >= g->world) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: bad argument");
+    const long long t = g->nextGather;
+    int rc = for_members(g, [g, t, pairsPerRank, root](int i) -> int { return member_gather(g, g->m[(size_t)i], t, pairsPerRank, root); });
+    if (rc != PS_OK) return rc;
+    g->nextGather = t + 1;
+    if (ticket) *ticket = t;
+    return PS_OK;
+}
+
+int ps_shard_wait(PsShardGroup *g, int64_t ticket, const float **hostRecords)
+{
+    if (hostRecords) *hostRecords = nullptr;
+    if (!g || ticket < 0 || ticket >= g->nextGather) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_wait: no such ticket");
     for (Member &mb : g->m) {
-        ncclResult_t r = ncclBroadcast(mb.blob, mb.blob, sizeof(PsShardRunParams), ncclUint8, root, mb.comm, mstream(mb));
-        if (r != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return sfail(g, PS_ERR_HIP, "ncclBroadcast", ncclGetErrorString(r));
+        Slot &s = mb.slot[ticket % kSlots];
+        if (s.ticket != ticket) continue; // the slot has moved on: that gather is complete, its records are gone
+        if (s.pending) {
+            SH_HIP(hipSetDevice(mb.device));
+            SH_HIP(hipEventSynchronize(s.done));
+            s.pending = false;
         }
-    }
-    SH_NCCL(ncclGroupEnd());
-    for (size_t i = 0; i < g->m.size(); ++i) {
-        Member &mb = g->m[i];
-        SH_HIP(hipSetDevice(mb.device));
-        SH_HIP(hipMemcpyAsync(&perLocal[i], mb.blob, sizeof(PsShardRunParams), hipMemcpyDeviceToHost, mstream(mb)));
-        SH_HIP(hipStreamSynchronize(mstream(mb)));
+        if (s.isRoot && hostRecords) *hostRecords = s.host;
     }
     return PS_OK;
 }
@@ -252,50 +582,17 @@ int ps_shard_gather_records(PsShardGroup *g, const PsPairResults *results, const
     if (pairsPerRank == 0) return PS_OK;
     const int rl = find_root(g, root);
     if (rl >= 0 && !hostRecords) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_gather_records: this process drives the root and needs hostRecords");
-    const size_t recFloats = (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS;
-    for (size_t i = 0; i < g->m.size(); ++i) {
-        Member &mb = g->m[i];
-        SH_HIP(hipSetDevice(mb.device));
-        if (mb.recCap < recFloats) {
-            SH_HIP(hipStreamSynchronize(mstream(mb)));
-            if (mb.rec) (void)hipFree(mb.rec);
-            mb.rec = nullptr;
-            SH_HIP(hipMalloc((void **)&mb.rec, recFloats * sizeof(float)));
-            mb.recCap = recFloats;
-        }
-        if ((int)i == rl && mb.gatheredCap < recFloats * (size_t)g->world) {
-            SH_HIP(hipStreamSynchronize(mstream(mb)));
-            if (mb.gathered) (void)hipFree(mb.gathered);
-            mb.gathered = nullptr;
-            SH_HIP(hipMalloc((void **)&mb.gathered, recFloats * (size_t)g->world * sizeof(float)));
-            mb.gatheredCap = recFloats * (size_t)g->world;
-        }
-        const int valid = validPairs ? validPairs[i] : pairsPerRank;
-        if (valid < 0 || valid > pairsPerRank || !results[i].pose || !results[i].stats)
-            return sfail(g, PS_ERR_BAD_ARG, "ps_shard_gather_records: bad results / validPairs");
-        hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((pairsPerRank + 255) / 256)), dim3(256), 0, mstream(mb), results[i].pose,
-                           results[i].stats, valid, pairsPerRank, mb.rec);
-        SH_HIP(hipGetLastError());
-    }
-    SH_NCCL(ncclGroupStart());
-    for (size_t i = 0; i < g->m.size(); ++i) {
-        Member &mb = g->m[i];
-        ncclResult_t r = ncclGather(mb.rec, (int)i == rl ? mb.gathered : nullptr, recFloats, ncclFloat, root, mb.comm, mstream(mb));
-        if (r != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return sfail(g, PS_ERR_HIP, "ncclGather", ncclGetErrorString(r));
-        }
-    }
-    SH_NCCL(ncclGroupEnd());
-    if (rl >= 0) {
-        Member &mb = g->m[(size_t)rl];
-        SH_HIP(hipSetDevice(mb.device));
-        SH_HIP(hipMemcpyAsync(hostRecords, mb.gathered, recFloats * (size_t)g->world * sizeof(float), hipMemcpyDeviceToHost, mstream(mb)));
-    }
-    for (Member &mb : g->m) {
-        SH_HIP(hipSetDevice(mb.device));
-        SH_HIP(hipStreamSynchronize(mstream(mb)));
-    }
+    int rc = for_members(g, [g, results, validPairs, pairsPerRank](int i) -> int {
+        return member_pack_from_context(g, g->m[(size_t)i], results[i], validPairs ? validPairs[i] : pairsPerRank, pairsPerRank);
+    });
+    if (rc != PS_OK) return rc;
+    int64_t t = -1;
+    rc = ps_shard_gather_records_async(g, pairsPerRank, root, &t);
+    if (rc != PS_OK) return rc;
+    const float *rec = nullptr;
+    rc = ps_shard_wait(g, t, &rec);
+    if (rc != PS_OK) return rc;
+    if (rl >= 0 && rec) memcpy(hostRecords, rec, (size_t)g->world * pairsPerRank * PS_SHARD_RECORD_FLOATS * sizeof(float));
     return PS_OK;
 }
 
@@ -304,7 +601,9 @@ int ps_shard_synchronize(PsShardGroup *g)
     if (!g) return PS_ERR_BAD_ARG;
     for (Member &mb : g->m) {
         SH_HIP(hipSetDevice(mb.device));
-        SH_HIP(hipStreamSynchronize(mstream(mb)));
+        if (mb.queue && ps_batch_queue_synchronize(mb.queue) != PS_OK) return sfail(g, PS_ERR_HIP, "ps_batch_queue_synchronize", ps_last_error(mb.ctx));
+        if (ps_context_synchronize(mb.ctx) != PS_OK) return sfail(g, PS_ERR_HIP, "ps_context_synchronize", ps_last_error(mb.ctx));
+        SH_HIP(hipStreamSynchronize(mb.commStream));
     }
     return PS_OK;
 }

@@ -393,7 +393,7 @@ int async_build(PsVoStream *s)
             c = nullptr;
             return fail(ctx, rc, "ps_vo_stream_configure_async: lane context");
         }
-        for (const OptDesc &o : kOptions) c->*(o.field) = ctx->*(o.field); // the lanes run what the stream's context would
+        psi_copy_options(c, ctx); // the lanes run what the stream's context would
     }
     a->lane.resize((size_t)(a->lanes + a->ahead));
     for (AsyncLane &l : a->lane) {

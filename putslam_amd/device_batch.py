@@ -125,3 +125,10 @@ def run_pairs_split(ctxs, streams, params, estimator, num_hypotheses, seed, K, f
     if join:
         for st in streams[:S]:
             cur.wait_stream(st)
+
+
+def run_pairs_queue(queue, params, cfg, K, frames: FrameSetDevice, batch: PairBatchDevice):
+    """The same batch as `run_pairs` through a PsBatchQueue (api.BatchQueue): the library splits it over its launch chains
+    (two: 45 % / 55 %), which are never joined.  Asynchronous; returns the batch's ticket -- `queue.wait(ticket)` (host),
+    `queue.wait_on_stream(ticket, stream)` (a stream of the caller's) or `queue.synchronize()` before the results are read."""
+    return queue.submit(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())

@@ -136,6 +136,29 @@ def test_bench_one_sequence_sharded_eight_ways_equals_unsharded(tmp_path):
         sharding.compose_trajectory(want[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)).tobytes()
 
 
+def test_bench_rccl_branch_through_the_batch_queue(tmp_path):
+    """The default submission of a multi-rank run: ONE ps_batch_queue_submit per step (the library's two chains, 45 % / 55 %),
+    records packed and gathered per chain on the chains' own streams (torch sees them as ExternalStreams) -- with a world of
+    one over RCCL, 25 pairs (13 would go to the queue's chains in turn, which the per-chain gathers of bench.py do not follow:
+    such runs keep the Python submission).  Equal to the non-distributed run and to --submit python, byte for byte."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = _env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY=0)
+    env.pop("PUTSLAM_BENCH_BACKEND", None)
+    args = ["--frames", "26"] + ARGS[2:]
+    outs = {}
+    for name, extra in (("dist", ["--force-dist"]), ("plain", []), ("python", ["--force-dist", "--submit", "python"])):
+        npy = tmp_path / (name + ".npy")
+        p = subprocess.run([sys.executable, bench, "--gpus", "1", "--dump-records", str(npy)] + extra + args, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout + p.stderr
+        j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert ("ps_batch_queue_submit" in j["config"]["submit"]) == (name != "python")
+        outs[name] = np.load(npy)
+    assert outs["dist"].shape == (1, 25, 18) and (outs["dist"][0, :, 17] > 0).all()
+    assert outs["dist"].tobytes() == outs["plain"].tobytes() == outs["python"].tobytes()
+
+
 @pytest.mark.parametrize("streams", [1, 3])
 def test_bench_rccl_branch_with_a_world_of_one(tmp_path, streams):
     """The RCCL branch itself (backend "nccl", device-resident payloads): `bench.py --force-dist` initialises the process

@@ -35,22 +35,32 @@ def _write_sequence(path, seq):
 
 
 @pytest.mark.parametrize("launch", ["one-process", "rank-per-process"])
-@pytest.mark.parametrize("estimator,est,H,ev", [("fixed", EST_FIXED, 768, 1), ("ransac", EST_RANSAC, 487, 0)])
-def test_native_gather_equals_python_batch_and_oracle(ctx, oracle, tmp_path, launch, estimator, est, H, ev):
-    """The records rank 0 gathers natively (ps_shard_broadcast_params -> ps_vo_pairs_device -> ps_shard_gather_records) are the
-    bytes sharding.pack_records makes of the oracle's results for the same sequence and seed."""
+@pytest.mark.parametrize("mode", ["queue+async", "queue+async+thread", "blocking"])
+@pytest.mark.parametrize("estimator,est,H,ev,frames", [("fixed", EST_FIXED, 768, 1, 14), ("fixed", EST_FIXED, 512, 1, 31), ("ransac", EST_RANSAC, 487, 0, 14)])
+def test_native_gather_equals_python_batch_and_oracle(ctx, oracle, tmp_path, launch, mode, estimator, est, H, ev, frames):
+    """The records rank 0 gathers natively are the bytes sharding.pack_records makes of the oracle's results for the same
+    sequence and seed -- through the default host loop (ps_shard_submit_all: a PsBatchQueue per member, records packed on the
+    chains; ps_shard_gather_records_async / ps_shard_wait: the gather on the communication stream, read one step later), the
+    same with the member on a host thread of its own (what a process that drives several GPUs runs; PUTSLAM_SHARD_THREADS=1
+    forces it for one member), and rounds 1 - 5's loop (ps_vo_pairs_device on the member's context + the blocking gather).
+    31 frames = 30 pairs: the queue splits the batch 13 + 17 over its two chains; 13 pairs go to the chains in turn."""
     from putslam_amd import sharding
-    seq = synth.make_sequence(14, 700, config=3, index=4242)
+    seq = synth.make_sequence(frames, 700, config=3, index=4242)
     _write_sequence(tmp_path / "seq0.bin", seq)
     seed = 0xB0B0
     dump = tmp_path / "records.bin"
     cmd = [_exe(), "--sequence-prefix", str(tmp_path / "seq"), "--estimator", estimator, "--hyp", str(H), "--error-version", str(ev),
-           "--seed", str(seed), "--steps", "2", "--dump", str(dump), "--traj-prefix", str(tmp_path / "traj")]
+           "--seed", str(seed), "--steps", "7", "--dump", str(dump), "--traj-prefix", str(tmp_path / "traj")]
     cmd += ["--gpus", "1"] if launch == "one-process" else ["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "id.bin")]
+    if mode == "blocking":
+        cmd.append("--blocking")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode.endswith("thread"):
+        env["PUTSLAM_SHARD_THREADS"] = "1"
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
-    got = np.fromfile(dump, np.float32).reshape(1, 13, sharding.RECORD_FLOATS)
+    assert ("blocking gather" if mode == "blocking" else "asynchronous gather") in p.stdout
+    got = np.fromfile(dump, np.float32).reshape(1, frames - 1, sharding.RECORD_FLOATS)
     prm = default_ransac_params(ev)
     cfg, _ = make_config(est, H, seed=seed)                      # rank 0: seed + 0
     c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=4)
@@ -60,7 +70,7 @@ def test_native_gather_equals_python_batch_and_oracle(ctx, oracle, tmp_path, lau
     inc = want[:, :16].reshape(-1, 4, 4).transpose(0, 2, 1)
     traj = sharding.compose_trajectory(inc)
     lines = open(tmp_path / "traj0.txt").read().strip().split("\n")
-    assert len(lines) == 14
+    assert len(lines) == frames
     for k, line in enumerate(lines):
         assert line.split()[1:] == sharding.format_tum_line(0.0, traj[k]).split()[1:], k
 
