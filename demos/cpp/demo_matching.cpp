@@ -24,12 +24,14 @@
 int main(int argc, char **argv)
 {
     std::vector<const char *> pos;
-    bool pipelined = false;
+    bool pipelined = false, ragged = false;
     int chunk = 32;
     for (int i = 1; i < argc; ++i) {
         if (std::strcmp(argv[i], "--pipelined") == 0) {
             pipelined = true;
             if (i + 1 < argc && std::atoi(argv[i + 1]) > 0) chunk = std::atoi(argv[++i]);
+        } else if (std::strcmp(argv[i], "--ragged") == 0) {
+            ragged = true; // the first third of the frames carries 2/5 of the keypoints: the pipelined form has to grow
         } else {
             pos.push_back(argv[i]);
         }
@@ -76,6 +78,13 @@ int main(int argc, char **argv)
         cv::Mat desc(N, 32, CV_8U);
         std::vector<Eigen::Vector3f> pts((size_t)N);
         world.observe(k, desc.data, reinterpret_cast<float *>(pts.data()));
+        if (ragged && k < frames / 3) { // (the leading rows of the observation: a random subset of the landmarks)
+            const int nk = N * 2 / 5;
+            cv::Mat part(nk, 32, CV_8U);
+            std::memcpy(part.data, desc.data, (size_t)nk * 32);
+            desc = part;
+            pts.resize((size_t)nk);
+        }
         Eigen::Matrix4f T;
         std::vector<cv::DMatch> inliers;
         double ratio = 0;

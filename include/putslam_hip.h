@@ -382,6 +382,13 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   block they lie in changes hands: the place goes on with a spare one while the caller reads).  push_async (at the first frame of a chunk) / push_many return
  *   PS_ERR_BUSY -- and take nothing -- when there is no place: pop first.  (Pinned frames handed to push_many are read in
  *   place: untouched until their results have been popped, as before.)
+ * Errors other than PS_ERR_BUSY from push_async / push_many / flush / reset (an allocation or a HIP call failed while a chunk
+ *   was being queued): whatever part of that chunk was queued is drained, the chunk's frames are DROPPED AS A UNIT -- for
+ *   push_async: every frame collected in the partly filled chunk, the one just pushed included; for push_many: the failing chunk
+ *   and the frames after it in the call (chunks before it are in flight and keep their numbering) -- and the stream goes on as
+ *   after ps_vo_stream_reset: the next frame has no predecessor, its pair is number 0 of a new epoch (cfg->seed + 0).  No
+ *   place is lost, nothing is in flight that pop would not return.  The reference's convention (no exceptions, fallback
+ *   outputs, src/TransformEst/RANSAC.cpp:77-80,161-164) has no counterpart for a lost frame: the status code is the signal.
  * ps_vo_stream_pop_many: results of the oldest chunk in flight, as HOST pointers into that lane's pinned result block
  *   (valid until the next pop_many / pop / configure / destroy of this stream).  wait = 0: out->count = 0 if that chunk
  *   has not finished (or nothing is in flight); wait = 1: blocks until it has.

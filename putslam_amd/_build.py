@@ -67,3 +67,14 @@ def build_hip(force=False, extra_hip_flags=(), out=None):
         for o in objs:
             os.remove(o)
     return lib
+
+
+DIAG_LIB = os.path.join(HERE, "libputslam_hip_diag.so")
+
+
+def build_hip_diag(force=False):
+    """The same library with -DPS_STREAM_DIAG: fault injection into the pipelined stream (tests/test_gpu_stream_async.py) and
+    the no-upload experiment of profiles/r05h.  A test artefact: nothing loads it unless PUTSLAM_HIP_LIB names it."""
+    if not force and not _stale(DIAG_LIB, sources()):
+        return DIAG_LIB
+    return build_hip(force=True, extra_hip_flags=["-DPS_STREAM_DIAG"], out=DIAG_LIB)

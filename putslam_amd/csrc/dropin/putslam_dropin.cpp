@@ -431,10 +431,68 @@ void FrameMatcher::resetPipeline()
     pipeFirst_ = true;
 }
 
+// (re)builds the pipelined stream with room for `cap` keypoints per frame; pair 0 of the new pipeline is pair `pairsSoFar` of
+// the sequence (it draws from seed + pairsSoFar, as it would have without the rebuild)
+bool FrameMatcher::buildPipeline(int cap, uint64_t pairsSoFar)
+{
+    Fused &f = *fused_;
+    if (f.pipe) {
+        ps_vo_stream_destroy(f.pipe);
+        f.pipe = nullptr;
+    }
+    f.pipeCap = cap;
+    if (ps_vo_stream_create(f.ctx, f.pipeCap, &f.pipe) != PS_OK) {
+        lastError_ = std::string("ps_vo_stream_create: ") + ps_last_error(f.ctx);
+        f.pipe = nullptr;
+        return false;
+    }
+    matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // matcher.cpp:491-492
+    RANSAC::parameters rp = matcherParameters.RANSACParams;
+    rp.iterationCount = ransacIterations(0.20); // RANSAC.cpp:30
+    const PsRansacParams prm = toPs(rp);
+    int a = ransacIterations(0.20), b = ransacIterations(rp.minimalInlierRatioThreshold);
+    int H = std::max(1, std::min(a > b ? a : b, PS_MAX_HYPOTHESES));
+    PsRansacConfig cfg;
+    cfg.estimator = PS_EST_RANSAC;
+    cfg.numHypotheses = H;
+    // pair k of the pipeline draws from seed + k: runVO's seeding (seed_ + frameCounter, the counter starting at 0 with the
+    // initial frame)
+    if (!pipeSeeded_) {
+        pipeSeed_ = seeded_ ? seed_ : (uint64_t)std::time(nullptr); // RANSAC.cpp:13
+        pipeSeeded_ = true;
+    }
+    cfg.seed = pipeSeed_ + pairsSoFar;
+    cfg.sampleIdx = nullptr;
+    float K[9];
+    bool haveK;
+    cameraToK(matcherParameters.cameraMatrixMat, K, haveK);
+    // what comes back per frame is what Matcher::match returns: the inlier matches in input order + the pose (matcher.cpp:452-516)
+    ps_vo_stream_set_result_mode(f.pipe, PS_RESULTS_INLIERS);
+    if (ps_vo_stream_configure_async(f.pipe, &prm, &cfg, haveK ? K : nullptr, pipeChunk_, pipeLanes_) != PS_OK) {
+        lastError_ = std::string("ps_vo_stream_configure_async: ") + ps_last_error(f.ctx);
+        ps_vo_stream_destroy(f.pipe);
+        f.pipe = nullptr;
+        return false;
+    }
+    f.pm.resize((size_t)f.pipeCap);
+    f.pmask.resize((size_t)f.pipeCap);
+    return true;
+}
+
 bool FrameMatcher::enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
 {
+    const int st = enqueueFrameStatus(descriptors, std::move(features3D));
+    if (st < 0) std::cerr << "putslam_hip: " << lastError_ << std::endl;
+    return st == 1;
+}
+
+int FrameMatcher::enqueueFrameStatus(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D)
+{
     const int n = (int)features3D.size();
-    if (n > PS_MAX_KPTS || (n > 0 && (descriptors.cols != PS_DESC_BYTES || descriptors.rows != n))) return false;
+    if (n > PS_MAX_KPTS || (n > 0 && (descriptors.cols != PS_DESC_BYTES || descriptors.rows != n))) {
+        lastError_ = "enqueueFrame: descriptors must be n x 32 bytes with n <= PS_MAX_KPTS rows, one per 3-D feature";
+        return -1;
+    }
     if (!fused_) fused_.reset(new Fused());
     Fused &f = *fused_;
     if (!f.ctx) {
@@ -442,51 +500,49 @@ bool FrameMatcher::enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f
         if (const char *e = std::getenv("PUTSLAM_HIP_DEVICE")) dev = std::atoi(e);
         if (ps_context_create(dev, &f.ctx) != PS_OK) {
             f.ctx = nullptr;
-            return false;
+            lastError_ = "ps_context_create failed (no usable HIP device; there is no CPU fallback)";
+            return -1;
         }
     }
     if (!f.pipe) {
-        // the pipeline's frame capacity is fixed when it is built: room for a quarter more keypoints than the first frame has
-        f.pipeCap = std::min(PS_MAX_KPTS, std::max(2048, n + n / 4));
-        if (ps_vo_stream_create(f.ctx, f.pipeCap, &f.pipe) != PS_OK) {
-            f.pipe = nullptr;
-            return false;
-        }
-        matcherParameters.RANSACParams.errorVersion = matcherParameters.RANSACParams.errorVersionVO; // matcher.cpp:491-492
-        RANSAC::parameters rp = matcherParameters.RANSACParams;
-        rp.iterationCount = ransacIterations(0.20); // RANSAC.cpp:30
-        const PsRansacParams prm = toPs(rp);
-        int a = ransacIterations(0.20), b = ransacIterations(rp.minimalInlierRatioThreshold);
-        int H = std::max(1, std::min(a > b ? a : b, PS_MAX_HYPOTHESES));
-        PsRansacConfig cfg;
-        cfg.estimator = PS_EST_RANSAC;
-        cfg.numHypotheses = H;
-        // pair k of the pipeline draws from seed + k: runVO's seeding (seed_ + frameCounter, the counter starting at 0 with the
-        // initial frame)
-        cfg.seed = seeded_ ? seed_ : (uint64_t)std::time(nullptr); // RANSAC.cpp:13
-        cfg.sampleIdx = nullptr;
-        float K[9];
-        bool haveK;
-        cameraToK(matcherParameters.cameraMatrixMat, K, haveK);
-        // what comes back per frame is what Matcher::match returns: the inlier matches in input order + the pose (matcher.cpp:452-516)
-        ps_vo_stream_set_result_mode(f.pipe, PS_RESULTS_INLIERS);
-        if (ps_vo_stream_configure_async(f.pipe, &prm, &cfg, haveK ? K : nullptr, pipeChunk_, pipeLanes_) != PS_OK) {
-            std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
-            ps_vo_stream_destroy(f.pipe);
-            f.pipe = nullptr;
-            return false;
-        }
-        f.pm.resize((size_t)f.pipeCap);
-        f.pmask.resize((size_t)f.pipeCap);
+        // room for a quarter more keypoints than the first frame has; a later frame with more rebuilds the pipeline (below)
+        pipeSeeded_ = false;
+        if (!buildPipeline(std::min(PS_MAX_KPTS, std::max(2048, n + n / 4)), 0)) return -1;
         pipeFirst_ = true;
     }
-    if (n > f.pipeCap) return false;
+    if (n > f.pipeCap) {
+        // A frame with more keypoints than the pipeline was built for (runVO's synchronous stream regrows in place; here chunks
+        // are in flight).  While results are pending the caller is told "busy" -- the `while (!enqueueFrame) dequeueResult` loop
+        // drains them --; with nothing pending the pipeline is rebuilt with more room, the previous frame goes in again as its
+        // initial frame and pair numbering (= the hypothesis seeds) continues where it was.
+        if (ps_vo_stream_pending(f.pipe) > 0) {
+            lastError_ = "enqueueFrame: the frame has more keypoints than the pipeline's capacity; dequeue the pending results, the "
+                         "pipeline is rebuilt then";
+            return 0;
+        }
+        const bool hadPrev = !pipeFirst_;
+        if (!buildPipeline(std::min(PS_MAX_KPTS, std::max(n + n / 4, 2 * f.pipeCap)), hadPrev ? (uint64_t)frameCounter : 0)) return -1;
+        if (hadPrev) {
+            const int np = (int)prevFeatures3D.size();
+            int rc = ps_vo_stream_push_async(f.pipe, prevDescriptors.data, np > 0 ? (size_t)prevDescriptors.step : (size_t)PS_DESC_BYTES,
+                                             reinterpret_cast<const float *>(prevFeatures3D.data()), np);
+            if (rc != PS_OK) {
+                lastError_ = std::string("ps_vo_stream_push_async (previous frame into the rebuilt pipeline): ") + ps_last_error(f.ctx);
+                return -1;
+            }
+        }
+    }
     int rc = ps_vo_stream_push_async(f.pipe, descriptors.data, n > 0 ? (size_t)descriptors.step : (size_t)PS_DESC_BYTES,
                                      reinterpret_cast<const float *>(features3D.data()), n);
-    if (rc == PS_ERR_BUSY) return false;
+    if (rc == PS_ERR_BUSY) {
+        lastError_ = "enqueueFrame: the pipeline is full; dequeue results first";
+        return 0;
+    }
     if (rc != PS_OK) {
-        std::cerr << "putslam_hip: " << ps_last_error(f.ctx) << std::endl;
-        return false;
+        // (the pipelined stream has dropped the chunk this frame belonged to and started a new epoch: the frames enqueued since
+        // the last submitted chunk have no results; include/putslam_hip.h)
+        lastError_ = std::string("ps_vo_stream_push_async: ") + ps_last_error(f.ctx);
+        return -1;
     }
     if (pipeFirst_) {
         frameCounter = 0; // detectInitFeatures, matcher.cpp:17-64
@@ -497,7 +553,7 @@ bool FrameMatcher::enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f
     features3D.swap(prevFeatures3D); // matcher.cpp:506-513: the enqueued frame is the previous one for whatever comes next
     prevDescriptors = descriptors;
     fusedSynced_ = false;
-    return true;
+    return 1;
 }
 
 bool FrameMatcher::flushFrames()

@@ -226,12 +226,18 @@ class FrameMatcher {
     // Results are those runVO returns for the same frames in the same order (pair k draws from seed + k either way).
     //   setPipeline    frames per submitted chunk (1 = lowest latency) and chunks in flight; before the first enqueueFrame
     //   enqueueFrame   the first frame after construction / resetPipeline is the initial one (detectInitFeatures); returns false
-    //                  when the pipeline is full: dequeue results first
+    //                  when the frame was NOT taken.  enqueueFrameStatus tells why: 1 = taken, 0 = busy -- the pipeline is full, or
+    //                  the frame has more keypoints than the pipeline was built for and results are still pending: dequeue
+    //                  results and call again (the `while (!enqueueFrame(..)) dequeueResult(..)` loop does; once drained the
+    //                  pipeline is rebuilt with more room and numbering continues) --, -1 = error (lastError() has the text;
+    //                  enqueueFrame also prints it): retrying the same frame will not help
     //   dequeueResult  1 = the next frame's result (in frame order), 0 = none ready (wait = false) or none pending,
     //                  -1 = error; a partly filled chunk is submitted when a waiting call finds nothing in flight
     //   flushFrames    submits a partly filled chunk now
     void setPipeline(int chunkFrames, int lanes);
     bool enqueueFrame(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D);
+    int enqueueFrameStatus(cv::Mat descriptors, std::vector<Eigen::Vector3f> features3D);
+    const std::string &lastError() const { return lastError_; }
     int dequeueResult(Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches, double &pointInlierRatio,
                       bool wait = true);
     bool flushFrames();
@@ -265,6 +271,10 @@ class FrameMatcher {
     bool fusedSynced_ = false; // the resident frame is prevDescriptors / prevFeatures3D
     int pipeChunk_ = 32, pipeLanes_ = 4;
     bool pipeFirst_ = true;    // the next enqueued frame has no predecessor
+    uint64_t pipeSeed_ = 0;    // hypothesis seed of the pipeline's pair 0 (pair k draws from pipeSeed_ + k, across rebuilds)
+    bool pipeSeeded_ = false;
+    std::string lastError_;
+    bool buildPipeline(int cap, uint64_t pairsSoFar);
     bool fusedMatchCall(const cv::Mat &descriptors, const std::vector<Eigen::Vector3f> &features3D,
                         Eigen::Matrix4f &estimatedTransformation, std::vector<cv::DMatch> &inlierMatches,
                         double &pointInlierRatio);

@@ -592,7 +592,6 @@ unsigned big_limit(int mode) { return mode == PS_REPROJECTION_ERROR ? 1536u : 12
 int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = false, bool adaptive = false, const void *dataKey = nullptr)
 {
     const int H = pl.H;
-    PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
     const int hb = (H + kBlock - 1) / kBlock;
     // pruned scoring: worth its second launch when the hypotheses beyond the prefix fill the chip by themselves
     const bool prunable = with_euclid_fast(ctx, pl.mode) ||
@@ -648,7 +647,11 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
                 b.mode = pl.mode; b.estimator = pl.sa.estimator; b.H = H; b.pclass = pclass; b.cap = cap; b.frames = dataKey;
                 b.hopeless = 0;
                 b.calls = 0;
-                // (the slot's counters are monotonic: what its previous kind left there is simply "seen")
+                // (the slot's counters are monotonic: what its previous kind left there is simply "seen" -- once it HAS landed:
+                // a call of the previous kind may still be in flight, and counts arriving after the snapshot would read as an
+                // observation of the new kind.  Recycling is rare -- more than eight kinds alternating on one context -- and
+                // drains the stream first.)
+                (void)hipStreamSynchronize(ctx->stream);
                 b.seen[0] = ((volatile unsigned *)ctx->bailHost)[2 * slot];
                 b.seen[1] = ((volatile unsigned *)ctx->bailHost)[2 * slot + 1];
             }
@@ -671,6 +674,14 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
             ctx->hopeless = b.hopeless;
         }
     }
+    // Complete scoring of a batch under a long cap is the reference's own worst case times P (850 000 iterations over every
+    // match, USAC_wrapper.cpp:70): minutes of GPU time behind an asynchronous call.  It is refused -- here, before the counts
+    // block (4 bytes per pair and hypothesis: hundreds of GB for such a batch) is asked for; the staged scoring (option "prune",
+    // the default) takes the same batch in milliseconds whenever the schedules end early.
+    if (adaptive && !pl.prune && (double)P * (double)H * (double)cap > 2.0e14)
+        return fail(ctx, PS_ERR_UNSUPPORTED, "complete scoring of this batch (pairs x hypotheses x matches > 2e14) would run for minutes: "
+                                             "leave the staged scoring on (option \"prune\") or pass fewer pairs per call");
+    PS_ENSURE(ctx->counts, (size_t)P * H * sizeof(int32_t));
     pl.msplit = pick_split((long long)P * (pl.prune ? 1 : hb), 32, 64, cap);
     pl.genSplit = pl.prune && ctx->genSplit != 0 && pl.msplit > 1;
     if (pl.genSplit) pl.msplit = pl.msplit * 2 < 32 ? pl.msplit * 2 : 32; // (the parts no longer repeat the prologue)
@@ -2051,12 +2062,6 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     } handoffGuard{ctx};
     rc = prepare_score(ctx, pl, P, cap, false, true, frames->desc);
     if (rc) return rc;
-    // Complete scoring of a batch under a long cap is the reference's own worst case times P (850 000 iterations over every
-    // match, USAC_wrapper.cpp:70): minutes of GPU time behind an asynchronous call.  It is refused; the staged scoring (option
-    // "prune", the default) takes the same batch in milliseconds whenever the schedules end early.
-    if (!pl.prune && (double)P * (double)pl.H * (double)cap > 2.0e14)
-        return fail(ctx, PS_ERR_UNSUPPORTED, "complete scoring of this batch (pairs x hypotheses x matches > 2e14) would run for minutes: "
-                                             "leave the staged scoring on (option \"prune\") or pass fewer pairs per call");
     rc = run_match_stage(ctx, *frames, pairs, P, true, pl.pa, out->matches, out->numMatches, 0);
     if (rc) return rc;
     rc = run_ransac_stage(ctx, pl, P, cap, out->matches, out->numMatches, cap, out->pose, out->inlierMask, out->stats, 2);

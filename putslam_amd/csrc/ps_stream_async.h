@@ -69,6 +69,7 @@ struct PsVoAsync {
     int ahead = 0;                        // places beyond one per lane: chunks queued on the lanes' streams behind the running ones
     std::vector<PsContext *> laneCtx;     // the lanes (owned)
     long long launchSeq = 0;              // chunks launched so far (chunk k runs on lane k % lanes)
+    long long diagLaunches = 0;           // launches attempted since configure (fault injection of -DPS_STREAM_DIAG builds counts these)
     std::vector<hipEvent_t> upEv;         // lanes + ahead + 1 events, one per chunk alive, by chunk number
     std::vector<uint8_t *> stagePool;     // lanes + ahead + 1 pinned staging areas for frames that arrive one at a time / in
                                           // pageable memory: [B x cap x 32 descriptors][B x cap x 12 points], by chunk number;
@@ -198,8 +199,10 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     const size_t cap = (size_t)s->cap;
     AsyncLane &l = a->lane[(size_t)a->tail];
     // consecutive chunks on consecutive lanes; a lane's stream orders the chunks it is given (its scratch arena is theirs in turn)
+    // (launchSeq, the place's state, tail and inFlight are committed at the END of this function: a chunk that could not be
+    // queued completely leaves the pipeline's bookkeeping as it found it -- async_abort_chunk does the rest)
     PsContext *lc = l.ctx = a->laneCtx[(size_t)(a->launchSeq % (long long)a->lanes)];
-    a->launchSeq++;
+    a->diagLaunches++;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t1 = now();
     const int P = c.n - c.first;
@@ -234,12 +237,26 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     out.numMatches = (int32_t *)(dres + a->offNum);
     PsRansacConfig c2 = a->cfg;
     c2.seed = a->cfg.seed + (uint64_t)c.firstPair;
-    int rc = ps_vo_pairs_device(lc, &a->prm, &c2, a->haveK ? a->K : nullptr, &fs, (const int32_t *)l.meta.p, P, &out);
+    int rc = PS_OK;
+#ifdef PS_STREAM_DIAG
+    // fault injection (tests/test_gpu_stream_async.py builds the library with -DPS_STREAM_DIAG; the shipped one does not contain
+    // this): the batched call of the N-th chunk since configure fails before / after it has queued its launches
+    static const char *diagFail = std::getenv("PUTSLAM_HIP_STREAM_DIAG_FAIL_CHUNK");
+    static const char *diagFailAfter = std::getenv("PUTSLAM_HIP_STREAM_DIAG_FAIL_AFTER");
+    if (diagFail && std::atoll(diagFail) == a->diagLaunches - 1) {
+        lc->err = "injected failure (PS_STREAM_DIAG)";
+        rc = PS_ERR_HIP;
+    }
+#endif
+    if (rc == PS_OK) rc = ps_vo_pairs_device(lc, &a->prm, &c2, a->haveK ? a->K : nullptr, &fs, (const int32_t *)l.meta.p, P, &out);
     if (rc != PS_OK) {
         ctx->err = std::string("pipelined chunk: ") + lc->err;
-        (void)hipStreamSynchronize(lc->stream);
         return rc;
     }
+#ifdef PS_STREAM_DIAG
+    if (diagFailAfter && std::atoll(diagFailAfter) == a->diagLaunches - 1)
+        return fail(ctx, PS_ERR_HIP, "pipelined chunk: injected failure behind the batched call (PS_STREAM_DIAG)");
+#endif
     const double t2 = now();
     // The download goes out on a stream of its own, behind an event, when the process has hardware queues to spare (async_build):
     // this runtime executes a device -> host hipMemcpyAsync as a blit kernel whatever stream it is queued on
@@ -286,14 +303,44 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     l.firstPair = c.firstPair;
     l.pairs = P;
     l.epoch = c.epoch;
+    a->launchSeq++;
     a->tail = (a->tail + 1) % (int)a->lane.size();
     a->inFlight++;
     return PS_OK;
 }
 
+// A chunk could not be queued (an allocation or a HIP call failed somewhere between its upload and its download).  Whatever
+// part of it WAS queued is drained -- nothing is in flight on a place that is still marked free --, the chunk's frames are
+// dropped as a unit, and the stream continues as after ps_vo_stream_reset: the next frame has no predecessor, pair numbering
+// restarts at 0, the epoch advances (include/putslam_hip.h).  Chunks submitted before keep their place, numbering and epoch.
+int async_abort_chunk(PsVoStream *s, int rc)
+{
+    PsVoAsync *a = s->async;
+    const std::string why = s->ctx->err;
+    if (a->copyStream) (void)hipStreamSynchronize(a->copyStream);
+    PsContext *lc = a->laneCtx.empty() ? nullptr : a->laneCtx[(size_t)(a->launchSeq % (long long)a->lanes)];
+    if (lc) (void)hipStreamSynchronize(lc->stream);
+    if (a->copyOutStream) (void)hipStreamSynchronize(a->copyOutStream);
+    (void)hipGetLastError();
+    a->prevPos = -1;
+    a->pairCounter = 0;
+    a->epoch++;
+    a->staged = 0;
+    s->ctx->err = why + " -- pipelined stream: the chunk's frames were dropped; the next frame starts a new epoch (pair numbering from 0)";
+    return rc;
+}
+
 // One chunk: n frames (pinned host memory: desc n x cap x 32, pts n x cap x 3; row counts nk) -> ring -> the next place, launched
 // on the next lane's stream.  The caller has checked async_room().
+int async_submit_body(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n);
+
 int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
+{
+    const int rc = async_submit_body(s, desc, pts, nk, n);
+    return rc == PS_OK ? PS_OK : async_abort_chunk(s, rc);
+}
+
+int async_submit_body(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
 {
     PsVoAsync *a = s->async;
     PsContext *ctx = s->ctx;
@@ -642,14 +689,16 @@ int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, 
         if (v.count == 0) return PS_OK;
     }
     const PsHostPairResults &v = a->view;
-    const size_t i = (size_t)a->cursor++, cap = (size_t)s->cap;
+    const size_t i = (size_t)a->cursor, cap = (size_t)s->cap;
     int nm = v.numMatches[i];
     if (a->resultMode == PS_RESULTS_INLIERS) nm = v.stats[i].numInliers; // the inlier matches only, as Matcher::match returns them
     if (a->resultMode == PS_RESULTS_POSES) nm = 0;
+    // (checked before the cursor moves: a call refused for its arguments loses no pair)
+    if (nm > 0 && (!matches || !inlierMask)) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: null output");
+    a->cursor++;
     memcpy(pose, v.pose + i * 16, 16 * sizeof(float));
     if (stats) *stats = v.stats[i];
     if (nm > 0) {
-        if (!matches || !inlierMask) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: null output");
         memcpy(matches, v.matches + i * cap, (size_t)nm * sizeof(PsDMatch));
         if (a->resultMode == PS_RESULTS_FULL)
             memcpy(inlierMask, v.inlierMask + i * cap, (size_t)nm);

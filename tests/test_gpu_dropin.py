@@ -86,6 +86,22 @@ def test_cpp_demo_matching_pipelined_writes_the_same_trajectory(tmp_path, chunk)
     assert a.read_text() == b.read_text() and len(a.read_text().strip().split("\n")) == 45
 
 
+@pytest.mark.parametrize("chunk", [1, 8])
+def test_cpp_pipelined_matcher_grows_with_the_frames(tmp_path, chunk):
+    """the pipelined drop-in fixed its frame capacity at the first frame and refused larger frames for ever.
+    A sequence whose first third carries 2200 keypoints and the rest 5500 (capacity 2750 at first): enqueueFrame answers
+    "busy" until the pending results are dequeued, rebuilds the pipeline with more room and continues -- same pairs, same
+    hypothesis seeds: the trajectory file equals the synchronous runVO's, which regrows its stream in place."""
+    exe = os.path.join(ROOT, "demos", "cpp", "demo_matching")
+    a, b = tmp_path / "sync.txt", tmp_path / "pipe.txt"
+    p = subprocess.run([exe, "24", "5500", str(a), "--ragged"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    q = subprocess.run([exe, "24", "5500", str(b), "--ragged", "--pipelined", str(chunk)], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout + q.stderr
+    assert "23 increments accepted, 0 rejected" in q.stdout
+    assert a.read_text() == b.read_text() and len(a.read_text().strip().split("\n")) == 24
+
+
 def test_reference_shaped_plugin_links_and_matches_oracle(oracle, tmp_path):
     """tests/cpp/test_reference_shaped.cpp: a translation unit with classes named putslam::Matcher / ::MatcherOpenCV and
     the reference's factories (bodies as INTEGRATION.md section 2 prescribes) linked against the drop-in.  N3: the

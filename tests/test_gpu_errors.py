@@ -117,3 +117,26 @@ def test_null_context_is_rejected_everywhere():
     assert L.ps_match_hamming256(None, _p(buf), 1, 32, _p(buf), 1, 32, _p(buf), C.byref(n)) == BAD_ARG
     assert L.ps_context_enable_timing(None, 1) == BAD_ARG
     assert L.ps_context_set_stream(None, None) == BAD_ARG
+
+
+def test_minutes_long_batch_is_refused_before_anything_is_allocated():
+    """complete scoring (option "prune" = 0) of a batch under USAC's cap -- 20 000 pairs x 850 000 hypotheses x
+    16 384 matches > 2e14 evaluations -- is refused with PS_ERR_UNSUPPORTED.  The refusal used to stand BEHIND the request for the
+    per-hypothesis counts block (4 bytes x pairs x hypotheses = 68 GB here, 400 GB for larger batches: an allocation failure or a
+    huge allocation instead of the message); now it comes first and the context's arena stays as small as it was."""
+    import torch
+    from putslam_amd import api
+    from putslam_amd._abi import EST_USAC
+    c = api.Context(0)
+    c.set_option("prune", 0)
+    before = c.get_option("arena_mib")
+    dummy = torch.zeros(4096, dtype=torch.uint8, device="cuda")          # never touched: the call is refused before any launch
+    p = dummy.data_ptr()
+    prm = default_ransac_params(0)
+    cfg, _ = make_config(EST_USAC, 850000, seed=1)
+    with pytest.raises(api.PsError) as e:
+        c.vo_pairs_device(prm, cfg, TUM_FR1_K, api.DeviceFrames(p, p, p, 20001, 16384), p, 20000, api.DeviceResults(p, p, p, p, p))
+    assert e.value.code == UNSUPPORTED and "run for minutes" in str(e.value)
+    assert c.get_option("arena_mib") <= before + 8                        # (stop tables only)
+    c.set_option("prune", 1)
+    c.close()

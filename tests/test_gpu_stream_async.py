@@ -466,3 +466,46 @@ if __name__ == "__main__":
     b = fuzz_stream(n, seed, verbose=True)
     print(f"stream fuzz done: {n} configurations, {b} mismatches")
     sys.exit(1 if b else 0)
+
+
+@pytest.mark.parametrize("where,chunk", [("FAIL_CHUNK", 3), ("FAIL_AFTER", 2), ("FAIL_CHUNK", 0)])
+def test_failed_chunk_is_dropped_as_a_unit(where, chunk):
+    """VERDICT round 5 item 6 / ADVICE: the error path of the pipelined stream is transactional.  A library built with
+    -DPS_STREAM_DIAG (putslam_amd/libputslam_hip_diag.so, loaded by path in a child process) fails the N-th chunk's batched call
+    before it has queued anything, or behind it (work in flight, no place taken yet); tests/stream_fault_case.py checks what the
+    header promises against the oracle -- the failing push reports it, the chunk's frames are dropped as a unit, later chunks
+    come back in a new epoch with pair numbering (hypothesis seeds) from 0, earlier ones keep theirs, no place is lost."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "putslam_amd", "libputslam_hip_diag.so")
+    assert os.path.exists(lib), "putslam_amd/libputslam_hip_diag.so is not built (__graft_entry__.build())"
+    env = dict(os.environ, PUTSLAM_HIP_LIB=lib)
+    env["PUTSLAM_HIP_STREAM_DIAG_" + where] = str(chunk)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "stream_fault_case.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ok: chunk %d failed" % chunk in p.stdout
+
+
+def test_pop_refused_for_its_arguments_loses_no_pair(ctx, seq64):
+    """ps_vo_stream_pop checks its output pointers before it moves on: a refused call returns the same pair next time."""
+    import ctypes as C
+    from putslam_amd import api
+    from putslam_amd._abi import DMATCH_DTYPE, STATS_DTYPE
+    seq, sets = seq64
+    prm, cfg, c = sets["e1"]
+    st = api.VoStream(ctx, 600)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=8, lanes=2)
+    for f in range(9):
+        assert st.push_async(seq["desc"][f], seq["pts"][f])
+    st.flush()
+    L = ctx._L
+    nm, pose = C.c_int(0), np.zeros(16, np.float32)
+    rc = L.ps_vo_stream_pop(st._h, 1, None, C.byref(nm), None, pose.ctypes.data_as(C.c_void_p), None)   # matches / mask missing
+    assert rc == -1
+    for p in range(8):                                 # every pair is still there, in order
+        r = st.pop(wait=True)
+        assert r is not None and r["pose"].T.reshape(-1).tobytes() == c["pose"][p].tobytes(), p
+    assert st.pop(wait=True) is None
+    st.close()
