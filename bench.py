@@ -772,9 +772,13 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     h2d, d2h = _link_rate(torch, dev)
     out = {}
 
-    def run(chunk, lanes, steps, check, warm_s=0.4, results=0, windows=1):
+    from putslam_amd.device_batch import pack_frames
+    hpk = api.PinnedBuffer((F, (cap * 44 + 15) // 16 * 16), np.uint8)     # the same frames, one block per frame (PS_FRAMES_PACKED)
+    hpk.array[:] = pack_frames(seq["desc"], seq["pts"], hpk.array.shape[1])
+
+    def run(chunk, lanes, steps, check, warm_s=0.4, results=0, windows=1, packed=True):
         st = api.VoStream(c0, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=results)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=results, packed=packed)
         lat, sub_t = [], {}
         state = {"pairs": 0, "inl": 0, "bad": 0, "step": 0}
 
@@ -803,7 +807,8 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
             while f < F:
                 n = min(chunk, F - f)
                 t_sub = time.perf_counter()
-                if st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n]):
+                if (st.push_many_packed(hpk.array[f:f + n], nk[f:f + n]) if packed else
+                        st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n])):
                     pairs = n - (1 if f == 0 else 0)
                     if pairs > 0:
                         sub_t[(ep + 1, first)] = t_sub            # (epoch = resets before the block's frames)
@@ -844,6 +849,8 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                "pairs_per_s_min": wins[0][1] / wins[0][0], "pairs_per_s_max": wins[-1][1] / wins[-1][0],
                "chunk_frames": chunk, "lanes": _stream_shape(chunk, lanes)[0], "places": sum(_stream_shape(chunk, lanes)),
                "results": ["full", "inliers", "poses"][results],
+               "frames": ("packed: one block per frame, one upload per chunk (ps_vo_stream_push_many_packed)" if packed else
+                          "two arrays: two uploads per chunk (ps_vo_stream_push_many)"),
                "h2d_GBps": steps * F * cap * 44 / el / 1e9,
                "d2h_GBps": (done * (cap * 17 + 108) if results == 0 else
                             (state["inl"] - inl0) * 16 + done * 108 if results == 1 else done * 108) / el / 1e9,
@@ -862,10 +869,12 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                         "bytes_in_per_frame": cap * 44, "bytes_out_per_pair": cap * 17 + 108,
                         "note": "host -> device bytes of the frames themselves over the timed legs' wall time; uploads, kernels "
                                 "and downloads of consecutive chunks overlap"}
-    main["workload"] = ("BASELINE configs[2] as written: %d frames streamed from pinned host memory per step (ps_vo_stream_push_many, "
-                        "chunks of %d frames on %d lanes), every pair's matches / mask / pose / stats downloaded (pop_many); same "
+    main["workload"] = ("BASELINE configs[2] as written: %d frames streamed from pinned host memory per step (ps_vo_stream_push_many_packed: "
+                        "one block per frame, one upload per chunk; chunks of %d frames on %d lanes), every pair's matches / mask / pose / stats downloaded (pop_many); same "
                         "parameters as the timed workload" % (F, args.stream_chunk, _stream_shape(args.stream_chunk, args.stream_lanes)[0]))
     out["streamed"] = main
+    # rounds 4 - 5's form, kept beside it: descriptors and points as two host arrays, two uploads per chunk
+    out["streamed/two_arrays"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=0.8, windows=3, packed=False)
     # what Matcher::match itself returns -- estimatedTransformation + inlierMatches (matcher.cpp:452-516) -- instead of every
     # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block
     out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
@@ -877,6 +886,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     out["streamed/chunk1"] = one
     hd.close()
     hp.close()
+    hpk.close()
     return out
 
 

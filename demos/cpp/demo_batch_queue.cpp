@@ -170,6 +170,7 @@ int main(int argc, char **argv)
     fs.nkpts = dNk;
     fs.numFrames = frames;
     fs.maxKpts = cap;
+    fs.descFrameStride = fs.ptsFrameStride = 0; // dense frames
     Results res;
     if (alloc_results(P, cap, res)) return 2;
 

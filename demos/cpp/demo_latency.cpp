@@ -103,6 +103,7 @@ int main(int argc, char **argv)
     fs.nkpts = dNk;
     fs.numFrames = 2;
     fs.maxKpts = N;
+    fs.descFrameStride = fs.ptsFrameStride = 0; // dense frames
     PsPairResults out;
     out.matches = dMatches;
     out.numMatches = dNum;

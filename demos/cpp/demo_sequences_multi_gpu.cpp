@@ -273,6 +273,7 @@ int main(int argc, char **argv)
         fs.nkpts = dev[(size_t)i].nk;
         fs.numFrames = seq[(size_t)i].frames;
         fs.maxKpts = seq[(size_t)i].cap;
+        fs.descFrameStride = fs.ptsFrameStride = 0; // dense frames
         PsShardJob &j = jobs[(size_t)i];
         j.params = &r.params;
         j.cfg = &cfg;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 1
+#define PS_ABI_VERSION 2          /* 2: PsFrameSet carries frame strides (packed frames) */
 #define PS_DESC_BYTES 32          /* ORB (matcherOpenCV.cpp:90) and LDB (ldb.cpp:61,657) rows: 256 bit */
 #define PS_MAX_KPTS 16384         /* keypoints per frame handled by one launch (LDS-resident cross-check) */
 #define PS_MAX_HYPOTHESES (1 << 20)
@@ -263,6 +263,13 @@ typedef struct PsFrameSet {
     const int32_t *nkpts;     /* numFrames keypoint counts (<= maxKpts) */
     int32_t numFrames;
     int32_t maxKpts;          /* row capacity per frame; also the capacity of per-pair outputs */
+    /* ABI 2: bytes from one frame's block to the next; 0 = dense (maxKpts x 32 / maxKpts x 12).  A frame set whose frames keep
+     * their descriptors and points together -- [maxKpts x 32 B][maxKpts x 12 B] per frame, what one transfer per frame or per
+     * chunk of frames delivers (the prevDescriptors / prevFeatures3D pair of matcher.h:379-384 as one block) -- has
+     * pts = desc + maxKpts x 32 and both strides = the frame's size.  descFrameStride: a multiple of 16, >= maxKpts x 32;
+     * ptsFrameStride: a multiple of 4, >= maxKpts x 12. */
+    size_t descFrameStride;
+    size_t ptsFrameStride;
 } PsFrameSet;
 
 typedef struct PsPairResults {
@@ -408,6 +415,17 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * numMatches is the number of cross-check matches in every mode.  Modes 1 and 2 are written by a kernel straight into the
  * lane's pinned block (no copy engine, no blit kernel beside the other lanes' launches). */
 typedef enum PsStreamResults { PS_RESULTS_FULL = 0, PS_RESULTS_INLIERS = 1, PS_RESULTS_POSES = 2 } PsStreamResults;
+/* How frames lie on the host and in the ring (ps_vo_stream_set_frame_layout, before ps_vo_stream_configure_async):
+ *   PS_FRAMES_TWO_ARRAYS  descriptors and points in two arrays (push_many's form): two uploads per chunk;
+ *   PS_FRAMES_PACKED      every frame is ONE block [maxKpts x 32 B descriptors][maxKpts x 12 B points] padded to
+ *                         ps_vo_stream_packed_stride() bytes (maxKpts x 44 rounded up to 16; 88 000 at 2000 keypoints) -- what
+ *                         a front end that detects, describes and back-projects a frame naturally fills, the reference's
+ *                         prevDescriptors / prevFeatures3D state (include/putslam/Matcher/matcher.h:379-384) as one block --,
+ *                         the ring in HBM has the same layout (PsFrameSet strides) and a chunk is ONE transfer: the link does
+ *                         not idle between a descriptor and a point upload (+ 10 ... 15 % at chunks of 125).
+ *                         ps_vo_stream_push_many_packed reads pinned frames in place (pageable ones are staged);
+ *                         push_async / push_many still work on such a stream: they fill packed staging blocks on the host. */
+typedef enum PsStreamFrames { PS_FRAMES_TWO_ARRAYS = 0, PS_FRAMES_PACKED = 1 } PsStreamFrames;
 
 typedef struct PsHostPairResults {
     const PsDMatch *matches;      /* count x maxKpts (PS_RESULTS_INLIERS: the inlier matches first; PS_RESULTS_POSES: NULL) */
@@ -426,6 +444,9 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
                                  int chunkFrames, int lanes);
 int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep, const float *pts, int n);
 int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nkpts, int numFrames);
+int ps_vo_stream_set_frame_layout(PsVoStream *s, int layout /* PsStreamFrames; takes effect at the next configure_async */);
+size_t ps_vo_stream_packed_stride(const PsVoStream *s);
+int ps_vo_stream_push_many_packed(PsVoStream *s, const uint8_t *frames, size_t frameStride, const int32_t *nkpts, int numFrames);
 int ps_vo_stream_flush(PsVoStream *s);
 int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out);
 int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, uint8_t *inlierMask, float *pose,

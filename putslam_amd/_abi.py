@@ -52,7 +52,8 @@ class PsRansacStats(C.Structure):
 
 class PsFrameSet(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("pts", C.c_void_p), ("nkpts", C.c_void_p),
-                ("numFrames", C.c_int32), ("maxKpts", C.c_int32)]
+                ("numFrames", C.c_int32), ("maxKpts", C.c_int32),
+                ("descFrameStride", C.c_size_t), ("ptsFrameStride", C.c_size_t)]     # ABI 2: 0 = dense frames
 
 
 class PsPairResults(C.Structure):

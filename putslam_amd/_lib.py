@@ -29,7 +29,7 @@ EXPORTED = [
     "ps_batch_queue_wait_on_stream", "ps_batch_queue_synchronize", "ps_batch_queue_chains", "ps_batch_queue_context",
     "ps_batch_queue_last_split", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
-    "ps_vo_stream_set_result_mode", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
+    "ps_vo_stream_set_result_mode", "ps_vo_stream_set_frame_layout", "ps_vo_stream_packed_stride", "ps_vo_stream_push_many_packed", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
     "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
@@ -150,6 +150,10 @@ def load_path(path):
     L.ps_vo_stream_set_result_mode.argtypes = [vp, i32]
     L.ps_vo_stream_push_async.argtypes = [vp, vp, sz, vp, i32]
     L.ps_vo_stream_push_many.argtypes = [vp, vp, vp, vp, i32]
+    L.ps_vo_stream_set_frame_layout.argtypes = [vp, i32]
+    L.ps_vo_stream_packed_stride.argtypes = [vp]
+    L.ps_vo_stream_packed_stride.restype = sz
+    L.ps_vo_stream_push_many_packed.argtypes = [vp, vp, sz, vp, i32]
     L.ps_vo_stream_flush.argtypes = [vp]
     L.ps_vo_stream_pop_many.argtypes = [vp, i32, C.POINTER(PsHostPairResults)]
     L.ps_vo_stream_pop.argtypes = [vp, i32, vp, C.POINTER(i32), vp, vp, vp]

@@ -272,7 +272,8 @@ class Context:
     # ---- A2 / A12: device-resident batch ----
     def vo_pairs_device(self, params, cfg, K, frames: "DeviceFrames", pairs_dev_ptr, P, out: "DeviceResults"):
         K = np.ascontiguousarray(K, np.float32)
-        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts)
+        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts,
+                        frames.desc_stride, frames.pts_stride)
         res = PsPairResults(out.matches_ptr, out.num_matches_ptr, out.mask_ptr, out.pose_ptr, out.stats_ptr)
         self._chk(self._L.ps_vo_pairs_device(self._h, C.byref(params), C.byref(cfg), _p(K), C.byref(fs),
                                              C.c_void_p(pairs_dev_ptr), int(P), C.byref(res)))
@@ -316,7 +317,8 @@ class BatchQueue:
     def submit(self, params, cfg, K, frames: "DeviceFrames", pairs_dev_ptr, P, out: "DeviceResults"):
         """Asynchronous; returns the batch's ticket."""
         K = np.ascontiguousarray(K, np.float32)
-        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts)
+        fs = PsFrameSet(frames.desc_ptr, frames.pts_ptr, frames.nkpts_ptr, frames.num_frames, frames.max_kpts,
+                        frames.desc_stride, frames.pts_stride)
         res = PsPairResults(out.matches_ptr, out.num_matches_ptr, out.mask_ptr, out.pose_ptr, out.stats_ptr)
         t = C.c_int64(-1)
         self._ctx._chk(self._ctx._L.ps_batch_queue_submit(self._h, C.byref(params), C.byref(cfg), _p(K), C.byref(fs),
@@ -390,10 +392,13 @@ class VoStream:
                     pose=self._pose.reshape(4, 4).T.copy(), stats=self._stats[0].copy())
 
     # ---- pipelined form (ps_vo_stream_configure_async ...): results come back with a lag, in pair order ----
-    def configure_async(self, params, cfg, K, chunk_frames=0, lanes=0, results=0):
-        """results: 0 = everything (PS_RESULTS_FULL), 1 = inlier matches + pose + stats, 2 = pose + stats."""
+    def configure_async(self, params, cfg, K, chunk_frames=0, lanes=0, results=0, packed=False):
+        """results: 0 = everything (PS_RESULTS_FULL), 1 = inlier matches + pose + stats, 2 = pose + stats.
+        packed: PS_FRAMES_PACKED -- every frame one block [cap x 32 B][cap x 12 B] of `packed_stride` bytes, on the host and in
+        the ring: one upload per chunk (push_many_packed)."""
         K = None if K is None else np.ascontiguousarray(K, np.float32)
         self._ctx._chk(self._ctx._L.ps_vo_stream_set_result_mode(self._h, int(results)))
+        self._ctx._chk(self._ctx._L.ps_vo_stream_set_frame_layout(self._h, 1 if packed else 0))
         self._ctx._chk(self._ctx._L.ps_vo_stream_configure_async(self._h, C.byref(params), C.byref(cfg), _p(K),
                                                                  int(chunk_frames), int(lanes)))
 
@@ -421,6 +426,22 @@ class VoStream:
             assert desc.shape[1:] == (self._cap, 32) and pts.shape[1:] == (self._cap, 3)
             dp, pp = _p(desc), _p(pts)
         return self._rc(self._ctx._L.ps_vo_stream_push_many(self._h, dp, pp, _p(nk), nk.shape[0]))
+
+    @property
+    def packed_stride(self):
+        """Bytes per frame of the packed layout (cap x 44 rounded up to a multiple of 16)."""
+        return int(self._ctx._L.ps_vo_stream_packed_stride(self._h))
+
+    def push_many_packed(self, frames, nkpts):
+        """frames: (F, packed_stride) u8, every row [cap x 32 B descriptors][cap x 12 B points][padding] -- a numpy array
+        (pinned: read in place) or a raw address; nkpts (F,) i32."""
+        nk = np.ascontiguousarray(nkpts, np.int32)
+        if isinstance(frames, int):
+            fp = C.c_void_p(frames)
+        else:
+            assert frames.flags.c_contiguous and frames.dtype == np.uint8 and frames.shape[1:] == (self.packed_stride,)
+            fp = _p(frames)
+        return self._rc(self._ctx._L.ps_vo_stream_push_many_packed(self._h, fp, self.packed_stride, _p(nk), nk.shape[0]))
 
     def flush(self):
         return self._rc(self._ctx._L.ps_vo_stream_flush(self._h))
@@ -495,9 +516,10 @@ class PinnedBuffer:
 class DeviceFrames:
     """Raw device pointers of a frame set (PsFrameSet)."""
 
-    def __init__(self, desc_ptr, pts_ptr, nkpts_ptr, num_frames, max_kpts):
+    def __init__(self, desc_ptr, pts_ptr, nkpts_ptr, num_frames, max_kpts, desc_stride=0, pts_stride=0):
         self.desc_ptr, self.pts_ptr, self.nkpts_ptr = desc_ptr, pts_ptr, nkpts_ptr
         self.num_frames, self.max_kpts = int(num_frames), int(max_kpts)
+        self.desc_stride, self.pts_stride = int(desc_stride), int(pts_stride)      # bytes between frames; 0 = dense
 
 
 class DeviceResults:

@@ -1034,9 +1034,19 @@ int ensure_records(PsContext *ctx, size_t P, size_t cap)
 
 // Kernels 1 + 2 for P pairs of a device-resident frame set.
 int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs, int P, bool withRecords,
-                    const PrepArgs &pa, PsDMatch *dMatches, int32_t *dNumMatches, int slot0)
+                    const PrepArgs &paIn, PsDMatch *dMatches, int32_t *dNumMatches, int slot0)
 {
     const int cap = fs.maxKpts;
+    // frame strides (PsFrameSet, ABI 2): dense unless the frames keep descriptors and points together
+    const size_t descStride = fs.descFrameStride ? fs.descFrameStride : (size_t)cap * 32;
+    const size_t ptsStride = fs.ptsFrameStride ? fs.ptsFrameStride : (size_t)cap * 12;
+    if ((descStride & 15) != 0 || descStride < (size_t)cap * 32 || (ptsStride & 3) != 0 || (fs.pts && ptsStride < (size_t)cap * 12) ||
+        descStride / 4 > (size_t)INT_MAX || ptsStride / 4 > (size_t)INT_MAX || ((uintptr_t)fs.desc & 15) != 0)
+        return fail(ctx, PS_ERR_BAD_ARG, "frame set: descFrameStride must be a multiple of 16 and >= maxKpts x 32 (desc 16-byte aligned), "
+                                         "ptsFrameStride a multiple of 4 and >= maxKpts x 12");
+    const int fstrideDw = (int)(descStride / 4);
+    PrepArgs pa = paIn;
+    pa.ptsStride = (int)(ptsStride / 4);
     PS_ENSURE(ctx->keys, (size_t)P * cap * sizeof(uint32_t));
     PS_ENSURE(ctx->mvalid, (size_t)P * sizeof(int32_t));
     PS_ENSURE(ctx->cmax, (size_t)P * sizeof(float2));
@@ -1079,7 +1089,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
             }
             tick(ctx, 5, false);
             hipLaunchKernelGGL(ps_hamming_mfma_fused<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
-                               ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                               ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, fstrideDw, tpf, groups, qsplit,
                                (uint32_t *)ctx->keys.p);
             tick(ctx, 5, true);
             PS_HIP(hipGetLastError());
@@ -1089,12 +1099,12 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         if ((long long)P * xchunks < 1024) xchunks = tpf < 64 ? tpf : 64;
         tick(ctx, 4, false);
         hipLaunchKernelGGL(ps_expand_query_fp4, dim3((unsigned)xchunks * (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, xchunks, (uint4 *)ctx->xq.p,
+                           (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, fstrideDw, tpf, xchunks, (uint4 *)ctx->xq.p,
                            qsplit > 1 ? (uint32_t *)ctx->keys.p : (uint32_t *)nullptr); // also clears the keys
         tick(ctx, 4, true);
         tick(ctx, 5, false);
         hipLaunchKernelGGL(ps_hamming_mfma<TT>, dim3((unsigned)(groups * qsplit) * (unsigned)P), dim3(kBlock), 0,
-                           ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, tpf, groups, qsplit,
+                           ctx->stream, (const uint32_t *)fs.desc, fs.nkpts, dPairs, cap, fstrideDw, tpf, groups, qsplit,
                            (const uint4 *)ctx->xq.p, (uint32_t *)ctx->keys.p);
         tick(ctx, 5, true);
         PS_HIP(hipGetLastError());
@@ -1113,7 +1123,7 @@ int run_match_stage(PsContext *ctx, const PsFrameSet &fs, const int32_t *dPairs,
         }
         tick(ctx, slot0, false);
         hipLaunchKernelGGL(ps_hamming_nn<TPL>, dim3((unsigned)(tiles * qsplit) * (unsigned)P), dim3(kBlock), 0, ctx->stream,
-                           (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, tiles, qsplit, (uint32_t *)ctx->keys.p);
+                           (const uint4 *)fs.desc, fs.nkpts, dPairs, cap, fstrideDw / 4, tiles, qsplit, (uint32_t *)ctx->keys.p);
         tick(ctx, slot0, true);
         PS_HIP(hipGetLastError());
     }
@@ -1504,6 +1514,7 @@ int ps_match_hamming256(PsContext *ctx, const uint8_t *query, int nq, size_t qst
     fs.nkpts = (const int32_t *)ctx->sNk.p;
     fs.numFrames = 2;
     fs.maxKpts = cap;
+    fs.descFrameStride = fs.ptsFrameStride = 0;
     PrepArgs pa{};
     pa.cap = cap;
     rc = run_match_stage(ctx, fs, (const int32_t *)ctx->sNk.p + 2, 1, false, pa, (PsDMatch *)ctx->sMatches.p,
@@ -2111,6 +2122,7 @@ struct PsVoStream {
     long long pushTimed = 0;
     struct PsVoAsync *async = nullptr; // the pipelined form's state (ps_stream_async.h); null = synchronous stream
     int asyncResultMode = 0;           // PsStreamResults of the next ps_vo_stream_configure_async
+    int asyncFrameLayout = 0;          // PsStreamFrames of the next ps_vo_stream_configure_async
 };
 static void async_release(PsVoStream *s); // (ps_stream_async.h)
 static int async_reset(PsVoStream *s);
@@ -2279,6 +2291,7 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
     fs.nkpts = (const int32_t *)s->meta.p;
     fs.numFrames = 2;
     fs.maxKpts = s->cap;
+    fs.descFrameStride = fs.ptsFrameStride = 0;
     Plan pl;
     rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
     if (rc) return rc;

@@ -78,7 +78,7 @@ PS_D uint32_t ham_key(const uint4 &a, const uint4 &b, const uint4 &x, const uint
 template <int TPL>
 __global__ __launch_bounds__(kBlock) void ps_hamming_nn(const uint4 *__restrict__ desc,
                                                         const int32_t *__restrict__ nkpts,
-                                                        const int32_t *__restrict__ pairs, int cap, int tiles,
+                                                        const int32_t *__restrict__ pairs, int cap, int fstride, int tiles,
                                                         int qsplit, uint32_t *__restrict__ keys)
 {
     const unsigned perPair = (unsigned)(tiles * qsplit);
@@ -92,8 +92,10 @@ __global__ __launch_bounds__(kBlock) void ps_hamming_nn(const uint4 *__restrict_
     if (t0 >= nt) return;
     const int q0 = (int)(((long long)nq * qs) / qsplit), q1 = (int)(((long long)nq * (qs + 1)) / qsplit);
 
-    const uint4 *__restrict__ tdesc = desc + (size_t)ft * cap * 2;
-    const uint4 *__restrict__ qdesc = desc + (size_t)fq * cap * 2;
+    // (fstride: uint4 units between consecutive frames' descriptor blocks -- cap * 2 for the dense frame set, the packed
+    // frame's stride when descriptors and points of a frame lie together, PsFrameSet::descFrameStride)
+    const uint4 *__restrict__ tdesc = desc + (size_t)ft * fstride;
+    const uint4 *__restrict__ qdesc = desc + (size_t)fq * fstride;
 
     uint4 a[TPL], b[TPL];
     uint32_t best[TPL];
@@ -265,6 +267,7 @@ struct PrepArgs {
     double thrE;            // inlierThresholdEuclidean
     int mode;               // RANSAC::ERROR_VERSION
     int cap;
+    int ptsStride;          // floats between consecutive frames' point blocks (PsFrameSet::ptsFrameStride / 4; cap * 3 when dense)
     int32_t *zeroCounts;    // optional: the first zeroH counts of every pair (row stride zeroStride) to clear for kernel 3's
     int zeroH;              // split-range atomics (saves a memset launch)
     int zeroStride;
@@ -395,8 +398,8 @@ __global__ __launch_bounds__(BLOCK) void ps_crosscheck_prep(const float *__restr
     }
     __syncthreads();
     phase_stamp(stamps, 1); // best[q] built
-    const float *pp = pts + (size_t)fq * cap * 3;
-    const float *cp = pts + (size_t)ft * cap * 3;
+    const float *pp = pts + (size_t)fq * a.ptsStride; // (floats between consecutive frames' point blocks: cap * 3 when dense)
+    const float *cp = pts + (size_t)ft * a.ptsStride;
     int base = 0, vbase = 0;
     // one candidate per thread and trip; the next trip's key and points are fetched before this trip's scan, so that the
     // gather's latency (the points were written by another launch: nothing is cached) runs beside it instead of in front of

@@ -74,9 +74,10 @@ PS_D int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 // o = s * 64 + h * 32 + r (the layout the MFMA kernel reads back linearly), i.e. dword 2s + h of row r.
 // Rows beyond the frame's count are written as zeros (0.0 in FP4); the MFMA kernel masks them anyway.
 // ------------------------------------------------------------------------------------------
+// (fstride in all three kernels: dwords between consecutive frames' descriptor blocks -- cap * 8 for the dense frame set)
 __global__ __launch_bounds__(kBlock) void ps_expand_query_fp4(const uint32_t *__restrict__ desc,
                                                               const int32_t *__restrict__ nkpts,
-                                                              const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                              const int32_t *__restrict__ pairs, int cap, int fstride, int tpf,
                                                               int chunks, uint4 *__restrict__ Xq,
                                                               uint32_t *__restrict__ keysInit)
 {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void ps_expand_query_fp4(const uint32_t *__
         for (int t = chunk * kBlock + threadIdx.x; t < cap; t += chunks * kBlock) keysInit[(size_t)p * cap + t] = kNoKey;
     const int fq = pairs[2 * p];
     const int nq = nkpts[fq];
-    const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
+    const uint32_t *__restrict__ q32 = desc + (size_t)fq * fstride;
     uint4 *__restrict__ out = Xq + (size_t)p * tpf * kTileU4;
     const int o = threadIdx.x, s = o >> 6, h = (o >> 5) & 1, r = o & 31;
     for (int tile = chunk; tile < tpf; tile += chunks) {
@@ -147,7 +148,7 @@ constexpr float kMfmaBase = 8388608.0f; // 2^23: unit spacing up to 2^24
 template <int TT>
 __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const uint32_t *__restrict__ desc,
                                                           const int32_t *__restrict__ nkpts,
-                                                          const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                          const int32_t *__restrict__ pairs, int cap, int fstride, int tpf,
                                                           int groups, int qsplit, const uint4 *__restrict__ Xq,
                                                           uint32_t *__restrict__ keys)
 {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma(const u
     const int T0 = (int)(((long long)nqTiles * qs) / qsplit), T1 = (int)(((long long)nqTiles * (qs + 1)) / qsplit);
 
     // B operands: this wave's train tiles, expanded in registers (rows beyond nt repeat the last row; never stored)
-    const uint32_t *__restrict__ t32 = desc + (size_t)ft * cap * 8;
+    const uint32_t *__restrict__ t32 = desc + (size_t)ft * fstride;
     v4i_t B[TT][4];
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
@@ -266,7 +267,7 @@ constexpr int kFuseChunk = 4; // query tiles per chunk: 2 x 4 x 4 KiB = 32 KiB o
 template <int TT>
 __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(const uint32_t *__restrict__ desc,
                                                                 const int32_t *__restrict__ nkpts,
-                                                                const int32_t *__restrict__ pairs, int cap, int tpf,
+                                                                const int32_t *__restrict__ pairs, int cap, int fstride, int tpf,
                                                                 int groups, int qsplit, uint32_t *__restrict__ keys)
 {
     __shared__ uint4 s_a[2][kFuseChunk][kTileU4];
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     const int T0 = (int)(((long long)nqTiles * qs) / qsplit), T1 = (int)(((long long)nqTiles * (qs + 1)) / qsplit);
 
     // B operands: this wave's train tiles, expanded in registers (rows beyond nt repeat the last row; never stored)
-    const uint32_t *__restrict__ t32 = desc + (size_t)ft * cap * 8;
+    const uint32_t *__restrict__ t32 = desc + (size_t)ft * fstride;
     v4i_t B[TT][4];
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock, PS_MFMA_WAVES) void ps_hamming_mfma_fused(c
     for (int i = 0; i < TT; ++i) best[i] = 0; // below every valid entry (their patterns are >= 0x4B000000)
 
     // expansion role of this thread: piece o = s * 64 + h * 32 + r of a tile = dword 2 s + h of row r
-    const uint32_t *__restrict__ q32 = desc + (size_t)fq * cap * 8;
+    const uint32_t *__restrict__ q32 = desc + (size_t)fq * fstride;
     const int es = tid >> 6, eh = (tid >> 5) & 1, er = tid & 31;
     // The last query tile of a frame may be partial (rows beyond nq must never win: their accumulators start from -1e30).
     // It is taken out of the main loop: left inside, the compiler turns the rare masking into 16 compares + 16 selects for

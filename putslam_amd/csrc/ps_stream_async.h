@@ -80,6 +80,8 @@ struct PsVoAsync {
     float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool haveK = false;
     Buf ringDesc, ringPts;
+    bool packed = false;                  // PS_FRAMES_PACKED: a frame's descriptors and points lie together, in the ring (ringDesc holds
+    size_t packStride = 0;                // ringFrames x packStride bytes, ringPts is unused) as on the host: ONE upload per chunk
     std::vector<int32_t> nkRing; // row counts of the ring's slots (host-authoritative; every chunk uploads a snapshot)
     hipStream_t copyStream = nullptr;    // uploads
     hipStream_t copyOutStream = nullptr; // downloads
@@ -185,7 +187,7 @@ int stage_area(PsVoStream *s, uint8_t **out)
 {
     PsVoAsync *a = s->async;
     uint8_t *&h = a->stagePool[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
-    if (!h) PSA_HIP(hipHostMalloc((void **)&h, (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+    if (!h) PSA_HIP(hipHostMalloc((void **)&h, a->packed ? (size_t)a->B * a->packStride : (size_t)a->B * s->cap * 44, hipHostMallocDefault));
     *out = h;
     return PS_OK;
 }
@@ -224,10 +226,11 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     PS_HIP(hipStreamWaitEvent(lc->stream, c.up, 0));
     PsFrameSet fs;
     fs.desc = (const uint8_t *)a->ringDesc.p;
-    fs.pts = (const float *)a->ringPts.p;
+    fs.pts = a->packed ? (const float *)((const uint8_t *)a->ringDesc.p + cap * 32) : (const float *)a->ringPts.p;
     fs.nkpts = (const int32_t *)l.meta.p + 2 * (size_t)a->B;
     fs.numFrames = a->ringFrames;
     fs.maxKpts = s->cap;
+    fs.descFrameStride = fs.ptsFrameStride = a->packed ? a->packStride : 0;
     uint8_t *dres = (uint8_t *)l.res.p;
     PsPairResults out;
     out.matches = (PsDMatch *)dres;
@@ -358,10 +361,15 @@ int async_submit_body(PsVoStream *s, const uint8_t *desc, const float *pts, cons
     if (!(diagNoUpload && a->chunkSeq > 64))
 #endif
     {
-        PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
-                              a->copyStream));
-        PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
-                              a->copyStream));
+        if (a->packed) { // (`desc` = the chunk's packed frames: ONE transfer, no idle link between a descriptor and a point upload)
+            PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * a->packStride, desc, (size_t)n * a->packStride,
+                                  hipMemcpyHostToDevice, a->copyStream));
+        } else {
+            PS_HIP(hipMemcpyAsync((uint8_t *)a->ringDesc.p + (size_t)pos0 * cap * 32, desc, (size_t)n * cap * 32, hipMemcpyHostToDevice,
+                                  a->copyStream));
+            PS_HIP(hipMemcpyAsync((uint8_t *)a->ringPts.p + (size_t)pos0 * cap * 12, pts, (size_t)n * cap * 12, hipMemcpyHostToDevice,
+                                  a->copyStream));
+        }
     }
     PS_HIP(hipEventRecord(ev, a->copyStream));
     for (int i = 0; i < n; ++i) a->nkRing[(size_t)(pos0 + i)] = nk[i];
@@ -398,7 +406,7 @@ int async_submit_staged(PsVoStream *s)
     int rc = stage_area(s, &h);
     if (rc) return rc;
     a->staged = 0; // (whatever happens below, these frames are not submitted a second time)
-    return async_submit(s, h, reinterpret_cast<const float *>(h + (size_t)a->B * cap * 32), a->stagedNk.data(), n);
+    return async_submit(s, h, a->packed ? nullptr : reinterpret_cast<const float *>(h + (size_t)a->B * cap * 32), a->stagedNk.data(), n);
 }
 
 // device / pinned blocks, streams, events and lane contexts of a freshly configured pipeline
@@ -417,8 +425,14 @@ int async_build(PsVoStream *s)
     a->upEv.assign((size_t)(a->lanes + a->ahead + 1), nullptr);
     a->stagePool.assign((size_t)(a->lanes + a->ahead + 1), nullptr);
     for (hipEvent_t &e : a->upEv) PS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
-    PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
+    a->packed = s->asyncFrameLayout == PS_FRAMES_PACKED;
+    a->packStride = (cap * 44 + 15) & ~(size_t)15;
+    if (a->packed) {
+        PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * a->packStride);
+    } else {
+        PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
+        PS_ENSURE(a->ringPts, (size_t)a->ringFrames * cap * 12);
+    }
     PS_HIP(hipStreamCreateWithFlags(&a->copyStream, hipStreamNonBlocking));
     PS_HIP(hipStreamCreateWithFlags(&a->copyOutStream, hipStreamNonBlocking));
     // A stream of its own for the downloads pays only when it also gets a hardware queue of its own: with the runtime's
@@ -564,8 +578,8 @@ int ps_vo_stream_push_async(PsVoStream *s, const uint8_t *desc, size_t descStep,
     rc = stage_area(s, &h);
     if (rc) return rc;
     const size_t cap = (size_t)s->cap;
-    uint8_t *hd = h + (size_t)a->staged * cap * 32;
-    uint8_t *hp = h + (size_t)a->B * cap * 32 + (size_t)a->staged * cap * 12;
+    uint8_t *hd = a->packed ? h + (size_t)a->staged * a->packStride : h + (size_t)a->staged * cap * 32;
+    uint8_t *hp = a->packed ? hd + cap * 32 : h + (size_t)a->B * cap * 32 + (size_t)a->staged * cap * 12;
     if (descStep == PS_DESC_BYTES) {
         if (n > 0) memcpy(hd, desc, (size_t)n * 32);
     } else {
@@ -609,12 +623,22 @@ int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts,
     if (rc) return rc;
     const size_t cap = (size_t)s->cap;
     // pinned frames are uploaded in place; pageable ones go through the lane's pinned staging area first
-    const bool inPlace = is_pinned_host(desc) && is_pinned_host(pts);
+    const bool inPlace = !a->packed && is_pinned_host(desc) && is_pinned_host(pts);
     for (int f0 = 0; f0 < numFrames; f0 += a->B) {
         const int n = numFrames - f0 < a->B ? numFrames - f0 : a->B;
         const uint8_t *d = desc + (size_t)f0 * cap * 32;
         const float *p = pts + (size_t)f0 * cap * 3;
-        if (!inPlace) {
+        if (a->packed) { // two host arrays into a packed ring: through the staging area, frame by frame
+            uint8_t *h = nullptr;
+            rc = stage_area(s, &h);
+            if (rc) return rc;
+            for (int i = 0; i < n; ++i) {
+                memcpy(h + (size_t)i * a->packStride, d + (size_t)i * cap * 32, (size_t)nkpts[f0 + i] * 32);
+                memcpy(h + (size_t)i * a->packStride + cap * 32, p + (size_t)i * cap * 3, (size_t)nkpts[f0 + i] * 12);
+            }
+            d = h;
+            p = nullptr;
+        } else if (!inPlace) {
             uint8_t *h = nullptr;
             rc = stage_area(s, &h);
             if (rc) return rc;
@@ -624,6 +648,55 @@ int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts,
             p = reinterpret_cast<const float *>(h + (size_t)a->B * cap * 32);
         }
         rc = async_submit(s, d, p, nkpts + f0, n);
+        if (rc) return rc;
+    }
+    return PS_OK;
+}
+
+int ps_vo_stream_set_frame_layout(PsVoStream *s, int layout)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    if (layout != PS_FRAMES_TWO_ARRAYS && layout != PS_FRAMES_PACKED)
+        return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_set_frame_layout: 0 (two arrays) or 1 (packed frames)");
+    s->asyncFrameLayout = layout;
+    return PS_OK;
+}
+
+size_t ps_vo_stream_packed_stride(const PsVoStream *s) { return s ? (((size_t)s->cap * 44 + 15) & ~(size_t)15) : 0; }
+
+int ps_vo_stream_push_many_packed(PsVoStream *s, const uint8_t *frames, size_t frameStride, const int32_t *nkpts, int numFrames)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    int rc = bind(s->ctx);
+    if (rc) return rc;
+    PsVoAsync *a = s->async;
+    if (!a) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many_packed: call ps_vo_stream_configure_async first");
+    if (!a->packed)
+        return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many_packed: the stream was configured for two arrays (ps_vo_stream_set_frame_layout "
+                                             "before ps_vo_stream_configure_async)");
+    if (numFrames < 0 || (numFrames > 0 && (!frames || !nkpts)) || frameStride != a->packStride)
+        return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many_packed: bad argument (frameStride must be ps_vo_stream_packed_stride())");
+    for (int i = 0; i < numFrames; ++i)
+        if (nkpts[i] < 0 || nkpts[i] > s->cap) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many_packed: row count out of range");
+    if (numFrames == 0) return PS_OK;
+    const int chunks = (numFrames + a->B - 1) / a->B;
+    const int need = chunks + (a->staged > 0 ? 1 : 0);
+    if (need > async_room(a))
+        return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many_packed: not enough room for these frames (pop results first, or push fewer)");
+    rc = async_submit_staged(s);
+    if (rc) return rc;
+    const bool inPlace = is_pinned_host(frames);
+    for (int f0 = 0; f0 < numFrames; f0 += a->B) {
+        const int n = numFrames - f0 < a->B ? numFrames - f0 : a->B;
+        const uint8_t *d = frames + (size_t)f0 * a->packStride;
+        if (!inPlace) {
+            uint8_t *h = nullptr;
+            rc = stage_area(s, &h);
+            if (rc) return rc;
+            memcpy(h, d, (size_t)n * a->packStride);
+            d = h;
+        }
+        rc = async_submit(s, d, nullptr, nkpts + f0, n);
         if (rc) return rc;
     }
     return PS_OK;

@@ -29,6 +29,34 @@ class FrameSetDevice:
                                 self.max_kpts)
 
 
+def pack_frames(desc, pts, stride=None):
+    """(F, cap, 32) u8 + (F, cap, 3) f32 -> (F, stride) u8: every frame one block [cap x 32 B descriptors][cap x 12 B points]
+    padded to `stride` bytes (default: cap x 44 rounded up to 16 -- PS_FRAMES_PACKED / ps_vo_stream_packed_stride)."""
+    F, cap = desc.shape[:2]
+    stride = ((cap * 44 + 15) // 16) * 16 if stride is None else int(stride)
+    out = np.zeros((F, stride), np.uint8)
+    out[:, :cap * 32] = np.ascontiguousarray(desc, np.uint8).reshape(F, cap * 32)
+    out[:, cap * 32:cap * 44] = np.ascontiguousarray(pts, np.float32).reshape(F, cap * 3).view(np.uint8)
+    return out
+
+
+class PackedFrameSetDevice:
+    """The same frames as FrameSetDevice with every frame's descriptors and points in ONE block (PsFrameSet strides, ABI 2)."""
+
+    def __init__(self, desc, pts, nkpts, device="cuda:0", stride=None):
+        self.device = torch.device(device)
+        packed = pack_frames(desc, pts, stride)
+        self.num_frames, self.max_kpts = desc.shape[0], desc.shape[1]
+        self.stride = packed.shape[1]
+        self.blocks = torch.from_numpy(packed).to(self.device)
+        self.nkpts = torch.from_numpy(np.ascontiguousarray(nkpts, np.int32)).to(self.device)
+
+    def view(self):
+        base = self.blocks.data_ptr()
+        return api.DeviceFrames(base, base + self.max_kpts * 32, self.nkpts.data_ptr(), self.num_frames, self.max_kpts,
+                                self.stride, self.stride)
+
+
 class PairBatchDevice:
     """Pairs (P,2) i32 and the per-pair outputs, all in HBM."""
 

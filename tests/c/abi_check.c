@@ -8,7 +8,7 @@ int abi_check(void)
     PsRansacParams p = {0, PS_REPROJECTION_ERROR, 0, 0, 0.04, 2.0, 0.0002, 0.2, 15, 3, 0};
     PsRansacConfig c = {PS_EST_RANSAC, 487, 42u, 0};
     PsRansacStats s;
-    PsFrameSet f = {0, 0, 0, 0, 0};
+    PsFrameSet f = {0, 0, 0, 0, 0, 0, 0};
     PsPairResults r = {0, 0, 0, 0, 0};
     PsHostPairResults h;
     PsShardRunParams sp;

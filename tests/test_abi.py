@@ -53,7 +53,7 @@ def test_struct_layout_matches_library():
     L = _lib.load()
     for name, size in _lib.struct_sizes().items():
         assert getattr(L, "ps_abi_sizeof_" + name)() == size, name
-    assert L.ps_abi_version() == 1
+    assert L.ps_abi_version() == 2        # 2: PsFrameSet carries frame strides
 
 
 def test_kernel_names_and_bytes_formula():

@@ -64,6 +64,38 @@ def test_smallest_batches(ctx, oracle, frames):
         _compare(g, c, len(seq["pairs"]))
 
 
+@pytest.mark.parametrize("cap,pad", [(600, 0), (333, 0), (333, 4096), (2000, 0)])
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_packed_frame_set_equals_dense(oracle, cap, pad, matcher):
+    """PsFrameSet strides (ABI 2): frames that keep descriptors and points together -- [cap x 32 B][cap x 12 B] per frame, any
+    stride that is a multiple of 16 -- through both matcher kernels and kernel 2: the oracle's bytes, which are the dense frame
+    set's; strides the kernels cannot take are refused."""
+    from putslam_amd import api
+    from putslam_amd.device_batch import PackedFrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(7, cap, config=3, index=8800 + cap)
+    nk = seq["nkpts"].copy()
+    nk[2], nk[5] = cap // 3, 0
+    pairs = np.array([[0, 1], [1, 2], [2, 3], [3, 4], [4, 5], [5, 6], [6, 0], [3, 1]], np.int32)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    cfg, _ = make_config(EST_FIXED, 700, seed=31)
+    c2 = api.Context(0)
+    c2.set_option("matcher", matcher)
+    stride = (cap * 44 + 15) // 16 * 16 + pad
+    fs = PackedFrameSetDevice(seq["desc"], seq["pts"], nk, stride=stride)
+    pb = PairBatchDevice(pairs, cap)
+    run_pairs(c2, prm, cfg, TUM_FR1_K, fs, pb)
+    g = pb.download()
+    c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], nk, pairs, threads=4)
+    _compare(g, c, len(pairs))
+    v = fs.view()
+    for ds, ps in ((stride + 8, stride), (cap * 32 - 16, stride), (stride, stride + 2), (stride, cap * 12 - 4)):
+        bad = api.DeviceFrames(v.desc_ptr, v.pts_ptr, v.nkpts_ptr, v.num_frames, v.max_kpts, ds, ps)
+        with pytest.raises(api.PsError) as e:
+            c2.vo_pairs_device(prm, cfg, TUM_FR1_K, bad, pb.pairs.data_ptr(), len(pairs), pb.view())
+        assert e.value.code == -1 and "FrameStride" in str(e.value)
+    c2.close()
+
+
 def test_ragged_frames_and_arbitrary_pairs(ctx, oracle):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
     seq = synth.make_sequence(6, 512, config=3, index=77)

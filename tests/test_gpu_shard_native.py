@@ -34,9 +34,13 @@ def _write_sequence(path, seq):
         np.ascontiguousarray(seq["pts"], np.float32).tofile(f)
 
 
-@pytest.mark.parametrize("launch", ["one-process", "rank-per-process"])
-@pytest.mark.parametrize("mode", ["queue+async", "queue+async+thread", "blocking"])
-@pytest.mark.parametrize("estimator,est,H,ev,frames", [("fixed", EST_FIXED, 768, 1, 14), ("fixed", EST_FIXED, 512, 1, 31), ("ransac", EST_RANSAC, 487, 0, 14)])
+CASES = [("one-process", "queue+async", "fixed", EST_FIXED, 768, 1, 14), ("rank-per-process", "queue+async", "fixed", EST_FIXED, 512, 1, 31),
+         ("one-process", "queue+async+thread", "fixed", EST_FIXED, 512, 1, 31), ("rank-per-process", "queue+async+thread", "ransac", EST_RANSAC, 487, 0, 14),
+         ("one-process", "blocking", "fixed", EST_FIXED, 768, 1, 14), ("rank-per-process", "blocking", "ransac", EST_RANSAC, 487, 0, 14),
+         ("one-process", "queue+async", "ransac", EST_RANSAC, 487, 0, 31)]
+
+
+@pytest.mark.parametrize("launch,mode,estimator,est,H,ev,frames", CASES)
 def test_native_gather_equals_python_batch_and_oracle(ctx, oracle, tmp_path, launch, mode, estimator, est, H, ev, frames):
     """The records rank 0 gathers natively are the bytes sharding.pack_records makes of the oracle's results for the same
     sequence and seed -- through the default host loop (ps_shard_submit_all: a PsBatchQueue per member, records packed on the

@@ -371,7 +371,9 @@ def fuzz_stream(iters, seed, verbose=False):
         prm = default_ransac_params(mode)
         cfg, _ = make_config(est, H, seed=int(rng.integers(0, 2 ** 40)))
         chunk, lanes = int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64])), int(rng.integers(2, 7))
-        form = int(rng.integers(0, 3))           # 0 pinned push_many, 1 pageable push_many, 2 push_async
+        packed = bool(rng.random() < 0.5)        # PS_FRAMES_PACKED: ring and host frames as one block per frame, one upload per chunk
+        # 0 pinned push_many, 1 pageable push_many, 2 push_async, 3 pinned push_many_packed, 4 pageable push_many_packed
+        form = int(rng.integers(0, 5)) if packed else int(rng.integers(0, 3))
         cut = int(rng.integers(1, F)) if (F > 3 and rng.random() < 0.4) else None      # a reset in front of frame `cut`
         epochs = [(0, F)] if cut is None else [(0, cut), (cut, F)]
         refs = []
@@ -391,7 +393,15 @@ def fuzz_stream(iters, seed, verbose=False):
         ahead = int(rng.integers(-1, 9))
         ctx.set_option("stream_ahead", ahead)      # chunks accepted and uploaded while every lane is busy (read by configure_async)
         st = api.VoStream(ctx, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=int(rng.integers(0, 3)))
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=int(rng.integers(0, 3)), packed=packed)
+        hpk = None
+        if form >= 3:
+            from putslam_amd.device_batch import pack_frames
+            pk = pack_frames(seq["desc"], seq["pts"], st.packed_stride)
+            if form == 3:
+                hpk = api.PinnedBuffer(pk.shape, np.uint8)
+                hpk.array[:] = pk
+                pk = hpk.array
         got = [0 for _ in epochs]
         ok = True
 
@@ -408,7 +418,7 @@ def fuzz_stream(iters, seed, verbose=False):
             except AssertionError as ex:
                 ok = False
                 if verbose:
-                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, ahead=ahead, form=form, cut=cut), repr(ex)[:300])
+                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, ahead=ahead, form=form, packed=packed, cut=cut), repr(ex)[:300])
             got[e] += b["count"]
             return True
 
@@ -426,6 +436,8 @@ def fuzz_stream(iters, seed, verbose=False):
                 n = 1
             elif form == 1:
                 pushed = st.push_many(seq["desc"][f:f + n], seq["pts"][f:f + n], nk[f:f + n])
+            elif form >= 3:
+                pushed = st.push_many_packed(pk[f:f + n], nk[f:f + n])
             else:
                 pushed = st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n])
             if pushed:
@@ -449,23 +461,71 @@ def fuzz_stream(iters, seed, verbose=False):
         st.close()
         hd.close()
         hp.close()
+        if hpk is not None:
+            hpk.close()
         bad += 0 if ok else 1
     ctx.close()
     ref_ctx.close()
     return bad
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3])
 def test_fuzz_stream_slice(seed):
     assert fuzz_stream(20, 7000 + seed, verbose=True) == 0
 
 
-if __name__ == "__main__":
-    import sys
-    n, seed = int(sys.argv[1]), int(sys.argv[2])
-    b = fuzz_stream(n, seed, verbose=True)
-    print(f"stream fuzz done: {n} configurations, {b} mismatches")
-    sys.exit(1 if b else 0)
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+@pytest.mark.parametrize("form", ["packed-pinned", "packed-pageable", "two-arrays-into-packed", "frame-by-frame-into-packed"])
+def test_packed_frames_equal_batch_and_oracle(ctx, seq64, chunk, form):
+    """one upload per chunk.  PS_FRAMES_PACKED -- every frame ONE block [cap x 32 B][cap x 12 B] on the
+    host and in the ring (the prevDescriptors / prevFeatures3D state of matcher.h:379-384 as one block; kernels 1 - 2 read the
+    frames through PsFrameSet's strides) -- gives the bytes of the batched call (= the oracle's) whatever the chunking and
+    whichever push form fills the ring."""
+    from putslam_amd import api
+    from putslam_amd.device_batch import pack_frames
+    seq, runs = seq64
+    prm, cfg, c = runs["e1"]
+    F, cap = seq["desc"].shape[:2]
+    st = api.VoStream(ctx, cap)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=3, packed=True)
+    assert st.packed_stride == (cap * 44 + 15) // 16 * 16
+    pk = pack_frames(seq["desc"], seq["pts"], st.packed_stride)
+    pinned = None
+    if form == "packed-pinned":
+        pinned = api.PinnedBuffer(pk.shape, np.uint8)
+        pinned.array[:] = pk
+        pk = pinned.array
+    got, f = 0, 0
+    while f < F:
+        n = min(F - f, 2 * chunk + 1)
+        if form.startswith("packed"):
+            ok = st.push_many_packed(pk[f:f + n], seq["nkpts"][f:f + n])
+        elif form.startswith("two"):
+            ok = st.push_many(seq["desc"][f:f + n], seq["pts"][f:f + n], seq["nkpts"][f:f + n])
+        else:
+            n = 1
+            ok = st.push_async(seq["desc"][f], seq["pts"][f])
+        if ok:
+            f += n
+            got = _drain(st, c, got, wait=False)
+        else:
+            blk = st.pop_many(wait=True)
+            assert blk["first_pair"] == got
+            _check_block(blk, c, got)
+            got += blk["count"]
+    st.flush()
+    got = _drain(st, c, got)
+    assert got == F - 1 and st.pending() == 0
+    # a stream configured for two arrays refuses packed frames (and says how to get them)
+    st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=3, packed=False)
+    with pytest.raises(api.PsError) as e:
+        st.push_many_packed(pk[:2], seq["nkpts"][:2])
+    assert "ps_vo_stream_set_frame_layout" in str(e.value)
+    st.close()
+    if pinned is not None:
+        pinned.close()
+
+
 
 
 @pytest.mark.parametrize("where,chunk", [("FAIL_CHUNK", 3), ("FAIL_AFTER", 2), ("FAIL_CHUNK", 0)])
@@ -509,3 +569,11 @@ def test_pop_refused_for_its_arguments_loses_no_pair(ctx, seq64):
         assert r is not None and r["pose"].T.reshape(-1).tobytes() == c["pose"][p].tobytes(), p
     assert st.pop(wait=True) is None
     st.close()
+
+
+if __name__ == "__main__":
+    import sys
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    b = fuzz_stream(n, seed, verbose=True)
+    print(f"stream fuzz done: {n} configurations, {b} mismatches")
+    sys.exit(1 if b else 0)
