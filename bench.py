@@ -1042,6 +1042,16 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
         bpp = float(np.mean([api.algorithmic_bytes(kpts, int(x["numMatchesIn"]), int(x["numMatchesValid"]), hyp) for x in st]))
         dom = max(kms, key=kms.get)
         ach = bpp * P / (kms[dom] * 1e-3) / 1e9
+        # HBM bytes of the dominant step from the rocprofv3 PMC passes of `bench.py --preset stress --error-version E`
+        # (profiles/run_stress_profiles.sh -> profiles/pmc_traffic.json), per launch chain step like `achieved`
+        traffic, traffic_src = None, None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            e = t.get("%dx%dxH%dxE%dxfixedx%sx%s" % (frames, kpts, hyp, ev, "mfma" if c0.get_option("matcher_used") == 1 else "valu",
+                                                      "fast" if c0.get_option("score") >= 1 else "exact"), {})
+            traffic, traffic_src = e.get(dom), e.get("_source")
+        except (OSError, ValueError):
+            pass
         out["stress/E%d" % ev] = {
             "workload": "BASELINE configs[4]: %d pairs x %d kpts, H = %d fixed, errorVersion %d, one launch chain" % (P, kpts, hyp, ev),
             "ms_per_step": ms, "pairs_per_s": P / (ms * 1e-3), "steps": n, "kernel_ms": kms, "kernel_ms_sum": sum(kms.values()),
@@ -1049,8 +1059,10 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
             "accepted_pairs": int(st["accepted"].sum()),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": P,
-                         "avg_launch_ms": kms[dom], "traffic": None,
+                         "avg_launch_ms": kms[dom], "traffic": traffic, "traffic_source": traffic_src,
                          "whole_call_frac": bpp * P / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if not args.no_cpu_baseline:
+            out["stress/E%d" % ev]["cpu"] = stress_cpu(seq, prm, cfg, hyp, st)
         if ctxs is not None and len(ctxs) >= 2 and P >= 4:
             # the same 8 pairs submitted like the timed region: two unequal chains (3 + 5 pairs) that are never joined
             b2 = [0, max(1, int(P * 0.45)), P]
@@ -1067,6 +1079,35 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
             torch.cuda.synchronize(dev)
             cms = (time.perf_counter() - tc) / n * 1e3
             out["stress/E%d" % ev]["chains"] = {"streams": 2, "bounds": b2, "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
+    return out
+
+
+def stress_cpu(seq, prm, cfg, hyp, st):
+    """The oracle on the stress configuration's own frames (the checker timed as a baseline, never the product): all 8 pairs on
+    min(cores, 8) threads (the oracle's parallelism is over pairs), and ONE pair on one thread when that fits the budget --
+    about 5 s of wall per error version (H x matches evaluations at ~10 ns each)."""
+    from oracle import oracle_py as po
+    from putslam_amd._abi import TUM_FR1_K
+    cores = usable_cores()
+    pairs = seq["pairs"]
+    P = len(pairs)
+    po.set_matcher_simd(True)
+    threads = max(1, min(cores, P))
+    t0 = time.perf_counter()
+    po.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], pairs, threads=threads)
+    wall = time.perf_counter() - t0
+    out = {"value": P / wall, "unit": "frame-pairs/s", "cores": threads, "kind": "port", "matcher": po.matcher_simd_kind(),
+           "sample": "the leg's %d pairs once, OpenMP over pairs on %d threads, %.2f s wall" % (P, threads, wall)}
+    est_one = wall * threads / P * (1.0 if threads <= P else 1.0)          # a pair's core-seconds in the run above
+    if est_one <= 2.5:
+        t1 = time.perf_counter()
+        po.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], pairs[:1], threads=1)
+        out["single_thread_value"] = 1.0 / (time.perf_counter() - t1)
+        out["single_thread_sample"] = "pair 0 on one thread, measured"
+    else:
+        out["single_thread_value"] = 1.0 / est_one
+        out["single_thread_sample"] = ("derived: a pair's core-seconds in the all-pairs run (one pair per thread); a measured pass "
+                                       "would take %.1f s of the line's budget" % est_one)
     return out
 
 

@@ -22,7 +22,7 @@ nk = np.ascontiguousarray(seq["nkpts"], np.int32)
 prm = default_ransac_params(ev)
 cfg, _ = make_config(est, hyp, seed=0xB0B0)
 ctx = api.Context(0)
-for chunk, lanes in ((125, 4), (125, 8), (250, 6)):
+for chunk, lanes in ((125, 0), (125, 4), (250, 0)):
     st = api.VoStream(ctx, cap)
     st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes)
     T = {"push": 0.0, "push_busy": 0.0, "wait": 0.0, "poll": 0.0}

@@ -62,6 +62,7 @@ struct PsContext {
     Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
     Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
     Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
+    Buf recShadow; // (-DPS_STREAM_DIAG builds with PUTSLAM_HIP_DIAG_SHADOW_RECORDS=1: kernel 2's records once more; never read)
     Buf tabR, tabU;
     // staging for the host-pointer entry points (device)
     Buf sDesc, sNk, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
@@ -560,6 +561,9 @@ RecPtrs rec_ptrs(PsContext *ctx, int cap, int mode)
     r.A = (float4 *)ctx->recA.p; r.B = (float4 *)ctx->recB.p; r.C = (float4 *)ctx->recC.p; r.D = (int4 *)ctx->recD.p;
     r.E = (float4 *)ctx->recE.p;
     r.F = (float2 *)ctx->recF.p;
+#ifdef PS_STREAM_DIAG
+    r.S = (float4 *)ctx->recShadow.p; // (null unless PUTSLAM_HIP_DIAG_SHADOW_RECORDS=1: ensure_records)
+#endif
     return r;
 }
 
@@ -1029,6 +1033,10 @@ int ensure_records(PsContext *ctx, size_t P, size_t cap)
     PS_ENSURE(ctx->recE, n * 16);
     // 40 B per match (reprojection kernels) or up to 64 B per match pair (Euclidean kernel, ps_score_euclid.h)
     PS_ENSURE(ctx->recF, n * 40 > P * ((cap + 1) / 2) * 64 ? n * 40 : P * ((cap + 1) / 2) * 64);
+#ifdef PS_STREAM_DIAG
+    static const bool shadow = std::getenv("PUTSLAM_HIP_DIAG_SHADOW_RECORDS") != nullptr && std::atoi(std::getenv("PUTSLAM_HIP_DIAG_SHADOW_RECORDS")) != 0;
+    if (shadow) PS_ENSURE(ctx->recShadow, n * 7 * 16);
+#endif
     return PS_OK;
 }
 
@@ -1311,7 +1319,7 @@ void ps_context_destroy(PsContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid,
+    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recShadow, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid,
                   &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
                   &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
                   &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};

@@ -282,6 +282,10 @@ struct RecPtrs {
     float4 *C;  // projections of prev and cur (realOld u v, realNew u v)
     int4 *D;    // (index in the match list, queryIdx, trainIdx, 0)
     float4 *E;  // offsets c - real of the decision-exact scoring paths: (cx - uOld, cx - uNew, cy - vOld, cy - vNew)
+#ifdef PS_STREAM_DIAG
+    float4 *S;  // -DPS_STREAM_DIAG builds only: a shadow block kernel 2 writes every record a second time into (7 x 16 B per match;
+                // nothing reads it): doubles kernel 2's write traffic for the A/B of profiles/r06*/records_traffic_ab.txt
+#endif
     float2 *F;  // the fast scoring kernel's packed match record for large launches, 40 B = 5 float2 per match, laid out as
                 // the SGPR pairs its packed instructions take (one s_load_dwordx8 + one dwordx2, no repacking; 8 B less
                 // scalar-cache footprint per match than prev + cur + offsets):
@@ -338,6 +342,14 @@ PS_D float write_records(const PrepArgs &a, const RecPtrs &r, int p, int v, int 
         f[0] = make_float2(cx_, px); f[1] = make_float2(cy_, py); f[2] = make_float2(cz_, pz);
         f[3] = make_float2(e.x, e.y); f[4] = make_float2(e.z, e.w);
     }
+#ifdef PS_STREAM_DIAG
+    if (r.S != nullptr) { // (diagnostic build: every record once more, into a block nothing reads)
+        float4 *sh = r.S + 7 * slot;
+        sh[0] = make_float4(px, py, pz, bound); sh[1] = make_float4(cx_, cy_, cz_, 1.0f); sh[2] = make_float4(ou, ov, nu, nv);
+        sh[3] = make_float4((float)srcIdx, (float)q, (float)t, 0.0f); sh[4] = make_float4(cx_, px, cy_, py);
+        sh[5] = make_float4(cz_, pz, e.x, e.y); sh[6] = make_float4(e.z, e.w, 0.0f, 0.0f);
+    }
+#endif
     // (a NaN offset reports an infinite bound: the decision-exact kernels then leave the pair to the value-exact code)
     const bool num = e.x == e.x && e.y == e.y && e.z == e.z && e.w == e.w;
     return num ? fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))) : INFINITY;

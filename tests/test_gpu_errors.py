@@ -137,6 +137,6 @@ def test_minutes_long_batch_is_refused_before_anything_is_allocated():
     with pytest.raises(api.PsError) as e:
         c.vo_pairs_device(prm, cfg, TUM_FR1_K, api.DeviceFrames(p, p, p, 20001, 16384), p, 20000, api.DeviceResults(p, p, p, p, p))
     assert e.value.code == UNSUPPORTED and "run for minutes" in str(e.value)
-    assert c.get_option("arena_mib") <= before + 8                        # (stop tables only)
+    assert c.get_option("arena_mib") <= before + 16                       # (the stop table of the cap: 850 000 doubles)
     c.set_option("prune", 1)
     c.close()
