@@ -80,6 +80,8 @@ assert STATS_DTYPE.itemsize == C.sizeof(PsRansacStats) == 40
 # (resources/datasetConfig/freiburg1_desk.xml:5-6,20; the same constants are hard-coded at RGBD.cpp:22-23).
 TUM_FR1_K = np.array([517.3, 0.0, 318.6, 0.0, 516.5, 255.3, 0.0, 0.0, 1.0], dtype=np.float32)
 TUM_DEPTH_SCALE = 5000.0
+# rgbDistortion (k1, k2, p1, p2, k3) of the same file, :7 -- what RGBD::removeImageDistortion is given (RGBD.cpp:254-314)
+TUM_FR1_DIST = (-0.0410, 0.3286, 0.0087, 0.0051, -0.5643)
 
 
 def default_ransac_params(error_version=EUCLIDEAN_ERROR, lc=False):

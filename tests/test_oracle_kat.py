@@ -377,7 +377,8 @@ def test_match_xyz_semantics(oracle):
 
 
 # ------------------------------------------------------------------ N4 undistortion
-TUM_FR1_DIST = [-0.0410, 0.3286, 0.0087, 0.0051, -0.5643]  # resources/datasetConfig/freiburg1_desk.xml:7
+from putslam_amd._abi import TUM_FR1_DIST  # noqa: E402  resources/datasetConfig/freiburg1_desk.xml:7
+TUM_FR1_DIST = list(TUM_FR1_DIST)
 
 
 def test_remove_image_distortion(oracle):

@@ -114,3 +114,26 @@ def test_recipe_roundtrip_through_collect_and_golden_checks(oracle, tmp_path, mo
     # nothing was written into the repository's own golden directory
     # (ref_usac.npz is the one reference-made fixture that exists: tests/golden/make_ref_usac_golden.py)
     assert [f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.startswith("ref_")] == ["ref_usac.npz"]
+
+
+def test_recipe_dry_run_resolves_every_path():
+    """`oracle/ref_recipe/run.sh --dry` builds and runs nothing: it resolves the recipe's files (and, where the reference is
+    present, the reference files the harnesses include or compile: src/TransformEst/kabschEst.cpp, its headers), prints every
+    command of the real run and exits 0 -- so the staged recipe cannot rot in an image without Eigen / OpenCV."""
+    import re
+    p = subprocess.run(["bash", os.path.join(RECIPE, "run.sh"), "--dry"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    cmds = [l[2:] for l in p.stdout.splitlines() if l.startswith("+ ")]
+    assert len(cmds) == 9 and sum(c.startswith("g++ ") for c in cmds) == 3
+    assert "ref_recipe dry run:" in p.stdout
+    for c in cmds:
+        for tok in c.split():
+            if tok.endswith((".cpp", ".py")):
+                if tok.startswith("/root/reference") and not os.path.isdir("/root/reference"):
+                    continue
+                assert os.path.exists(tok), tok
+    # the three harness outputs the real run would collect are the ones collect.py reads
+    collect = open(os.path.join(RECIPE, "collect.py")).read()
+    for out in ("eigen_core.out", "kabsch.out", "bfmatcher.out"):
+        assert any(c.endswith(out) for c in cmds) and out in collect
+    assert not re.search(r"MISSING", p.stderr)
