@@ -843,6 +843,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         wins.sort(key=lambda w: w[1] / w[0])
         el, done, inl_done = wins[len(wins) // 2]
         inl0 = state["inl"] - inl_done                      # (so that the download figure below is the median window's)
+        st_graphs = st.graph_launches()
         st.close()
         lat_ms = np.array(sorted(lat)) * 1e3
         leg = {"pairs_per_s": done / el, "ms_per_step": el / steps * 1e3, "steps": steps, "pairs": done, "windows": windows,
@@ -859,6 +860,8 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                                      "what": "push_many call of the chunk -> its results readable on the host"} if len(lat_ms) else None)}
         if check:
             leg["equals_batched_call"] = state["bad"] == 0
+        if chunk <= 4:
+            leg["chunks_replayed_from_graphs"] = st_graphs
         return leg
 
     steps = max(10, min(40, 2 * args.steps))
@@ -882,8 +885,9 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     out["streamed/chunk250"] = run(250, args.stream_lanes, steps, check=0)
     small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
     out["streamed/chunk32"] = small
-    one = run(1, args.stream_lanes, 3, check=0, warm_s=0.1)
+    one = run(1, args.stream_lanes, 3, check=1, warm_s=0.2)
     out["streamed/chunk1"] = one
+    out["streamed/chunk4"] = run(4, args.stream_lanes, 3, check=0, warm_s=0.2)
     hd.close()
     hp.close()
     hpk.close()

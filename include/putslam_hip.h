@@ -368,6 +368,13 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * library sets GPU_MAX_HW_QUEUES = 16 itself when it is loaded and the variable is unset (see PsBatchQueue above); with fewer than lanes + 6 the downloads
  * are queued on the lanes' own streams instead of a stream of their own (results identical, 10 - 20 % slower).
  *
+ * Small chunks (chunkFrames <= 4; 1 is the reference's own call shape): a chunk of one to four frames is launch-bound, so every
+ * place keeps a private copy of its frames (the previous frame is read again from its pinned staging slot: no ring, no copy
+ * stream) and replays its whole chunk -- frames in by a copy kernel, kernels 1 - 4, results out by a kernel -- from ONE captured
+ * hipGraph, with row counts, seed and frame addresses travelling as data.  Frames always go through the library's pinned staging
+ * areas in this form (88 KB per 2000-keypoint frame); pop_many's pointers are a copy.  PUTSLAM_HIP_STREAM_MINI=0 keeps the
+ * ring form for such chunks, PUTSLAM_HIP_NO_GRAPH=1 ordinary launches (results identical either way).
+ *
  * Pair k of the stream (frames k, k+1 counted from the last reset; frame k is the query = previous frame) draws its
  * hypotheses from the seeded stream cfg->seed + k: the results are byte for byte those of ONE ps_vo_pairs_device call
  * over the whole sequence with the same cfg, whatever the chunking.
@@ -453,6 +460,8 @@ int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, 
                      PsRansacStats *stats);
 /* Pairs submitted or staged whose results have not been popped yet (negative PsStatus on error). */
 int ps_vo_stream_pending(const PsVoStream *s);
+/* Pushes (synchronous form) / chunks (pipelined form, chunkFrames <= 4) replayed from a captured hipGraph so far. */
+long long ps_vo_stream_graph_launches(const PsVoStream *s);
 /* Pinned (page-locked) host memory for frames handed to ps_vo_stream_push_many in place; NULL on failure. */
 void *ps_host_alloc(size_t bytes);
 void ps_host_free(void *p);

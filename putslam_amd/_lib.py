@@ -30,7 +30,7 @@ EXPORTED = [
     "ps_batch_queue_last_split", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_vo_stream_set_result_mode", "ps_vo_stream_set_frame_layout", "ps_vo_stream_packed_stride", "ps_vo_stream_push_many_packed", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
-    "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_host_alloc", "ps_host_free",
+    "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_vo_stream_graph_launches", "ps_host_alloc", "ps_host_free",
     "ps_algorithmic_bytes", "ps_kernel_names", "ps_last_kernel_times_ms", "ps_kernel_time_totals",
     "ps_context_enable_timing",
     "ps_debug_ransac_counts", "ps_debug_limits", "ps_debug_keys_clean", "ps_debug_fastdiv", "ps_debug_mathcheck", "ps_debug_score_stats", "ps_debug_score_stats_ex", "ps_debug_stage_survivors", "ps_debug_stage_order", "ps_debug_stamps",
@@ -158,6 +158,8 @@ def load_path(path):
     L.ps_vo_stream_pop_many.argtypes = [vp, i32, C.POINTER(PsHostPairResults)]
     L.ps_vo_stream_pop.argtypes = [vp, i32, vp, C.POINTER(i32), vp, vp, vp]
     L.ps_vo_stream_pending.argtypes = [vp]
+    L.ps_vo_stream_graph_launches.argtypes = [vp]
+    L.ps_vo_stream_graph_launches.restype = C.c_longlong
     L.ps_host_alloc.argtypes = [sz]
     L.ps_host_alloc.restype = vp
     L.ps_host_free.argtypes = [vp]

@@ -452,6 +452,10 @@ class VoStream:
     def pending(self):
         return self._ctx._L.ps_vo_stream_pending(self._h)
 
+    def graph_launches(self):
+        """Pushes / small chunks replayed from a captured hipGraph so far."""
+        return int(self._ctx._L.ps_vo_stream_graph_launches(self._h))
+
     def pop_many(self, wait=True, copy=True):
         """Results of the oldest chunk in flight: None if nothing is ready, else dict(first_pair, epoch, matches (n, cap),
         numMatches, inlierMask, pose (n, 16), stats).  copy=False: views of the pinned block, valid until the next pop."""

@@ -2041,6 +2041,46 @@ __global__ void __launch_bounds__(256) ps_copy_segments(CopySegs cs)
 }
 
 
+// Small chunks of the pipelined stream (chunkFrames <= 4: ps_stream_async.h, "mini" chunks): everything that changes from chunk to
+// chunk travels as DATA through this block, so that a place's whole chunk -- frames in, kernels 1 - 4, results out -- is one
+// captured hipGraph.  The host fills it in the place's pinned meta block; ps_mini_copy_in copies it to the device meta block,
+// which the kernels behind it read (row counts, pair list, seed).
+constexpr int kMiniFrames = 4;
+struct MiniMeta {
+    int32_t pairs[2 * kMiniFrames]; // the chunk's pairs in the place's private frame set: slot 0 = the previous frame (halo), 1 .. n = the chunk's
+    int32_t nk[kMiniFrames + 1];    // row counts of the private frames
+    int32_t n, first, pad;          // frames in the chunk; 1 = its first frame has no predecessor (slot 0 is not copied)
+    unsigned long long seed;        // hypothesis seed of the chunk's first pair (cfg->seed + its number in the stream)
+    const uint8_t *src[kMiniFrames + 1]; // device views of the pinned packed frames [cap x 32 B][cap x 12 B]: [0] the halo, [1 .. n] the chunk's
+};
+
+// Frames of a mini chunk from pinned host memory into the place's private frame set (packed layout, `stride` bytes per frame),
+// and the meta block with them.  grid = (kMiniFrames + 1) x groups work-groups: frame f is swept by `groups` of them.  The reads go
+// over the link: 88 KB per 2000-keypoint frame, a few microseconds (the synchronous ps_vo_stream_push moves its frame the same way).
+__global__ void __launch_bounds__(256) ps_mini_copy_in(const MiniMeta *__restrict__ hm, MiniMeta *__restrict__ dm, uint8_t *__restrict__ frames,
+                                                       int cap, unsigned long long stride, int groups)
+{
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(MiniMeta) / 4)
+        reinterpret_cast<uint32_t *>(dm)[threadIdx.x] = reinterpret_cast<const uint32_t *>(hm)[threadIdx.x];
+    const int f = (int)(blockIdx.x / (unsigned)groups), g = (int)(blockIdx.x % (unsigned)groups);
+    const int n = hm->n, first = hm->first;
+    if (f > n || (f == 0 && first)) return;
+    const int rows = hm->nk[f];
+    const uint8_t *__restrict__ src = hm->src[f];
+    uint8_t *__restrict__ dst = frames + (size_t)f * stride;
+    const size_t t0 = (size_t)g * blockDim.x + threadIdx.x, step = (size_t)groups * blockDim.x;
+    { // descriptors: rows x 32 bytes, 16 per lane
+        const uint4 *__restrict__ sv = reinterpret_cast<const uint4 *>(src);
+        uint4 *__restrict__ dv = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = t0; i < (size_t)rows * 2; i += step) dv[i] = sv[i];
+    }
+    { // points: rows x 12 bytes behind the cap x 32 descriptor bytes, 4 per lane
+        const uint32_t *__restrict__ sv = reinterpret_cast<const uint32_t *>(src + (size_t)cap * 32);
+        uint32_t *__restrict__ dv = reinterpret_cast<uint32_t *>(dst + (size_t)cap * 32);
+        for (size_t i = t0; i < (size_t)rows * 3; i += step) dv[i] = sv[i];
+    }
+}
+
 // Results of a chunk of the pipelined stream written straight into the lane's mapped pinned block, only what the caller asked
 // for (PsStreamResults): mode 1 = the INLIER matches of every pair in input order (what Matcher::match hands back,
 // matcher.cpp:452-516: `inlierMatches`) + pose + stats + match count; mode 2 = pose + stats + match count.  One work-group per

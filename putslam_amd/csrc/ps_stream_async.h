@@ -48,6 +48,11 @@ struct AsyncLane {
     int32_t *hmetaDev = nullptr; // device views of the pinned blocks (hipHostGetDevicePointer)
     uint8_t *hresDev = nullptr;
     hipEvent_t evRun = nullptr, evDone = nullptr; // behind the chunk's kernels / its download
+    // small chunks (PsVoAsync::mini): the place's private frames [1 + B] in the packed layout (slot 0 = the frame before the
+    // chunk's first one), its chunk as a captured graph, and the arena generation of its lane the graph's pointers belong to
+    Buf frames;
+    hipGraphExec_t gexec = nullptr;
+    unsigned long long gexecGen = 0;
     int state = 0;            // 0 free, 1 chunk in flight
     long long firstPair = 0;
     int pairs = 0;
@@ -80,6 +85,20 @@ struct PsVoAsync {
     float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool haveK = false;
     Buf ringDesc, ringPts;
+    // Small chunks (chunkFrames <= 4, the reference's own call shape at 1: src/Matcher/matcher.cpp:452-516): a chunk is launch-bound
+    // -- two uploads, a meta kernel, six or seven launches, an event pair and a download, 85 us of host and queue time for 55 us of
+    // kernels: round 5's pipeline was no faster than the synchronous push there.  In this form every place owns a private frame set
+    // and its whole chunk is ONE captured hipGraph (frames in by a copy kernel from the pinned staging area, kernels 1 - 4, results
+    // out by a kernel into the place's pinned block); what changes between chunks -- row counts, the seed, where the frames lie --
+    // travels as data (psdev::MiniMeta).  No ring, no copy streams, no cross-lane dependency: the halo frame is read again from
+    // the previous chunk's staging slot.
+    bool mini = false;
+    std::vector<uint8_t *> stagePoolDev;  // device views of the staging areas (mini chunks read them from kernels)
+    const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot
+    int haloNk = 0;
+    std::vector<unsigned long long> laneWarmGen; // per lane: arena generation an un-captured full chunk has run with (0 = none)
+    std::vector<uint8_t> viewBuf;         // pop_many's copy of a mini chunk's results (its place is free at once)
+    long long graphLaunches = 0;          // chunks replayed from a graph (option "stream_graph_launches", read only)
     bool packed = false;                  // PS_FRAMES_PACKED: a frame's descriptors and points lie together, in the ring (ringDesc holds
     size_t packStride = 0;                // ringFrames x packStride bytes, ringPts is unused) as on the host: ONE upload per chunk
     std::vector<int32_t> nkRing; // row counts of the ring's slots (host-authoritative; every chunk uploads a snapshot)
@@ -104,6 +123,7 @@ struct PsVoAsync {
                                           // process has few hardware queues (GPU_MAX_HW_QUEUES < lanes + 6), or forced either
                                           // way by PUTSLAM_HIP_STREAM_DOWNLOADS_ON_LANE=0|1
     int cursor = 0;                       // ps_vo_stream_pop: next pair of the held view
+    bool haveView = false;                // pop_many has handed out a block that has not been released yet
     PsHostPairResults view{};
     double dbgT[3] = {0, 0, 0};        // PUTSLAM_HIP_STREAM_DEBUG=1: host seconds inside the uploads' / the batched call's /
     long long dbgN = 0;                   // the downloads' submission, printed when the pipeline is released
@@ -142,6 +162,8 @@ void async_free(PsVoAsync *a)
         release(l.res);
         if (l.hmeta) (void)hipHostFree(l.hmeta);
         if (l.hres) (void)hipHostFree(l.hres);
+        release(l.frames);
+        if (l.gexec) (void)hipGraphExecDestroy(l.gexec);
         if (l.evRun) (void)hipEventDestroy(l.evRun);
         if (l.evDone) (void)hipEventDestroy(l.evDone);
     }
@@ -187,7 +209,10 @@ int stage_area(PsVoStream *s, uint8_t **out)
 {
     PsVoAsync *a = s->async;
     uint8_t *&h = a->stagePool[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
-    if (!h) PSA_HIP(hipHostMalloc((void **)&h, a->packed ? (size_t)a->B * a->packStride : (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+    if (!h) {
+        PSA_HIP(hipHostMalloc((void **)&h, a->packed ? (size_t)a->B * a->packStride : (size_t)a->B * s->cap * 44, hipHostMallocDefault));
+        if (a->mini) PSA_HIP(hipHostGetDevicePointer((void **)&a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())], h, 0));
+    }
     *out = h;
     return PS_OK;
 }
@@ -321,8 +346,9 @@ int async_abort_chunk(PsVoStream *s, int rc)
     PsVoAsync *a = s->async;
     const std::string why = s->ctx->err;
     if (a->copyStream) (void)hipStreamSynchronize(a->copyStream);
-    PsContext *lc = a->laneCtx.empty() ? nullptr : a->laneCtx[(size_t)(a->launchSeq % (long long)a->lanes)];
+    PsContext *lc = a->laneCtx.empty() ? nullptr : a->laneCtx[(size_t)((a->mini ? (long long)a->tail : a->launchSeq) % (long long)a->lanes)];
     if (lc) (void)hipStreamSynchronize(lc->stream);
+    a->haloDev = nullptr;
     if (a->copyOutStream) (void)hipStreamSynchronize(a->copyOutStream);
     (void)hipGetLastError();
     a->prevPos = -1;
@@ -337,9 +363,183 @@ int async_abort_chunk(PsVoStream *s, int rc)
 // on the next lane's stream.  The caller has checked async_room().
 int async_submit_body(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n);
 
+using psdev::MiniMeta;
+using psdev::ps_mini_copy_in;
+
+// The launches of one mini chunk on its lane's stream: frames in, kernels 1 - 4, results out (what a place's graph holds).
+int mini_enqueue(PsVoStream *s, AsyncLane &l, PsContext *lc, const Plan &pl, int P)
+{
+    PsVoAsync *a = s->async;
+    PsContext *ctx = s->ctx;
+    const size_t cap = (size_t)s->cap;
+    MiniMeta *dm = (MiniMeta *)l.meta.p;
+    const int groups = 8;
+    hipLaunchKernelGGL(ps_mini_copy_in, dim3((unsigned)((a->B + 1) * groups)), dim3(256), 0, lc->stream, (const MiniMeta *)l.hmetaDev, dm,
+                       (uint8_t *)l.frames.p, s->cap, (unsigned long long)a->packStride, groups);
+    PS_HIP(hipGetLastError());
+    PsFrameSet fs;
+    fs.desc = (const uint8_t *)l.frames.p;
+    fs.pts = (const float *)((const uint8_t *)l.frames.p + cap * 32);
+    fs.nkpts = dm->nk;
+    fs.numFrames = a->B + 1;
+    fs.maxKpts = s->cap;
+    fs.descFrameStride = fs.ptsFrameStride = a->packStride;
+    uint8_t *dres = (uint8_t *)l.res.p;
+    int rc = run_match_stage(lc, fs, dm->pairs, P, true, pl.pa, (PsDMatch *)dres, (int32_t *)(dres + a->offNum), 0);
+    if (rc == PS_OK)
+        rc = run_ransac_stage(lc, pl, P, s->cap, (const PsDMatch *)dres, (const int32_t *)(dres + a->offNum), s->cap, (float *)(dres + a->offPose),
+                              dres + a->offMask, (PsRansacStats *)(dres + a->offStats), 2);
+    if (rc != PS_OK) {
+        ctx->err = std::string("pipelined chunk: ") + lc->err;
+        return rc;
+    }
+    if (a->resultMode != PS_RESULTS_FULL) {
+        hipLaunchKernelGGL(ps_pack_results_to_host, dim3((unsigned)P), dim3(kBlock), 0, lc->stream, (const PsDMatch *)dres,
+                           (const int32_t *)(dres + a->offNum), (const uint8_t *)(dres + a->offMask), (const float *)(dres + a->offPose),
+                           (const PsRansacStats *)(dres + a->offStats), s->cap, a->resultMode, (PsDMatch *)l.hresDev,
+                           (float *)(l.hresDev + a->offPose), (PsRansacStats *)(l.hresDev + a->offStats), (int32_t *)(l.hresDev + a->offNum));
+    } else {
+        const size_t p = (size_t)P;
+        CopySegs down{};
+        const size_t off[5] = {0, a->offMask, a->offPose, a->offStats, a->offNum};
+        const size_t len[5] = {p * cap * sizeof(PsDMatch), (p * cap + 3) & ~(size_t)3, p * 64, p * sizeof(PsRansacStats), p * sizeof(int32_t)};
+        for (int k = 0; k < 5; ++k) {
+            down.src[k] = dres + off[k];
+            down.dst[k] = l.hresDev + off[k];
+            down.bytes[k] = len[k];
+        }
+        down.n = 5;
+        const unsigned groupsOut = (unsigned)((len[0] / 16 + 255) / 256);
+        hipLaunchKernelGGL(ps_copy_segments, dim3(groupsOut < 1 ? 1 : (groupsOut > 32 ? 32 : groupsOut)), dim3(256), 0, lc->stream, down);
+    }
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+// One mini chunk: the n frames staged in `h` (packed layout) -> the next place, on that place's lane.  The caller has checked
+// async_room().
+int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
+{
+    PsVoAsync *a = s->async;
+    PsContext *ctx = s->ctx;
+    const uint8_t *hDev = a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
+    a->chunkSeq++;
+    const int first = a->prevPos >= 0 ? 0 : 1;
+    const int P = n - first;
+    const uint8_t *haloWas = a->haloDev;
+    const int haloNkWas = a->haloNk;
+    // (the stream's latest frame from now on: the next chunk reads it from this staging slot, which is written again only
+    // lanes + ahead + 1 chunks later -- by then this chunk AND its successor have been popped)
+    a->haloDev = hDev + (size_t)(n - 1) * a->packStride;
+    a->haloNk = nk[n - 1];
+    a->prevPos = 0;
+    if (P <= 0) return PS_OK; // a lone first frame: nothing to run, no place taken
+    const int place = a->tail;
+    AsyncLane &l = a->lane[(size_t)place];
+    const int laneIdx = place % a->lanes; // (fixed per place: the place's graph holds its lane's arena pointers)
+    PsContext *lc = l.ctx = a->laneCtx[(size_t)laneIdx];
+    a->diagLaunches++;
+    MiniMeta *hm = (MiniMeta *)l.hmeta;
+    memset(hm, 0, sizeof *hm);
+    for (int i = 0; i < P; ++i) { // query = previous frame, train = current (matcher.cpp:470-471)
+        hm->pairs[2 * i] = first + i;
+        hm->pairs[2 * i + 1] = first + i + 1;
+    }
+    hm->nk[0] = first ? 0 : haloNkWas;
+    for (int i = 0; i < n; ++i) hm->nk[1 + i] = nk[i];
+    hm->n = n;
+    hm->first = first;
+    hm->seed = a->cfg.seed + (uint64_t)a->pairCounter;
+    hm->src[0] = first ? nullptr : haloWas;
+    for (int i = 0; i < n; ++i) hm->src[1 + i] = hDev + (size_t)i * a->packStride;
+    int rc = PS_OK;
+#ifdef PS_STREAM_DIAG
+    static const char *diagFail = std::getenv("PUTSLAM_HIP_STREAM_DIAG_FAIL_CHUNK");
+    static const char *diagFailAfter = std::getenv("PUTSLAM_HIP_STREAM_DIAG_FAIL_AFTER");
+    if (diagFail && std::atoll(diagFail) == a->diagLaunches - 1) return fail(ctx, PS_ERR_HIP, "pipelined chunk: injected failure (PS_STREAM_DIAG)");
+#endif
+    const bool full = P == a->B && !first;
+    bool launched = false;
+    if (full && s->graphsEnabled) { // (PUTSLAM_HIP_NO_GRAPH=1 at ps_vo_stream_create: ordinary launches)
+        if (l.gexec && l.gexecGen != lc->arenaGen) { // the lane's arena has moved since the capture
+            (void)hipGraphExecDestroy(l.gexec);
+            l.gexec = nullptr;
+        }
+        if (!l.gexec && a->laneWarmGen[(size_t)laneIdx] == lc->arenaGen && lc->arenaGen != 0) {
+            // an un-captured full chunk has sized this lane's arena: capture the place's chunk
+            Plan pl;
+            rc = make_plan(lc, &a->prm, &a->cfg, a->haveK ? a->K : nullptr, s->cap, s->cap, pl);
+            if (rc == PS_OK) {
+                pl.ma.seedDev = reinterpret_cast<const uint64_t *>(&((MiniMeta *)l.meta.p)->seed);
+                rc = prepare_score(lc, pl, P, s->cap);
+            }
+            if (rc == PS_OK) {
+                PS_ENSURE(lc->keys, (size_t)P * s->cap * sizeof(uint32_t));
+                rc = keys_clean(lc, (size_t)P * s->cap * sizeof(uint32_t)); // (outside the capture: a replay finds the block as its capture did)
+            }
+            if (rc != PS_OK) {
+                ctx->err = std::string("pipelined chunk: ") + lc->err;
+                return rc;
+            }
+            if (lc->arenaGen == a->laneWarmGen[(size_t)laneIdx]) {
+                hipGraph_t graph = nullptr;
+                if (hipStreamBeginCapture(lc->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int r = mini_enqueue(s, l, lc, pl, P);
+                    const hipError_t e2 = hipStreamEndCapture(lc->stream, &graph);
+                    if (r == PS_OK && e2 == hipSuccess && graph && hipGraphInstantiate(&l.gexec, graph, nullptr, nullptr, 0) != hipSuccess) l.gexec = nullptr;
+                    if (r != PS_OK || e2 != hipSuccess) l.gexec = nullptr;
+                    if (graph) (void)hipGraphDestroy(graph);
+                }
+                if (!l.gexec) {
+                    s->graphsEnabled = false; // capture is not available here: ordinary launches from now on
+                    (void)hipGetLastError();
+                    ctx->err.clear();
+                } else {
+                    l.gexecGen = lc->arenaGen;
+                }
+            }
+        }
+        if (l.gexec) {
+            PS_HIP(hipGraphLaunch(l.gexec, lc->stream));
+            a->graphLaunches++;
+            launched = true;
+        }
+    }
+    if (!launched) {
+        Plan pl;
+        rc = make_plan(lc, &a->prm, &a->cfg, a->haveK ? a->K : nullptr, s->cap, s->cap, pl);
+        if (rc == PS_OK) {
+            pl.ma.seedDev = reinterpret_cast<const uint64_t *>(&((MiniMeta *)l.meta.p)->seed);
+            rc = prepare_score(lc, pl, P, s->cap);
+        }
+        if (rc != PS_OK) {
+            ctx->err = std::string("pipelined chunk: ") + lc->err;
+            return rc;
+        }
+        rc = mini_enqueue(s, l, lc, pl, P);
+        if (rc != PS_OK) return rc;
+        if (full) a->laneWarmGen[(size_t)laneIdx] = lc->arenaGen;
+    }
+#ifdef PS_STREAM_DIAG
+    if (diagFailAfter && std::atoll(diagFailAfter) == a->diagLaunches - 1)
+        return fail(ctx, PS_ERR_HIP, "pipelined chunk: injected failure behind the batched call (PS_STREAM_DIAG)");
+#endif
+    PS_HIP(hipEventRecord(l.evDone, lc->stream));
+    a->dbgN++;
+    l.state = 1;
+    l.firstPair = a->pairCounter;
+    l.pairs = P;
+    l.epoch = a->epoch;
+    a->pairCounter += P;
+    a->launchSeq++;
+    a->tail = (a->tail + 1) % (int)a->lane.size();
+    a->inFlight++;
+    return PS_OK;
+}
+
 int async_submit(PsVoStream *s, const uint8_t *desc, const float *pts, const int32_t *nk, int n)
 {
-    const int rc = async_submit_body(s, desc, pts, nk, n);
+    const int rc = s->async->mini ? mini_submit_body(s, const_cast<uint8_t *>(desc), nk, n) : async_submit_body(s, desc, pts, nk, n);
     return rc == PS_OK ? PS_OK : async_abort_chunk(s, rc);
 }
 
@@ -427,7 +627,17 @@ int async_build(PsVoStream *s)
     for (hipEvent_t &e : a->upEv) PS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     a->packed = s->asyncFrameLayout == PS_FRAMES_PACKED;
     a->packStride = (cap * 44 + 15) & ~(size_t)15;
-    if (a->packed) {
+    {
+        // small chunks as one graph per place (PsVoAsync::mini); PUTSLAM_HIP_STREAM_MINI=0 keeps round 5's form for them (A/B, tests)
+        const char *m = std::getenv("PUTSLAM_HIP_STREAM_MINI");
+        a->mini = a->B <= psdev::kMiniFrames && !(m && std::atoi(m) == 0);
+    }
+    if (a->mini) {
+        a->packed = true; // (the staging areas: one block per frame, as the copy-in kernel reads them)
+        a->laneWarmGen.assign((size_t)a->lanes, 0);
+        a->stagePoolDev.assign(a->stagePool.size(), nullptr);
+        a->viewBuf.assign((a->resBytes + 15) & ~(size_t)15, 0);
+    } else if (a->packed) {
         PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * a->packStride);
     } else {
         PS_ENSURE(a->ringDesc, (size_t)a->ringFrames * cap * 32);
@@ -457,10 +667,12 @@ int async_build(PsVoStream *s)
         psi_copy_options(c, ctx); // the lanes run what the stream's context would
     }
     a->lane.resize((size_t)(a->lanes + a->ahead));
+    const size_t metaBytes = std::max(((size_t)2 * B + a->ringFrames) * sizeof(int32_t), sizeof(psdev::MiniMeta));
     for (AsyncLane &l : a->lane) {
-        PS_ENSURE(l.meta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t));
+        if (a->mini) PS_ENSURE(l.frames, (B + 1) * a->packStride);
+        PS_ENSURE(l.meta, metaBytes);
         PS_ENSURE(l.res, (a->resBytes + 15) & ~(size_t)15);
-        PS_HIP(hipHostMalloc((void **)&l.hmeta, ((size_t)2 * B + a->ringFrames) * sizeof(int32_t), hipHostMallocDefault));
+        PS_HIP(hipHostMalloc((void **)&l.hmeta, metaBytes, hipHostMallocDefault));
         PS_HIP(hipHostMalloc((void **)&l.hres, (a->resBytes + 15) & ~(size_t)15, hipHostMallocDefault));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hmetaDev, l.hmeta, 0));
         PS_HIP(hipHostGetDevicePointer((void **)&l.hresDev, l.hres, 0));
@@ -478,7 +690,34 @@ void release_view(PsVoAsync *a)
         a->heldHres = a->heldHresDev = nullptr;
     }
     a->cursor = 0;
+    a->haveView = false;
     memset(&a->view, 0, sizeof a->view);
+}
+
+// Several frames into a stream of mini chunks (push_many / push_many_packed): staged one by one, every full chunk submitted --
+// all or nothing: places for every chunk these frames complete, and one for a chunk they leave partly filled.
+int mini_push_frames(PsVoStream *s, const uint8_t *desc, size_t descStride, const uint8_t *pts, size_t ptsStride, const int32_t *nkpts, int numFrames)
+{
+    PsVoAsync *a = s->async;
+    const size_t cap = (size_t)s->cap;
+    const int total = a->staged + numFrames;
+    const int need = total / a->B + (total % a->B > 0 ? 1 : 0);
+    if (need > async_room(a)) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough room for these frames (pop results first, or push fewer)");
+    for (int f = 0; f < numFrames; ++f) {
+        uint8_t *h = nullptr;
+        int rc = stage_area(s, &h);
+        if (rc) return rc;
+        uint8_t *hd = h + (size_t)a->staged * a->packStride;
+        memcpy(hd, desc + (size_t)f * descStride, (size_t)nkpts[f] * 32);
+        memcpy(hd + cap * 32, pts + (size_t)f * ptsStride, (size_t)nkpts[f] * 12);
+        a->stagedNk[(size_t)a->staged] = nkpts[f];
+        a->staged++;
+        if (a->staged == a->B) {
+            rc = async_submit_staged(s);
+            if (rc) return rc;
+        }
+    }
+    return PS_OK;
 }
 
 } // namespace
@@ -614,6 +853,7 @@ int ps_vo_stream_push_many(PsVoStream *s, const uint8_t *desc, const float *pts,
     for (int i = 0; i < numFrames; ++i)
         if (nkpts[i] < 0 || nkpts[i] > s->cap) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many: row count out of range");
     if (numFrames == 0) return PS_OK;
+    if (a->mini) return mini_push_frames(s, desc, (size_t)s->cap * 32, reinterpret_cast<const uint8_t *>(pts), (size_t)s->cap * 12, nkpts, numFrames);
     // places needed: one for the frames push_async has staged, one per chunk of these frames -- all or nothing
     const int chunks = (numFrames + a->B - 1) / a->B;
     const int need = chunks + (a->staged > 0 ? 1 : 0);
@@ -679,6 +919,7 @@ int ps_vo_stream_push_many_packed(PsVoStream *s, const uint8_t *frames, size_t f
     for (int i = 0; i < numFrames; ++i)
         if (nkpts[i] < 0 || nkpts[i] > s->cap) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_push_many_packed: row count out of range");
     if (numFrames == 0) return PS_OK;
+    if (a->mini) return mini_push_frames(s, frames, a->packStride, frames + (size_t)s->cap * 32, a->packStride, nkpts, numFrames);
     const int chunks = (numFrames + a->B - 1) / a->B;
     const int need = chunks + (a->staged > 0 ? 1 : 0);
     if (need > async_room(a))
@@ -724,13 +965,25 @@ int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out)
         }
         if (q != hipSuccess) return async_fail(s, PS_ERR_HIP, "hipEventQuery", q);
     }
-    // the lane's block becomes the held one, the spare one the lane's: the lane is free now
     uint8_t *blk = l.hres;
-    a->heldHres = l.hres;
-    a->heldHresDev = l.hresDev;
-    l.hres = a->spareHres;
-    l.hresDev = a->spareHresDev;
-    a->spareHres = a->spareHresDev = nullptr;
+    if (a->mini) {
+        // a mini chunk's results are a few tens of KB: copied out, so that the place keeps its pinned block (its graph writes
+        // there) and is free at once
+        const size_t p = (size_t)l.pairs, cap = (size_t)s->cap;
+        blk = a->viewBuf.data();
+        if (a->resultMode != PS_RESULTS_POSES) memcpy(blk, l.hres, p * cap * sizeof(PsDMatch));
+        if (a->resultMode == PS_RESULTS_FULL) memcpy(blk + a->offMask, l.hres + a->offMask, p * cap);
+        memcpy(blk + a->offPose, l.hres + a->offPose, p * 64);
+        memcpy(blk + a->offStats, l.hres + a->offStats, p * sizeof(PsRansacStats));
+        memcpy(blk + a->offNum, l.hres + a->offNum, p * sizeof(int32_t));
+    } else {
+        // the lane's block becomes the held one, the spare one the lane's: the lane is free now
+        a->heldHres = l.hres;
+        a->heldHresDev = l.hresDev;
+        l.hres = a->spareHres;
+        l.hresDev = a->spareHresDev;
+        a->spareHres = a->spareHresDev = nullptr;
+    }
     out->matches = a->resultMode == PS_RESULTS_POSES ? nullptr : (const PsDMatch *)blk;
     out->inlierMask = a->resultMode == PS_RESULTS_FULL ? blk + a->offMask : nullptr;
     out->resultMode = a->resultMode;
@@ -744,6 +997,7 @@ int ps_vo_stream_pop_many(PsVoStream *s, int wait, PsHostPairResults *out)
     a->head = (a->head + 1) % (int)a->lane.size();
     a->inFlight--;
     a->view = *out;
+    a->haveView = true;
     return PS_OK;
 }
 
@@ -754,7 +1008,7 @@ int ps_vo_stream_pop(PsVoStream *s, int wait, PsDMatch *matches, int *nmatches, 
     PsVoAsync *a = s->async;
     if (!a || !nmatches || !pose) return async_fail(s, PS_ERR_BAD_ARG, "ps_vo_stream_pop: bad argument / stream not configured");
     *nmatches = -1;
-    if (!a->heldHres || a->cursor >= a->view.count) {
+    if (!a->haveView || a->cursor >= a->view.count) {
         PsHostPairResults v;
         // (a frame that waits in a partly filled chunk is not submitted by a pop: ps_vo_stream_flush does that)
         int rc = ps_vo_stream_pop_many(s, wait, &v);
@@ -789,9 +1043,15 @@ int ps_vo_stream_pending(const PsVoStream *s)
     int n = 0;
     for (const AsyncLane &l : a->lane)
         if (l.state == 1) n += l.pairs;
-    if (a->heldHres) n += a->view.count - a->cursor;
+    if (a->haveView) n += a->view.count - a->cursor;
     if (a->staged > 0) n += a->staged - (a->prevPos >= 0 ? 0 : 1);
     return n;
+}
+
+long long ps_vo_stream_graph_launches(const PsVoStream *s)
+{
+    if (!s) return PS_ERR_BAD_ARG;
+    return s->graphLaunches + (s->async ? s->async->graphLaunches : 0);
 }
 
 void *ps_host_alloc(size_t bytes)
