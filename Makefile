@@ -8,8 +8,9 @@ SHARD := putslam_amd/libputslam_shard.so
 
 all: $(LIB) $(DROPIN) $(SHARD) oracle
 
-$(LIB): $(CSRC)/ps_capi.hip $(CSRC)/ps_kernels.h $(CSRC)/ps_matcher_mfma.h $(CSRC)/ps_score_fast.h $(CSRC)/ps_score_euclid.h $(CSRC)/ps_device_math.h $(CSRC)/ps_stream_async.h include/putslam_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/ps_capi.hip -o $@
+# (the recipe -- one device translation unit + host-only ones -- lives in putslam_amd/_build.py)
+$(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.cpp) include/putslam_hip.h
+	python -c "from putslam_amd import _build; _build.build_hip()"
 
 $(DROPIN): $(CSRC)/dropin/putslam_dropin.cpp $(CSRC)/dropin/putslam_dropin.h $(CSRC)/dropin/putslam_compat_types.h $(LIB)
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I$(CSRC)/dropin $< -o $@ -Lputslam_amd -lputslam_hip '-Wl,-rpath,$$ORIGIN'

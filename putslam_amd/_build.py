@@ -25,8 +25,8 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "
 
 DEVICE_TU = "ps_capi.hip"
 DEVICE_DEPS = ["ps_kernels.h", "ps_matcher_mfma.h", "ps_score_fast.h", "ps_score_euclid.h", "ps_device_math.h",
-               "ps_stream_async.h", "ps_internal.h"]
-HOST_TUS = ["ps_env.cpp", "ps_batch_queue.cpp"]
+               "ps_stream_async.h", "ps_stream_push.h", "ps_diag.h", "ps_internal.h"]
+HOST_TUS = ["ps_context.cpp", "ps_env.cpp", "ps_batch_queue.cpp"]
 HOST_DEPS = ["ps_internal.h"]
 HEADER = os.path.join(ROOT, "include", "putslam_hip.h")
 

@@ -303,7 +303,8 @@ class BatchQueue:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._ctx._L.ps_batch_queue_destroy(self._h)
+            if getattr(self._ctx, "_h", None):
+                self._ctx._L.ps_batch_queue_destroy(self._h)
             self._h = None
             for c in self.contexts:
                 c.close()
@@ -366,7 +367,10 @@ class VoStream:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._ctx._L.ps_vo_stream_destroy(self._h)
+            # (a stream outliving its context -- a test that failed before closing it, collected after the context fixture -- is
+            # leaked, not destroyed through a dangling context)
+            if getattr(self._ctx, "_h", None):
+                self._ctx._L.ps_vo_stream_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,7 +1,6 @@
-// ps_capi.hip -- C ABI of the MI355X-native PUTSLAM front end (include/putslam_hip.h).
-//
-// Host side: one PsContext = one HIP stream + one grow-only scratch arena (the reference's
-// Matcher/RANSAC objects are per-thread instances with no shared state, PUTSLAM.cpp:566,570).
+// ps_capi.hip -- the device translation unit of libputslam_hip.so (include/putslam_hip.h): the kernels (ps_kernels.h and
+// friends), the plan of a call and every launch.  PsContext itself -- stream, scratch arena, option table, stop-table builders,
+// timing record -- lives in ps_context.cpp / ps_internal.h, host-only; so do the batch queue and the environment default.
 // There is no CPU fallback anywhere in this file: every entry point launches the HIP kernels
 // of ps_kernels.h or fails with a negative PsStatus.
 #include "ps_kernels.h"
@@ -22,12 +21,9 @@
 
 using namespace psdev;
 
-namespace {
+static_assert(kPsReorderMargin == kReorderMargin && kPsReorderTopMax == kReorderTopMax, "ps_internal.h mirrors ps_score_fast.h");
 
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
+namespace {
 
 constexpr int kWidePairs = 16; // batches of at most this many pairs run kernel 2 with 1024-thread work-groups
 // where the staged scoring takes over from complete scoring (prepare_score): batch size in work units = pairs x
@@ -37,173 +33,9 @@ struct StagedFrom {
 };
 constexpr StagedFrom kStagedFromEuclidFixed = {7.8e5, 250.0}, kStagedFromReprojFixed = {1.3e6, 500.0},
                      kStagedFromEuclidAdaptive = {6.0e4, 0.0}, kStagedFromReprojAdaptive = {4.5e4, 0.0};
-constexpr int kMaxTimed = 8;   // kernels timed per call
-constexpr int kTimingRing = 128; // calls kept (HIP events on the launch stream around every kernel)
-
 } // namespace
 
-struct PsContext {
-    int device = 0;
-    hipStream_t own = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t handoff = nullptr; // recorded at every exit of the asynchronous call (ps_vo_pairs_device) once it has queued work:
-                                  // a newly selected stream waits for it
-    bool handoffPending = false;
-    std::string err;
-    char arch[64] = {0};
-    // scratch arena (device)
-    Buf keys, recA, recB, recC, recD, recE, recF, counts, mvalid, cmax, idxList, raw;
-    Buf models; // [P][H][12] hypothesis models parked by kernel 3 for kernel 4 (small batches) and for the later stages
-                // of the staged scoring (large batches)
-    Buf survA, survB, survN; // staged scoring: survivor lists [P][H] of stages 1 / 2 and their counters [2][P]
-    Buf validMask;           // staged scoring, stage 0 in two launches: which prefix hypotheses have a model, [P][prefix / 64]
-    Buf frontRec;            // staged scoring: the pre-test operands of the all-reject front, [P][cap / 2][10] floats
-    Buf prefInfo;            // staged scoring: per pair (best count, trip limit) of the prefix, written by ps_stage_reorder
-    Buf recF2, permBuf;      // staged scoring: the reordered hot record of stages 1+ and position -> original match [P][cap]
-    Buf dbgCnt; // {parked evaluations, evaluations} of the fast scoring kernel (option "score_stats")
-    Buf xq; // FP4 image of every pair's query frame (ps_matcher_mfma.h)
-    Buf recShadow; // (-DPS_STREAM_DIAG builds with PUTSLAM_HIP_DIAG_SHADOW_RECORDS=1: kernel 2's records once more; never read)
-    Buf tabR, tabU;
-    // staging for the host-pointer entry points (device)
-    Buf sDesc, sNk, sMatches, sNumM, sMask, sPose, sStats, sMisc0, sMisc1, sMisc2;
-    // cached stop tables
-    int tabEstimator = -1, tabH = -1, tabRN = 0, tabUN = 0, tabIter0 = 0;
-    double tabMinRatio = -1.0;
-    float tabTiny = 0.0f;
-    // timing
-    bool timing = false;
-    std::vector<hipEvent_t> ev; // [kTimingRing][kMaxTimed][2], created when timing is first enabled
-    long long timedCalls = 0;   // calls recorded since timing was (re)enabled
-    int curCall = 0;            // ring slot of the call being recorded
-    int nTimed = 0;             // highest timed slot + 1
-    unsigned slotMask[kTimingRing] = {0}; // per kept call: which slots were recorded
-    // tuning overrides (options "qsplit" / "msplit"; 0 = automatic)
-    int forceQsplit = 0, forceMsplit = 0;
-    // kernel variants (option "matcher"): 1 = FP4 MFMA matcher, 0 = integer VALU matcher,
-    // 2 = by batch size (default): the MFMA form costs one more launch (the FP4 expansion), which a handful of pairs does
-    // not earn back
-    int matcher = 2;
-    int matcherUsed = 1; // what the last matching call ran (1 MFMA, 0 VALU)
-    // matrix-core matcher: 1 = the work-group expands its query tiles itself through LDS (default), 0 = round 2's form
-    // with the FP4 image of the query frames written to HBM by a launch of its own (option "matcher_fused")
-    int matcherFused = 1;
-    // 1 = the decision-exact kernels (ps_score_fast.h / ps_score_euclid.h, default), 0 = the value-exact ps_ransac_score<MODE>
-    // (the matrix-core scoring experiment of round 2 -- split-f16 transforms on v_mfma_f32_32x32x16_f16, correct, no gain on
-    // the headline -- left the tree in round 4: profiles/variants/ps_score_mfma.h.txt)
-    int scoreFast = 1;
-    int scoreStats = 0;
-    // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
-    // abandon later hypotheses that cannot become records (default), 0 = every hypothesis is scored completely
-    int prune = 1;
-    // staged scoring: stages 1+ sweep the matches in the order ps_stage_reorder writes (those the prefix's best hypotheses
-    // reject first: hypotheses end sooner, ps_score_fast.h).  1 = always, 0 = never (original order), 2 (default) = for the
-    // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
-    // extra launch (6 us per call) buys nothing (option "reorder")
-    int reorder = 2;
-    int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (option "reorder_gran": 2 .. 64; finer cuts
-                          // shorten stage 1 and lengthen stages 2 / 3 by as much, profiles/r03n)
-    int genSplit = 1;    // staged scoring: stage 0 as two launches -- the prefix's models once, then the sweep with the match range
-                         // split over twice as many work-groups (option "gensplit" = 0: one launch, every part repeats the
-                         // sample -> SVD chain)
-    int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (option "singlerest")
-    int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (option "pretest")
-    int listRsplit3 = 4; // option "list_r3": work-groups the last stage's match range is split over
-    int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
-    int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
-    int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
-    int streamCopyKernels = 1; // option "stream_copy_kernels": ps_vo_stream_push moves its frame in / results out with a copy
-                               // kernel over mapped pinned memory (1) or with hipMemcpyAsync (0: rounds 1 - 4)
-    int streamAhead = -1; // option "stream_ahead": places of the pipelined stream beyond one per lane (chunks queued behind the running
-                          // ones); -1 = six places in all
-    int modelRoomMiB = 0; // option "model_room_mib": room for the staged scoring's parked models (0 = 256 MiB adaptive / 2 GiB fixed)
-    int reorderTop = 8, reorderMargin = kReorderMargin, reorderC2div = 16; // (options "reorder_top" / "reorder_margin" / "reorder_c2div")
-    int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
-    Buf stamps;
-    // Every (re)allocation of an arena block bumps this: captured graphs (ps_vo_stream_push) carry the pointers of the
-    // blocks they were captured with and are dropped when the generation they saw is no longer the current one.
-    unsigned long long arenaGen = 0;
-    // what the LAST scoring step left in the staged-scoring buffers (ps_debug_stage_survivors / ps_debug_stage_order):
-    // pairs and capacity the survivor counters / the order were laid out with, 0 = that step was not staged / not reordered
-    int stagedP = 0, stagedCap = 0, reorderedP = 0;
-    int lastModelH = 0; // hypotheses per pair with a parked-model slot in the last scoring step (0: nothing parked)
-    // "Nothing to gain" policy of the staged scoring (option "bail", Euclidean metrics, fixed schedule, batched calls):
-    // ps_stage_reorder counts the pairs it replayed and those whose prefix leaves nothing to abandon (stage 1 sweeps every match:
-    // hopeless data, no pair accepted); kernel 4 forwards the two counters to mapped host memory.  While the last observation
-    // says "most pairs", the next calls OF THE SAME KIND score completely -- one launch, what the staged form costs on such data
-    // is its extra launches, 14 - 19 % (profiles/r03p/data_sweep.txt) -- and every 16th call probes with the staged form again.
-    // Results are bit-identical either way; the observation arrives asynchronously, so the switch lags the data by a call or two.
-    // The state is kept per KIND of call -- (errorVersion, estimator, H, batch-size class, frame capacity, frame set) --, eight
-    // kinds at a time: a context that alternates a mostly failing batch (loop-closure candidates) with good VO batches keeps
-    // the staged form for the good ones (round 4 kept ONE flag per context: ADVICE round 4).  Adaptive schedules never drop the
-    // staged form: under a long cap complete scoring is the minutes-long path.
-    struct BailKind {
-        int mode = -1, estimator = 0, H = 0, pclass = 0, cap = 0;
-        const void *frames = nullptr;
-        unsigned seen[2] = {0, 0};
-        int hopeless = 0, calls = 0;
-        unsigned long long used = 0; // (least recently used slot is recycled)
-    };
-    static constexpr int kBailKinds = 8;
-    BailKind bailKinds[kBailKinds];
-    unsigned long long bailClock = 0;
-    int bailSlot = -1;            // slot of the last call the policy looked at
-    Buf bailCnt;                  // device: [kBailKinds]{pairs replayed, pairs with nothing to gain}, monotonic per slot
-    unsigned *bailHost = nullptr; // mapped host mirror [kBailKinds][2]
-    unsigned *bailHostDev = nullptr;
-    int hopeless = 0;             // state of the last call's kind (option "hopeless", read only)
-    // The keys block is all-ones at rest: kernel 2 puts kNoKey back into every entry it reads, so the matcher forms that merge
-    // their query splits with atomicMin need no clearing launch in front of them (a single pair paid a memset launch and its
-    // gap for that on every call: 6 of 96 us).  keysCleanPtr / keysCleanBytes = the block and the leading bytes the invariant
-    // holds for once the stream's queued work has drained; a fresh or regrown block is cleared once, completely.
-    void *keysCleanPtr = nullptr;
-    size_t keysCleanBytes = 0;
-};
-
 namespace {
-
-int fail(PsContext *c, int code, const char *what, hipError_t e = hipSuccess)
-{
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-#define PS_HIP(call)                                                  \
-    do {                                                              \
-        hipError_t e_ = (call);                                       \
-        if (e_ != hipSuccess) return fail(ctx, PS_ERR_HIP, #call, e_); \
-    } while (0)
-
-int ensure(PsContext *ctx, Buf &b, size_t bytes)
-{
-    if (bytes <= b.cap) return PS_OK;
-    // (a quarter more than asked for, 16 MiB at most: the large blocks -- counts and parked models under a long cap -- grow in
-    // steps of the batch size, not by doubling)
-    size_t want = bytes + (bytes / 4 < ((size_t)16 << 20) ? bytes / 4 : ((size_t)16 << 20)) + 256;
-    if (b.p) {
-        // The old block may still be referenced by work queued on the stream.
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(ctx, PS_ERR_HIP, "hipStreamSynchronize", e);
-        (void)hipFree(b.p);
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) return fail(ctx, PS_ERR_ALLOC, "hipMalloc", e);
-    b.cap = want;
-    ctx->arenaGen++;
-    return PS_OK;
-}
-#define PS_ENSURE(buf, bytes)                        \
-    do {                                             \
-        int rc_ = ensure(ctx, (buf), (bytes));       \
-        if (rc_ != PS_OK) return rc_;                \
-    } while (0)
 
 // The matcher forms that merge with atomicMin start from an all-ones keys block (see PsContext::keysCleanPtr).
 int keys_clean(PsContext *ctx, size_t bytes)
@@ -213,127 +45,6 @@ int keys_clean(PsContext *ctx, size_t bytes)
     ctx->keysCleanPtr = ctx->keys.p;
     ctx->keysCleanBytes = ctx->keys.cap;
     return PS_OK;
-}
-
-void release(Buf &b)
-{
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.cap = 0;
-}
-
-// RANSAC::computeRANSACIteration (reference src/TransformEst/RANSAC.cpp:457-461) evaluated with the
-// host's libm exactly as the reference evaluates it; the int conversion (UB there for huge
-// quotients) saturates.
-int ransac_iterations_host(double inlierRatio, double successProbability = 0.98, int numberOfPairs = 3)
-{
-    double v = std::log(1 - successProbability) / std::log(1 - std::pow(inlierRatio, numberOfPairs));
-    if (!(v < 2147483647.0)) return INT_MAX;
-    if (v < 0) return 0;
-    return (int)v;
-}
-
-// USAC<T>::updateStandardStopping (reference include/putslam/USAC/USAC.h:944-971) as a function of the
-// good-model probability, with confThreshold 0.99 and maxHypotheses 850000 (USAC_wrapper.cpp:66,70).
-constexpr unsigned kUsacMaxHyp = 850000u;
-unsigned usac_stopping_host(double prob_good_model)
-{
-    if (prob_good_model < DBL_EPSILON) return kUsacMaxHyp;
-    if (1 - prob_good_model < DBL_EPSILON) return 1;
-    double n = std::log(1 - 0.99) / std::log(1 - prob_good_model);
-    return (unsigned)std::ceil(n);
-}
-
-// Threshold tables: the device never evaluates log/pow, it binary-searches these host-built
-// (hence libm-identical) step positions.
-void build_ransac_table(double minRatio, int H, std::vector<float> &tab, int &iter0, float &tiny)
-{
-    // For r below ~6e-6, 1 - r^3 rounds to 1, log(1) = +0 and the quotient is -inf: the reference's
-    // int(-inf) is UB (INT_MIN on x86: the loop ends); ransac_iterations_host returns 0 there.  The
-    // step positions below are searched above that range, and the range itself is passed to the
-    // device as `tiny` (limit 0), so device and host agree for every float ratio.
-    uint32_t tlo = 0, thi;
-    {
-        float probe = 1e-4f; // iterations(1e-4) saturates at INT_MAX
-        memcpy(&thi, &probe, 4);
-        while (thi - tlo > 1) {
-            uint32_t mid = tlo + (thi - tlo) / 2;
-            float mf;
-            memcpy(&mf, &mid, 4);
-            if (ransac_iterations_host((double)mf) == 0) tlo = mid; else thi = mid;
-        }
-        memcpy(&tiny, &tlo, 4); // largest float whose quotient is -inf
-    }
-    int itersMin = ransac_iterations_host(minRatio);
-    int kcap = itersMin < H ? itersMin : H;
-    if (kcap < 0) kcap = 0;
-    tab.resize((size_t)kcap);
-    uint32_t one;
-    float onef = 1.0f;
-    memcpy(&one, &onef, 4);
-    uint32_t hi = one; // iterations(1.0) = 0 <= k for every k
-    for (int k = 0; k < kcap; ++k) {
-        // smallest float r in (0,1] with iterations(r) <= k.  The table is non-increasing in k, so the
-        // previous entry (iterations <= k-1 <= k) is a valid upper end of the bracket.
-        uint32_t lo = thi; // just above the -inf range: iterations saturate at INT_MAX > k
-        while (hi - lo > 1) {
-            uint32_t mid = lo + (hi - lo) / 2;
-            float mf;
-            memcpy(&mf, &mid, 4);
-            if (ransac_iterations_host((double)mf) <= k) hi = mid; else lo = mid;
-        }
-        memcpy(&tab[(size_t)k], &hi, 4);
-    }
-    int i0 = ransac_iterations_host(0.20); // RANSAC ctor, RANSAC.cpp:30
-    iter0 = i0 < H ? i0 : H;
-}
-
-void build_usac_table(int H, std::vector<double> &tab)
-{
-    int n = H < (int)kUsacMaxHyp ? H : (int)kUsacMaxHyp;
-    tab.resize((size_t)(n > 0 ? n : 0));
-    uint64_t oneb;
-    double oned = 1.0;
-    memcpy(&oneb, &oned, 8);
-    uint64_t hiPrev = oneb;
-    // The bisection runs where the rule is monotone.  Below p = 1.07e-9 the quotient exceeds 2^32 and the reference's
-    // (unsigned) cast is undefined (x86 keeps the low 32 bits: pseudo-random in p); a probe in that region that happens to
-    // land below the target sent the bisection to the region's edge and every later entry with it -- rounds 1 to 4 built
-    // tables that were right up to entry 78 774 only, so that schedules that should run longer (fewer than 4 % inliers)
-    // stopped there.  From 2^-29 = 1.86e-9 up the quotient is below 2.5e9: every target (< 850 000) lies above it.
-    // Good-model probabilities below 1.07e-9 (three or four inliers among more than 1777 / 2820 matches) get the cap,
-    // where the reference's cast is undefined and the oracle returns what x86 makes of it.
-    const double pFloor = 1.862645149230957e-09; // 2^-29
-    uint64_t floorb;
-    memcpy(&floorb, &pFloor, 8);
-    for (int k = 0; k < n; ++k) {
-        unsigned target = (unsigned)k + 1u; // smallest p with stopping(p) <= k+1
-        uint64_t lo = floorb, hi = hiPrev;  // stopping(2^-29) = 2.47e9 > target
-        if (target >= kUsacMaxHyp) {
-            tab[(size_t)k] = 0.0;
-            continue;
-        }
-        {
-            // The root of log(0.01) / log(1 - p) = target in closed form brackets the entry to a few thousand neighbouring
-            // doubles; either end is taken only if the rule itself confirms it, so the bisection's invariant -- and its
-            // result -- are those of the wide bracket (850 000 entries: 0.41 s instead of 0.75).
-            const double ps = -std::expm1(std::log(1 - 0.99) / (double)target);
-            const double a = ps * (1.0 - 1e-11), b = ps * (1.0 + 1e-11);
-            uint64_t ab, bb;
-            memcpy(&ab, &a, 8);
-            memcpy(&bb, &b, 8);
-            if (ab > lo && ab < hi && usac_stopping_host(a) > target) lo = ab;
-            if (bb > lo && bb < hi && usac_stopping_host(b) <= target) hi = bb;
-        }
-        while (hi - lo > 1) {
-            uint64_t mid = lo + (hi - lo) / 2;
-            double md;
-            memcpy(&md, &mid, 8);
-            if (usac_stopping_host(md) <= target) hi = mid; else lo = mid;
-        }
-        memcpy(&tab[(size_t)k], &hi, 8);
-        hiPrev = hi;
-    }
 }
 
 double sq_bound_f64(double thr)
@@ -1176,131 +887,12 @@ struct TimingOff {
     ~TimingOff() { c->timing = saved; }
 };
 
-int bind(PsContext *ctx)
-{
-    if (!ctx) return PS_ERR_BAD_ARG;
-    hipError_t e = hipSetDevice(ctx->device);
-    if (e != hipSuccess) return fail(ctx, PS_ERR_HIP, "hipSetDevice", e);
-    ctx->err.clear();
-    return PS_OK;
-}
-
-
-// ---- options: one table for ps_context_set_option / ps_context_get_option / the PUTSLAM_HIP_* environment ----
-// Every kernel variant and every tuning knob of the staged scoring is settable per context (the environment only
-// supplies the initial value), so that tests can run each twin next to the default in one process.
-struct OptDesc {
-    const char *name;      // option name of ps_context_set_option
-    const char *env;       // PUTSLAM_HIP_<env>: initial value (nullptr: none)
-    int PsContext::*field;
-    int lo, hi;            // accepted range
-    const char *what;      // error text
-    bool shape = false;    // a launch-shape / tuning knob of the staged scoring and the sweeps: every value gives the same results;
-                           // kept for the parity tests and A/B measurements, addressed as "debug.<name>" (not part of the surface)
-};
-const OptDesc kOptions[] = {
-    {"matcher", "MATCHER", &PsContext::matcher, 0, 2, "matcher: 0 (VALU), 1 (MFMA) or 2 (by batch size)"},
-    {"matcher_fused", "MATCHER_FUSED", &PsContext::matcherFused, 0, 1, "matcher_fused: 0 or 1"},
-    {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
-    {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
-    {"prune", "PRUNE", &PsContext::prune, 0, 2, "prune: 0 (complete scoring), 1 (staged from the cost model's batch size on) or 2 (staged whenever possible)"},
-    {"reorder", "REORDER", &PsContext::reorder, 0, 2, "reorder: 0, 1 or 2"},
-    {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024", true},
-    {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024", true},
-    // staged scoring (ps_score_fast.h): the twins of its launch forms ...
-    {"gensplit", "GENSPLIT", &PsContext::genSplit, 0, 1, "gensplit: 0 (stage 0 as one launch) or 1 (models, then the sweep)", true},
-    {"singlerest", "SINGLEREST", &PsContext::singleRest, 0, 1, "singlerest: 0 (three stages) or 1 (one stage after the prefix, adaptive schedules)", true},
-    {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)", true},
-    // ... and its tuning knobs
-    {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over", true},
-    {"list_g2", "LISTG2", &PsContext::listGroups2, 0, 64, "list_g2: 0 (automatic) .. 64 work-groups per pair of stage 2", true},
-    {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3", true},
-    {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)", true},
-    {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kReorderTopMax, "reorder_top: 1 .. 16 voters", true},
-    {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches", true},
-    {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64", true},
-    {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64", true},
-    {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
-    {"stream_copy_kernels", "STREAM_COPY_KERNELS", &PsContext::streamCopyKernels, 0, 1, "stream_copy_kernels: 0 (hipMemcpyAsync) or 1 (copy kernels over mapped pinned memory)"},
-    {"stream_ahead", "STREAM_AHEAD", &PsContext::streamAhead, -1, 8, "stream_ahead: -1 (automatic: six places in all) or 0 .. 8 chunks the pipelined stream takes beyond one per lane (queued on the lanes' streams)"},
-    {"model_room_mib", "MODEL_ROOM_MIB", &PsContext::modelRoomMiB, 0, 65536, "model_room_mib: 0 (default) .. 65536 MiB for the staged scoring's parked models"},
-};
-const OptDesc *find_option(const char *name)
-{
-    const bool dbg = strncmp(name, "debug.", 6) == 0;
-    if (dbg) name += 6;
-    for (const OptDesc &o : kOptions)
-        if (o.shape == dbg && strcmp(name, o.name) == 0) return &o;
-    return nullptr;
-}
-// value checks beyond the range
-bool option_value_ok(const OptDesc &o, int v)
-{
-    if (v < o.lo || v > o.hi) return false;
-    if (strcmp(o.name, "prefix") == 0) return (v & 63) == 0;
-    if (strcmp(o.name, "reorder_gran") == 0) return (v & (v - 1)) == 0;
-    return true;
-}
-int parse_option_text(const OptDesc &o, const char *v)
-{
-    if (strcmp(o.name, "score") == 0) {
-        if (strcmp(v, "exact") == 0) return 0;
-        if (strcmp(v, "fast") == 0) return 1;
-    }
-    if (strcmp(o.name, "matcher") == 0) {
-        if (strcmp(v, "valu") == 0) return 0;
-        if (strcmp(v, "mfma") == 0) return 1;
-        if (strcmp(v, "auto") == 0) return 2;
-    }
-    // (a number, all of it: "mfma" for an option that takes no such word, or a typo, is not 0 -- it is ignored)
-    char *end = nullptr;
-    const long x = std::strtol(v, &end, 10);
-    if (end == v || *end != '\0' || x < INT_MIN || x > INT_MAX) return INT_MIN;
-    return (int)x;
-}
-
 } // namespace
 
 extern "C" {
 
-int ps_abi_version(void) { return PS_ABI_VERSION; }
-
-size_t ps_abi_sizeof_dmatch(void) { return sizeof(PsDMatch); }
-size_t ps_abi_sizeof_params(void) { return sizeof(PsRansacParams); }
-size_t ps_abi_sizeof_config(void) { return sizeof(PsRansacConfig); }
-size_t ps_abi_sizeof_stats(void) { return sizeof(PsRansacStats); }
-size_t ps_abi_sizeof_frameset(void) { return sizeof(PsFrameSet); }
-size_t ps_abi_sizeof_results(void) { return sizeof(PsPairResults); }
-size_t ps_abi_sizeof_host_results(void) { return sizeof(PsHostPairResults); }
-
-int ps_context_create(int device, PsContext **out)
+void psi_kernel_attributes(void)
 {
-    if (!out) return PS_ERR_BAD_ARG;
-    *out = nullptr;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return PS_ERR_NO_DEVICE; // no CPU fallback: fail loudly
-    if (device < 0 || device >= n) return PS_ERR_BAD_ARG;
-    if (hipSetDevice(device) != hipSuccess) return PS_ERR_HIP;
-    PsContext *ctx = new PsContext();
-    ctx->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        strncpy(ctx->arch, prop.gcnArchName, sizeof(ctx->arch) - 1);
-    }
-    if (hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
-        return PS_ERR_HIP;
-    }
-    ctx->stream = ctx->own;
-    for (const OptDesc &o : kOptions) { // initial values from the environment (out-of-range values are ignored)
-        if (!o.env) continue;
-        const std::string name = std::string("PUTSLAM_HIP_") + o.env;
-        if (const char *v = std::getenv(name.c_str())) {
-            const int x = parse_option_text(o, v);
-            if (option_value_ok(o, x)) ctx->*(o.field) = x;
-        }
-    }
     // the cross-check kernel keeps best[q] for up to PS_MAX_KPTS queries in LDS (64 KiB of the CU's 160 KiB)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
@@ -1310,185 +902,6 @@ int ps_context_create(int device, PsContext **out)
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ps_crosscheck_prep<false, 1024>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PS_MAX_KPTS * 4);
-    *out = ctx;
-    return PS_OK;
-}
-
-void ps_context_destroy(PsContext *ctx)
-{
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->recShadow, &ctx->models, &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec, &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid,
-                  &ctx->cmax, &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk,
-                  &ctx->sMatches, &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats,
-                  &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
-    for (Buf *b : all) release(*b);
-    for (hipEvent_t e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->bailHost) (void)hipHostFree(ctx->bailHost);
-    if (ctx->handoff) (void)hipEventDestroy(ctx->handoff);
-    if (ctx->own) (void)hipStreamDestroy(ctx->own);
-    delete ctx;
-}
-
-int ps_context_set_stream(PsContext *ctx, void *s)
-{
-    if (!ctx) return PS_ERR_BAD_ARG;
-    hipStream_t next = s ? (hipStream_t)s : ctx->own;
-    if (next == ctx->stream) return PS_OK;
-    int rc = bind(ctx);
-    if (rc) return rc;
-    // The scratch arena and the stop tables belong to the context, not to a stream: work queued on the new stream
-    // must not start before the work already queued on the old one has finished with them.  The event was recorded
-    // at the end of the last asynchronous call, on the stream that call ran on: the previous stream is not touched
-    // here, so it may already have been destroyed by its owner.
-    if (ctx->handoff && ctx->handoffPending) PS_HIP(hipStreamWaitEvent(next, ctx->handoff, 0));
-    ctx->stream = next;
-    return PS_OK;
-}
-
-void *ps_context_stream(PsContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
-int ps_context_device(const PsContext *ctx) { return ctx ? ctx->device : (int)PS_ERR_BAD_ARG; }
-
-int ps_context_set_option(PsContext *ctx, const char *name, int value)
-{
-    if (!ctx || !name) return PS_ERR_BAD_ARG;
-    if (strcmp(name, "stamps") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PS_ERR_BAD_ARG, "stamps: 0 or 1");
-        if (value) {
-            int rc = bind(ctx);
-            if (rc) return rc;
-            PS_ENSURE(ctx->stamps, 16 * sizeof(unsigned long long));
-            PS_HIP(hipMemsetAsync(ctx->stamps.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
-        }
-        ctx->stampsOn = value;
-        return PS_OK;
-    }
-    const OptDesc *o = find_option(name);
-    if (!o) return fail(ctx, PS_ERR_BAD_ARG, "unknown option");
-    if (!option_value_ok(*o, value)) return fail(ctx, PS_ERR_BAD_ARG, o->what);
-    ctx->*(o->field) = value;
-    if (strcmp(name, "bail") == 0) { // (setting the option also forgets what the policy has observed: every kind starts staged)
-        for (PsContext::BailKind &b : ctx->bailKinds) b = PsContext::BailKind();
-        ctx->hopeless = 0;
-        ctx->bailSlot = -1;
-    }
-    return PS_OK;
-}
-
-int ps_context_get_option(const PsContext *ctx, const char *name)
-{
-    if (!ctx || !name) return PS_ERR_BAD_ARG;
-    if (strcmp(name, "matcher_used") == 0) return ctx->matcherUsed;
-    if (strcmp(name, "stamps") == 0) return ctx->stampsOn;
-    if (strcmp(name, "last_staged_pairs") == 0) return ctx->stagedP;       // pairs of the last scoring step if it was staged, else 0
-    if (strcmp(name, "hopeless") == 0) return ctx->hopeless;               // the "nothing to gain" policy's current state
-    if (strcmp(name, "arena_mib") == 0) {                                  // device memory the context's scratch arena holds, MiB
-        const Buf *all[] = {&ctx->keys, &ctx->recA, &ctx->recB, &ctx->recC, &ctx->recD, &ctx->recE, &ctx->recF, &ctx->models,
-                            &ctx->survA, &ctx->survB, &ctx->survN, &ctx->recF2, &ctx->permBuf, &ctx->prefInfo, &ctx->frontRec,
-                            &ctx->validMask, &ctx->stamps, &ctx->dbgCnt, &ctx->bailCnt, &ctx->counts, &ctx->mvalid, &ctx->cmax,
-                            &ctx->idxList, &ctx->raw, &ctx->xq, &ctx->tabR, &ctx->tabU, &ctx->sDesc, &ctx->sNk, &ctx->sMatches,
-                            &ctx->sNumM, &ctx->sMask, &ctx->sPose, &ctx->sStats, &ctx->sMisc0, &ctx->sMisc1, &ctx->sMisc2};
-        size_t sum = 0;
-        for (const Buf *b : all) sum += b->cap;
-        return (int)((sum + (((size_t)1 << 20) - 1)) >> 20);
-    }
-    if (strcmp(name, "hw_queues_seen") == 0) return psi_hw_queues_seen();   // GPU_MAX_HW_QUEUES when the library was loaded (ps_env.cpp)
-    if (strcmp(name, "last_model_slots") == 0) return ctx->lastModelH;     // hypotheses per pair with a parked-model slot, last scoring step
-    if (strcmp(name, "last_reordered_pairs") == 0) return ctx->reorderedP; // ... and reordered (ps_stage_reorder ran)
-    const OptDesc *o = find_option(name);
-    return o ? ctx->*(o->field) : (int)PS_ERR_BAD_ARG;
-}
-
-int ps_context_synchronize(PsContext *ctx)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    return PS_OK;
-}
-
-const char *ps_last_error(const PsContext *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-// (ps_internal.h: for the library's other translation units)
-void psi_set_error(PsContext *ctx, const char *what)
-{
-    if (ctx) ctx->err = what ? what : "";
-}
-
-void psi_copy_options(PsContext *dst, const PsContext *src)
-{
-    if (!dst || !src) return;
-    for (const OptDesc &o : kOptions) dst->*(o.field) = src->*(o.field);
-}
-const char *ps_device_arch(const PsContext *ctx) { return ctx ? ctx->arch : ""; }
-
-int ps_context_enable_timing(PsContext *ctx, int enable)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (enable && ctx->ev.empty()) {
-        ctx->ev.assign((size_t)kTimingRing * kMaxTimed * 2, nullptr);
-        for (hipEvent_t &e : ctx->ev) PS_HIP(hipEventCreate(&e));
-    }
-    ctx->timing = enable != 0;
-    ctx->timedCalls = 0;
-    ctx->curCall = 0;
-    ctx->nTimed = 0;
-    memset(ctx->slotMask, 0, sizeof ctx->slotMask);
-    return PS_OK;
-}
-
-int ps_last_kernel_times_ms(PsContext *ctx, float *ms)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!ctx->timing || ctx->timedCalls == 0) return 0;
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < ctx->nTimed; ++i) {
-        float t = 0.f;
-        size_t b = ((size_t)ctx->curCall * kMaxTimed + i) * 2;
-        if (ctx->slotMask[ctx->curCall] & (1u << i)) PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
-        ms[i] = t;
-    }
-    return ctx->nTimed;
-}
-
-int ps_kernel_time_totals(PsContext *ctx, double *sum_ms, int *launches)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    for (int i = 0; i < kMaxTimed; ++i) {
-        sum_ms[i] = 0.0;
-        launches[i] = 0;
-    }
-    if (!ctx->timing || ctx->timedCalls == 0) return 0;
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    long long n = ctx->timedCalls < kTimingRing ? ctx->timedCalls : kTimingRing;
-    for (long long c = 0; c < n; ++c)
-        for (int i = 0; i < ctx->nTimed; ++i) {
-            if (!(ctx->slotMask[c] & (1u << i))) continue;
-            float t = 0.f;
-            size_t b = ((size_t)c * kMaxTimed + i) * 2;
-            PS_HIP(hipEventElapsedTime(&t, ctx->ev[b], ctx->ev[b + 1]));
-            sum_ms[i] += t;
-            launches[i] += 1;
-        }
-    return ctx->nTimed;
-}
-
-const char *ps_kernel_names(void)
-{
-    return "ps_hamming_nn\0ps_crosscheck_prep\0ps_ransac_score\0ps_select_refit\0ps_expand_query_fp4\0ps_hamming_mfma\0";
-}
-
-uint64_t ps_algorithmic_bytes(int nkpts, int matchesIn, int matchesValid, int H)
-{
-    // descriptors read + matches written + 3-D points read + match index
-    // pairs read by RANSAC + sample triplets + inlier counts + final mask + pose.
-    return 2ull * nkpts * 32 + 16ull * matchesIn + 2ull * nkpts * 12 + 8ull * matchesValid + 12ull * H + 4ull * H +
-           (uint64_t)matchesValid + 64ull;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1645,222 +1058,9 @@ int ps_ransac_rigid3d(PsContext *ctx, const PsRansacParams *params, const PsRans
                              nullptr);
 }
 
-// Diagnostic twin of ps_ransac_rigid3d that also returns the per-hypothesis inlier counts the
-// scoring kernel produced (length = hypotheses actually scored, returned through *numScored).
-int ps_debug_ransac_counts(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
-                           const float *prev, int nprev, const float *cur, int ncur, const PsDMatch *matches, int m,
-                           int32_t *counts, int *numScored)
-{
-    if (!cfg || !counts || !numScored) return PS_ERR_BAD_ARG;
-    std::vector<PsDMatch> inl((size_t)(m > 0 ? m : 1));
-    float pose[16];
-    int ninl = 0;
-    PsRansacStats st;
-    // the number of scored hypotheses follows the same rule as make_plan
-    int H = cfg->numHypotheses;
-    if (cfg->estimator == PS_EST_RANSAC && params) {
-        int a = ransac_iterations_host(0.20), b = ransac_iterations_host(params->minimalInlierRatioThreshold);
-        int most = a > b ? a : b;
-        if (most < H) H = most;
-        if (H < 1) H = 1;
-    } else if (cfg->estimator == PS_EST_USAC && H > (int)kUsacMaxHyp)
-        H = (int)kUsacMaxHyp;
-    *numScored = H;
-    return ransac_host_entry(ctx, params, cfg, K, prev, nprev, cur, ncur, matches, m, pose, inl.data(), &ninl, nullptr,
-                             &st, counts);
-}
-
-// Diagnostic: bitwise comparison of the shared-reciprocal division with the '/' operator on random inputs.
-int ps_debug_fastdiv(PsContext *ctx, uint64_t seed, int blocks, int perThread, uint64_t *mismatches, uint64_t *tested)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!mismatches || !tested || blocks < 1 || perThread < 1) return PS_ERR_BAD_ARG;
-    PS_ENSURE(ctx->sMisc2, 16);
-    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(ps_fastdiv_check, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, seed, perThread,
-                       (unsigned long long *)ctx->sMisc2.p, (unsigned long long *)ctx->sMisc2.p + 1);
-    PS_HIP(hipGetLastError());
-    uint64_t h[2] = {0, 0};
-    PS_HIP(hipMemcpyAsync(h, ctx->sMisc2.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    *mismatches = h[0];
-    *tested = h[1];
-    return PS_OK;
-}
-
-// Diagnostic: the exact short forms of the square root / reciprocal / shared-denominator quotients (ps_device_math.h)
-// against sqrtf and '/', bit for bit (modes: see ps_mathcheck).  `elements` = how many elements to test: modes 0 / 1 walk
-// consecutive float patterns from 1.0f (0x40001000 of them reach past +inf, 0x00800001 cover [1, 2]), modes 2 .. 4 draw
-// random operands.
-int ps_debug_mathcheck(PsContext *ctx, int mode, uint64_t seed, uint64_t elements, uint64_t *mismatches, uint64_t *tested)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!mismatches || !tested || mode < 0 || mode > 4 || elements < 1 || elements > ((uint64_t)1 << 34)) return PS_ERR_BAD_ARG;
-    PS_ENSURE(ctx->sMisc2, 16);
-    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
-    const int perThread = 1024;
-    const uint64_t threads = (elements + perThread - 1) / perThread;
-    const unsigned blocks = (unsigned)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(ps_mathcheck, dim3(blocks), dim3(kBlock), 0, ctx->stream, mode, seed, perThread,
-                       (unsigned long long)elements, (unsigned long long *)ctx->sMisc2.p, (unsigned long long *)ctx->sMisc2.p + 1);
-    PS_HIP(hipGetLastError());
-    uint64_t h[2] = {0, 0};
-    PS_HIP(hipMemcpyAsync(h, ctx->sMisc2.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    *mismatches = h[0];
-    *tested = h[1];
-    return PS_OK;
-}
-
-// Diagnostic: how many evaluations the last fast scoring launch parked for the value-exact code (option "score_stats").
-int ps_debug_score_stats(PsContext *ctx, uint64_t *parked, uint64_t *evaluations)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!parked || !evaluations) return PS_ERR_BAD_ARG;
-    *parked = *evaluations = 0;
-    if (!ctx->dbgCnt.p) return PS_OK;
-    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    *parked = h[0];
-    *evaluations = h[1];
-    return PS_OK;
-}
-
-// Diagnostic: all eight counters of the last scoring step (option "score_stats"): [0] evaluations handed to the
-// value-exact code, [1] (hypothesis, match) evaluations made (lanes of partially filled wavefronts included; with the
-// staged scoring this is what is left of the complete sweep); the rest reserved.
-int ps_debug_score_stats_ex(PsContext *ctx, uint64_t *out8)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!out8) return PS_ERR_BAD_ARG;
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
-    if (!ctx->dbgCnt.p) return PS_OK;
-    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PS_HIP(hipMemcpyAsync(h, ctx->dbgCnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 8; ++i) out8[i] = h[i];
-    return PS_OK;
-}
-
-// Diagnostic: how many hypotheses of every pair survived stages 1 and 2 of the LAST staged scoring step (zeros if that
-// call was not staged); out = [2][P].
-int ps_debug_stage_survivors(PsContext *ctx, int P, int32_t *out)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!out || P <= 0) return PS_ERR_BAD_ARG;
-    memset(out, 0, (size_t)2 * P * sizeof(int32_t));
-    if (ctx->stagedP == 0) return PS_OK; // the last scoring step was not staged
-    if (P != ctx->stagedP) // (the counters are laid out [2][P] with the P of the call that wrote them)
-        return fail(ctx, PS_ERR_BAD_ARG, "ps_debug_stage_survivors: the last staged scoring step had a different number of pairs");
-    if (!ctx->survN.p || ctx->survN.cap < (size_t)2 * P * sizeof(int32_t)) return PS_OK;
-    PS_HIP(hipMemcpyAsync(out, ctx->survN.p, (size_t)2 * P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    return PS_OK;
-}
-
-// Diagnostic: the order in which stages 1+ of the LAST staged, reordered scoring step swept every pair's matches
-// (ps_stage_reorder): perm[p][i] = match of the original record arrays at position i, front[p] = how many of the leading
-// positions hold matches every voter rejected and found far off.  PS_ERR_BAD_ARG if the context holds no such order for
-// P pairs of `cap` matches.
-int ps_debug_stage_order(PsContext *ctx, int P, int cap, int32_t *perm, int32_t *front)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!perm || !front || P <= 0 || cap <= 0) return PS_ERR_BAD_ARG;
-    if (P != ctx->reorderedP || cap != ctx->stagedCap || !ctx->permBuf.p ||
-        ctx->permBuf.cap < (size_t)P * cap * sizeof(int32_t) || !ctx->prefInfo.p ||
-        ctx->prefInfo.cap < (size_t)4 * P * sizeof(int32_t))
-        return fail(ctx, PS_ERR_BAD_ARG, "no reordered scoring step of that size in this context");
-    std::vector<int32_t> info((size_t)4 * P);
-    PS_HIP(hipMemcpyAsync(perm, ctx->permBuf.p, (size_t)P * cap * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipMemcpyAsync(info.data(), ctx->prefInfo.p, info.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    for (int p = 0; p < P; ++p) front[p] = info[(size_t)4 * p + 2];
-    return PS_OK;
-}
-
-// Diagnostic: the shader-clock stamps kernels 2 and 4 of the LAST call wrote (option "stamps"): out16[0..3] = kernel 2
-// (start, best[q] built, matches compacted + records, end), out16[4..9] = kernel 4 (start, selection, inlier pass,
-// refit, re-selection, end), of work-group 0.  Differences are shader-clock ticks (s_memtime).
-int ps_debug_stamps(PsContext *ctx, uint64_t *out16)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!out16) return PS_ERR_BAD_ARG;
-    for (int i = 0; i < 16; ++i) out16[i] = 0;
-    if (!ctx->stamps.p) return PS_OK;
-    unsigned long long h[16];
-    PS_HIP(hipMemcpyAsync(h, ctx->stamps.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 16; ++i) out16[i] = h[i];
-    return PS_OK;
-}
-
-// Diagnostic: how many words of the context's keys block are not all-ones once the queued work has drained (the matcher forms
-// that merge their query splits with atomicMin rely on kernel 2 putting kNoKey back into every entry it read; see
-// PsContext::keysCleanPtr).  *bad must come back 0 after any sequence of calls, failed ones included.
-int ps_debug_keys_clean(PsContext *ctx, uint64_t *bad)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!bad) return PS_ERR_BAD_ARG;
-    *bad = 0;
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    if (!ctx->keys.p || ctx->keysCleanPtr != ctx->keys.p || ctx->keysCleanBytes == 0) return PS_OK; // nothing is claimed to be clean
-    PS_ENSURE(ctx->sMisc2, 16);
-    PS_HIP(hipMemsetAsync(ctx->sMisc2.p, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(ps_count_not_ones, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->keys.p,
-                       ctx->keysCleanBytes / sizeof(uint32_t), (unsigned long long *)ctx->sMisc2.p);
-    PS_HIP(hipGetLastError());
-    unsigned long long h = 0;
-    PS_HIP(hipMemcpyAsync(&h, ctx->sMisc2.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    *bad = h;
-    return PS_OK;
-}
-
-// Diagnostic: device-side trip limits for every inlier count 1..M (see ps_limits_table).
-int ps_debug_limits(PsContext *ctx, int estimator, double minRatio, int H, int M, int32_t *out)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (M < 1 || !out) return PS_ERR_BAD_ARG;
-    SelectArgs sa{};
-    sa.estimator = estimator;
-    sa.H = H;
-    rc = prepare_tables(ctx, estimator, minRatio, H, sa);
-    if (rc) return rc;
-    PS_ENSURE(ctx->sMisc2, (size_t)M * sizeof(int32_t));
-    hipLaunchKernelGGL(ps_limits_table, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, sa, M,
-                       (int32_t *)ctx->sMisc2.p);
-    PS_HIP(hipGetLastError());
-    PS_HIP(hipMemcpyAsync(out, ctx->sMisc2.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    return PS_OK;
-}
+#include "ps_diag.h" // ps_debug_*: the parity tests' diagnostics (no reference counterpart)
 
 // ---------------------------------------------------------------------------------------------
-int ps_predicted_level(int octave, double detDist, double curDist)
-{
-    // Matcher::matchXYZ, matcher.cpp:639-652,681-692 with scaleFactor 1.2 / nLevels 8 (matcher.h:26-28); host libm
-    // exactly as the reference evaluates it.
-    const double scaleFactor = 1.2;
-    const int nLevels = 8;
-    const double logScaleFactor = std::log(scaleFactor);
-    double detLevelScaleFactor = std::pow(scaleFactor, octave);
-    double curLevelScaleFactor = detLevelScaleFactor * detDist / curDist;
-    int curLevel = (int)std::ceil(std::log(curLevelScaleFactor) / logScaleFactor);
-    if (curLevel < 0) curLevel = 0;
-    if (curLevel > nLevels - 1) curLevel = nLevels - 1;
-    return curLevel;
-}
-
 int ps_match_xyz(PsContext *ctx, const float *mapPos, const uint8_t *mapDesc, size_t mapDescStep, const int32_t *mapLevel,
                  int nmap, const float *curPos, const uint8_t *curDesc, size_t curDescStep, const int32_t *curLevel, int ncur,
                  double sphereRadius, double acceptRatio, PsDMatch *out, int cap, int *nout)
@@ -2087,340 +1287,7 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
     return rc;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Streaming form of Matcher::match (reference src/Matcher/matcher.cpp:452-516): the previous frame's
-// descriptors and 3-D points stay resident in HBM (the prevDescriptors / prevFeatures3D members,
-// matcher.h:379-384), each push uploads only the new frame.
-struct PsVoStream {
-    PsContext *ctx = nullptr;
-    int cap = 0;
-    long long frames = 0;   // frames pushed so far
-    int curSlot = 0;        // slot of the most recent frame
-    int32_t nkSlot[2] = {0, 0}; // row count of the frame resident in each slot
-    Buf desc, pts, meta;    // [2][cap][32], [2][cap][3], int32 {nk0, nk1, prevSlot, curSlot, seedLo, seedHi}
-    // One contiguous result block on the device and its pinned host mirror, so a push needs ONE
-    // device-to-host copy and ONE synchronisation: [PsRansacStats][pose 16 f32][numMatches i32 + pad]
-    // [matches cap x 16 B][mask cap B]
-    Buf res;
-    uint8_t *hres = nullptr;   // pinned
-    uint8_t *hin = nullptr;    // pinned staging of the incoming frame: [cap x 32 B][cap x 12 B][4 x i32]
-    uint8_t *hresDev = nullptr, *hinDev = nullptr; // their device views (hipHostGetDevicePointer): the copy kernels' side
-    size_t offPose = 0, offNum = 0, offMatches = 0, offMask = 0, resBytes = 0;
-    // A push is launch-bound (three copies in, four kernels, one copy out): once the scratch
-    // arena has been sized by an ordinary push with the same parameters the sequence is captured into one hipGraph
-    // per frame slot and replayed with a single launch.  Everything that changes between pushes travels as data:
-    // the frame (full-capacity copies from the pinned staging area), its row count and slot (meta) and the seed.
-    bool graphsEnabled = true;
-    bool warm = false;          // an un-captured push has run with `key`
-    struct Key {
-        PsRansacParams prm;
-        int estimator, numHypotheses;
-        float K[9];
-        int options[32];               // every option of the context (kernel variants, the staged scoring's knobs), stamps
-        unsigned long long arenaGen;   // PsContext::arenaGen the captured launches' pointers belong to: ANY block of the
-                                       // context that is (re)allocated afterwards -- by this stream or by another call on
-                                       // the same context -- invalidates the graphs
-    } key{};
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    long long graphLaunches = 0;
-    // PUTSLAM_HIP_PUSH_TIMING=1: host-side phases of the synchronous push, printed to stderr when the stream is destroyed
-    // (staging copy | plan + tables + key | submission | wait for the GPU | results out), microseconds per push
-    bool pushTiming = false;
-    double pushPhase[5] = {0, 0, 0, 0, 0};
-    long long pushTimed = 0;
-    struct PsVoAsync *async = nullptr; // the pipelined form's state (ps_stream_async.h); null = synchronous stream
-    int asyncResultMode = 0;           // PsStreamResults of the next ps_vo_stream_configure_async
-    int asyncFrameLayout = 0;          // PsStreamFrames of the next ps_vo_stream_configure_async
-};
-static void async_release(PsVoStream *s); // (ps_stream_async.h)
-static int async_reset(PsVoStream *s);
-
-int ps_vo_stream_create(PsContext *ctx, int maxKpts, PsVoStream **out)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!out || maxKpts < 1 || maxKpts > PS_MAX_KPTS) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_create: bad argument");
-    PsVoStream *s = new PsVoStream();
-    s->ctx = ctx;
-    s->cap = maxKpts;
-    if (const char *v = std::getenv("PUTSLAM_HIP_PUSH_TIMING")) s->pushTiming = std::strtol(v, nullptr, 10) != 0;
-    *out = s;
-    const size_t cap = (size_t)maxKpts;
-    s->offPose = sizeof(PsRansacStats);
-    s->offNum = s->offPose + 16 * sizeof(float);
-    s->offMatches = s->offNum + 16;
-    s->offMask = s->offMatches + cap * sizeof(PsDMatch);
-    s->resBytes = s->offMask + cap;
-    PS_ENSURE(s->desc, 2 * cap * 32);
-    PS_ENSURE(s->pts, 2 * cap * 12);
-    PS_ENSURE(s->meta, 8 * sizeof(int32_t));
-    PS_ENSURE(s->res, (s->resBytes + 3) & ~(size_t)3);
-    PS_HIP(hipHostMalloc((void **)&s->hres, (s->resBytes + 3) & ~(size_t)3, hipHostMallocDefault));
-    PS_HIP(hipHostMalloc((void **)&s->hin, cap * 44 + 32, hipHostMallocDefault));
-    memset(s->hin, 0, cap * 44 + 32); // rows beyond a frame's count are copied by the captured graph, never read
-    if (hipHostGetDevicePointer((void **)&s->hresDev, s->hres, 0) != hipSuccess || hipHostGetDevicePointer((void **)&s->hinDev, s->hin, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        s->hresDev = s->hinDev = nullptr; // (no device view: the pushes use hipMemcpyAsync)
-    }
-    PS_HIP(hipMemsetAsync(s->meta.p, 0, 8 * sizeof(int32_t), ctx->stream));
-    if (const char *v = std::getenv("PUTSLAM_HIP_NO_GRAPH")) s->graphsEnabled = std::atoi(v) == 0;
-    return PS_OK;
-}
-
-void ps_vo_stream_destroy(PsVoStream *s)
-{
-    if (!s) return;
-    if (s->ctx) {
-        (void)hipSetDevice(s->ctx->device);
-        (void)hipStreamSynchronize(s->ctx->stream);
-    }
-    if (s->pushTiming && s->pushTimed > 0)
-        fprintf(stderr, "[putslam_hip] %lld replayed pushes, host phases in us: staging copy %.1f | plan, tables, key %.1f | submission %.1f | "
-                        "wait for the GPU %.1f | results out %.1f\n", s->pushTimed, s->pushPhase[0] / s->pushTimed, s->pushPhase[1] / s->pushTimed,
-                s->pushPhase[2] / s->pushTimed, s->pushPhase[3] / s->pushTimed, s->pushPhase[4] / s->pushTimed);
-    async_release(s);
-    for (hipGraphExec_t &g : s->gexec)
-        if (g) {
-            (void)hipGraphExecDestroy(g);
-            g = nullptr;
-        }
-    Buf *all[] = {&s->desc, &s->pts, &s->meta, &s->res};
-    for (Buf *b : all) release(*b);
-    if (s->hres) (void)hipHostFree(s->hres);
-    if (s->hin) (void)hipHostFree(s->hin);
-    delete s;
-}
-
-int ps_vo_stream_reset(PsVoStream *s)
-{
-    if (!s) return PS_ERR_BAD_ARG;
-    if (s->async) return async_reset(s);
-    s->frames = 0;
-    s->curSlot = 0;
-    return PS_OK;
-}
-
-int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
-                      const uint8_t *desc, size_t descStep, const float *pts, int n, PsDMatch *matches, int *nmatches,
-                      uint8_t *inlierMask, float *pose, PsRansacStats *stats)
-{
-    if (!s) return PS_ERR_BAD_ARG;
-    PsContext *ctx = s->ctx;
-    int rc = bind(ctx);
-    if (rc) return rc;
-    TimingOff toff(ctx);
-    if (pose) identity16(pose);
-    if (nmatches) *nmatches = 0;
-    if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->bestHypothesis = -1;
-        stats->pointInlierRatio = NAN;
-    }
-    if (s->async) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: the stream is configured for the pipelined form (push_async / push_many)");
-    if (n < 0 || n > s->cap || (n > 0 && (!desc || !pts)) || descStep < PS_DESC_BYTES || !pose || !nmatches ||
-        (n > 0 && (!matches || !inlierMask)) || !cfg)
-        return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_push: bad argument");
-    if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming call");
-    const bool first = s->frames == 0;
-    const int slot = first ? 0 : 1 - s->curSlot;
-    const int prevSlot = s->curSlot;
-    const size_t cap = (size_t)s->cap;
-    using PushClock = std::chrono::steady_clock;
-    PushClock::time_point tp[6];
-    if (s->pushTiming) tp[0] = PushClock::now();
-    // incoming frame -> pinned staging -> HBM (asynchronous; the staging area is free again after the
-    // synchronisation that ends the previous push)
-    uint8_t *hd = s->hin;
-    float *hp = reinterpret_cast<float *>(s->hin + cap * 32);
-    // meta block exactly as it lies on the device: {nk[slot 0], nk[slot 1], prevSlot, slot, seedLo, seedHi} -- ONE copy per push
-    // (round 3 sent the row count, the slot pair and the seed as three copies: each is a node of the captured graph with a few
-    // microseconds of its own)
-    int32_t *hm = reinterpret_cast<int32_t *>(s->hin + cap * 44);
-    for (int i = 0; i < n; ++i) memcpy(hd + (size_t)i * 32, desc + (size_t)i * descStep, 32);
-    if (n > 0) memcpy(hp, pts, (size_t)n * 12);
-    hm[slot] = n;
-    hm[1 - slot] = s->nkSlot[1 - slot];
-    hm[2] = prevSlot; // query = previous frame, train = current (matcher.cpp:470-471)
-    hm[3] = slot;
-    memcpy(&hm[4], &cfg->seed, sizeof(uint64_t));
-    if (s->pushTiming) tp[1] = PushClock::now();
-    // The stream's state (curSlot, frames) is committed only when the push has succeeded: after a failed push
-    // (bad parameters, a HIP error) the resident frame is still the previous one and the next push matches against it.
-    auto commit = [&]() {
-        s->curSlot = slot;
-        s->nkSlot[slot] = n;
-        s->frames++;
-    };
-    // Frame in / results out as ONE kernel each over the mapped pinned staging blocks (ps_copy_segments) instead of three and one
-    // hipMemcpyAsync: a copy of this size is a node of its own with 5 - 8 us of latency in the captured graph, the kernel reads
-    // the 88 KB of a 2000-keypoint frame over the link in 4 (option "stream_copy_kernels" = 0: the copies of rounds 1 - 4).
-    const bool copyKernels = ctx->streamCopyKernels != 0 && s->hinDev != nullptr && s->hresDev != nullptr;
-    auto copy_in = [&](size_t rows) -> int {
-        if (copyKernels) {
-            CopySegs up{};
-            int k = 0;
-            if (rows > 0) {
-                up.src[k] = s->hinDev;
-                up.dst[k] = (uint8_t *)s->desc.p + (size_t)slot * cap * 32;
-                up.bytes[k++] = rows * 32;
-                up.src[k] = s->hinDev + cap * 32;
-                up.dst[k] = (uint8_t *)s->pts.p + (size_t)slot * cap * 12;
-                up.bytes[k++] = rows * 12;
-            }
-            up.src[k] = s->hinDev + cap * 44;
-            up.dst[k] = s->meta.p;
-            up.bytes[k++] = 6 * sizeof(int32_t);
-            up.n = k;
-            const unsigned groups = (unsigned)((rows * 32 / 16 + 255) / 256);
-            hipLaunchKernelGGL(ps_copy_segments, dim3(groups < 1 ? 1 : (groups > 64 ? 64 : groups)), dim3(256), 0, ctx->stream, up);
-            PS_HIP(hipGetLastError());
-            return PS_OK;
-        }
-        if (rows > 0) {
-            PS_HIP(hipMemcpyAsync((uint8_t *)s->desc.p + (size_t)slot * cap * 32, hd, rows * 32, hipMemcpyHostToDevice,
-                                  ctx->stream));
-            PS_HIP(hipMemcpyAsync((float *)s->pts.p + (size_t)slot * cap * 3, hp, rows * 12, hipMemcpyHostToDevice,
-                                  ctx->stream));
-        }
-        PS_HIP(hipMemcpyAsync(s->meta.p, hm, 6 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        return PS_OK;
-    };
-    if (first) { // detectInitFeatures (matcher.cpp:17-64): nothing to match against yet
-        rc = copy_in((size_t)n);
-        if (rc) return rc;
-        PS_HIP(hipStreamSynchronize(ctx->stream));
-        commit();
-        *nmatches = -1;
-        return PS_OK;
-    }
-    PsFrameSet fs;
-    fs.desc = (const uint8_t *)s->desc.p;
-    fs.pts = (const float *)s->pts.p;
-    fs.nkpts = (const int32_t *)s->meta.p;
-    fs.numFrames = 2;
-    fs.maxKpts = s->cap;
-    fs.descFrameStride = fs.ptsFrameStride = 0;
-    Plan pl;
-    rc = make_plan(ctx, params, cfg, K, s->cap, s->cap, pl);
-    if (rc) return rc;
-    pl.ma.seedDev = reinterpret_cast<const uint64_t *>((const int32_t *)s->meta.p + 4);
-    rc = prepare_score(ctx, pl, 1, s->cap);
-    if (rc) return rc;
-    // (outside the capture: a captured push then holds no clearing node, and a replay finds the block as its capture did)
-    PS_ENSURE(ctx->keys, (size_t)s->cap * sizeof(uint32_t));
-    rc = keys_clean(ctx, (size_t)s->cap * sizeof(uint32_t));
-    if (rc) return rc;
-    uint8_t *dres = (uint8_t *)s->res.p;
-    auto enqueue = [&](size_t rows) -> int {
-        int r = copy_in(rows);
-        if (r) return r;
-        r = run_match_stage(ctx, fs, (const int32_t *)s->meta.p + 2, 1, true, pl.pa, (PsDMatch *)(dres + s->offMatches),
-                            (int32_t *)(dres + s->offNum), 0);
-        if (r) return r;
-        r = run_ransac_stage(ctx, pl, 1, s->cap, (const PsDMatch *)(dres + s->offMatches),
-                             (const int32_t *)(dres + s->offNum), s->cap, (float *)(dres + s->offPose), dres + s->offMask,
-                             (PsRansacStats *)dres, 2);
-        if (r) return r;
-        if (copyKernels) {
-            CopySegs down{};
-            down.src[0] = dres;
-            down.dst[0] = s->hresDev;
-            down.bytes[0] = (s->resBytes + 3) & ~(size_t)3;
-            down.n = 1;
-            const unsigned groups = (unsigned)((s->resBytes / 16 + 255) / 256);
-            hipLaunchKernelGGL(ps_copy_segments, dim3(groups < 1 ? 1 : (groups > 32 ? 32 : groups)), dim3(256), 0, ctx->stream, down);
-            PS_HIP(hipGetLastError());
-            return PS_OK;
-        }
-        PS_HIP(hipMemcpyAsync(s->hres, dres, s->resBytes, hipMemcpyDeviceToHost, ctx->stream));
-        return PS_OK;
-    };
-    PsVoStream::Key key;
-    memset(&key, 0, sizeof key);
-    // field by field: the caller's struct may carry indeterminate padding bytes, the key is compared with memcmp
-    key.prm.verbose = params->verbose;
-    key.prm.errorVersion = params->errorVersion;
-    key.prm.errorVersionVO = params->errorVersionVO;
-    key.prm.errorVersionMap = params->errorVersionMap;
-    key.prm.inlierThresholdEuclidean = params->inlierThresholdEuclidean;
-    key.prm.inlierThresholdReprojection = params->inlierThresholdReprojection;
-    key.prm.inlierThresholdMahalanobis = params->inlierThresholdMahalanobis;
-    key.prm.minimalInlierRatioThreshold = params->minimalInlierRatioThreshold;
-    key.prm.minimalNumberOfMatches = params->minimalNumberOfMatches;
-    key.prm.usedPairs = params->usedPairs;
-    key.prm.iterationCount = params->iterationCount;
-    {
-        static_assert(sizeof kOptions / sizeof kOptions[0] + 1 <= sizeof key.options / sizeof key.options[0], "key.options too small");
-        int n = 0;
-        for (const OptDesc &o : kOptions) key.options[n++] = ctx->*(o.field);
-        key.options[n++] = ctx->stampsOn;
-    }
-    key.estimator = cfg->estimator;
-    key.numHypotheses = cfg->numHypotheses;
-    if (K) memcpy(key.K, K, sizeof key.K);
-    key.arenaGen = ctx->arenaGen; // (make_plan / prepare_score above may already have grown a block: then no replay)
-    const bool sameKey = s->warm && memcmp(&key, &s->key, sizeof key) == 0;
-    if (!sameKey) { // new parameters: the next ordinary push re-sizes scratch and tables, graphs are rebuilt after it
-        for (hipGraphExec_t &g : s->gexec)
-            if (g) {
-                (void)hipGraphExecDestroy(g);
-                g = nullptr;
-            }
-    }
-    bool launched = false;
-    if (s->pushTiming) tp[2] = PushClock::now();
-    if (s->graphsEnabled && sameKey) {
-        if (!s->gexec[slot]) {
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                int r = enqueue(cap);
-                hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
-                if (r == PS_OK && e2 == hipSuccess && graph &&
-                    hipGraphInstantiate(&s->gexec[slot], graph, nullptr, nullptr, 0) != hipSuccess)
-                    s->gexec[slot] = nullptr;
-                if (r != PS_OK || e2 != hipSuccess) s->gexec[slot] = nullptr;
-                if (graph) (void)hipGraphDestroy(graph);
-            }
-            if (!s->gexec[slot]) {
-                s->graphsEnabled = false; // capture is not available here: stay on ordinary launches
-                (void)hipGetLastError();
-                ctx->err.clear();
-            }
-        }
-        if (s->gexec[slot]) {
-            PS_HIP(hipGraphLaunch(s->gexec[slot], ctx->stream));
-            s->graphLaunches++;
-            launched = true;
-        }
-    }
-    if (!launched) {
-        rc = enqueue((size_t)n);
-        if (rc) return rc;
-        key.arenaGen = ctx->arenaGen; // the blocks as this ordinary push left them
-        memcpy(&s->key, &key, sizeof key); // (bytewise, padding included: the key is compared with memcmp)
-        s->warm = true;
-    }
-    if (s->pushTiming) tp[3] = PushClock::now();
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    if (s->pushTiming) tp[4] = PushClock::now();
-    commit();
-    int32_t nm = 0;
-    memcpy(&nm, s->hres + s->offNum, sizeof nm);
-    memcpy(pose, s->hres + s->offPose, 16 * sizeof(float));
-    if (stats) memcpy(stats, s->hres, sizeof *stats);
-    if (nm > 0) {
-        memcpy(matches, s->hres + s->offMatches, (size_t)nm * sizeof(PsDMatch));
-        memcpy(inlierMask, s->hres + s->offMask, (size_t)nm);
-    }
-    *nmatches = nm;
-    if (s->pushTiming && launched) {
-        tp[5] = PushClock::now();
-        for (int i = 0; i < 5; ++i) s->pushPhase[i] += std::chrono::duration<double, std::micro>(tp[i + 1] - tp[i]).count();
-        s->pushTimed++;
-    }
-    return PS_OK;
-}
+#include "ps_stream_push.h" // ps_vo_stream_create / _push: the synchronous streaming form
 
 } // extern "C"
 

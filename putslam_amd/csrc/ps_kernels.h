@@ -2066,16 +2066,20 @@ __global__ void __launch_bounds__(256) ps_mini_copy_in(const MiniMeta *__restric
     const int n = hm->n, first = hm->first;
     if (f > n || (f == 0 && first)) return;
     const int rows = hm->nk[f];
-    const uint8_t *__restrict__ src = hm->src[f];
+    // (the frame's address comes out of memory: told to be a global address, or the compiler emits FLAT loads for it)
+    typedef unsigned __attribute__((ext_vector_type(4))) u4v_t;
+    typedef const u4v_t __attribute__((address_space(1))) *gu4_t;
+    typedef const uint32_t __attribute__((address_space(1))) *gu32_t;
+    const uintptr_t src = reinterpret_cast<uintptr_t>(hm->src[f]);
     uint8_t *__restrict__ dst = frames + (size_t)f * stride;
     const size_t t0 = (size_t)g * blockDim.x + threadIdx.x, step = (size_t)groups * blockDim.x;
     { // descriptors: rows x 32 bytes, 16 per lane
-        const uint4 *__restrict__ sv = reinterpret_cast<const uint4 *>(src);
-        uint4 *__restrict__ dv = reinterpret_cast<uint4 *>(dst);
+        gu4_t sv = (gu4_t)src;
+        u4v_t *__restrict__ dv = reinterpret_cast<u4v_t *>(dst);
         for (size_t i = t0; i < (size_t)rows * 2; i += step) dv[i] = sv[i];
     }
     { // points: rows x 12 bytes behind the cap x 32 descriptor bytes, 4 per lane
-        const uint32_t *__restrict__ sv = reinterpret_cast<const uint32_t *>(src + (size_t)cap * 32);
+        gu32_t sv = (gu32_t)(src + (size_t)cap * 32);
         uint32_t *__restrict__ dv = reinterpret_cast<uint32_t *>(dst + (size_t)cap * 32);
         for (size_t i = t0; i < (size_t)rows * 3; i += step) dv[i] = sv[i];
     }

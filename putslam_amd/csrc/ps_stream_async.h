@@ -694,25 +694,27 @@ void release_view(PsVoAsync *a)
     memset(&a->view, 0, sizeof a->view);
 }
 
-// Several frames into a stream of mini chunks (push_many / push_many_packed): staged one by one, every full chunk submitted --
-// all or nothing: places for every chunk these frames complete, and one for a chunk they leave partly filled.
+// Several frames into a stream of mini chunks (push_many / push_many_packed), with push_many's contract: frames staged by
+// push_async before go first, as a chunk of their own; these frames follow in chunks of at most chunkFrames, the last one
+// included -- everything is submitted when the call returns.  All or nothing: a place for every one of those chunks.
 int mini_push_frames(PsVoStream *s, const uint8_t *desc, size_t descStride, const uint8_t *pts, size_t ptsStride, const int32_t *nkpts, int numFrames)
 {
     PsVoAsync *a = s->async;
     const size_t cap = (size_t)s->cap;
-    const int total = a->staged + numFrames;
-    const int need = total / a->B + (total % a->B > 0 ? 1 : 0);
+    const int need = (a->staged > 0 ? 1 : 0) + (numFrames + a->B - 1) / a->B;
     if (need > async_room(a)) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough room for these frames (pop results first, or push fewer)");
+    int rc = async_submit_staged(s);
+    if (rc) return rc;
     for (int f = 0; f < numFrames; ++f) {
         uint8_t *h = nullptr;
-        int rc = stage_area(s, &h);
+        rc = stage_area(s, &h);
         if (rc) return rc;
         uint8_t *hd = h + (size_t)a->staged * a->packStride;
         memcpy(hd, desc + (size_t)f * descStride, (size_t)nkpts[f] * 32);
         memcpy(hd + cap * 32, pts + (size_t)f * ptsStride, (size_t)nkpts[f] * 12);
         a->stagedNk[(size_t)a->staged] = nkpts[f];
         a->staged++;
-        if (a->staged == a->B) {
+        if (a->staged == a->B || f == numFrames - 1) {
             rc = async_submit_staged(s);
             if (rc) return rc;
         }
