@@ -947,6 +947,12 @@ def latency_leg(kpts=2000, calls=600):
     out["pair_host_time_in_call_us"] = float(m.group(1)) if m else None
     if out["pushed_frame_us"]:
         out["pushed_frames_per_s"] = 1e6 / out["pushed_frame_us"]
+    # (d): the pipelined form at one frame per chunk, from the same C++ host
+    for i, key in ((0, "pipelined_chunk1"), (1, "pipelined_chunk1_inliers")):
+        m = re.search(r"\(d%d\)[^\n]*: ([0-9.]+) frames/s, result lag median ([0-9.]+) us  p90 ([0-9.]+)  \((\d+) chunks from graphs" % i, p.stdout)
+        if m:
+            out[key] = {"frames_per_s": float(m.group(1)), "result_lag_us_p50": float(m.group(2)), "result_lag_us_p90": float(m.group(3)),
+                        "chunks_from_graphs": int(m.group(4))}
     return out
 
 

@@ -5,7 +5,9 @@
 //   (b) the same call queued back to back on the context's stream, one synchronisation at the end: the GPU side of the
 //       chain (kernels 1 - 4 of consecutive calls run in order, the host runs ahead);
 //   (c) ps_vo_stream_push: Matcher::match's call shape (src/Matcher/matcher.cpp:452-516) -- host frame in, matches / mask /
-//       pose / stats out, one synchronisation inside.
+//       pose / stats out, one synchronisation inside;
+//   (d) the pipelined form at one frame per chunk: ps_vo_stream_push_async per frame, the result one or more calls late (every
+//       place replays its chunk from a captured hipGraph; six in flight).
 // usage: demo_latency [kpts=2000] [errorVersion=0] [calls=2000]
 #include <hip/hip_runtime.h>
 
@@ -163,6 +165,63 @@ int main(int argc, char **argv)
     std::printf("(c) ps_vo_stream_push, host frame in, results out: median %.1f us  p10 %.1f  p90 %.1f  (%d of %d increments accepted)\n",
                 percentile(push, 0.5), percentile(push, 0.1), percentile(push, 0.9), accepted, pushes);
     ps_vo_stream_destroy(s);
+
+    // ---- (d): the same frames through the PIPELINED form, one frame per chunk (the reference's call shape with the result one
+    // call late): ps_vo_stream_push_async per frame, results taken as they complete.  Every place replays its chunk from a
+    // captured hipGraph; six chunks are in flight.
+    for (int mode = 0; mode < 2; ++mode) { // 0 = every match + mask (what (c) returns), 1 = the inlier matches (what Matcher::match returns)
+        PsVoStream *ps = nullptr;
+        PSCHK(ps_vo_stream_create(ctx, N, &ps));
+        cfg.seed = 3;
+        PSCHK(ps_vo_stream_set_result_mode(ps, mode == 0 ? PS_RESULTS_FULL : PS_RESULTS_INLIERS));
+        PSCHK(ps_vo_stream_configure_async(ps, &prm, &cfg, K, 1, 0));
+        std::vector<clk::time_point> sent;
+        std::vector<double> lag;
+        long long popped = 0, acc = 0;
+        PsHostPairResults blk;
+        auto take = [&](int wait) -> int {
+            if (ps_vo_stream_pop_many(ps, wait, &blk) != PS_OK) return -1;
+            if (blk.count == 0) return 0;
+            const auto now = clk::now();
+            for (int i = 0; i < blk.count; ++i) {
+                lag.push_back(us(sent[(size_t)(blk.firstPair + i + 1)], now)); // pair k completes with frame k + 1
+                acc += blk.stats[i].accepted;
+            }
+            popped += blk.count;
+            return blk.count;
+        };
+        const int total = calls + 3 * frames;
+        clk::time_point tStart;
+        long long poppedAtStart = 0;
+        for (int i = 0; i < total; ++i) {
+            const int rep = i / frames, k = i % frames, f = (rep & 1) ? frames - 1 - k : k;
+            if (i == 3 * frames) { // (warm: graphs captured, chip at its clock)
+                tStart = clk::now();
+                poppedAtStart = popped;
+                lag.clear();
+            }
+            sent.push_back(clk::now());
+            for (;;) {
+                const int rc = ps_vo_stream_push_async(ps, &desc[(size_t)f * N * 32], 32, &pts[(size_t)f * N * 3], N);
+                if (rc == PS_OK) break;
+                if (rc != PS_ERR_BUSY || take(1) < 0) {
+                    std::fprintf(stderr, "push_async: %s\n", ps_last_error(ctx));
+                    return 2;
+                }
+            }
+            while (take(0) > 0) {
+            }
+        }
+        while (take(1) > 0) {
+        }
+        const double sec = std::chrono::duration<double>(clk::now() - tStart).count();
+        std::printf("(d%d) ps_vo_stream_push_async, one frame per chunk, %s: %.0f frames/s, result lag median %.1f us  p90 %.1f  "
+                    "(%lld chunks from graphs, %lld of %lld increments accepted)\n",
+                    mode, mode == 0 ? "every match + mask out" : "inlier matches out", (double)(popped - poppedAtStart) / sec, percentile(lag, 0.5),
+                    percentile(lag, 0.9), ps_vo_stream_graph_launches(ps), acc, popped);
+        if (popped != total - 1 || acc < popped - 2 * (total / frames) - 2) accepted = -1; // (every pair came back; turn-around frames aside, accepted)
+        ps_vo_stream_destroy(ps);
+    }
     ps_context_destroy(ctx);
     // every pushed pair but the turn-around frames (same frame twice: accepted too, identity motion) must have been accepted
     return accepted == pushes ? 0 : 1;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warm", type=float, default=0.5, help="seconds of untimed steps before every row")
     ap.add_argument("--results", type=int, default=0, help="0 = everything, 1 = inlier matches + pose + stats, 2 = pose + stats")
+    ap.add_argument("--packed", type=int, default=0, help="1 = PS_FRAMES_PACKED: one block per frame, one upload per chunk (push_many_packed)")
     ap.add_argument("--grid", default="125x4,125x6,125x8,166x4,166x6,250x4,250x6,64x8,32x8")
     a = ap.parse_args()
     from putslam_amd import api, synth
@@ -35,6 +36,10 @@ def main():
     hd.array[:] = seq["desc"]
     hp.array[:] = seq["pts"]
     nk = np.ascontiguousarray(seq["nkpts"], np.int32)
+    if a.packed:
+        from putslam_amd.device_batch import pack_frames
+        hpk = api.PinnedBuffer((F, (cap * 44 + 15) // 16 * 16), np.uint8)
+        hpk.array[:] = pack_frames(seq["desc"], seq["pts"], hpk.array.shape[1])
     prm = default_ransac_params(a.ev)
     cfg, _ = make_config(est, a.hyp, seed=0xB0B0)
     ctx = api.Context(0)
@@ -45,7 +50,7 @@ def main():
         chunk, lanes = (int(v) for v in item.split("x"))
         ctx.set_option("stream_ahead", ahead)
         st = api.VoStream(ctx, cap)
-        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=a.results)
+        st.configure_async(prm, cfg, TUM_FR1_K, chunk_frames=chunk, lanes=lanes, results=a.results, packed=bool(a.packed))
         done = [0]
 
         def take(wait):
@@ -61,7 +66,7 @@ def main():
             f = 0
             while f < F:
                 n = min(chunk, F - f)
-                if st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n]):
+                if (st.push_many_packed(hpk.array[f:f + n], nk[f:f + n]) if a.packed else st.push_many(hd.array[f:f + n], hp.array[f:f + n], nk[f:f + n])):
                     f += n
                     while take(False):
                         pass
