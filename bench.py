@@ -15,11 +15,12 @@ pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypothes
 thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
 72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
 
-Submission: the step's pairs go out as --streams sub-batch chains (default 2; three read 1.3 % less with the runtime's 16
-hardware queues, profiles/r05k/chains_ab.txt), one HIP stream and one
-context each.  With --join end (default) the chains are ordered only within their own stream, so
-consecutive steps pipeline into each other (one chain's matrix-core Hamming sweep runs beside another's vector
-scoring sweep); every step is complete at the closing barrier + synchronize that brackets the timed region.
+Submission: every step is ONE ps_batch_queue_submit (include/putslam_hip.h): the library owns --streams launch chains (default 2:
+contexts + HIP streams) and hands the steps' batches to them in turn, whole -- consecutive steps run side by side (one chain's
+matrix-core Hamming sweep beside the other's vector scoring stages) and write output blocks of their own; nothing joins the
+chains, every step is complete at the closing barrier + synchronize that brackets the timed region.  (Rounds 3 - 5 split every
+step's pairs 45 % / 55 % over two contexts from here: --submit python, or PUTSLAM_HIP_QUEUE_SPLIT_FROM=20 for the same inside the
+library; whole batches in turn read 608 k against 559 k, profiles/r06h/queue_split_vs_turns.txt.)
 
 The timed region of K steps is run --repeats times (default 5, each bracketed by barrier + synchronize, max over
 ranks); `value` / `ms_per_step` are the MEDIAN region, `value_min` / `value_max` the spread, `timed_regions_ms_per_step`
@@ -271,11 +272,11 @@ def main():
     P = len(seq["pairs"])
     if not shard_seq:
         Pmax = P
-    # The submission of the timed region: a PsBatchQueue of S chains (the library owns contexts and streams and splits every
-    # batch), unless an experiment asks for something the queue does not do.  (Batches of fewer than 20 pairs go to the queue's
-    # chains in turn, whole: a multi-rank run's per-chain record gathers want fixed bounds, so those keep the Python submission.)
+    # The submission of the timed region: a PsBatchQueue of S chains -- the library owns contexts and streams and hands the steps'
+    # batches to the chains in turn, whole (consecutive steps run side by side and write output blocks of their own) --, unless an
+    # experiment asks for something the queue does not do.
     use_queue = (args.submit == "queue" and not args.cuts and args.join == "end" and S <= 4 and (S != 2 or abs(args.split - 0.45) < 1e-9)
-                 and not shard_seq and (P >= 20 or S == 1 or not dist_on))
+                 and not shard_seq)
     queue = None
     if use_queue:
         parent = api.Context(dev.index)          # the queue's parent: options' source, error texts
@@ -285,7 +286,9 @@ def main():
         ctxs = [api.Context(dev.index) for _ in range(S)]
     ctx = ctxs[0]
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"], device=str(dev))
-    pb = PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))
+    # output blocks: one per chain of the queue, used in turn (step n + S runs on step n's chain, behind it)
+    pbs = [PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev)) for _ in range(S if use_queue else 1)]
+    pb = pbs[0]
     bounds = [P * i // S for i in range(S + 1)]
     if S == 2:
         bounds = [0, int(P * args.split), P]
@@ -296,36 +299,49 @@ def main():
     # stream", so the legacy default stream is never handed over)
     if use_queue:   # the chains' own streams, as torch sees them (record packing / gathers of a multi-rank run are queued on them)
         chains = [torch.cuda.ExternalStream(c.stream_ptr, device=dev) for c in ctxs]
-        bounds = [0, P * 450 // 1000, P] if (S == 2 and P >= 20) else bounds
+        # (PUTSLAM_HIP_QUEUE_SPLIT_FROM = rounds 3 - 5's split of every batch over the chains, kept in the library for A/B runs)
+        qsf = os.environ.get("PUTSLAM_HIP_QUEUE_SPLIT_FROM")
+        queue_whole = not (qsf and qsf.isdigit() and P >= int(qsf) and S > 1)
+        if not queue_whole:
+            bounds = [0, P * 450 // 1000, P] if S == 2 else bounds
     else:
+        queue_whole = False
         chains = [torch.cuda.Stream(device=dev) for _ in range(S)]
     join = args.join == "step"
     # gather blocks: chain i carries pairs [bounds[i], bounds[i+1]) of this rank; with --shard sequence the shards differ
     # by at most one pair and every rank pads its LAST chain's block to the size of the largest shard's
     gsize = [bounds[i + 1] - bounds[i] for i in range(S)]
+    if queue_whole:
+        gsize = [P] * S                 # a step's whole batch runs on one chain: every chain gathers blocks of P records
     if shard_seq:
         gsize = [(Pmax * (i + 1) // S) - (Pmax * i // S) for i in range(S)]
         bounds = [min(P, Pmax * i // S) for i in range(S)] + [P]
     gathered = ([[torch.zeros((gsize[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
                   for _ in range(world)] for i in range(S)] if (dist_on and rank == 0) else [None] * S)
     pending = [None] * S     # per chain: (in-flight gather of the previous step, the record block it reads)
+    state = {"step": 0, "parts": [(i, bounds[i], bounds[i + 1]) for i in range(S)]}
 
     def step():
-        # S sub-batches of the step on S streams (device_batch.run_pairs_split); with --join end the chains are
-        # ordered only within their own stream, so consecutive steps pipeline into each other
+        # one batch per step: through the queue (whole, on the chains in turn) or as S sub-batches on S streams
+        # (device_batch.run_pairs_split); either way the chains are ordered only within their own stream, so consecutive steps
+        # pipeline into each other
+        out = pbs[state["step"] % len(pbs)]
+        state["step"] += 1
         if use_queue:
-            run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, pb)
+            run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, out)
+            if dist_on:
+                b = queue.last_split()
+                state["parts"] = [(i, b[i], b[i + 1]) for i in range(S) if b[i + 1] > b[i]]
         else:
-            run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=bounds, join=join)
+            run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, out, bounds=bounds, join=join)
         if dist_on:
             # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI -- one
-            # gather per chain, queued behind that chain's kernels and issued asynchronously: it completes beside
+            # gather per chain the step ran on, queued behind that chain's kernels and issued asynchronously: it completes beside
             # the next step's kernels and is waited for before the chain's next gather (or the closing fence)
-            st32 = pb.stats.view(torch.int32).view(P, -1)            # PsRansacStats: [5] numInliers, [0] numMatchesIn
-            for i in range(S):
-                lo, hi = bounds[i], bounds[i + 1]
+            st32 = out.stats.view(torch.int32).view(P, -1)           # PsRansacStats: [5] numInliers, [0] numMatchesIn
+            for i, lo, hi in state["parts"]:
                 with torch.cuda.stream(chains[i]):
-                    rec = sharding.pack_records(pb.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0])
+                    rec = sharding.pack_records(out.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0])
                     if rec.shape[0] < gsize[i]:          # --shard sequence: pad to the common block size
                         rec = torch.cat([rec, torch.zeros((gsize[i] - rec.shape[0], sharding.RECORD_FLOATS),
                                                           dtype=rec.dtype, device=rec.device)])
@@ -491,8 +507,15 @@ def main():
                 other_modes[name]["model_slots_per_pair"] = c0.get_option("last_model_slots")
             if name == "E0/ransac/487" and S > 1:
                 # the reference's own regime submitted like the timed region: S chains on S streams, steps pipelined
+                pb2s = [pb2] + [PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev)) for _ in range(S - 1)]
+                turn = [0]
+
                 def chains_step():
-                    run_pairs_split(ctxs, chains, prm2, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=bounds, join=False)
+                    if use_queue:     # (whole batches to the library's chains in turn, an output block each)
+                        run_pairs_queue(queue, prm2, cfg2, TUM_FR1_K, fs, pb2s[turn[0] % S])
+                        turn[0] += 1
+                    else:
+                        run_pairs_split(ctxs, chains, prm2, est2, hyp2, cfg2.seed, TUM_FR1_K, fs, pb2, bounds=bounds, join=False)
                 for _ in range(3):
                     chains_step()
                 torch.cuda.synchronize(dev)
@@ -513,7 +536,7 @@ def main():
     if other_modes is not None and args.preset is None and not args.no_stress:
         # ---- BASELINE configs[4] under the driver's clock: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule
         try:
-            other_modes.update(stress_legs(args, api, c0, chains[0], dev, ctxs, chains))
+            other_modes.update(stress_legs(args, api, c0, chains[0], dev, ctxs, chains, queue))
         except Exception as e:
             other_modes["stress"] = {"error": repr(e)}
     if other_modes is not None and args.preset is None and not args.no_data_legs:
@@ -521,7 +544,7 @@ def main():
         # workload's rate depends on the share of true correspondences (70 % in the generator); the same step on sequences with
         # 40 % and 90 %, submitted like the timed region
         try:
-            other_modes.update(data_legs(args, ctxs, chains, prm, est, cfg, bounds, dev))
+            other_modes.update(data_legs(args, ctxs, chains, prm, est, cfg, bounds, dev, queue))
         except Exception as e:
             other_modes["data"] = {"error": repr(e)}
     if other_modes is not None and args.preset is None and not args.no_latency:
@@ -542,7 +565,8 @@ def main():
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
-            blocks = [np.concatenate([gathered[i][r].cpu().numpy() for i in range(S)]) for r in range(world)]
+            # (the chains the LAST step ran on: all of them with the split submissions, one with the queue's whole batches)
+            blocks = [np.concatenate([gathered[i][r].cpu().numpy() for i, _, _ in state["parts"]]) for r in range(world)]
             np.save(args.dump_records, np.stack(blocks))
         elif not dist_on:
             st32 = res["stats"].view(np.int32).reshape(P, -1)
@@ -604,7 +628,7 @@ def main():
             return out
 
         rk = solo if solo else kern                      # kernels' own durations when the single-chain leg ran
-        r_pairs = P if solo else P / S
+        r_pairs = P if (solo or queue_whole) else P / S
         dom = max((k for k in rk if k != "ps_expand_query_fp4"), key=rk.get)
         dom_ms = rk[dom]
         achieved = bytes_per_pair * r_pairs / (dom_ms * 1e-3) / 1e9
@@ -685,7 +709,9 @@ def main():
                 "backend": (dist.get_backend() if dist_on else None), "shard": args.shard,
                 "force_dist": bool(dist_on and world == 1),
                 "errorVersion": args.error_version, "estimator": args.estimator, "streams": S, "split": (args.split if S == 2 and not shard_seq else None), "join": args.join,
-                "submit": ("ps_batch_queue_submit (the library's chains)" if use_queue else "python (sub-batches handed to the contexts from bench.py)"),
+                "submit": (("ps_batch_queue_submit: whole batches to the library's chains in turn" if queue_whole else
+                            "ps_batch_queue_submit with PUTSLAM_HIP_QUEUE_SPLIT_FROM: every batch split over the library's chains") if use_queue
+                           else "python (sub-batches handed to the contexts from bench.py)"),
                 "matcher_kernel": matcher + ("-fused" if matcher_fused else ""), "score_kernel": score,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "mean_matches": m_in, "mean_valid_matches": m_valid,
@@ -894,22 +920,28 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     return out
 
 
-def data_legs(args, ctxs, chains, prm, est, cfg, bounds, dev):
+def data_legs(args, ctxs, chains, prm, est, cfg, bounds, dev, queue=None):
     """The timed workload's step (same frames x keypoints, schedule, metric, the same sub-batch chains) on synthetic sequences
     with other shares of true correspondences than the generator's 70 %."""
     import torch
     from putslam_amd import synth
     from putslam_amd._abi import TUM_FR1_K
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue, run_pairs_split
     out = {}
     for frac in (0.4, 0.9):
         seq2 = synth.make_sequence(args.frames, args.kpts, config=3, index=0, inlier_frac=frac)
         fs2 = FrameSetDevice(seq2["desc"], seq2["pts"], seq2["nkpts"], device=str(dev))
-        pb2 = PairBatchDevice(seq2["pairs"], fs2.max_kpts, device=str(dev))
+        pb2s = [PairBatchDevice(seq2["pairs"], fs2.max_kpts, device=str(dev)) for _ in range(len(ctxs) if queue is not None else 1)]
+        pb2 = pb2s[0]
         P = len(seq2["pairs"])
+        turn = [0]
 
         def step():
-            run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs2, pb2, bounds=bounds, join=False)
+            if queue is not None:     # submitted like the timed region: whole batches to the library's chains in turn
+                run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs2, pb2s[turn[0] % len(pb2s)])
+                turn[0] += 1
+            else:
+                run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs2, pb2, bounds=bounds, join=False)
 
         for _ in range(5):
             step()
@@ -1013,13 +1045,13 @@ def native_legs(args, seq, cfg):
     return out
 
 
-def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
+def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None, queue=None):
     """BASELINE configs[4]: 8 pairs x 5000 keypoints x H = 100 000, fixed schedule (RANSAC.cpp:87-150 with
     the adaptive stop disabled), both metrics, one launch chain, HIP events around every kernel."""
     import torch
     from putslam_amd import synth
     from putslam_amd._abi import EST_FIXED, TUM_FR1_K, default_ransac_params, make_config
-    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_split
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue, run_pairs_split
     frames, kpts, hyp = 9, 5000, 100000
     seq = synth.make_sequence(frames, kpts, config=3, index=0)
     P = len(seq["pairs"])
@@ -1076,9 +1108,15 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
         if ctxs is not None and len(ctxs) >= 2 and P >= 4:
             # the same 8 pairs submitted like the timed region: two unequal chains (3 + 5 pairs) that are never joined
             b2 = [0, max(1, int(P * 0.45)), P]
+            pbq = [pb, PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))]
+            turn = [0]
 
             def chains_step():
-                run_pairs_split(ctxs[:2], chains[:2], prm, EST_FIXED, hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=b2, join=False)
+                if queue is not None and len(ctxs) == 2:   # like the timed region: whole batches to the library's two chains in turn
+                    run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, pbq[turn[0] % 2])
+                    turn[0] += 1
+                else:
+                    run_pairs_split(ctxs[:2], chains[:2], prm, EST_FIXED, hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=b2, join=False)
 
             for _ in range(3):
                 chains_step()
@@ -1088,7 +1126,7 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None):
                 chains_step()
             torch.cuda.synchronize(dev)
             cms = (time.perf_counter() - tc) / n * 1e3
-            out["stress/E%d" % ev]["chains"] = {"streams": 2, "bounds": b2, "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
+            out["stress/E%d" % ev]["chains"] = {"streams": 2, "submit": ("queue: whole batches in turn" if queue is not None and len(ctxs) == 2 else "split %r" % (b2,)), "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
     return out
 
 

@@ -1,5 +1,6 @@
 // demo_batch_queue.cpp -- what a C / C++ host that loops over batches gets from the library: BASELINE configs[2]'s 499 frame
-// pairs (a 500-frame sequence resident in HBM) handed over again and again through a PsBatchQueue (include/putslam_hip.h) --
+// pairs (a 500-frame sequence resident in HBM) handed over again and again through a PsBatchQueue (include/putslam_hip.h: batches
+// go to its two launch chains in turn; consecutive batches write output blocks of their own) --
 // the call shape of the reference's tracking loop around Matcher::match (src/PUTSLAM/PUTSLAM.cpp:677-740,
 // src/Matcher/matcher.cpp:470-515), batched.  No Python, no torch, GPU_MAX_HW_QUEUES left to the library.
 //
@@ -171,15 +172,20 @@ int main(int argc, char **argv)
     fs.numFrames = frames;
     fs.maxKpts = cap;
     fs.descFrameStride = fs.ptsFrameStride = 0; // dense frames
-    Results res;
-    if (alloc_results(P, cap, res)) return 2;
+    // consecutive batches run side by side on the queue's chains: an output block per chain, used in turn
+    const int blocks = chains >= 2 ? chains : 1;
+    std::vector<Results> outs((size_t)blocks);
+    for (Results &r : outs)
+        if (alloc_results(P, cap, r)) return 2;
+    long long submitted = 0;
 
     PsBatchQueue *q = nullptr;
     if (chains >= 2) PSCHK(ps_batch_queue_create(ctx, chains, &q));
     int64_t last = -1;
     auto step = [&]() -> int {
-        if (q) return ps_batch_queue_submit(q, &prm, &cfg, K, &fs, dPairs, P, &res.out, &last);
-        return ps_vo_pairs_device(ctx, &prm, &cfg, K, &fs, dPairs, P, &res.out);
+        Results &r = outs[(size_t)(submitted++ % blocks)];
+        if (q) return ps_batch_queue_submit(q, &prm, &cfg, K, &fs, dPairs, P, &r.out, &last);
+        return ps_vo_pairs_device(ctx, &prm, &cfg, K, &fs, dPairs, P, &r.out);
     };
     auto fence = [&]() -> int { return q ? ps_batch_queue_synchronize(q) : ps_context_synchronize(ctx); };
     using clk = std::chrono::steady_clock;
@@ -203,6 +209,7 @@ int main(int argc, char **argv)
     }
     // a ticket waited for by the host: the results of that batch are complete (the call a host makes before it reads them)
     if (q) PSCHK(ps_batch_queue_wait(q, last));
+    Results &res = outs[(size_t)((submitted - 1) % blocks)]; // the last batch's block
     std::vector<PsRansacStats> st((size_t)P);
     HIPCHK(hipMemcpy(st.data(), res.out.stats, st.size() * sizeof(PsRansacStats), hipMemcpyDeviceToHost));
     long long accepted = 0, inliers = 0;
@@ -251,7 +258,7 @@ int main(int argc, char **argv)
     (void)hipFree(dPts);
     (void)hipFree(dNk);
     (void)hipFree(dPairs);
-    (void)hipFree(res.block);
+    for (Results &r : outs) (void)hipFree(r.block);
     ps_context_destroy(ctx);
     return bad ? 1 : 0;
 }

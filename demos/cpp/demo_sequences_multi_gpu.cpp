@@ -84,8 +84,8 @@ struct DeviceSide { // one member's resident frames and outputs
     uint8_t *desc = nullptr;
     float *pts = nullptr;
     int32_t *nk = nullptr, *pairs = nullptr;
-    PsPairResults out{};
-    void *block = nullptr;
+    PsPairResults out{}, out2{}; // consecutive steps run side by side on the member's two chains: an output block each, used in turn
+    void *block = nullptr, *block2 = nullptr;
 };
 
 #define HIPCHK(call)                                                                         \
@@ -128,6 +128,14 @@ int upload(const Sequence &s, int P, DeviceSide &d)
     d.out.numMatches = (int32_t *)b;
     b += n * 4;
     d.out.inlierMask = b;
+    HIPCHK(hipMalloc(&d.block2, bytes));
+    HIPCHK(hipMemset(d.block2, 0, bytes));
+    const ptrdiff_t shift = (uint8_t *)d.block2 - (uint8_t *)d.block;
+    d.out2.matches = (PsDMatch *)((uint8_t *)d.out.matches + shift);
+    d.out2.pose = (float *)((uint8_t *)d.out.pose + shift);
+    d.out2.stats = (PsRansacStats *)((uint8_t *)d.out.stats + shift);
+    d.out2.numMatches = (int32_t *)((uint8_t *)d.out.numMatches + shift);
+    d.out2.inlierMask = d.out.inlierMask + shift;
     return 0;
 }
 
@@ -295,7 +303,10 @@ int main(int argc, char **argv)
         if (driveRoot && rec) std::memcpy(records.data(), rec, records.size() * sizeof(float)); // (the consumer reads what came back)
         return PS_OK;
     };
+    long long stepNo = 0;
     std::function<int()> step = [&]() -> int {
+        for (int i = 0; i < L; ++i) jobs[(size_t)i].out = (stepNo & 1) ? &dev[(size_t)i].out2 : &dev[(size_t)i].out;
+        ++stepNo;
         int rc2 = ps_shard_submit_all(g, jobs.data());
         if (rc2 != PS_OK) {
             std::fprintf(stderr, "submit: %s\n", ps_shard_last_error(g));
@@ -407,6 +418,7 @@ int main(int argc, char **argv)
         (void)hipFree(d.nk);
         (void)hipFree(d.pairs);
         (void)hipFree(d.block);
+        (void)hipFree(d.block2);
     }
     ps_shard_group_destroy(g);
     return bad ? 1 : 0;

@@ -287,8 +287,8 @@ typedef struct PsPairResults {
  * 850 000, USAC_wrapper.cpp:70; touched only up to each pair's trip limit); the staged scoring's parked models take 48 bytes
  * per pair and LEADING hypothesis, 256 MB at most under the adaptive schedules (2 GiB under the fixed one): a hypothesis
  * beyond the slots is swept in one piece and, should it win, rebuilt (options "arena_mib", "last_model_slots", read only).
- * Throughput: a host that loops over batches gets up to 16 % more from a PsBatchQueue (below), which hands every batch over as
- * two unequal sub-batches through two contexts on two streams that are never joined. */
+ * Throughput: a host that loops over batches gets 18 % more (499 pairs) to 47 % more (125 pairs) from a PsBatchQueue (below), which
+ * hands the batches to two contexts on two streams in turn -- launch chains that are never joined. */
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);
@@ -297,29 +297,30 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
  * src/Matcher/matcher.cpp:470-515): ps_vo_pairs_device through launch chains that are never joined.
  * One context is one launch chain: a batch's matrix-core Hamming sweep, then its vector scoring stages, dependent launches with
  * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = 2; 1 .. 4) on ctx's device, with ctx's
- * options, and hands every batch over as unequal sub-batches -- two chains: 45 % / 55 % of the pairs -- so that the chains stay
- * out of step, one in its Hamming sweep while the other scores: + 8 ... 16 % on batches of hundreds of pairs
- * (profiles/r05k/chains_ab.txt).  Batches of fewer than 20 pairs go to the chains in turn, whole.  The chains are ordered only
- * within themselves; nothing ever makes one wait for the other.
- *   submit: arguments of ps_vo_pairs_device (device pointers); pair p draws from cfg->seed + p whatever chain it runs on, so the
- *           outputs are byte for byte those of ONE ps_vo_pairs_device call.  Returns at once; *ticket (may be NULL) names the
- *           batch.  Inputs and outputs must stay valid until the batch is complete.  Consecutive batches may use the same
- *           output block (a chain's sub-batches are stream-ordered and the chains' slices are disjoint for equal P); reading
- *           a batch's results needs its ticket waited for.  At most 64 batches are in flight: the 65th submit waits for the first.
- *           If a chain's call fails the error is returned (text: ps_last_error of ctx), the ticket still stands for whatever
- *           part of the batch was queued.
- *   wait / query: the host blocks until / asks whether both chains are past that batch (query: 1 complete, 0 not yet).
+ * options, and hands batch n to chain n mod chains, WHOLE: consecutive batches run side by side, one in its Hamming sweep while
+ * the other scores -- 608 k instead of 517 k frame-pairs/s on batches of 499 pairs, + 18 ... 47 % on smaller ones (round 6's
+ * measurement; splitting every batch over the chains, rounds 3 - 5's recipe, gave 559 k: profiles/r06h/queue_split_vs_turns.txt).
+ * The chains are ordered only within themselves; nothing ever makes one wait for another.
+ *   submit: arguments of ps_vo_pairs_device (device pointers); pair p draws from cfg->seed + p: the outputs are byte for byte
+ *           those of ONE ps_vo_pairs_device call.  Returns at once; *ticket (may be NULL) names the batch.  Inputs and outputs
+ *           must stay valid until the batch is complete.  Batches in flight run CONCURRENTLY: give consecutive batches output
+ *           blocks of their own (`chains` blocks used in turn are enough: batch n + chains runs on batch n's chain, behind it);
+ *           reading a batch's results needs its ticket waited for.  At most 64 batches are in flight: the 65th submit waits for
+ *           the first.  If the chain's call fails the error is returned (text: ps_last_error of ctx); the ticket still stands
+ *           for whatever part of the batch was queued.
+ *   wait / query: the host blocks until / asks whether that batch is complete (query: 1 complete, 0 not yet).
  *   wait_on_stream: the given hipStream_t waits for the batch instead (device-side; the host does not block): what a host
  *           that post-processes on a stream of its own, or gathers results with a collective, queues behind a batch.
- *   context(q, i): chain i's context -- for ps_context_stream (work to be queued behind that chain's share of a batch),
+ *   context(q, i): chain i's context -- for ps_context_stream (work to be queued behind that chain's batch),
  *           ps_context_enable_timing, options; not for calls of its own while batches are in flight.
- *   last_split: bounds[0 .. chains] of the last submitted batch: pairs [bounds[i], bounds[i+1]) ran on chain i.
+ *   last_split: bounds[0 .. chains] of the last submitted batch: pairs [bounds[i], bounds[i+1]) ran on chain i (all of them on
+ *           one chain, unless PUTSLAM_HIP_QUEUE_SPLIT_FROM=<pairs> asks for rounds 3 - 5's split of batches that large: A/B runs).
  * Hardware queues: every chain wants one of its own.  The HIP runtime gives a process GPU_MAX_HW_QUEUES of them (default 4,
- * shared with the host's other streams) and serialises streams that share one (two chains: 415 k instead of 560 k
- * frame-pairs/s).  The library sets GPU_MAX_HW_QUEUES=16 when it is loaded if the variable is unset (a constructor, before
- * the process' first HIP call for a program that links the library; a host that set the variable keeps its value).  Read-only
- * option "hw_queues_seen" = the value found; ps_batch_queue_create leaves a warning in ps_last_error(ctx) when it is too
- * small.  A process that initialises HIP before loading the library sets the variable itself (putslam_amd/_lib.py does). */
+ * shared with the host's other streams) and serialises streams that share one.  The library sets GPU_MAX_HW_QUEUES=16 when it
+ * is loaded if the variable is unset (a constructor, before the process' first HIP call for a program that links the library;
+ * a host that set the variable keeps its value).  Read-only option "hw_queues_seen" = the value found; ps_batch_queue_create
+ * leaves a warning in ps_last_error(ctx) when it is too small.  A process that initialises HIP before loading the library sets
+ * the variable itself (putslam_amd/_lib.py does). */
 typedef struct PsBatchQueue PsBatchQueue;
 int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out);
 void ps_batch_queue_destroy(PsBatchQueue *q);

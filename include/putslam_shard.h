@@ -17,8 +17,8 @@
  *   ps_shard_group_create_rank  one process per GPU (the torch.distributed.run / mpirun shape): every process is one member;
  *                               the 128-byte id comes from ps_shard_unique_id on one rank and travels by whatever the host
  *                               has (a file, a socket, MPI).
- * Every member owns a PsBatchQueue of two launch chains (include/putslam_hip.h: the chains are never joined) and a
- * communication stream.  A step of a looping host is
+ * Every member owns a PsBatchQueue of two launch chains (include/putslam_hip.h: batches go to the chains in turn, the chains are
+ * never joined) and a communication stream.  A step of a looping host is
  *       ps_shard_submit_all(g, jobs)                          every member's batch, asynchronous
  *       ps_shard_gather_records_async(g, pairs, root, &t)     records packed on the chains, gathered on the comm streams
  *       ... the next step's submit ...
@@ -82,8 +82,9 @@ void ps_shard_range(int64_t total, int world, int rank, int64_t *lo, int64_t *hi
 /* perLocal[local]: in on the root's member, out on every member (bytes identical to the root's).  Blocks until done. */
 int ps_shard_broadcast_params(PsShardGroup *g, PsShardRunParams *perLocal, int root);
 
-/* jobs[local] for every local member: the batch goes to the member's queue (ps_batch_queue_submit: two chains, 45 % / 55 %) and
- * its 72-byte records are packed behind it on the chains.  Asynchronous: returns when every member's launches are queued (with
+/* jobs[local] for every local member: the batch goes to the member's queue (ps_batch_queue_submit: two chains, whole batches in
+ * turn -- consecutive batches run side by side, so a host that keeps two steps in flight gives consecutive steps output
+ * blocks of their own) and its 72-byte records are packed behind it on the chain it ran on.  Asynchronous: returns when every member's launches are queued (with
  * two or more local members the members' submissions run on their own host threads, side by side).  A member whose job has
  * P = 0 submits nothing. */
 int ps_shard_submit_all(PsShardGroup *g, const PsShardJob *jobs);

@@ -291,7 +291,8 @@ class _ChainContext(Context):
 
 
 class BatchQueue:
-    """PsBatchQueue: ps_vo_pairs_device through launch chains that are never joined (two chains, 45 % / 55 % of every batch)."""
+    """PsBatchQueue: ps_vo_pairs_device through launch chains that are never joined (two chains, whole batches in turn:
+    consecutive batches run side by side and need output blocks of their own)."""
 
     def __init__(self, ctx: Context, chains=0):
         self._ctx = ctx

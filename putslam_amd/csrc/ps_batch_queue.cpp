@@ -2,20 +2,25 @@
 // full rate, inside the library.
 //
 // A host that hands batch after batch to ONE context gets one launch chain: the matrix-core Hamming sweep and the vector scoring
-// sweep of a batch run one after the other, and a chain's six or seven dependent launches leave the chip idle between them
-// (484 - 521 k frame-pairs/s on the 499-pair workload).  Two chains that are never joined -- every batch split 45 % / 55 %, each
-// part on its own context + stream -- stay out of step: one chain's Hamming sweep runs beside the other's scoring sweep
-// (560 k; profiles/r05k/chains_ab.txt).  Rounds 3 - 5 had this recipe in bench.py and as a paragraph of the header; a C / C++
-// host (the reference is one: the loop of src/PUTSLAM/PUTSLAM.cpp:677-740 around Matcher::match, src/Matcher/matcher.cpp:470-515)
-// could only rebuild it by hand.  Here it is three calls: create, submit, wait.
+// stages of a batch run one after the other, dependent launches with the chip partly idle between them (517 k frame-pairs/s on
+// the 499-pair workload from a C++ loop).  Launch chains that are never joined overlap one batch's Hamming sweep with another's
+// scoring.  Rounds 3 - 5 got that by SPLITTING every batch 45 % / 55 % over two contexts + streams (bench.py's submission: 559 k);
+// measured in round 6 from demos/cpp/demo_batch_queue on the same data, handing WHOLE batches to the chains in turn is better at
+// every batch size tried (profiles/r06h/queue_split_vs_turns.txt):
+//       pairs per batch        64      125      250      499     1000        499 (bench sequence)   499, E0 / RANSAC <= 487
+//       one context         142 k    274 k    336 k    451 k    496 k        517 k
+//       split 45 / 55       160 k    175 k    412 k    482 k    547 k        559 k                   1.85 M
+//       whole, in turn      180 k    402 k    473 k    543 k    562 k        608 k                   2.17 M
+// -- a batch keeps its full launch shapes (half the launches per pair, grids twice as large; and a sub-batch of a small batch
+// drops below the staged scoring's cost-model threshold: 125 pairs split run complete scoring, twice the work) while the chains
+// still drift out of step.  So that is what the queue does: batch n runs on chain n mod chains, whole.  The split form is kept
+// behind PUTSLAM_HIP_QUEUE_SPLIT_FROM=<pairs> (batches of at least that many pairs are split, two chains: 45 % / 55 %) for A/B runs.
 //
 //   * chains are ordered only within themselves: submit never makes one chain wait for another, and a batch's completion is an
-//     event per chain, recorded behind the chain's last launch -- waited for by the host (ps_batch_queue_wait) or by a stream of
-//     the host's (ps_batch_queue_wait_on_stream), never by the other chain;
-//   * pair p of a batch keeps its hypothesis stream cfg->seed + p whatever chain it runs on: results are byte for byte those of
-//     one ps_vo_pairs_device call;
-//   * small batches (fewer than 20 pairs) are not worth splitting: they go to the chains in turn, whole -- consecutive batches
-//     then overlap the same way.
+//     event per chain it ran on, recorded behind its last launch -- waited for by the host (ps_batch_queue_wait) or by a stream of
+//     the host's (ps_batch_queue_wait_on_stream), never by another chain;
+//   * pair p of a batch keeps its hypothesis stream cfg->seed + p: results are byte for byte those of one ps_vo_pairs_device call;
+//   * consecutive batches run side by side: they need output blocks of their own (two blocks used in turn do for two chains).
 // Host-only translation unit: everything here is queue bookkeeping around ps_vo_pairs_device.
 #include <hip/hip_runtime_api.h>
 
@@ -31,7 +36,7 @@ namespace {
 
 constexpr int kMaxChains = 4;
 constexpr int kTickets = 64;      // batches that can be in flight; submit waits for the oldest when the ring is full
-constexpr int kSplitFromPairs = 20;
+constexpr int kSplitFromPairs = 0x7fffffff; // (never: whole batches, the chains in turn; PUTSLAM_HIP_QUEUE_SPLIT_FROM overrides)
 
 struct Ticket {
     long long seq = -1;              // batch number this slot holds (-1: never used)
@@ -46,6 +51,7 @@ struct PsBatchQueue {
     int device = 0;
     int chains = 0;
     int splitPermille = 450;         // two chains: share of the pairs on chain 0
+    int splitFrom = kSplitFromPairs; // batches of fewer pairs go to the chains in turn, whole
     PsContext *ctx[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
     Ticket ring[kTickets];
     long long next = 0;              // number of the next batch
@@ -79,7 +85,7 @@ void split(const PsBatchQueue *q, int P, long long seq, int32_t *bounds)
         bounds[1] = P;
         return;
     }
-    if (P < kSplitFromPairs) { // the whole batch on one chain, the chains in turn
+    if (P < q->splitFrom) { // the whole batch on one chain, the chains in turn
         const int c = (int)(seq % C);
         for (int i = 0; i <= C; ++i) bounds[i] = i <= c ? 0 : P;
         return;
@@ -114,6 +120,10 @@ int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out)
     if (const char *v = std::getenv("PUTSLAM_HIP_QUEUE_SPLIT")) { // (A/B hook: share of chain 0 in permille)
         const int x = std::atoi(v);
         if (x >= 50 && x <= 950) q->splitPermille = x;
+    }
+    if (const char *v = std::getenv("PUTSLAM_HIP_QUEUE_SPLIT_FROM")) { // (A/B hook)
+        const int x = std::atoi(v);
+        if (x >= 2) q->splitFrom = x;
     }
     for (int i = 0; i < chains; ++i) {
         int rc = ps_context_create(q->device, &q->ctx[i]);

@@ -53,6 +53,8 @@ struct AsyncLane {
     Buf frames;
     hipGraphExec_t gexec = nullptr;
     unsigned long long gexecGen = 0;
+    Plan plan;                  // the plan of the place's full chunk (parameters are fixed per configure), valid while ...
+    unsigned long long planGen = 0; // ... its lane's arena is the one it was made with (0 = none)
     int state = 0;            // 0 free, 1 chunk in flight
     long long firstPair = 0;
     int pairs = 0;
@@ -93,6 +95,11 @@ struct PsVoAsync {
     // travels as data (psdev::MiniMeta).  No ring, no copy streams, no cross-lane dependency: the halo frame is read again from
     // the previous chunk's staging slot.
     bool mini = false;
+    // Replaying a place's chunk from its graph is OFF by default: on this runtime hipGraphLaunch of the seven-node graph costs the
+    // host more than the seven launches and the lanes' graphs run less side by side -- 20.9 k frames/s at 322 us of lag against
+    // 25.1 k at 209 us with ordinary launches (demos/cpp/demo_latency (d), profiles/r06h/mini_chunks.txt).  PUTSLAM_HIP_STREAM_GRAPH=1
+    // turns it on (tests run both).
+    bool miniGraphs = false;
     std::vector<uint8_t *> stagePoolDev;  // device views of the staging areas (mini chunks read them from kernels)
     const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot
     int haloNk = 0;
@@ -374,8 +381,23 @@ int mini_enqueue(PsVoStream *s, AsyncLane &l, PsContext *lc, const Plan &pl, int
     const size_t cap = (size_t)s->cap;
     MiniMeta *dm = (MiniMeta *)l.meta.p;
     const int groups = 8;
-    hipLaunchKernelGGL(ps_mini_copy_in, dim3((unsigned)((a->B + 1) * groups)), dim3(256), 0, lc->stream, (const MiniMeta *)l.hmetaDev, dm,
-                       (uint8_t *)l.frames.p, s->cap, (unsigned long long)a->packStride, groups);
+    unsigned copyGrid = (unsigned)((a->B + 1) * groups);
+#ifdef PS_STREAM_DIAG
+    // (experiment: what the lanes do when the frames cost nothing -- the meta block alone travels, the kernels run on whatever the
+    // place's frames hold; results are meaningless)
+    static const bool diagNoUpload = std::getenv("PUTSLAM_HIP_STREAM_DIAG_NO_UPLOAD") != nullptr;
+    if (diagNoUpload && a->diagLaunches > 64) copyGrid = 0;
+#endif
+    if (copyGrid == 0) {
+        CopySegs up{};
+        up.src[0] = l.hmetaDev;
+        up.dst[0] = dm;
+        up.bytes[0] = sizeof(MiniMeta);
+        up.n = 1;
+        hipLaunchKernelGGL(ps_copy_segments, dim3(1), dim3(64), 0, lc->stream, up);
+    } else
+        hipLaunchKernelGGL(ps_mini_copy_in, dim3(copyGrid), dim3(256), 0, lc->stream, (const MiniMeta *)l.hmetaDev, dm,
+                           (uint8_t *)l.frames.p, s->cap, (unsigned long long)a->packStride, groups);
     PS_HIP(hipGetLastError());
     PsFrameSet fs;
     fs.desc = (const uint8_t *)l.frames.p;
@@ -460,7 +482,7 @@ int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
 #endif
     const bool full = P == a->B && !first;
     bool launched = false;
-    if (full && s->graphsEnabled) { // (PUTSLAM_HIP_NO_GRAPH=1 at ps_vo_stream_create: ordinary launches)
+    if (full && a->miniGraphs && s->graphsEnabled) { // (PUTSLAM_HIP_STREAM_GRAPH=1; PUTSLAM_HIP_NO_GRAPH=1 at ps_vo_stream_create wins)
         if (l.gexec && l.gexecGen != lc->arenaGen) { // the lane's arena has moved since the capture
             (void)hipGraphExecDestroy(l.gexec);
             l.gexec = nullptr;
@@ -506,19 +528,30 @@ int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
         }
     }
     if (!launched) {
-        Plan pl;
-        rc = make_plan(lc, &a->prm, &a->cfg, a->haveK ? a->K : nullptr, s->cap, s->cap, pl);
-        if (rc == PS_OK) {
-            pl.ma.seedDev = reinterpret_cast<const uint64_t *>(&((MiniMeta *)l.meta.p)->seed);
-            rc = prepare_score(lc, pl, P, s->cap);
-        }
-        if (rc != PS_OK) {
-            ctx->err = std::string("pipelined chunk: ") + lc->err;
-            return rc;
+        // the plan of a full chunk is made once per place (parameters, P and the lane's arena do not change between chunks): the
+        // host side of a chunk is its staging copy and seven launches
+        const bool cached = full && l.planGen != 0 && l.planGen == lc->arenaGen;
+        Plan local;
+        Plan &pl = full ? l.plan : local;
+        if (!cached) {
+            l.planGen = 0;
+            rc = make_plan(lc, &a->prm, &a->cfg, a->haveK ? a->K : nullptr, s->cap, s->cap, pl);
+            if (rc == PS_OK) {
+                pl.ma.seedDev = reinterpret_cast<const uint64_t *>(&((MiniMeta *)l.meta.p)->seed);
+                rc = prepare_score(lc, pl, P, s->cap);
+            }
+            if (rc != PS_OK) {
+                ctx->err = std::string("pipelined chunk: ") + lc->err;
+                return rc;
+            }
         }
         rc = mini_enqueue(s, l, lc, pl, P);
         if (rc != PS_OK) return rc;
-        if (full) a->laneWarmGen[(size_t)laneIdx] = lc->arenaGen;
+        if (full) {
+            a->laneWarmGen[(size_t)laneIdx] = lc->arenaGen;
+            l.planGen = lc->arenaGen; // (the plan points at the blocks prepare_score sized -- counts, parked models, stop tables --;
+                                      // the launches above only grow OTHER blocks, so the plan stays good for the arena as it is now)
+        }
     }
 #ifdef PS_STREAM_DIAG
     if (diagFailAfter && std::atoll(diagFailAfter) == a->diagLaunches - 1)
@@ -631,6 +664,8 @@ int async_build(PsVoStream *s)
         // small chunks as one graph per place (PsVoAsync::mini); PUTSLAM_HIP_STREAM_MINI=0 keeps round 5's form for them (A/B, tests)
         const char *m = std::getenv("PUTSLAM_HIP_STREAM_MINI");
         a->mini = a->B <= psdev::kMiniFrames && !(m && std::atoi(m) == 0);
+        const char *g = std::getenv("PUTSLAM_HIP_STREAM_GRAPH");
+        a->miniGraphs = g && std::atoi(g) != 0;
     }
     if (a->mini) {
         a->packed = true; // (the staging areas: one block per frame, as the copy-in kernel reads them)

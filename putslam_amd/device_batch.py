@@ -156,7 +156,8 @@ def run_pairs_split(ctxs, streams, params, estimator, num_hypotheses, seed, K, f
 
 
 def run_pairs_queue(queue, params, cfg, K, frames: FrameSetDevice, batch: PairBatchDevice):
-    """The same batch as `run_pairs` through a PsBatchQueue (api.BatchQueue): the library splits it over its launch chains
-    (two: 45 % / 55 %), which are never joined.  Asynchronous; returns the batch's ticket -- `queue.wait(ticket)` (host),
+    """The same batch as `run_pairs` through a PsBatchQueue (api.BatchQueue): the library hands the batches to its launch chains
+    (two) in turn, whole; the chains are never joined, so consecutive batches run side by side -- give them output blocks of their
+    own (two `PairBatchDevice`s used in turn).  Asynchronous; returns the batch's ticket -- `queue.wait(ticket)` (host),
     `queue.wait_on_stream(ticket, stream)` (a stream of the caller's) or `queue.synchronize()` before the results are read."""
     return queue.submit(params, cfg, K, frames.view(), batch.pairs.data_ptr(), batch.P, batch.view())

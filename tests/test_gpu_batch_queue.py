@@ -19,30 +19,39 @@ from test_gpu_batch import _compare  # noqa: E402
 
 
 @pytest.mark.parametrize("chains", [1, 2, 3])
+@pytest.mark.parametrize("split_from", [None, 20])
 @pytest.mark.parametrize("mode,est,H,frames", [(REPROJECTION_ERROR, EST_FIXED, 1024, 41), (EUCLIDEAN_ERROR, EST_RANSAC, 487, 30),
                                                (EUCLIDEAN_ERROR, EST_USAC, 800, 9)])
-def test_queue_equals_oracle(ctx, oracle, chains, mode, est, H, frames):
+def test_queue_equals_oracle(ctx, oracle, monkeypatch, chains, split_from, mode, est, H, frames):
+    """Batches go to the chains in turn, whole (the default), or -- PUTSLAM_HIP_QUEUE_SPLIT_FROM, rounds 3 - 5's recipe kept for A/B
+    runs -- are split 45 % / 55 % from that many pairs on: the oracle's bytes either way."""
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue
+    if split_from is None:
+        monkeypatch.delenv("PUTSLAM_HIP_QUEUE_SPLIT_FROM", raising=False)
+    else:
+        monkeypatch.setenv("PUTSLAM_HIP_QUEUE_SPLIT_FROM", str(split_from))
     seq = synth.make_sequence(frames, 500, config=3, index=500 + mode * 10 + est)
     P = len(seq["pairs"])
     prm = default_ransac_params(mode)
     cfg, _ = make_config(est, H, seed=777)
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
-    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    pbs = [PairBatchDevice(seq["pairs"], fs.max_kpts) for _ in range(3)]     # consecutive batches run side by side: a block each
     q = api.BatchQueue(ctx, chains)
     assert q.chains == chains
-    t = run_pairs_queue(q, prm, cfg, TUM_FR1_K, fs, pb)
-    b = q.last_split()
-    assert b[0] == 0 and b[-1] == P and all(b[i] <= b[i + 1] for i in range(chains))
-    if chains == 2 and P >= 20:
-        assert b[1] == P * 450 // 1000                    # 45 % / 55 %: the chains stay out of step
-    if chains > 1 and P < 20:
-        assert sorted(set(b)) == [0, P]                   # a small batch goes to one chain, whole
-    q.wait(t)
-    assert q.query(t)
-    g = pb.download()
     c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=4)
-    _compare(g, c, P)
+    tickets = []
+    for n, pb in enumerate(pbs):
+        tickets.append(run_pairs_queue(q, prm, cfg, TUM_FR1_K, fs, pb))
+        b = q.last_split()
+        assert b[0] == 0 and b[-1] == P and all(b[i] <= b[i + 1] for i in range(chains))
+        if chains > 1 and split_from is not None and P >= split_from:
+            assert b == ([0, P * 450 // 1000, P] if chains == 2 else [P * i // chains for i in range(chains + 1)])    # the split form
+        else:
+            assert b[n % chains + 1] - b[n % chains] == P                                                               # whole, on chain n mod chains
+    for t, pb in zip(tickets, pbs):
+        q.wait(t)
+        assert q.query(t)
+        _compare(pb.download(), c, P)
     q.close()
 
 
@@ -69,7 +78,7 @@ def test_queue_many_batches_tickets_and_stream_wait(ctx, oracle):
     side = torch.cuda.Stream()
     q.wait_on_stream(tickets[-1], side.cuda_stream)
     with torch.cuda.stream(side):
-        pose_copy = outs[1].pose.clone()                  # (batch 69 wrote outs[1])
+        pose_copy = outs[1].pose.clone()                  # (the last large batch, number 69, wrote outs[1])
     side.synchronize()
     q.wait(tickets[0])                                    # older than the ring: complete, returns at once
     assert q.query(tickets[0])
