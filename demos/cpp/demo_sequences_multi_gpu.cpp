@@ -262,9 +262,10 @@ int main(int argc, char **argv)
         dev[(size_t)i].device = ps_shard_device(g, i);
         if (upload(seq[(size_t)i], P, dev[(size_t)i])) return 2;
     }
-    // ---- the host loop: every step submits every member's batch (asynchronous: a PsBatchQueue of two chains per member, the
-    // members on their own host threads) and starts the gather of its records; the records of step n are waited for after
-    // step n + 1 has been submitted, so nothing ever drains a GPU (at most PS_SHARD_GATHERS_IN_FLIGHT gathers are outstanding)
+    // ---- the host loop: every step submits every member's batch (asynchronous: a PsBatchQueue of two chains per member, whole
+    // batches in turn; the members on their own host threads) and starts the gather of its records; the records of step n are
+    // waited for after step n + 2 has been submitted, so nothing ever drains a GPU (at most PS_SHARD_GATHERS_IN_FLIGHT gathers are
+    // outstanding)
     std::vector<PsRansacConfig> cfgs((size_t)L);
     std::vector<PsFrameSet> fsets((size_t)L);
     std::vector<PsShardJob> jobs((size_t)L);
@@ -292,7 +293,7 @@ int main(int argc, char **argv)
         j.out = &dev[(size_t)i].out;
     }
     std::vector<float> records(driveRoot ? (size_t)W * P * PS_SHARD_RECORD_FLOATS : 0);
-    int64_t inFlight = -1;
+    std::vector<int64_t> inFlight; // gathers started and not read yet, oldest first (two are kept outstanding)
     auto take = [&](int64_t t) -> int { // the records of gather t: complete, on the host
         const float *rec = nullptr;
         int rc2 = ps_shard_wait(g, t, &rec);
@@ -319,13 +320,23 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "gather: %s\n", ps_shard_last_error(g));
             return rc2;
         }
-        if (inFlight >= 0 && (rc2 = take(inFlight)) != PS_OK) return rc2; // the previous step's records
-        inFlight = t;
+        inFlight.push_back(t);
+        // the records of the step before the previous one: with two chains per member two steps run side by side, and the host
+        // must not wait for the older of them before the next one is queued (of PS_SHARD_GATHERS_IN_FLIGHT = 4 record blocks
+        // three are in use)
+        while (inFlight.size() > 2) {
+            if ((rc2 = take(inFlight.front())) != PS_OK) return rc2;
+            inFlight.erase(inFlight.begin());
+        }
         return PS_OK;
     };
     auto drain = [&]() -> int {
-        int rc2 = inFlight >= 0 ? take(inFlight) : PS_OK;
-        inFlight = -1;
+        int rc2 = PS_OK;
+        while (!inFlight.empty() && rc2 == PS_OK) {
+            rc2 = take(inFlight.front());
+            inFlight.erase(inFlight.begin());
+        }
+        inFlight.clear();
         return rc2;
     };
     if (step() != PS_OK || drain() != PS_OK) return 2; // warm-up (code objects, stop tables, scratch arenas)

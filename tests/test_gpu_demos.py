@@ -40,7 +40,8 @@ def test_demo_matching_scored_with_the_tum_protocol(ctx, tmp_path):
 
 
 def test_cpp_demo_latency_runs_through_the_c_abi(ctx):
-    """demos/cpp/demo_latency: single-pair call + synchronize, back-to-back calls and ps_vo_stream_push timed from C++ (the
+    """demos/cpp/demo_latency: single-pair call + synchronize, back-to-back calls, ps_vo_stream_push and the pipelined form at one
+    frame per chunk timed from C++ (the
     figures bench.py's `other_modes["latency"]` reports); here: it runs, every increment is accepted, the figures parse."""
     import os
     import re
@@ -50,9 +51,12 @@ def test_cpp_demo_latency_runs_through_the_c_abi(ctx):
         pytest.fail("demos/cpp/demo_latency is not built (__graft_entry__.build())")
     p = subprocess.run([exe, "1000", "0", "200"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    us = [float(x) for x in re.findall(r"(?:median|300:) ([0-9.]+) us", p.stdout)]
-    assert len(us) == 3 and all(5.0 < v < 2000.0 for v in us), p.stdout
+    us = [float(re.search(tag + r"[^\n]*?(?:median|300:) ([0-9.]+) us", p.stdout).group(1)) for tag in (r"\(a\)", r"\(b\)", r"\(c\)")]
+    assert all(5.0 < v < 2000.0 for v in us), p.stdout
     assert us[1] <= us[0]                                    # the chain alone is never slower than call + synchronize
+    # (d): the pipelined form at one frame per chunk -- every pair came back (exit code 0 checks that) and it beats the synchronous push
+    d = [float(x) for x in re.findall(r"\(d[01]\)[^\n]*: ([0-9.]+) frames/s", p.stdout)]
+    assert len(d) == 2 and all(v > 1.2e6 / us[2] for v in d), p.stdout
 
 
 def test_demo_usac(ctx):

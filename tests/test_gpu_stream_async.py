@@ -536,13 +536,14 @@ def test_packed_frames_equal_batch_and_oracle(ctx, seq64, chunk, form):
 @pytest.mark.parametrize("form", ["graph", "no-graph", "ring"])
 @pytest.mark.parametrize("results", [0, 1, 2])
 def test_small_chunks_equal_batch_and_oracle(ctx, seq64, chunk, form, results, monkeypatch):
-    """chunks of one to four frames (one = the reference's own call shape, matcher.cpp:452-516) as ONE
-    captured hipGraph per place -- frames in from the pinned staging area by a copy kernel, kernels 1 - 4, results out by a kernel;
-    row counts, seed and frame addresses are data.  The bytes are the batched call's (= the oracle's) with the graphs, with
-    ordinary launches of the same form (PUTSLAM_HIP_NO_GRAPH=1) and with round 5's ring form (PUTSLAM_HIP_STREAM_MINI=0), in every
-    result mode, frames pushed one at a time and several at a time, across a reset."""
+    """chunks of one to four frames (one = the reference's own call shape, matcher.cpp:452-516) with a
+    private frame set per place -- frames in from the pinned staging area by a copy kernel, kernels 1 - 4, results out by a kernel;
+    row counts, seed and frame addresses are data.  The bytes are the batched call's (= the oracle's) with ordinary launches (the
+    default), with every place's chunk replayed from a captured hipGraph (PUTSLAM_HIP_STREAM_GRAPH=1) and with round 5's ring form
+    (PUTSLAM_HIP_STREAM_MINI=0), in every result mode, frames pushed one at a time and several at a time, across a reset."""
     from putslam_amd import api
     monkeypatch.setenv("PUTSLAM_HIP_NO_GRAPH", "1" if form == "no-graph" else "0")
+    monkeypatch.setenv("PUTSLAM_HIP_STREAM_GRAPH", "1" if form == "graph" else "0")    # (off by default: slower on this runtime, profiles/r06h)
     monkeypatch.setenv("PUTSLAM_HIP_STREAM_MINI", "0" if form == "ring" else "1")
     seq, runs = seq64
     prm, cfg, c = runs["e1"]
