@@ -146,7 +146,7 @@ def parse():
     ap.add_argument("--no-data-legs", action="store_true", help="skip the legs with 40 %% / 90 %% true correspondences")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (demos/cpp/demo_latency)")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] legs (5000 keypoints, H = 100 000)")
-    ap.add_argument("--stream-chunk", type=int, default=125, help="frames per chunk of the streamed leg")
+    ap.add_argument("--stream-chunk", type=int, default=250, help="frames per chunk of the streamed leg (125 and 500 are reported beside it)")
     ap.add_argument("--stream-lanes", type=int, default=0, help="lanes of the streamed leg: launch chains that run side by side (the library's stream_ahead places queue more chunks behind them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
@@ -776,10 +776,11 @@ def _link_rate(torch, dev, mb=64, reps=8):
 
 def _stream_shape(chunk, lanes):
     """(lanes, places beyond one per lane) ps_vo_stream_configure_async uses for `lanes` = 0 and option stream_ahead = -1 (the
-    defaults): six places in all; three launch chains from 192 frames per chunk on, six below."""
+    defaults): by chunk size -- two lanes + one more place from 96 frames per chunk on, two + two from 48, three + three below, six
+    lanes for chunks of one to four frames."""
     if lanes == 0:
-        lanes = 3 if chunk >= 192 else 6
-    return lanes, max(0, 6 - lanes)
+        lanes = 2 if chunk >= 48 else (3 if chunk > 4 else 6)
+    return lanes, (1 if chunk >= 96 else (2 if chunk >= 48 else max(0, 6 - lanes)))
 
 
 def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
@@ -908,7 +909,9 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block
     out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
     out["streamed/poses"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=2)   # (a host that only composes the trajectory)
-    out["streamed/chunk250"] = run(250, args.stream_lanes, steps, check=0)
+    for other in (125, 250, 500):
+        if other != args.stream_chunk:
+            out["streamed/chunk%d" % other] = run(other, args.stream_lanes, steps, check=0)
     small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
     out["streamed/chunk32"] = small
     one = run(1, args.stream_lanes, 3, check=1, warm_s=0.2)

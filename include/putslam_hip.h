@@ -381,7 +381,9 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  * over the whole sequence with the same cfg, whatever the chunking.
  *
  * ps_vo_stream_configure_async: parameters of the pipelined form, fixed until the next configure (which drains).  chunkFrames
- *   1..1024 (0 = 128), lanes 2..8 (0 = 6, or 3 from 192 frames per chunk on).  cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.
+ *   1..1024 (0 = 128), lanes 2..8 (0 = by chunk size: 2 from 48 frames per chunk on, 3 below, 6 for chunks of one to four frames).
+ *   cfg->sampleIdx must be NULL.  The lanes inherit the options of the stream's context.  Throughput grows with the chunk: 417 /
+ *   504 / 550 k frame-pairs/s at 125 / 250 / 500 frames of 2000 keypoints per chunk (1.2 / 2.0 / 2.7 ms from push to results).
  * ps_vo_stream_push_async: ONE frame (host pointers, rows of descStep bytes) is copied into the pinned staging area of
  *   the chunk being collected; the chunk is submitted when it is full.  Returns at once.
  * ps_vo_stream_push_many: numFrames frames laid out like a PsFrameSet on the HOST (desc numFrames x maxKpts x 32 B,
@@ -391,7 +393,8 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *   Frames staged by push_async before are submitted first, as a chunk of their own.
  * ps_vo_stream_flush: submits a partly filled chunk.
  * Flow control: a chunk needs a PLACE (a meta block, device and pinned result blocks, events); there are lanes + `ahead` of
- *   them (context option "stream_ahead", 0 .. 8, or -1 = six places in all, the default; read by configure_async).  An accepted chunk is uploaded and
+ *   them (context option "stream_ahead", 0 .. 8, or -1 = by chunk size, the default: 1 from 96 frames per chunk on, 2 from 48,
+ *   else six places in all; read by configure_async).  An accepted chunk is uploaded and
  *   launched at once, on the next lane in turn -- behind that lane's running chunk if it has one --, so a lane never waits for
  *   the host between chunks.  A place is busy from the launch of its chunk until pop_many has returned its results (the pinned
  *   block they lie in changes hands: the place goes on with a spare one while the caller reads).  push_async (at the first frame of a chunk) / push_many return

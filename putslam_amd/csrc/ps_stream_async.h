@@ -794,9 +794,12 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     if (!params || !cfg) return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: null params/config");
     if (cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are not supported by the streaming calls");
     if (chunkFrames == 0) chunkFrames = 128;
-    // (measured, profiles/r05h/stream_ab_*.txt: six places in all; large chunks fill the chip by themselves and run best as three
-    // launch chains with three more chunks queued behind them, small ones as six chains)
-    if (lanes == 0) lanes = chunkFrames >= 192 ? 3 : 6;
+    // Lanes and places by chunk size, measured (profiles/r06i/stream_lanes_places.txt; round 5 ran six places in all, as six or
+    // three lanes): chunks of a hundred frames and more fill the chip by themselves and run best as TWO launch chains with ONE more
+    // chunk queued behind them -- 417 / 504 / 550 k frame-pairs/s at 125 / 250 / 500 frames per chunk against 398 / 474 / 445 k
+    // with six places -- the same finding as the batch queue's (whole batches to two chains in turn); chunks of 48 .. 95 frames two
+    // lanes and four places; smaller ones three lanes and six places; one to four frames six lanes (PsVoAsync::mini).
+    if (lanes == 0) lanes = chunkFrames >= 48 ? 2 : (chunkFrames > psdev::kMiniFrames ? 3 : 6);
     if (chunkFrames < 1 || chunkFrames > 1024 || lanes < 2 || lanes > 8)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_stream_configure_async: chunkFrames 1..1024, lanes 2..8");
     {
@@ -813,7 +816,7 @@ int ps_vo_stream_configure_async(PsVoStream *s, const PsRansacParams *params, co
     s->async = a;
     a->B = chunkFrames;
     a->lanes = lanes;
-    a->ahead = ctx->streamAhead >= 0 ? ctx->streamAhead : (lanes < 6 ? 6 - lanes : 0);
+    a->ahead = ctx->streamAhead >= 0 ? ctx->streamAhead : (chunkFrames >= 96 ? 1 : (chunkFrames >= 48 ? 2 : (lanes < 6 ? 6 - lanes : 0)));
     a->ringFrames = (lanes + a->ahead + 2) * chunkFrames;
     a->prm = *params;
     a->cfg = *cfg;
