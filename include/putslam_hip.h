@@ -172,9 +172,9 @@ int ps_context_device(const PsContext *ctx);
  * measurements, answer only to the name "debug.<knob>" (and PUTSLAM_HIP_<KNOB> at context creation) and may change between
  * versions: qsplit / msplit (work-groups the query range of kernel 1 / the match range of kernel 3 is split over, 0 =
  * automatic), gensplit (stage 0 as two launches, models then sweep), singlerest (one stage after the prefix under the adaptive
- * schedules), pretest (stage 1's one-direction pre-test), prefix (64 / 128 / 192 / 256 hypotheses of stage 0), list_g2 /
- * list_g3 / list_r3 (work-groups per pair of stages 2 / 3, range split of stage 3), reorder_top (voters), reorder_margin,
- * reorder_c2div, reorder_gran (where the stages' ranges are cut).
+ * schedules), pretest (stage 1's one-direction pre-test), prefix (64 / 128 / 192 / 256 hypotheses of stage 0), list_g2
+ * (work-groups per pair of stage 2), reorder_top (voters), reorder_margin.  (list_g3, list_r3, reorder_c2div and reorder_gran
+ * left in round 6: every A/B had their other values within 1 % of the defaults; they are constants of the library now.)
  * ps_context_get_option returns the value or a negative PsStatus. */
 int ps_context_set_option(PsContext *ctx, const char *name, int value);
 int ps_context_get_option(const PsContext *ctx, const char *name);

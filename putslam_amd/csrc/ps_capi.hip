@@ -26,6 +26,11 @@ static_assert(kPsReorderMargin == kReorderMargin && kPsReorderTopMax == kReorder
 namespace {
 
 constexpr int kWidePairs = 16; // batches of at most this many pairs run kernel 2 with 1024-thread work-groups
+// Tuning constants of the staged scoring that were per-context knobs until round 5 (debug.list_r3 / list_g3 / reorder_c2div /
+// reorder_gran); every A/B since round 3 put their other values within 1 % of these (profiles/r03n, r04b), so they are constants:
+// work-groups the last stage's match range is split over; where the stages' ranges are cut (multiples of kReorderGran matches, the
+// second cut at 1 / kReorderC2div of the range); stage 3 runs one looping work-group per eight possible ones (list_groups).
+constexpr int kListRsplit3 = 4, kReorderGran = 64, kReorderC2div = 16;
 // where the staged scoring takes over from complete scoring (prepare_score): batch size in work units = pairs x
 // (ceil(H / 256) - 1) x frame capacity, threshold = base + perRow x frame capacity (profiles/r05c/staged_crossover.txt)
 struct StagedFrom {
@@ -515,12 +520,12 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         // profiles/r04b/ab_euclid_list_groups.txt)
         const int auto2 = with_euclid_fast(ctx, pl.mode) ? (all / 8 > 2 ? all / 8 : 2) : 64; // (many hypotheses: lists can be long)
         const int want = pl.reorder ? (stage == 2 ? (ctx->listGroups2 > 0 ? ctx->listGroups2 : auto2)
-                                                  : (ctx->listGroups3 > 0 ? ctx->listGroups3 : auto3)) : all;
+                                                  : auto3) : all;
         return want < all ? want : all;
     };
     // the last stage: work-groups its match range is split over (their counts add up in counts[]; a short survivor list
     // swept by one wavefront per SIMD pays the full latency of every record load, 0.25 us per match)
-    auto list_rsplit = [&](int stage) { return (pl.reorder && stage == kStages) ? ctx->listRsplit3 : 1; };
+    auto list_rsplit = [&](int stage) { return (pl.reorder && stage == kStages) ? kListRsplit3 : 1; };
     // stage 1's one-direction pre-test on the far-off front of the reordered record: the reprojection metrics (ps_score_fast.h)
     const bool usePretest = pl.reorder && ctx->pretest != 0 &&
                             (pl.mode == PS_EUCLIDEAN_AND_REPROJECTION_ERROR || pl.mode == PS_REPROJECTION_ERROR);
@@ -555,8 +560,8 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
         st.loopGroups = stage == 1 ? loopGroups : 0;
         st.single = lastStage == 1 ? 1 : 0;
         st.margin = ctx->reorderMargin;
-        st.gran = with_euclid_fast(ctx, pl.mode) ? 64 : ctx->reorderGran;
-        st.c2div = ctx->reorderC2div;
+        st.gran = kReorderGran;
+        st.c2div = kReorderC2div;
         return st;
     };
     // the hot record of stages 1+: reordered between stage 0 and stage 1 (ps_stage_reorder) unless the option is off

@@ -152,14 +152,10 @@ const OptDesc kOptions[] = {
     {"singlerest", "SINGLEREST", &PsContext::singleRest, 0, 1, "singlerest: 0 (three stages) or 1 (one stage after the prefix, adaptive schedules)", true},
     {"pretest", "PRETEST", &PsContext::pretest, 0, 1, "pretest: 0 or 1 (stage 1's one-direction pre-test)", true},
     // ... and its tuning knobs
-    {"list_r3", "LISTR3", &PsContext::listRsplit3, 1, 32, "list_r3: 1 .. 32 work-groups the last stage's match range is split over", true},
     {"list_g2", "LISTG2", &PsContext::listGroups2, 0, 64, "list_g2: 0 (automatic) .. 64 work-groups per pair of stage 2", true},
-    {"list_g3", "LISTG3", &PsContext::listGroups3, 0, 512, "list_g3: 0 (automatic) .. 512 work-groups per pair of stage 3", true},
     {"prefix", "PREFIX", &PsContext::forcePrefix, 0, 256, "prefix: 0 (default) or 64, 128, 192, 256 hypotheses of stage 0 (fixed schedule)", true},
     {"reorder_top", "REORDER_TOP", &PsContext::reorderTop, 1, kPsReorderTopMax, "reorder_top: 1 .. 16 voters", true},
     {"reorder_margin", "REORDER_MARGIN", &PsContext::reorderMargin, 1, 4096, "reorder_margin: 1 .. 4096 matches", true},
-    {"reorder_c2div", "REORDER_C2DIV", &PsContext::reorderC2div, 1, 64, "reorder_c2div: 1 .. 64", true},
-    {"reorder_gran", "REORDER_GRAN", &PsContext::reorderGran, 2, 64, "reorder_gran: 2, 4, 8, 16, 32 or 64", true},
     {"bail", "BAIL", &PsContext::bail, 0, 1, "bail: 0 or 1 (pairs whose prefix leaves nothing to abandon are swept in one stage)"},
     {"stream_copy_kernels", "STREAM_COPY_KERNELS", &PsContext::streamCopyKernels, 0, 1, "stream_copy_kernels: 0 (hipMemcpyAsync) or 1 (copy kernels over mapped pinned memory)"},
     {"stream_ahead", "STREAM_AHEAD", &PsContext::streamAhead, -1, 8, "stream_ahead: -1 (automatic: six places in all) or 0 .. 8 chunks the pipelined stream takes beyond one per lane (queued on the lanes' streams)"},
@@ -178,7 +174,6 @@ bool option_value_ok(const OptDesc &o, int v)
 {
     if (v < o.lo || v > o.hi) return false;
     if (strcmp(o.name, "prefix") == 0) return (v & 63) == 0;
-    if (strcmp(o.name, "reorder_gran") == 0) return (v & (v - 1)) == 0;
     return true;
 }
 int parse_option_text(const OptDesc &o, const char *v)

@@ -85,15 +85,12 @@ struct PsContext {
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the
     // extra launch (6 us per call) buys nothing (option "reorder")
     int reorder = 2;
-    int reorderGran = 64; // stage cuts of the reprojection kernels: multiples of this (option "reorder_gran": 2 .. 64; finer cuts
-                          // shorten stage 1 and lengthen stages 2 / 3 by as much, profiles/r03n)
     int genSplit = 1;    // staged scoring: stage 0 as two launches -- the prefix's models once, then the sweep with the match range
                          // split over twice as many work-groups (option "gensplit" = 0: one launch, every part repeats the
                          // sample -> SVD chain)
     int singleRest = 1;  // adaptive schedules, no reordering: one stage after the prefix instead of three (option "singlerest")
     int pretest = 1;     // stage 1: one-direction pre-test on the all-reject front (option "pretest")
-    int listRsplit3 = 4; // option "list_r3": work-groups the last stage's match range is split over
-    int listGroups2 = 0, listGroups3 = 0; // work-groups per pair of stages 2 / 3 (options list_g2 / list_g3; 0 = automatic)
+    int listGroups2 = 0; // work-groups per pair of stage 2 (option "list_g2"; 0 = automatic)
     int forcePrefix = 0; // option "prefix": hypotheses stage 0 scores completely under the fixed schedule (64 .. 256; 0 = default)
     int bail = 1;        // option "bail": a pair whose prefix leaves nothing to abandon is swept in ONE stage (ps_stage_reorder)
     int streamCopyKernels = 1; // option "stream_copy_kernels": ps_vo_stream_push moves its frame in / results out with a copy
@@ -101,7 +98,7 @@ struct PsContext {
     int streamAhead = -1; // option "stream_ahead": places of the pipelined stream beyond one per lane (chunks queued behind the running
                           // ones); -1 = six places in all
     int modelRoomMiB = 0; // option "model_room_mib": room for the staged scoring's parked models (0 = 256 MiB adaptive / 2 GiB fixed)
-    int reorderTop = 8, reorderMargin = kPsReorderMargin, reorderC2div = 16; // (options "reorder_top" / "reorder_margin" / "reorder_c2div")
+    int reorderTop = 8, reorderMargin = kPsReorderMargin; // (options "reorder_top" / "reorder_margin")
     int stampsOn = 0; // option "stamps": kernels 2 and 4 record their phase boundaries (ps_debug_stamps)
     Buf stamps;
     // Every (re)allocation of an arena block bumps this: captured graphs (ps_vo_stream_push) carry the pointers of the

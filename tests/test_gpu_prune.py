@@ -15,8 +15,8 @@ from putslam_amd._abi import (ADAPTIVE_ERROR, EST_FIXED, EST_RANSAC, EST_USAC, E
 pytestmark = pytest.mark.gpu
 
 # launch-shape / tuning knobs: every value gives the same results; addressed as "debug.<name>" (include/putslam_hip.h)
-SHAPE_KNOBS = ("qsplit", "msplit", "gensplit", "singlerest", "pretest", "list_r3", "list_g2", "list_g3", "prefix", "reorder_top",
-               "reorder_margin", "reorder_c2div", "reorder_gran")
+SHAPE_KNOBS = ("qsplit", "msplit", "gensplit", "singlerest", "pretest", "list_g2", "prefix", "reorder_top", "reorder_margin")
+RETIRED_KNOBS = ("list_r3", "list_g3", "reorder_c2div", "reorder_gran")   # constants of the library since round 6
 STAT_FIELDS = ("numMatchesIn", "numMatchesValid", "bestHypothesis", "bestInlierCount", "iterationsRun", "numInliers",
                "accepted", "bestInlierRatio", "pointInlierRatio")
 
@@ -156,9 +156,8 @@ def test_reordered_record_is_a_permutation_with_the_rejected_matches_in_front(or
 TWINS = [
     dict(pretest=0), dict(gensplit=0), dict(singlerest=0), dict(bail=0),
     dict(prefix=64), dict(prefix=128),
-    dict(list_g2=1, list_g3=1, list_r3=1), dict(list_g2=7, list_g3=3, list_r3=32), dict(list_r3=2, list_g3=512),
-    dict(reorder_top=1), dict(reorder_top=16, reorder_margin=1), dict(reorder_margin=300, reorder_c2div=1),
-    dict(reorder_c2div=64, reorder_gran=2), dict(reorder_gran=8, pretest=0),
+    dict(list_g2=1), dict(list_g2=7), dict(list_g2=64, pretest=0),
+    dict(reorder_top=1), dict(reorder_top=16, reorder_margin=1), dict(reorder_margin=300),
     dict(msplit=3), dict(msplit=32, gensplit=0),
     # parked models in proportion to the work (round 5): with room for 1 MiB of them only the leading few hundred hypotheses of
     # every pair have a slot, the others are swept in one piece by stage 1 and rebuilt by kernel 4 when one of them wins
@@ -197,9 +196,9 @@ def test_option_names_and_ranges():
                  "model_room_mib") + tuple("debug." + k for k in SHAPE_KNOBS):
         v = c.get_option(name)
         c.set_option(name, v)   # every default is a legal value
-    for name, bad in (("debug.prefix", 100), ("debug.prefix", 320), ("debug.reorder_gran", 12), ("debug.reorder_gran", 1),
-                      ("debug.list_r3", 0), ("debug.reorder_top", 17), ("prune", 3), ("no_such_option", 0),
-                      ("list_r3", 4), ("msplit", 0), ("debug.prune", 1)):   # (the two families do not answer to each other's names)
+    for name, bad in (("debug.prefix", 100), ("debug.prefix", 320), ("debug.list_g2", 65), ("debug.reorder_top", 17), ("prune", 3),
+                      ("no_such_option", 0), ("list_g2", 4), ("msplit", 0), ("debug.prune", 1)) + \
+            tuple(("debug." + k, 4) for k in RETIRED_KNOBS):   # (the two families do not answer to each other's names; retired knobs are gone)
         with pytest.raises(api.PsError):
             c.set_option(name, bad)
     c.close()
