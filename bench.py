@@ -912,7 +912,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
     for other in (125, 250, 500):
         if other != args.stream_chunk:
             out["streamed/chunk%d" % other] = run(other, args.stream_lanes, steps, check=0)
-    small = run(32, args.stream_lanes, max(5, steps // 2), check=0)
+    small = run(32, args.stream_lanes, max(5, steps // 2), check=0, warm_s=0.6, windows=3)
     out["streamed/chunk32"] = small
     one = run(1, args.stream_lanes, 3, check=1, warm_s=0.2)
     out["streamed/chunk1"] = one
