@@ -43,7 +43,7 @@ int main(int argc, char **argv)
 
     putslam_hip::FrameMatcher *matcher = putslam_hip::createFrameMatcher();
     matcher->setSampleSeed(42);
-    if (pipelined) matcher->setPipeline(chunk, 4);
+    if (pipelined) matcher->setPipeline(chunk, 0); // (lanes: the library's choice by chunk size)
     putslam_hip::VOTrajectory vo;
     FILE *traj = trajPath ? std::fopen(trajPath, "w") : nullptr;
     double worstT = 0, worstR = 0, seconds = 0;

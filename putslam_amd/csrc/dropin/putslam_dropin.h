@@ -269,7 +269,7 @@ class FrameMatcher {
     struct Fused;
     std::unique_ptr<Fused> fused_;
     bool fusedSynced_ = false; // the resident frame is prevDescriptors / prevFeatures3D
-    int pipeChunk_ = 32, pipeLanes_ = 4;
+    int pipeChunk_ = 32, pipeLanes_ = 0; // (lanes 0 = the library's choice by chunk size)
     bool pipeFirst_ = true;    // the next enqueued frame has no predecessor
     uint64_t pipeSeed_ = 0;    // hypothesis seed of the pipeline's pair 0 (pair k draws from pipeSeed_ + k, across rebuilds)
     bool pipeSeeded_ = false;

@@ -141,3 +141,80 @@ def test_cpp_host_loop_without_the_environment_variable():
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "hw_queues_seen 2 (GPU_MAX_HW_QUEUES=2)" in p.stdout
+
+
+def fuzz_queue(iters, seed, verbose=False):
+    """Random frame sets (ragged, empty frames), pair lists, schedules, metrics, chain counts and both submission forms (whole
+    batches in turn / split) through a PsBatchQueue, several batches in flight with output blocks in turn, against ONE
+    ps_vo_pairs_device call per batch on a context of its own.  Returns the number of configurations with a difference."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs, run_pairs_queue
+    from test_gpu_batch import STAT_FIELDS
+    rng = np.random.default_rng(seed)
+    parent, ref_ctx = api.Context(0), api.Context(0)
+    bad = 0
+    for it in range(iters):
+        F = int(rng.integers(2, 70))
+        cap = int(rng.choice([64, 200, 333, 700, 1200]))
+        seq = synth.make_sequence(F, cap, config=3, index=int(rng.integers(0, 2 ** 31)), inlier_frac=float(rng.uniform(0.1, 0.9)),
+                                  noise=float(10 ** rng.uniform(-3.5, -1.8)))
+        nk = seq["nkpts"].copy()
+        if rng.random() < 0.5:
+            for f in rng.integers(0, F, max(1, F // 5)):
+                nk[f] = int(rng.integers(0, cap + 1))
+        P = int(rng.integers(1, 3 * F))
+        pairs = rng.integers(0, F, (P, 2)).astype(np.int32)
+        mode = int(rng.choice([0, 1, 2, 4]))
+        est, H = [(EST_RANSAC, 487), (EST_USAC, int(rng.integers(300, 3000))), (EST_FIXED, int(rng.integers(257, 5000)))][int(rng.integers(0, 3))]
+        prm = default_ransac_params(mode)
+        chains = int(rng.integers(1, 5))
+        sf = rng.choice([None, 2, 20, 60])
+        if sf is None:
+            os.environ.pop("PUTSLAM_HIP_QUEUE_SPLIT_FROM", None)
+        else:
+            os.environ["PUTSLAM_HIP_QUEUE_SPLIT_FROM"] = str(int(sf))
+        fs = FrameSetDevice(seq["desc"], seq["pts"], nk)
+        q = api.BatchQueue(parent, chains)
+        nb = int(rng.integers(1, 7))
+        outs = [PairBatchDevice(pairs, cap) for _ in range(nb)]
+        seeds = [int(rng.integers(0, 2 ** 40)) for _ in range(nb)]
+        tickets = []
+        for b in range(nb):
+            cfg, _ = make_config(est, H, seed=seeds[b])
+            tickets.append(run_pairs_queue(q, prm, cfg, TUM_FR1_K, fs, outs[b]))
+        ok = True
+        for b in rng.permutation(nb):
+            q.wait(tickets[b])
+            cfg, _ = make_config(est, H, seed=seeds[b])
+            ref = PairBatchDevice(pairs, cap)
+            run_pairs(ref_ctx, prm, cfg, TUM_FR1_K, fs, ref)
+            g, r = outs[b].download(), ref.download()
+            same = np.array_equal(g["numMatches"], r["numMatches"]) and g["pose"].tobytes() == r["pose"].tobytes()
+            for p in range(P):
+                n = int(r["numMatches"][p])
+                same = same and g["matches"][p, :n].tobytes() == r["matches"][p, :n].tobytes() and np.array_equal(g["inlierMask"][p, :n], r["inlierMask"][p, :n])
+                for f in STAT_FIELDS:
+                    a_, b_ = g["stats"][p][f], r["stats"][p][f]
+                    same = same and (a_ == b_ or (np.isnan(a_) and np.isnan(b_)))
+            if not same:
+                ok = False
+                if verbose:
+                    print("MISMATCH", it, dict(F=F, cap=cap, P=P, mode=mode, est=est, H=H, chains=chains, split_from=sf, batch=int(b), batches=nb))
+        q.close()
+        bad += 0 if ok else 1
+    os.environ.pop("PUTSLAM_HIP_QUEUE_SPLIT_FROM", None)
+    parent.close()
+    ref_ctx.close()
+    return bad
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_queue_slice(seed):
+    assert fuzz_queue(12, 9100 + seed, verbose=True) == 0
+
+
+if __name__ == "__main__":
+    import sys
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    b = fuzz_queue(n, seed, verbose=True)
+    print(f"queue fuzz done: {n} configurations, {b} mismatches")
+    sys.exit(1 if b else 0)
