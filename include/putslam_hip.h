@@ -371,10 +371,13 @@ int ps_vo_stream_push(PsVoStream *s, const PsRansacParams *params, const PsRansa
  *
  * Small chunks (chunkFrames <= 4; 1 is the reference's own call shape): a chunk of one to four frames is launch-bound, so every
  * place keeps a private copy of its frames (the previous frame is read again from its pinned staging slot: no ring, no copy
- * stream) and replays its whole chunk -- frames in by a copy kernel, kernels 1 - 4, results out by a kernel -- from ONE captured
- * hipGraph, with row counts, seed and frame addresses travelling as data.  Frames always go through the library's pinned staging
- * areas in this form (88 KB per 2000-keypoint frame); pop_many's pointers are a copy.  PUTSLAM_HIP_STREAM_MINI=0 keeps the
- * ring form for such chunks, PUTSLAM_HIP_NO_GRAPH=1 ordinary launches (results identical either way).
+ * stream, no event pair) and its whole chunk is seven launches on the place's lane -- frames in by a copy kernel, kernels 1 - 4,
+ * results out by a kernel --, with row counts, seed and frame addresses travelling as data: 25 - 28 k frames/s at 0.2 ms of lag from
+ * one host thread, twice the synchronous push.  (PUTSLAM_HIP_STREAM_GRAPH=1 replays each place's chunk from ONE captured hipGraph
+ * instead: measured slower on this runtime, profiles/r06h/mini_chunks.txt.)  Frames go through the library's pinned staging
+ * areas in this form (88 KB per 2000-keypoint frame) unless they are pinned packed blocks handed to
+ * ps_vo_stream_push_many_packed, which are read in place (untouched until the pair that has a frame as its PREVIOUS frame has been
+ * popped); pop_many's pointers are a copy.  PUTSLAM_HIP_STREAM_MINI=0 keeps the ring form for such chunks (results identical).
  *
  * Pair k of the stream (frames k, k+1 counted from the last reset; frame k is the query = previous frame) draws its
  * hypotheses from the seeded stream cfg->seed + k: the results are byte for byte those of ONE ps_vo_pairs_device call

@@ -101,7 +101,8 @@ struct PsVoAsync {
     // turns it on (tests run both).
     bool miniGraphs = false;
     std::vector<uint8_t *> stagePoolDev;  // device views of the staging areas (mini chunks read them from kernels)
-    const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot
+    const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot (or in the caller's pinned memory)
+    const uint8_t *inPlaceDev = nullptr;  // set for ONE mini_submit_body call: the chunk's frames lie in the caller's pinned memory
     int haloNk = 0;
     std::vector<unsigned long long> laneWarmGen; // per lane: arena generation an un-captured full chunk has run with (0 = none)
     std::vector<uint8_t> viewBuf;         // pop_many's copy of a mini chunk's results (its place is free at once)
@@ -444,7 +445,10 @@ int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
 {
     PsVoAsync *a = s->async;
     PsContext *ctx = s->ctx;
-    const uint8_t *hDev = a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
+    // the chunk's frames as the copy-in kernel sees them: the staging area they were collected in, or -- pinned packed frames
+    // handed over by ps_vo_stream_push_many_packed (PsVoAsync::inPlaceDev) -- the caller's own memory, read in place
+    const uint8_t *hDev = a->inPlaceDev ? a->inPlaceDev : a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
+    a->inPlaceDev = nullptr;
     a->chunkSeq++;
     const int first = a->prevPos >= 0 ? 0 : 1;
     const int P = n - first;
@@ -740,6 +744,23 @@ int mini_push_frames(PsVoStream *s, const uint8_t *desc, size_t descStride, cons
     if (need > async_room(a)) return async_fail(s, PS_ERR_BUSY, "ps_vo_stream_push_many: not enough room for these frames (pop results first, or push fewer)");
     int rc = async_submit_staged(s);
     if (rc) return rc;
+    // Pinned packed frames are read in place by the copy-in kernel (88 KB less for the host to copy per 2000-keypoint frame): as
+    // with the ring form they stay untouched until the results of their frames -- for a chunk's last frame: of the NEXT pair,
+    // which reads it as its previous frame -- have been popped.
+    if (descStride == a->packStride && pts == desc + cap * 32 && is_pinned_host(desc)) {
+        uint8_t *dev = nullptr;
+        if (hipHostGetDevicePointer((void **)&dev, const_cast<uint8_t *>(desc), 0) == hipSuccess && dev) {
+            for (int f0 = 0; f0 < numFrames; f0 += a->B) {
+                const int n = numFrames - f0 < a->B ? numFrames - f0 : a->B;
+                a->inPlaceDev = dev + (size_t)f0 * a->packStride;
+                rc = async_submit(s, desc + (size_t)f0 * a->packStride, nullptr, nkpts + f0, n);
+                a->inPlaceDev = nullptr;
+                if (rc) return rc;
+            }
+            return PS_OK;
+        }
+        (void)hipGetLastError();
+    }
     for (int f = 0; f < numFrames; ++f) {
         uint8_t *h = nullptr;
         rc = stage_area(s, &h);
