@@ -149,7 +149,7 @@ def parse():
     ap.add_argument("--stream-chunk", type=int, default=250, help="frames per chunk of the streamed leg (125 and 500 are reported beside it)")
     ap.add_argument("--stream-lanes", type=int, default=0, help="lanes of the streamed leg: launch chains that run side by side (the library's stream_ahead places queue more chunks behind them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
     a = ap.parse_args()
     if a.preset == "demoMatching":
         a.frames = 2
@@ -892,7 +892,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         return leg
 
     steps = max(10, min(40, 2 * args.steps))
-    main = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=1.5, windows=5)   # the last step's poses against the batched call's
+    main = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=1.0, windows=5)   # the last step's poses against the batched call's
     main["roofline"] = {"bound": "pcie", "achieved": main["h2d_GBps"], "peak": PCIE_GEN5_X16_GBS, "unit": "GB/s",
                         "frac": main["h2d_GBps"] / PCIE_GEN5_X16_GBS, "measured_link_h2d_GBps": h2d,
                         "measured_link_d2h_GBps": d2h, "frac_of_measured": main["h2d_GBps"] / h2d,
@@ -904,7 +904,7 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                         "parameters as the timed workload" % (F, args.stream_chunk, _stream_shape(args.stream_chunk, args.stream_lanes)[0]))
     out["streamed"] = main
     # rounds 4 - 5's form, kept beside it: descriptors and points as two host arrays, two uploads per chunk
-    out["streamed/two_arrays"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=0.8, windows=3, packed=False)
+    out["streamed/two_arrays"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=0.5, windows=3, packed=False)
     # what Matcher::match itself returns -- estimatedTransformation + inlierMatches (matcher.cpp:452-516) -- instead of every
     # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block
     out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
@@ -963,7 +963,7 @@ def data_legs(args, ctxs, chains, prm, est, cfg, bounds, dev, queue=None):
     return out
 
 
-def latency_leg(kpts=2000, calls=600):
+def latency_leg(kpts=2000, calls=400):
     """One 2000-keypoint pair in the reference's own regime (errorVersion 0, <= 487 iterations) through the C ABI, as a C++
     host sees it: (a) device-resident pair, call + synchronize; (b) the same call back to back (the GPU side of the chain);
     (c) ps_vo_stream_push, host frame in / results out (Matcher::match's call shape, matcher.cpp:452-516)."""
@@ -1012,7 +1012,7 @@ def native_legs(args, seq, cfg):
         exe = os.path.join(ROOT, "demos", "cpp", "demo_batch_queue")
         if os.path.exists(exe):
             for name, chains in (("batch_queue_cpp", 2), ("batch_queue_cpp/one_context", 1)):
-                p = subprocess.run([exe, "--sequence", path, "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--chains", str(chains)]
+                p = subprocess.run([exe, "--sequence", path, "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--warm-seconds", "0.6", "--chains", str(chains)]
                                    + common + (["--check"] if chains == 2 else []), capture_output=True, text=True, timeout=180, env=env)
                 m = re.search(r"batch_queue: chains (\d+), median ([0-9.]+) frame-pairs/s, min ([0-9.]+), max ([0-9.]+).*hw_queues_seen (\d+) \(GPU_MAX_HW_QUEUES=([^)]*)\)", p.stdout)
                 leg = {"rc": p.returncode, "what": ("demos/cpp/demo_batch_queue: a C++ loop of ps_batch_queue_submit calls over the timed workload's "
@@ -1031,7 +1031,7 @@ def native_legs(args, seq, cfg):
             out["batch_queue_cpp"] = {"error": "demos/cpp/demo_batch_queue is not built (__graft_entry__.build())"}
         exe = os.path.join(ROOT, "demos", "cpp", "demo_sequences_multi_gpu")
         if os.path.exists(exe):
-            p = subprocess.run([exe, "--gpus", "1", "--sequence-prefix", os.path.join(td, "seq"), "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--warm-seconds", "1"]
+            p = subprocess.run([exe, "--gpus", "1", "--sequence-prefix", os.path.join(td, "seq"), "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--warm-seconds", "0.6"]
                                + common, capture_output=True, text=True, timeout=180, env=env)
             m = re.search(r"median ([0-9.]+) frame-pairs/s in all, min ([0-9.]+), max ([0-9.]+)", p.stdout)
             leg = {"rc": p.returncode, "what": "demos/cpp/demo_sequences_multi_gpu --gpus 1: include/putslam_shard.h with a world of one -- a batch queue per "

@@ -5,7 +5,7 @@
 // src/Matcher/matcher.cpp:470-515), batched.  No Python, no torch, GPU_MAX_HW_QUEUES left to the library.
 //
 //   demo_batch_queue [--sequence f.bin] [--frames 500] [--kpts 2000] [--hyp 4096] [--estimator fixed|ransac|usac]
-//                    [--error-version 1] [--seed 45232] [--steps 20] [--warmup 5] [--repeats 5] [--chains 2] [--check]
+//                    [--error-version 1] [--seed 45232] [--steps 20] [--warmup 5] [--warm-seconds 1] [--repeats 5] [--chains 2] [--check]
 //   --sequence: int32 frames, int32 cap, int32 nkpts[frames], uint8 desc[frames][cap][32], float pts[frames][cap][3]
 //               (what bench.py writes for its own workload); otherwise a synthetic sequence is generated (synth_frames.h).
 //   --chains 1: the same loop through ONE context (ps_vo_pairs_device), for comparison.
@@ -74,6 +74,7 @@ int main(int argc, char **argv)
 {
     int frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 20, warmup = 5, repeats = 5, chains = 2;
     bool check = false;
+    double warmSeconds = 1.0;
     uint64_t seed = 0xB0B0;
     std::string estimator = "fixed", seqPath;
     for (int i = 1; i < argc; ++i) {
@@ -91,6 +92,7 @@ int main(int argc, char **argv)
         else if (a == "--repeats") repeats = std::atoi(next());
         else if (a == "--chains") chains = std::atoi(next());
         else if (a == "--check") check = true;
+        else if (a == "--warm-seconds") warmSeconds = std::atof(next());
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
@@ -193,7 +195,7 @@ int main(int argc, char **argv)
     PSCHK(fence());
     { // ... and until the chip has been busy for a second (clock ramp), whole steps, outside the timed regions
         const auto t0 = clk::now();
-        while (std::chrono::duration<double>(clk::now() - t0).count() < 1.0) {
+        while (std::chrono::duration<double>(clk::now() - t0).count() < warmSeconds) {
             for (int i = 0; i < 20; ++i) PSCHK(step());
             PSCHK(fence());
         }
