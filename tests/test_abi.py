@@ -157,3 +157,31 @@ def test_device_code_has_no_scratch_or_flat_instructions(tmp_path):
         sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
         assert len(sizes) >= 30 and len(sizes) <= len(names)
         assert all(v == 0 for v in sizes), [v for v in sizes if v]
+
+
+def test_library_sets_its_hardware_queue_default_when_loaded():
+    """csrc/ps_env.cpp: a constructor sets GPU_MAX_HW_QUEUES=16 when the library is loaded and the variable is unset -- before the
+    process' first HIP call for a program that links it --, never overrides a host's own value, and remembers what it found
+    (read-only option "hw_queues_seen"; ps_batch_queue_create warns when it is too small).  Checked in fresh processes that load
+    the library with plain ctypes (putslam_amd/_lib.py sets the variable itself at import, for processes whose torch is first)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "putslam_amd", "libputslam_hip.so")
+    code = ("import ctypes, os; L = ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+            "print(L.psi_hw_queues_seen(), L.psi_hw_queues_defaulted(), (g(b'GPU_MAX_HW_QUEUES') or b'').decode())" % lib)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["16", "1", "16"]
+    env["GPU_MAX_HW_QUEUES"] = "3"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split() == ["3", "0", "3"]
+
+
+def test_batch_queue_and_shard_entry_points_reject_nulls_without_a_gpu():
+    from putslam_amd import _lib
+    L = _lib.load()
+    q = ctypes.c_void_p()
+    assert L.ps_batch_queue_create(None, 2, ctypes.byref(q)) == -1 and not q.value       # PS_ERR_BAD_ARG: no parent context
+    assert L.ps_batch_queue_submit(None, None, None, None, None, None, 0, None, None) == -1
+    assert L.ps_batch_queue_wait(None, 0) == -1 and L.ps_batch_queue_query(None, 0) == -1
+    assert L.ps_batch_queue_chains(None) == -1 and not L.ps_batch_queue_context(None, 0)
+    L.ps_batch_queue_destroy(None)                                                       # (harmless)
+    assert L.ps_vo_stream_graph_launches(None) == -1 and L.ps_vo_stream_packed_stride(None) == 0
