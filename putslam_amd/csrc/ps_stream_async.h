@@ -103,6 +103,9 @@ struct PsVoAsync {
     std::vector<uint8_t *> stagePoolDev;  // device views of the staging areas (mini chunks read them from kernels)
     const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot (or in the caller's pinned memory)
     const uint8_t *inPlaceDev = nullptr;  // set for ONE mini_submit_body call: the chunk's frames lie in the caller's pinned memory
+    uint8_t *loneHost = nullptr, *loneDev = nullptr; // a lone first frame's own pinned block (it takes no place, so no staging area)
+    hipEvent_t loneReadEv = nullptr;      // behind the chunk that read that block as its previous frame
+    bool loneReadPending = false, haloIsLone = false;
     int haloNk = 0;
     std::vector<unsigned long long> laneWarmGen; // per lane: arena generation an un-captured full chunk has run with (0 = none)
     std::vector<uint8_t> viewBuf;         // pop_many's copy of a mini chunk's results (its place is free at once)
@@ -177,6 +180,8 @@ void async_free(PsVoAsync *a)
     }
     for (PsContext *c : a->laneCtx)
         if (c) ps_context_destroy(c);
+    if (a->loneHost) (void)hipHostFree(a->loneHost);
+    if (a->loneReadEv) (void)hipEventDestroy(a->loneReadEv);
     if (a->spareHres) (void)hipHostFree(a->spareHres);
     if (a->heldHres) (void)hipHostFree(a->heldHres);
     for (hipEvent_t e : a->upEv)
@@ -357,6 +362,7 @@ int async_abort_chunk(PsVoStream *s, int rc)
     PsContext *lc = a->laneCtx.empty() ? nullptr : a->laneCtx[(size_t)((a->mini ? (long long)a->tail : a->launchSeq) % (long long)a->lanes)];
     if (lc) (void)hipStreamSynchronize(lc->stream);
     a->haloDev = nullptr;
+    a->haloIsLone = false;
     if (a->copyOutStream) (void)hipStreamSynchronize(a->copyOutStream);
     (void)hipGetLastError();
     a->prevPos = -1;
@@ -447,19 +453,51 @@ int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
     PsContext *ctx = s->ctx;
     // the chunk's frames as the copy-in kernel sees them: the staging area they were collected in, or -- pinned packed frames
     // handed over by ps_vo_stream_push_many_packed (PsVoAsync::inPlaceDev) -- the caller's own memory, read in place
-    const uint8_t *hDev = a->inPlaceDev ? a->inPlaceDev : a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
+    const bool inPlace = a->inPlaceDev != nullptr;
+    const uint8_t *hDev = inPlace ? a->inPlaceDev : a->stagePoolDev[(size_t)(a->chunkSeq % (long long)a->stagePool.size())];
     a->inPlaceDev = nullptr;
-    a->chunkSeq++;
     const int first = a->prevPos >= 0 ? 0 : 1;
     const int P = n - first;
     const uint8_t *haloWas = a->haloDev;
     const int haloNkWas = a->haloNk;
-    // (the stream's latest frame from now on: the next chunk reads it from this staging slot, which is written again only
-    // lanes + ahead + 1 chunks later -- by then this chunk AND its successor have been popped)
+    const bool haloWasLone = a->haloIsLone;
+    if (P <= 0) {
+        // A lone first frame (the stream's first, or the first after a reset): nothing to run, no place taken -- and therefore no
+        // staging area either: the areas rotate with the LAUNCHED chunks, which is what makes their reuse safe (an area is written
+        // again lanes + ahead + 1 launched chunks later: by then its chunk AND the successor that reads its last frame as the
+        // previous one have been popped).  Round 6's first form let such a frame keep its area and advance the rotation: every
+        // reset moved the reuse one chunk closer, until a new frame could be staged over a frame an in-flight chunk had not read
+        // yet (found by the stream fuzz: 17 of 15 000 configurations, all with a reset and chunks of one or two frames).  The frame
+        // moves to a buffer of its own instead; that buffer is written again only after the chunk that read it has finished.
+        if (inPlace) {
+            a->haloDev = hDev; // (the caller's pinned memory: untouched until the pair it is the previous frame of has been popped)
+            a->haloIsLone = false;
+        } else {
+            if (!a->loneHost) {
+                PS_HIP(hipHostMalloc((void **)&a->loneHost, a->packStride, hipHostMallocDefault));
+                PS_HIP(hipHostGetDevicePointer((void **)&a->loneDev, a->loneHost, 0));
+                PS_HIP(hipEventCreateWithFlags(&a->loneReadEv, hipEventDisableTiming));
+            }
+            if (a->loneReadPending) {
+                PS_HIP(hipEventSynchronize(a->loneReadEv));
+                a->loneReadPending = false;
+            }
+            const size_t cap = (size_t)s->cap;
+            memcpy(a->loneHost, h, (size_t)nk[0] * 32);
+            memcpy(a->loneHost + cap * 32, h + cap * 32, (size_t)nk[0] * 12);
+            a->haloDev = a->loneDev;
+            a->haloIsLone = true;
+        }
+        a->haloNk = nk[0];
+        a->prevPos = 0;
+        return PS_OK;
+    }
+    a->chunkSeq++;
+    // (the stream's latest frame from now on: the next chunk reads it from this staging slot -- or from the caller's pinned block)
     a->haloDev = hDev + (size_t)(n - 1) * a->packStride;
     a->haloNk = nk[n - 1];
+    a->haloIsLone = false;
     a->prevPos = 0;
-    if (P <= 0) return PS_OK; // a lone first frame: nothing to run, no place taken
     const int place = a->tail;
     AsyncLane &l = a->lane[(size_t)place];
     const int laneIdx = place % a->lanes; // (fixed per place: the place's graph holds its lane's arena pointers)
@@ -562,6 +600,10 @@ int mini_submit_body(PsVoStream *s, uint8_t *h, const int32_t *nk, int n)
         return fail(ctx, PS_ERR_HIP, "pipelined chunk: injected failure behind the batched call (PS_STREAM_DIAG)");
 #endif
     PS_HIP(hipEventRecord(l.evDone, lc->stream));
+    if (haloWasLone && !first) { // this chunk read the lone-frame buffer as its previous frame: the buffer is free again behind it
+        PS_HIP(hipEventRecord(a->loneReadEv, lc->stream));
+        a->loneReadPending = true;
+    }
     a->dbgN++;
     l.state = 1;
     l.firstPair = a->pairCounter;

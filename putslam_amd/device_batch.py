@@ -72,6 +72,10 @@ class PairBatchDevice:
         self.mask = torch.zeros((P, cap), dtype=torch.uint8, device=self.device)
         self.pose = torch.zeros((P, 16), dtype=torch.float32, device=self.device)
         self.stats = torch.zeros((P, STATS_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        # torch fills the blocks on its current stream; the library's chains run on streams of their own that are NOT ordered with
+        # it (non-blocking streams): a fill still pending when a chain writes results would zero them afterwards (found by the queue
+        # fuzz on batches of three pairs).  The blocks are ready when the constructor returns.
+        torch.cuda.current_stream(self.device).synchronize()
 
     def view(self):
         return api.DeviceResults(self.matches.data_ptr(), self.num_matches.data_ptr(), self.mask.data_ptr(),

@@ -3,6 +3,8 @@
 The call shape is the reference's: one frame at a time, the previous frame kept as state (src/Matcher/matcher.cpp:452-516 in the
 loop of src/PUTSLAM/PUTSLAM.cpp:677-740).  Whatever the chunking, the results must be the bytes of ONE batched call over the
 sequence (pair k draws from seed + k), i.e. the oracle's vo_pairs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -348,6 +350,9 @@ def test_both_download_forms_in_a_process_with_sixteen_hardware_queues():
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 
 
+CHUNK_CHOICES = [int(x) for x in os.environ.get("PUTSLAM_FUZZ_CHUNKS", "1,2,3,5,8,16,33,64").split(",")]   # (targeted soaks: e.g. 1,2,4)
+
+
 def fuzz_stream(iters, seed, verbose=False):
     """Random sequences (ragged row counts, empty frames), schedules, metrics, chunk sizes, lane counts, push forms (in-place
     pinned / pageable / one frame at a time), resets and partial flushes through the pipelined stream, against ONE batched call
@@ -370,7 +375,7 @@ def fuzz_stream(iters, seed, verbose=False):
         est, H = [(EST_RANSAC, 487), (EST_USAC, int(rng.integers(300, 3000))), (EST_FIXED, int(rng.integers(257, 3000)))][int(rng.integers(0, 3))]
         prm = default_ransac_params(mode)
         cfg, _ = make_config(est, H, seed=int(rng.integers(0, 2 ** 40)))
-        chunk, lanes = int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64])), int(rng.integers(2, 7))
+        chunk, lanes = int(rng.choice(CHUNK_CHOICES)), int(rng.integers(2, 7))
         packed = bool(rng.random() < 0.5)        # PS_FRAMES_PACKED: ring and host frames as one block per frame, one upload per chunk
         # 0 pinned push_many, 1 pageable push_many, 2 push_async, 3 pinned push_many_packed, 4 pageable push_many_packed
         form = int(rng.integers(0, 5)) if packed else int(rng.integers(0, 3))
@@ -418,7 +423,8 @@ def fuzz_stream(iters, seed, verbose=False):
             except AssertionError as ex:
                 ok = False
                 if verbose:
-                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, ahead=ahead, form=form, packed=packed, cut=cut), repr(ex)[:300])
+                    print("MISMATCH", it, dict(F=F, cap=cap, mode=mode, est=est, H=H, chunk=chunk, lanes=lanes, ahead=ahead, form=form, packed=packed, cut=cut,
+                                               epoch=e, first_pair=b["first_pair"], count=b["count"]), repr(ex)[:300])
             got[e] += b["count"]
             return True
 
