@@ -666,8 +666,10 @@ int async_submit_body(PsVoStream *s, const uint8_t *desc, const float *pts, cons
     a->dbgT[0] += now() - t0;
     if (P <= 0) {
         // a lone first frame: nothing to run, no lane taken; its staging area (if it came through one) is reused by the
-        // next push, so the upload is waited for here
+        // next push, so the upload is waited for here -- and the areas' rotation does not advance: it follows the LAUNCHED chunks
+        // (an area is written again lanes + ahead + 1 launched chunks later, when its own chunk has been popped)
         PS_HIP(hipStreamSynchronize(a->copyStream));
+        a->chunkSeq--;
         return PS_OK;
     }
     a->pairCounter += P;
