@@ -180,6 +180,7 @@ int main(int argc, char **argv)
     for (Results &r : outs)
         if (alloc_results(P, cap, r)) return 2;
     long long submitted = 0;
+    HIPCHK(hipDeviceSynchronize()); // (the blocks' clearing was queued on the null stream; the queue's chains are not ordered with it)
 
     PsBatchQueue *q = nullptr;
     if (chains >= 2) PSCHK(ps_batch_queue_create(ctx, chains, &q));

@@ -136,6 +136,7 @@ int upload(const Sequence &s, int P, DeviceSide &d)
     d.out2.stats = (PsRansacStats *)((uint8_t *)d.out.stats + shift);
     d.out2.numMatches = (int32_t *)((uint8_t *)d.out.numMatches + shift);
     d.out2.inlierMask = d.out.inlierMask + shift;
+    HIPCHK(hipDeviceSynchronize()); // (the clearing above was queued on the null stream; the member's chains are not ordered with it)
     return 0;
 }
 
