@@ -218,9 +218,11 @@ int member_init(PsShardGroup *g, Member &mb)
 
 void start_workers(PsShardGroup *g)
 {
-    const char *force = std::getenv("PUTSLAM_SHARD_THREADS"); // (test hook: "1" = a thread even for a single member, "0" = never)
-    g->threaded = g->m.size() >= 2;
-    if (force) g->threaded = std::atoi(force) != 0;
+    // Two members or more: always threaded (one RCCL call per thread on that thread's communicator; a single thread issuing the
+    // members' collectives one after the other would need ncclGroupStart / End around them).  PUTSLAM_SHARD_THREADS=1 is a test
+    // hook: a worker thread for a single member too, so that the one-GPU boxes exercise the threaded path.
+    const char *force = std::getenv("PUTSLAM_SHARD_THREADS");
+    g->threaded = g->m.size() >= 2 || (force && std::atoi(force) != 0);
     if (!g->threaded) return;
     for (Member &mb : g->m) {
         mb.worker = new Worker();
