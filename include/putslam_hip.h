@@ -304,8 +304,9 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
  *   submit: arguments of ps_vo_pairs_device (device pointers); pair p draws from cfg->seed + p: the outputs are byte for byte
  *           those of ONE ps_vo_pairs_device call.  Returns at once; *ticket (may be NULL) names the batch.  Inputs and outputs
  *           must stay valid until the batch is complete.  Batches in flight run CONCURRENTLY: give consecutive batches output
- *           blocks of their own (`chains` blocks used in turn are enough: batch n + chains runs on batch n's chain, behind it);
- *           reading a batch's results needs its ticket waited for.  At most 64 batches are in flight: the 65th submit waits for
+ *           blocks of their own (`chains` blocks used in turn are enough: batch n + chains runs on batch n's chain, behind it).
+ *           A batch that is handed the block (out->pose) of a batch still in flight on another chain is queued behind that one on
+ *           its chain instead -- correct, and as fast as one context.  Reading a batch's results needs its ticket waited for.  At most 64 batches are in flight: the 65th submit waits for
  *           the first.  If the chain's call fails the error is returned (text: ps_last_error of ctx); the ticket still stands
  *           for whatever part of the batch was queued.
  *   wait / query: the host blocks until / asks whether that batch is complete (query: 1 complete, 0 not yet).

@@ -56,6 +56,10 @@ struct PsBatchQueue {
     Ticket ring[kTickets];
     long long next = 0;              // number of the next batch
     int32_t lastBounds[kMaxChains + 1] = {0, 0, 0, 0, 0};
+    // the output block (its pose array) and the number of the last whole batch every chain was given: a batch that writes the block
+    // of a batch still in flight on ANOTHER chain follows it on that chain instead of racing it
+    const void *lastOut[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+    long long lastSeq[kMaxChains] = {-1, -1, -1, -1};
 };
 
 namespace {
@@ -200,6 +204,29 @@ int ps_batch_queue_submit(PsBatchQueue *q, const PsRansacParams *params, const P
     }
     int32_t bounds[kMaxChains + 1];
     split(q, P, seq, bounds);
+    if (q->chains > 1 && P > 0 && P < q->splitFrom) {
+        // Whole batches run side by side on different chains, so two of them must not write the same output block.  A host that
+        // hands over the block of a batch that is still in flight on another chain gets stream order instead of a race: the new
+        // batch follows that one on ITS chain (and the pair run one after the other: blocks of their own, in turn, is how a
+        // host gets the queue's rate).
+        int mine = 0;
+        for (int i = 0; i < q->chains; ++i)
+            if (bounds[i + 1] > bounds[i]) mine = i;
+        for (int j = 0; j < q->chains; ++j) {
+            if (j == mine || q->lastOut[j] != (const void *)out->pose || q->lastSeq[j] < 0) continue;
+            Ticket &tj = q->ring[q->lastSeq[j] % kTickets];
+            if (tj.seq != q->lastSeq[j] || !tj.used[j]) continue; // (older than the ring: complete)
+            const hipError_t e = hipEventQuery(tj.ev[j]);
+            if (e == hipErrorNotReady) {
+                (void)hipGetLastError();
+                for (int i = 0; i <= q->chains; ++i) bounds[i] = i <= j ? 0 : P;
+                mine = j;
+                break;
+            }
+        }
+        q->lastOut[mine] = (const void *)out->pose;
+        q->lastSeq[mine] = seq;
+    }
     const size_t cap = (size_t)frames->maxKpts;
     bool used[kMaxChains] = {false, false, false, false};
     int rcAll = PS_OK;

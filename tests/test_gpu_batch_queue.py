@@ -99,6 +99,33 @@ def test_queue_many_batches_tickets_and_stream_wait(ctx, oracle):
     q.close()
 
 
+def test_batches_sharing_an_output_block_are_kept_in_order(ctx):
+    """Whole batches run side by side on different chains; a host that reuses ONE output block for consecutive batches (different
+    seeds: different results) must still find the LAST batch's results there -- the queue queues such a batch behind the one that
+    is in flight on the other chain instead of letting them race."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs, run_pairs_queue
+    seq = synth.make_sequence(40, 600, config=3, index=4711)
+    prm = default_ransac_params(REPROJECTION_ERROR)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    out = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    q = api.BatchQueue(ctx, 2)
+    for rnd in range(5):
+        chains_used = set()
+        for b in range(6):
+            cfg, _ = make_config(EST_FIXED, 1500, seed=50 + 10 * rnd + b)
+            t = run_pairs_queue(q, prm, cfg, TUM_FR1_K, fs, out)
+            sp = q.last_split()
+            chains_used.add([i for i in range(2) if sp[i + 1] > sp[i]][0])
+        q.wait(t)
+        assert q.query(t)
+        ref = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(ctx, prm, cfg, TUM_FR1_K, fs, ref)
+        _compare(out.download(), ref.download(), len(seq["pairs"]))
+        assert len(chains_used) == 1                      # back to back on one block: one chain
+        q.synchronize()
+    q.close()
+
+
 def test_queue_inherits_options_and_reports_errors(ctx):
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue
     c2 = api.Context(0)
