@@ -26,14 +26,21 @@ byq = collections.defaultdict(list)
 for e in ev:
     byq[e[3]].append(e)
 spans, gaps, kcount = [], [], []
+per = collections.OrderedDict()               # kernel name -> [durations], [gap in front of it]
+pos = {q: {id(e): n for n, e in enumerate(l)} for q, l in byq.items()}
 for i in sel:
     s0, e0, n0, q = ev[i]
     lst = byq[q]
-    j = lst.index(ev[i])
+    j = pos[q][id(ev[i])]
+    per.setdefault(n0, ([], []))[0].append((e0 - s0) / 1e3)
     k = j + 1
     last_end, prev_end, n = e0, e0, 1
     while k < len(lst) and not lst[k][2].startswith("ps_mini_copy_in"):
-        gaps.append((lst[k][0] - prev_end) / 1e3)
+        g = (lst[k][0] - prev_end) / 1e3
+        gaps.append(g)
+        d = per.setdefault(lst[k][2], ([], []))
+        d[0].append((lst[k][1] - lst[k][0]) / 1e3)
+        d[1].append(g)
         prev_end = lst[k][1]
         last_end = lst[k][1]
         n += 1
@@ -55,6 +62,8 @@ with open(out + "/summary.txt", "w") as f:
     f.write("graph replay %s: %d chunks analysed, %.1f kernels per chunk\n" % ("ON" if graph == "1" else "off", len(sel), sum(kcount) / len(kcount)))
     f.write("chunk span (copy-in start -> last kernel end): median %.1f us, p90 %.1f us\n" % (spans[len(spans) // 2], spans[int(len(spans) * 0.9)]))
     f.write("gap between consecutive kernels of a chunk: median %.1f us, p90 %.1f us\n" % (gaps[len(gaps) // 2], gaps[int(len(gaps) * 0.9)]))
+    for name, (du, ga) in per.items():
+        f.write("   %-42s runs %6.1f us (mean), starts %5.1f us after the kernel in front of it ends\n" % (name, sum(du) / len(du), (sum(ga) / len(ga)) if ga else 0.0))
     f.write("chip busy with some kernel %.1f %% of the window; kernels side by side %.2f on average; chunk rate %.0f /s\n"
             % (100.0 * union(win) / (w1 - w0), sum(e - s for s, e in win) / max(union(win), 1), len(sel) / ((w1 - w0) / 1e9)))
 print(open(out + "/summary.txt").read())
