@@ -150,7 +150,6 @@ struct Plan {
     int bailSlot = 0;       // ... for this kind of call (PsContext::bailKinds)
     int prefix = 0;     // 256 (fixed schedule) or 64 (adaptive schedules)
     int lastStage = 0;  // staged scoring: 1 = ONE stage after the prefix (adaptive schedules without reordering), else kStages
-    HostOut hostOut{};  // kernel 4 also writes the results to these (mapped pinned memory; the pipelined stream's small chunks)
 };
 
 int make_plan(PsContext *ctx, const PsRansacParams *prm, const PsRansacConfig *cfg, const float *K, int cap,
@@ -734,7 +733,7 @@ int run_ransac_stage(PsContext *ctx, const Plan &pl, int P, int cap, const PsDMa
                        dMatches, dNumMatches, matchStride, pl.ma, pl.sc, sa, (int32_t *)ctx->idxList.p, dPose,
                        dMask, dStats, ctx->stampsOn ? (unsigned long long *)ctx->stamps.p : (unsigned long long *)nullptr,
                        (pl.bailWatch && pl.reorder) ? (const unsigned *)ctx->bailCnt.p + 2 * pl.bailSlot : (const unsigned *)nullptr,
-                       (pl.bailWatch && pl.reorder) ? ctx->bailHostDev + 2 * pl.bailSlot : (unsigned *)nullptr, pl.hostOut);
+                       (pl.bailWatch && pl.reorder) ? ctx->bailHostDev + 2 * pl.bailSlot : (unsigned *)nullptr);
     tick(ctx, slot0 + 1, true);
     PS_HIP(hipGetLastError());
     return PS_OK;

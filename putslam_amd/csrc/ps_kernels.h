@@ -275,17 +275,6 @@ struct PrepArgs {
     int skipE, skipF;       // the reprojection kernels' record forms no launch of this call will read (RecPtrs::E / ::F)
 };
 
-// Optional second destination of kernel 4's outputs + the pair's matches: the device views of a mapped pinned host block laid out
-// like PsPairResults (all null: none).  Used by the pipelined stream's small chunks, which would otherwise pay a launch to copy
-// their results out.
-struct HostOut {
-    PsDMatch *matches;
-    uint8_t *mask;
-    float *pose;
-    PsRansacStats *stats;
-    int32_t *numMatches;
-};
-
 // Where kernel 2 puts the records of the depth-valid matches (scratch arena, [P][cap] each unless noted).
 struct RecPtrs {
     float4 *A;  // prev xyz + squared Euclid bound
@@ -1077,8 +1066,7 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
                                                           uint8_t *__restrict__ maskOut,
                                                           PsRansacStats *__restrict__ statsOut,
                                                           unsigned long long *__restrict__ stamps,
-                                                          const unsigned *__restrict__ bailDev, unsigned *__restrict__ bailHost,
-                                                          HostOut hc)
+                                                          const unsigned *__restrict__ bailDev, unsigned *__restrict__ bailHost)
 {
     phase_stamp(stamps, 4);
     // the staged scoring's "nothing to gain" counters (ps_stage_reorder) on their way to the host's policy: two plain stores
@@ -1433,25 +1421,8 @@ __global__ __launch_bounds__(BLOCK) void ps_select_refit(const float4 *__restric
         st.bestInlierRatio = ratioF;
         st.pointInlierRatio = (double)s_uniq[1] / (double)s_uniq[0];
         statsOut[p] = st;
-        if (hc.pose != nullptr) { // (small chunks of the pipelined stream: see below)
-            store_pose(hc.pose + (size_t)p * 16, out);
-            hc.stats[p] = st;
-            hc.numMatches[p] = nIn;
-        }
     }
     phase_stamp(stamps, 9); // (4) pointInlierRatio, pose and statistics stored
-    if (hc.pose != nullptr) {
-        // Small chunks of the pipelined stream (one to four frames, ps_stream_async.h): the pair's results go straight into the
-        // place's mapped pinned block -- the launch that used to copy them out was one of a chunk's seven, and at one frame per
-        // chunk the stream is bound by the host thread's launches (profiles/r06n).  Every cross-check match (written by kernel 2)
-        // and the mask (written above by whichever thread found an inlier) of this pair; posted writes over the link.
-        __syncthreads();
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(matches + (size_t)p * matchStride);
-        uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(hc.matches + (size_t)p * matchStride);
-        for (int i = tid; i < nIn; i += BLOCK) dst[i] = src[i];
-        uint8_t *__restrict__ hm = hc.mask + (size_t)p * matchStride;
-        for (int i = tid; i < nIn; i += BLOCK) hm[i] = mask[i];
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -100,7 +100,6 @@ struct PsVoAsync {
     // 25.1 k at 209 us with ordinary launches (demos/cpp/demo_latency (d), profiles/r06h/mini_chunks.txt).  PUTSLAM_HIP_STREAM_GRAPH=1
     // turns it on (tests run both).
     bool miniGraphs = false;
-    bool miniK4Out = true; // kernel 4 writes a small chunk's full results into the pinned block itself (PUTSLAM_HIP_STREAM_K4OUT=0: a copy launch)
     std::vector<uint8_t *> stagePoolDev;  // device views of the staging areas (mini chunks read them from kernels)
     const uint8_t *haloDev = nullptr;     // device view of the stream's latest frame in its staging slot (or in the caller's pinned memory)
     const uint8_t *inPlaceDev = nullptr;  // set for ONE mini_submit_body call: the chunk's frames lie in the caller's pinned memory
@@ -416,20 +415,9 @@ int mini_enqueue(PsVoStream *s, AsyncLane &l, PsContext *lc, const Plan &pl, int
     fs.descFrameStride = fs.ptsFrameStride = a->packStride;
     uint8_t *dres = (uint8_t *)l.res.p;
     int rc = run_match_stage(lc, fs, dm->pairs, P, true, pl.pa, (PsDMatch *)dres, (int32_t *)(dres + a->offNum), 0);
-    // (every match + mask + pose + stats wanted: kernel 4 writes them into the place's pinned block itself -- one launch less)
-    const bool k4out = a->resultMode == PS_RESULTS_FULL && a->miniK4Out;
-    Plan withOut;
-    if (k4out) {
-        withOut = pl;
-        withOut.hostOut.matches = (PsDMatch *)l.hresDev;
-        withOut.hostOut.mask = l.hresDev + a->offMask;
-        withOut.hostOut.pose = (float *)(l.hresDev + a->offPose);
-        withOut.hostOut.stats = (PsRansacStats *)(l.hresDev + a->offStats);
-        withOut.hostOut.numMatches = (int32_t *)(l.hresDev + a->offNum);
-    }
     if (rc == PS_OK)
-        rc = run_ransac_stage(lc, k4out ? withOut : pl, P, s->cap, (const PsDMatch *)dres, (const int32_t *)(dres + a->offNum), s->cap,
-                              (float *)(dres + a->offPose), dres + a->offMask, (PsRansacStats *)(dres + a->offStats), 2);
+        rc = run_ransac_stage(lc, pl, P, s->cap, (const PsDMatch *)dres, (const int32_t *)(dres + a->offNum), s->cap, (float *)(dres + a->offPose),
+                              dres + a->offMask, (PsRansacStats *)(dres + a->offStats), 2);
     if (rc != PS_OK) {
         ctx->err = std::string("pipelined chunk: ") + lc->err;
         return rc;
@@ -439,7 +427,7 @@ int mini_enqueue(PsVoStream *s, AsyncLane &l, PsContext *lc, const Plan &pl, int
                            (const int32_t *)(dres + a->offNum), (const uint8_t *)(dres + a->offMask), (const float *)(dres + a->offPose),
                            (const PsRansacStats *)(dres + a->offStats), s->cap, a->resultMode, (PsDMatch *)l.hresDev,
                            (float *)(l.hresDev + a->offPose), (PsRansacStats *)(l.hresDev + a->offStats), (int32_t *)(l.hresDev + a->offNum));
-    } else if (!k4out) {
+    } else {
         const size_t p = (size_t)P;
         CopySegs down{};
         const size_t off[5] = {0, a->offMask, a->offPose, a->offStats, a->offNum};
@@ -726,8 +714,6 @@ int async_build(PsVoStream *s)
         a->mini = a->B <= psdev::kMiniFrames && !(m && std::atoi(m) == 0);
         const char *g = std::getenv("PUTSLAM_HIP_STREAM_GRAPH");
         a->miniGraphs = g && std::atoi(g) != 0;
-        const char *k4 = std::getenv("PUTSLAM_HIP_STREAM_K4OUT");
-        a->miniK4Out = !(k4 && std::atoi(k4) == 0);
     }
     if (a->mini) {
         a->packed = true; // (the staging areas: one block per frame, as the copy-in kernel reads them)

@@ -539,7 +539,7 @@ def test_packed_frames_equal_batch_and_oracle(ctx, seq64, chunk, form):
 
 
 @pytest.mark.parametrize("chunk", [1, 2, 4])
-@pytest.mark.parametrize("form", ["graph", "no-graph", "ring", "copy-launch"])
+@pytest.mark.parametrize("form", ["graph", "no-graph", "ring"])
 @pytest.mark.parametrize("results", [0, 1, 2])
 def test_small_chunks_equal_batch_and_oracle(ctx, seq64, chunk, form, results, monkeypatch):
     """chunks of one to four frames (one = the reference's own call shape, matcher.cpp:452-516) with a
@@ -551,8 +551,6 @@ def test_small_chunks_equal_batch_and_oracle(ctx, seq64, chunk, form, results, m
     monkeypatch.setenv("PUTSLAM_HIP_NO_GRAPH", "1" if form == "no-graph" else "0")
     monkeypatch.setenv("PUTSLAM_HIP_STREAM_GRAPH", "1" if form == "graph" else "0")    # (off by default: slower on this runtime, profiles/r06h)
     monkeypatch.setenv("PUTSLAM_HIP_STREAM_MINI", "0" if form == "ring" else "1")
-    # (default: kernel 4 writes a chunk's full results into the pinned block itself; "copy-launch" = a launch of its own does)
-    monkeypatch.setenv("PUTSLAM_HIP_STREAM_K4OUT", "0" if form == "copy-launch" else "1")
     seq, runs = seq64
     prm, cfg, c = runs["e1"]
     F, cap = seq["desc"].shape[:2]
