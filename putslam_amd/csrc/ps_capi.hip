@@ -1255,6 +1255,15 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_pairs_device: bad frame set");
     if (!out->matches || !out->numMatches || !out->inlierMask || !out->pose || !out->stats)
         return fail(ctx, PS_ERR_BAD_ARG, "ps_vo_pairs_device: null output");
+    {
+        // (frame strides are checked here, before anything is planned or allocated; run_match_stage checks them again for its
+        // other callers)
+        const size_t ds = frames->descFrameStride ? frames->descFrameStride : (size_t)frames->maxKpts * 32;
+        const size_t ps = frames->ptsFrameStride ? frames->ptsFrameStride : (size_t)frames->maxKpts * 12;
+        if ((ds & 15) != 0 || ds < (size_t)frames->maxKpts * 32 || (ps & 3) != 0 || ps < (size_t)frames->maxKpts * 12 || ((uintptr_t)frames->desc & 15) != 0)
+            return fail(ctx, PS_ERR_BAD_ARG, "frame set: descFrameStride must be a multiple of 16 and >= maxKpts x 32 (desc 16-byte aligned), "
+                                             "ptsFrameStride a multiple of 4 and >= maxKpts x 12");
+    }
     if (cfg && cfg->sampleIdx) return fail(ctx, PS_ERR_BAD_ARG, "explicit sample streams are per call, not per batch");
     const int cap = frames->maxKpts;
     Plan pl;
