@@ -2,10 +2,10 @@
 # rocprofv3 evidence for BASELINE configs[4] (8 pairs x 5000 keypoints x H = 100 000, fixed schedule; the loop
 # of reference src/TransformEst/RANSAC.cpp:87-150) at the current library: for each error version a kernel trace + stats pass
 # and the two HBM traffic passes (FETCH_SIZE / WRITE_SIZE, separate, as MI355X_MICROARCH.md prescribes).  One launch chain,
-# Python submission (every kernel alone on the chip).  usage (GPU box, repo root): bash profiles/run_stress_profiles.sh r06s
+# Python submission (every kernel alone on the chip).  usage (GPU box, repo root): bash profiles/run_stress_profiles.sh r06t
 # Then, here: python profiles/summarize.py <tag>_E0 9x5000xH100000xE0xfixedxmfmaxfast ; the same for E1.
 set -u
-TAG=${1:-r06s}
+TAG=${1:-r06t}
 export GPU_MAX_HW_QUEUES=16
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for E in 0 1; do
