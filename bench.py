@@ -683,6 +683,23 @@ def main():
                                                         "note": "SQ_INSTS_VALU of the profiled run / this run's duration"}
             except Exception:
                 pass
+        # What the step needs of the chip's ISSUE capacity -- the unit that binds it: busy SIMD-cycles of the
+        # profiled run (4 cycles per vector wave-instruction, SQ_ACTIVE_INST_VALU, + the matrix pipe's busy cycles, which add up
+        # on gfx950) over 1024 SIMDs at 2.4 GHz, against THIS run's time per step
+        issue = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{args.frames}x{args.kpts}xH{args.hyp}xE{args.error_version}x{args.estimator}x{matcher}x{score}"
+            sqp = os.path.join(ROOT, os.path.dirname(t[key]["_source"]), "sq_counters.json")
+            sq = json.load(open(sqp))
+            busy = sum(4.0 * float(c.get("SQ_ACTIVE_INST_VALU", 0.0)) + float(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)) for c in sq.values())
+            floor_ms = busy / (1024.0 * 2.4e9) * 1e3
+            step_ms = elapsed / args.steps * 1e3
+            issue = {"bound": "issue (vector + matrix pipe, 1024 SIMDs x 2.4 GHz)", "busy_simd_cycles_per_step": busy,
+                     "ms_per_step_at_full_issue": floor_ms, "ms_per_step": step_ms, "frac": floor_ms / step_ms,
+                     "source": os.path.relpath(sqp, ROOT) + " (profiled single-chain run of the same workload, not this one)"}
+        except Exception:
+            pass
         out = {
             "metric": "frame-pairs/s (match+RANSAC+Kabsch), 640x480 @ 2000 kpts",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -726,6 +743,7 @@ def main():
                                  "region: the kernel alone on the chip" if solo else "timed region"),
                          "bound_actual": bounds_solo.get(dom, {}).get("bound"),
                          "bound_actual_frac": bounds_solo.get(dom, {}).get("frac"),
+                         "issue": issue,
                          "note": "the path is compute-bound (VALU issue for the scoring sweep, MFMA for the Hamming "
                                  "sweep), not HBM-bound: see kernel_bounds"},
             "kernel_ms": rk,
