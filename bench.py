@@ -15,8 +15,8 @@ pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypothes
 thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
 72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
 
-Submission: every step is ONE ps_batch_queue_submit (include/putslam_hip.h): the library owns --streams launch chains (default 2:
-contexts + HIP streams) and hands the steps' batches to them in turn, whole -- consecutive steps run side by side (one chain's
+Submission: every step is ONE ps_batch_queue_submit (include/putslam_hip.h): the library owns --streams launch chains (default 4:
+contexts + HIP streams; 2 read 601 k, 3 and 4 609 - 610 k, profiles/r06u) and hands the steps' batches to them in turn, whole -- consecutive steps run side by side (one chain's
 matrix-core Hamming sweep beside the other's vector scoring stages) and write output blocks of their own; nothing joins the
 chains, every step is complete at the closing barrier + synchronize that brackets the timed region.  (Rounds 3 - 5 split every
 step's pairs 45 % / 55 % over two contexts from here: --submit python, or PUTSLAM_HIP_QUEUE_SPLIT_FROM=20 for the same inside the
@@ -108,7 +108,7 @@ def parse():
     ap.add_argument("--preset", default=None, choices=["demoMatching", "sequence", "stress"],
                     help="BASELINE configs: demoMatching = configs[1] (one pair per step), sequence = configs[2] "
                          "(default), stress = configs[4] (5000 kpts, H = 100000, 8 pairs per step)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="sub-batch chains of the step, one HIP stream and one context (scratch arena) each; with "
                          "--join end they run freely, so one chain's popcount sweep overlaps another's scoring sweep")
     ap.add_argument("--join", default="end", choices=["step", "end"],
@@ -275,7 +275,7 @@ def main():
     # The submission of the timed region: a PsBatchQueue of S chains -- the library owns contexts and streams and hands the steps'
     # batches to the chains in turn, whole (consecutive steps run side by side and write output blocks of their own) --, unless an
     # experiment asks for something the queue does not do.
-    use_queue = (args.submit == "queue" and not args.cuts and args.join == "end" and S <= 4 and (S != 2 or abs(args.split - 0.45) < 1e-9)
+    use_queue = (args.submit == "queue" and not args.cuts and args.join == "end" and S <= 8 and (S != 2 or abs(args.split - 0.45) < 1e-9)
                  and not shard_seq)
     queue = None
     if use_queue:
@@ -1029,18 +1029,18 @@ def native_legs(args, seq, cfg):
         steps = str(max(10, args.steps))
         exe = os.path.join(ROOT, "demos", "cpp", "demo_batch_queue")
         if os.path.exists(exe):
-            for name, chains in (("batch_queue_cpp", 2), ("batch_queue_cpp/one_context", 1)):
+            for name, chains in (("batch_queue_cpp", max(2, args.streams)), ("batch_queue_cpp/one_context", 1)):
                 p = subprocess.run([exe, "--sequence", path, "--seed", str(cfg.seed), "--steps", steps, "--repeats", "5", "--warm-seconds", "0.6", "--chains", str(chains)]
-                                   + common + (["--check"] if chains == 2 else []), capture_output=True, text=True, timeout=180, env=env)
+                                   + common + (["--check"] if chains >= 2 else []), capture_output=True, text=True, timeout=180, env=env)
                 m = re.search(r"batch_queue: chains (\d+), median ([0-9.]+) frame-pairs/s, min ([0-9.]+), max ([0-9.]+).*hw_queues_seen (\d+) \(GPU_MAX_HW_QUEUES=([^)]*)\)", p.stdout)
                 leg = {"rc": p.returncode, "what": ("demos/cpp/demo_batch_queue: a C++ loop of ps_batch_queue_submit calls over the timed workload's "
-                                                     "sequence, GPU_MAX_HW_QUEUES unset in its environment" if chains == 2 else
+                                                     "sequence, GPU_MAX_HW_QUEUES unset in its environment" if chains >= 2 else
                                                      "the same loop through ONE context (ps_vo_pairs_device)")}
                 if m:
                     leg.update({"chains": int(m.group(1)), "pairs_per_s": float(m.group(2)), "pairs_per_s_min": float(m.group(3)),
                                 "pairs_per_s_max": float(m.group(4)), "hw_queues_seen": int(m.group(5)), "env_GPU_MAX_HW_QUEUES_after_load": m.group(6),
                                 "steps": int(steps), "regions": 5})
-                    if chains == 2:
+                    if chains >= 2:
                         leg["equals_one_call"] = "check against one ps_vo_pairs_device call: equal" in p.stdout
                 else:
                     leg["error"] = (p.stdout + p.stderr)[-400:]
@@ -1129,12 +1129,13 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None, queue=None):
         if ctxs is not None and len(ctxs) >= 2 and P >= 4:
             # the same 8 pairs submitted like the timed region: two unequal chains (3 + 5 pairs) that are never joined
             b2 = [0, max(1, int(P * 0.45)), P]
-            pbq = [pb, PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev))]
+            nq = len(ctxs) if queue is not None else 2
+            pbq = [pb] + [PairBatchDevice(seq["pairs"], fs.max_kpts, device=str(dev)) for _ in range(nq - 1)]
             turn = [0]
 
             def chains_step():
-                if queue is not None and len(ctxs) == 2:   # like the timed region: whole batches to the library's two chains in turn
-                    run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, pbq[turn[0] % 2])
+                if queue is not None:   # like the timed region: whole batches to the library's chains in turn, an output block each
+                    run_pairs_queue(queue, prm, cfg, TUM_FR1_K, fs, pbq[turn[0] % nq])
                     turn[0] += 1
                 else:
                     run_pairs_split(ctxs[:2], chains[:2], prm, EST_FIXED, hyp, cfg.seed, TUM_FR1_K, fs, pb, bounds=b2, join=False)
@@ -1147,7 +1148,7 @@ def stress_legs(args, api, c0, chain, dev, ctxs=None, chains=None, queue=None):
                 chains_step()
             torch.cuda.synchronize(dev)
             cms = (time.perf_counter() - tc) / n * 1e3
-            out["stress/E%d" % ev]["chains"] = {"streams": 2, "submit": ("queue: whole batches in turn" if queue is not None and len(ctxs) == 2 else "split %r" % (b2,)), "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
+            out["stress/E%d" % ev]["chains"] = {"streams": nq, "submit": ("queue: whole batches in turn" if queue is not None else "split %r" % (b2,)), "ms_per_step": cms, "pairs_per_s": P / (cms * 1e-3), "steps": n}
     return out
 
 

@@ -1,11 +1,11 @@
 // demo_batch_queue.cpp -- what a C / C++ host that loops over batches gets from the library: BASELINE configs[2]'s 499 frame
 // pairs (a 500-frame sequence resident in HBM) handed over again and again through a PsBatchQueue (include/putslam_hip.h: batches
-// go to its two launch chains in turn; consecutive batches write output blocks of their own) --
+// go to its launch chains in turn; consecutive batches write output blocks of their own) --
 // the call shape of the reference's tracking loop around Matcher::match (src/PUTSLAM/PUTSLAM.cpp:677-740,
 // src/Matcher/matcher.cpp:470-515), batched.  No Python, no torch, GPU_MAX_HW_QUEUES left to the library.
 //
 //   demo_batch_queue [--sequence f.bin] [--frames 500] [--kpts 2000] [--hyp 4096] [--estimator fixed|ransac|usac]
-//                    [--error-version 1] [--seed 45232] [--steps 20] [--warmup 5] [--warm-seconds 1] [--repeats 5] [--chains 2] [--check]
+//                    [--error-version 1] [--seed 45232] [--steps 20] [--warmup 5] [--warm-seconds 1] [--repeats 5] [--chains 4] [--check]
 //   --sequence: int32 frames, int32 cap, int32 nkpts[frames], uint8 desc[frames][cap][32], float pts[frames][cap][3]
 //               (what bench.py writes for its own workload); otherwise a synthetic sequence is generated (synth_frames.h).
 //   --chains 1: the same loop through ONE context (ps_vo_pairs_device), for comparison.
@@ -72,7 +72,7 @@ int alloc_results(int P, int cap, Results &r)
 
 int main(int argc, char **argv)
 {
-    int frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 20, warmup = 5, repeats = 5, chains = 2;
+    int frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 20, warmup = 5, repeats = 5, chains = 4;
     bool check = false;
     double warmSeconds = 1.0;
     uint64_t seed = 0xB0B0;

@@ -296,7 +296,7 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
 /* ---- A2, for a host that loops over batches (the loop of src/PUTSLAM/PUTSLAM.cpp:677-740 around Matcher::match,
  * src/Matcher/matcher.cpp:470-515): ps_vo_pairs_device through launch chains that are never joined.
  * One context is one launch chain: a batch's matrix-core Hamming sweep, then its vector scoring stages, dependent launches with
- * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = 2; 1 .. 4) on ctx's device, with ctx's
+ * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = 2; 1 .. PS_BATCH_QUEUE_MAX_CHAINS) on ctx's device, with ctx's
  * options, and hands batch n to chain n mod chains, WHOLE: consecutive batches run side by side, one in its Hamming sweep while
  * the other scores -- 608 k instead of 517 k frame-pairs/s on batches of 499 pairs, + 18 ... 47 % on smaller ones (round 6's
  * measurement; splitting every batch over the chains, rounds 3 - 5's recipe, gave 559 k: profiles/r06h/queue_split_vs_turns.txt).
@@ -322,6 +322,7 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
  * a host that set the variable keeps its value).  Read-only option "hw_queues_seen" = the value found; ps_batch_queue_create
  * leaves a warning in ps_last_error(ctx) when it is too small.  A process that initialises HIP before loading the library sets
  * the variable itself (putslam_amd/_lib.py does). */
+#define PS_BATCH_QUEUE_MAX_CHAINS 8
 typedef struct PsBatchQueue PsBatchQueue;
 int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out);
 void ps_batch_queue_destroy(PsBatchQueue *q);

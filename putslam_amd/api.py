@@ -291,8 +291,8 @@ class _ChainContext(Context):
 
 
 class BatchQueue:
-    """PsBatchQueue: ps_vo_pairs_device through launch chains that are never joined (two chains, whole batches in turn:
-    consecutive batches run side by side and need output blocks of their own)."""
+    """PsBatchQueue: ps_vo_pairs_device through launch chains that are never joined (chains = 0: the library's default, four;
+    whole batches in turn: consecutive batches run side by side and need output blocks of their own, `chains` of them in turn)."""
 
     def __init__(self, ctx: Context, chains=0):
         self._ctx = ctx

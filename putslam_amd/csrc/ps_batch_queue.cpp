@@ -34,14 +34,15 @@
 
 namespace {
 
-constexpr int kMaxChains = 4;
+constexpr int kMaxChains = PS_BATCH_QUEUE_MAX_CHAINS;
+constexpr int kDefaultChains = 4; // (profiles/r06u/small_batch_chains.txt: the best count at every batch size tried)
 constexpr int kTickets = 64;      // batches that can be in flight; submit waits for the oldest when the ring is full
 constexpr int kSplitFromPairs = 0x7fffffff; // (never: whole batches, the chains in turn; PUTSLAM_HIP_QUEUE_SPLIT_FROM overrides)
 
 struct Ticket {
     long long seq = -1;              // batch number this slot holds (-1: never used)
-    bool used[kMaxChains] = {false, false, false, false};
-    hipEvent_t ev[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[kMaxChains] = {};
+    hipEvent_t ev[kMaxChains] = {};
 };
 
 } // namespace
@@ -52,14 +53,18 @@ struct PsBatchQueue {
     int chains = 0;
     int splitPermille = 450;         // two chains: share of the pairs on chain 0
     int splitFrom = kSplitFromPairs; // batches of fewer pairs go to the chains in turn, whole
-    PsContext *ctx[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
+    PsContext *ctx[kMaxChains] = {};
     Ticket ring[kTickets];
     long long next = 0;              // number of the next batch
-    int32_t lastBounds[kMaxChains + 1] = {0, 0, 0, 0, 0};
+    int32_t lastBounds[kMaxChains + 1] = {};
     // the output block (its pose array) and the number of the last whole batch every chain was given: a batch that writes the block
     // of a batch still in flight on ANOTHER chain follows it on that chain instead of racing it
-    const void *lastOut[kMaxChains] = {nullptr, nullptr, nullptr, nullptr};
-    long long lastSeq[kMaxChains] = {-1, -1, -1, -1};
+    const void *lastOut[kMaxChains] = {};
+    long long lastSeq[kMaxChains];
+    PsBatchQueue()
+    {
+        for (long long &x : lastSeq) x = -1;
+    }
 };
 
 namespace {
@@ -112,9 +117,9 @@ int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out)
     if (!out) return PS_ERR_BAD_ARG;
     *out = nullptr;
     if (!ctx) return PS_ERR_BAD_ARG;
-    if (chains == 0) chains = 2;
+    if (chains == 0) chains = kDefaultChains;
     if (chains < 1 || chains > kMaxChains) {
-        psi_set_error(ctx, "ps_batch_queue_create: chains 1 .. 4 (0 = 2)");
+        psi_set_error(ctx, "ps_batch_queue_create: chains 1 .. 8 (0 = 2)");
         return PS_ERR_BAD_ARG;
     }
     PsBatchQueue *q = new PsBatchQueue();
@@ -138,6 +143,8 @@ int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out)
             return rc;
         }
         psi_copy_options(q->ctx[i], ctx);
+        // batches on different chains overlap: the staged scoring pays from far smaller batches on (prepare_score)
+        if (chains > 1 && ps_context_get_option(q->ctx[i], "side_by_side") < chains) (void)ps_context_set_option(q->ctx[i], "side_by_side", chains);
     }
     if (hipSetDevice(q->device) != hipSuccess) {
         ps_batch_queue_destroy(q);
@@ -228,7 +235,7 @@ int ps_batch_queue_submit(PsBatchQueue *q, const PsRansacParams *params, const P
         q->lastSeq[mine] = seq;
     }
     const size_t cap = (size_t)frames->maxKpts;
-    bool used[kMaxChains] = {false, false, false, false};
+    bool used[kMaxChains] = {};
     int rcAll = PS_OK;
     for (int i = 0; i < q->chains; ++i) {
         const int lo = bounds[i], hi = bounds[i + 1];

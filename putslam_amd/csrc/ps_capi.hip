@@ -38,6 +38,13 @@ struct StagedFrom {
 };
 constexpr StagedFrom kStagedFromEuclidFixed = {7.8e5, 250.0}, kStagedFromReprojFixed = {1.3e6, 500.0},
                      kStagedFromEuclidAdaptive = {6.0e4, 0.0}, kStagedFromReprojAdaptive = {4.5e4, 0.0};
+// ... and where it does when the context is one of several launch chains that run side by side (option "side_by_side": the
+// chains of a PsBatchQueue, the lanes of the pipelined stream): the other chains' kernels fill the gaps between the staged form's
+// dependent, chip-underfilling launches, so what is left of its price is the work of the extra launches -- the crossover lies
+// 3 - 9 times lower (profiles/r06u/concurrent_crossover.txt: four chains, 500 ... 4000 keypoints x H = 1024 ... 16384 x 2 ... 64
+// pairs; batches of 16 / 32 / 64 pairs of the bench workload's shape gain 1.25 / 1.65 / 2.0 x)
+constexpr StagedFrom kStagedFromEuclidFixedSbs = {2.5e5, 50.0}, kStagedFromReprojFixedSbs = {2.0e5, 75.0},
+                     kStagedFromEuclidAdaptiveSbs = {2.4e4, 0.0}, kStagedFromReprojAdaptiveSbs = {2.4e4, 0.0};
 } // namespace
 
 namespace {
@@ -334,7 +341,14 @@ int prepare_score(PsContext *ctx, Plan &pl, int P, int cap, bool complete = fals
     const double units = (double)P * (double)(hb - 1) * (double)cap;
     const StagedFrom sf = with_euclid_fast(ctx, pl.mode) ? (pl.sa.estimator == PS_EST_FIXED ? kStagedFromEuclidFixed : kStagedFromEuclidAdaptive)
                                                          : (pl.sa.estimator == PS_EST_FIXED ? kStagedFromReprojFixed : kStagedFromReprojAdaptive);
-    const double stagedFrom = sf.base + sf.perRow * (double)cap;
+    double stagedFrom = sf.base + sf.perRow * (double)cap;
+    if (ctx->sideBySide >= 2) {
+        const StagedFrom sb = with_euclid_fast(ctx, pl.mode) ? (pl.sa.estimator == PS_EST_FIXED ? kStagedFromEuclidFixedSbs : kStagedFromEuclidAdaptiveSbs)
+                                                             : (pl.sa.estimator == PS_EST_FIXED ? kStagedFromReprojFixedSbs : kStagedFromReprojAdaptiveSbs);
+        const double sbs = sb.base + sb.perRow * (double)cap;
+        // (two chains hide half of one another's gaps: half way between the two crossovers, on the logarithmic scale)
+        stagedFrom = ctx->sideBySide >= 3 ? sbs : std::sqrt(sbs * stagedFrom);
+    }
     pl.prune = !complete && ctx->prune != 0 && prunable && H > kPrefixFixed && (ctx->prune == 2 || units >= stagedFrom);
     pl.bailWatch = false;
     pl.bailSlot = 0;

@@ -144,6 +144,7 @@ const OptDesc kOptions[] = {
     {"score", "SCORE", &PsContext::scoreFast, 0, 1, "score: 0 (value-exact kernels) or 1 (decision-exact kernels)"},
     {"score_stats", nullptr, &PsContext::scoreStats, 0, 1, "score_stats: 0 or 1"},
     {"prune", "PRUNE", &PsContext::prune, 0, 2, "prune: 0 (complete scoring), 1 (staged from the cost model's batch size on) or 2 (staged whenever possible)"},
+    {"side_by_side", "SIDE_BY_SIDE", &PsContext::sideBySide, 0, 16, "side_by_side: 0 (the context runs alone) or the number of launch chains it shares the chip with"},
     {"reorder", "REORDER", &PsContext::reorder, 0, 2, "reorder: 0, 1 or 2"},
     {"qsplit", "QSPLIT", &PsContext::forceQsplit, 0, 1024, "qsplit: 0 (automatic) .. 1024", true},
     {"msplit", "MSPLIT", &PsContext::forceMsplit, 0, 1024, "msplit: 0 (automatic) .. 1024", true},

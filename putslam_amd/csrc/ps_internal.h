@@ -80,6 +80,10 @@ struct PsContext {
     // pruned scoring (ps_score_euclid.h): 1 = large batches score the first 256 hypotheses of every pair completely and
     // abandon later hypotheses that cannot become records (default), 0 = every hypothesis is scored completely
     int prune = 1;
+    // launch chains that run side by side with this one (option "side_by_side"; 0 = the context runs alone): a PsBatchQueue and
+    // the pipelined stream set it on their private contexts.  Chains that overlap hide one another's launch gaps, so the staged
+    // scoring's dependent launches cost throughput next to nothing and its crossover lies at far smaller batches (prepare_score)
+    int sideBySide = 0;
     // staged scoring: stages 1+ sweep the matches in the order ps_stage_reorder writes (those the prefix's best hypotheses
     // reject first: hypotheses end sooner, ps_score_fast.h).  1 = always, 0 = never (original order), 2 (default) = for the
     // fixed schedule only: under the adaptive schedules the trip limit usually ends the scoring inside the prefix, and the

@@ -35,7 +35,7 @@ static_assert(PS_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
 namespace {
 
 constexpr int kSlots = PS_SHARD_GATHERS_IN_FLIGHT;
-constexpr int kMaxChains = 4;
+constexpr int kMaxChains = PS_BATCH_QUEUE_MAX_CHAINS;
 constexpr int kProducers = kMaxChains + 1; // the queue's chains + the member's own context stream (the blocking form)
 
 struct Slot { // the buffers of one gather on one member

@@ -748,6 +748,10 @@ int async_build(PsVoStream *s)
             return fail(ctx, rc, "ps_vo_stream_configure_async: lane context");
         }
         psi_copy_options(c, ctx); // the lanes run what the stream's context would
+        // Chunks on different lanes overlap, so the staged scoring pays from smaller batches on (prepare_score) -- from chunks of
+        // 48 frames on: below, a chunk's extra launches cost more than its abandoned evaluations save (chunks of 32 / 64 frames on
+        // three lanes, E1 / fixed / H = 4096: complete 204 k / 251 k, staged 156 k / 301 k frame-pairs/s, profiles/r06u/stream_small_chunks.txt)
+        if (a->lanes > 1 && B >= 48 && c->sideBySide < a->lanes) c->sideBySide = a->lanes;
     }
     a->lane.resize((size_t)(a->lanes + a->ahead));
     const size_t metaBytes = std::max(((size_t)2 * B + a->ringFrames) * sizeof(int32_t), sizeof(psdev::MiniMeta));

@@ -192,12 +192,12 @@ def test_staged_twins_equal_complete(twin, case):
 
 def test_option_names_and_ranges():
     c = api.Context(0)
-    for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "reorder", "bail", "stamps", "stream_copy_kernels",
+    for name in ("matcher", "matcher_fused", "score", "score_stats", "prune", "side_by_side", "reorder", "bail", "stamps", "stream_copy_kernels",
                  "model_room_mib") + tuple("debug." + k for k in SHAPE_KNOBS):
         v = c.get_option(name)
         c.set_option(name, v)   # every default is a legal value
     for name, bad in (("debug.prefix", 100), ("debug.prefix", 320), ("debug.list_g2", 65), ("debug.reorder_top", 17), ("prune", 3),
-                      ("no_such_option", 0), ("list_g2", 4), ("msplit", 0), ("debug.prune", 1)) + \
+                      ("side_by_side", 17), ("side_by_side", -1), ("no_such_option", 0), ("list_g2", 4), ("msplit", 0), ("debug.prune", 1)) + \
             tuple(("debug." + k, 4) for k in RETIRED_KNOBS):   # (the two families do not answer to each other's names; retired knobs are gone)
         with pytest.raises(api.PsError):
             c.set_option(name, bad)
@@ -465,3 +465,50 @@ def test_cost_model_picks_the_form_by_batch_size_and_both_forms_agree(mode, est,
         assert (c.get_option("last_staged_pairs") > 0) == expect_staged, (P, c.get_option("last_staged_pairs"))
         c.close()
         _same(g, _run(seq, prm, cfg, 0 if expect_staged else 1), P)
+
+
+@pytest.mark.parametrize("mode,est,H,kpts,sbs,below,above", [
+    # a context that shares the chip with other launch chains (option "side_by_side": the chains of a PsBatchQueue, the lanes of
+    # the pipelined stream) takes the staged form from far smaller batches on (ps_capi.hip: kStagedFrom*Sbs); with TWO chains the
+    # point lies half way, on the logarithmic scale
+    (EUCLIDEAN_ERROR, EST_FIXED, 4096, 500, 4, 30, 44),      # 2.5e5 + 50 x 500 = 2.75e5: 37 pairs (alone: 121)
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 4, 32, 46),   # 2.0e5 + 75 x 400 = 2.3e5: 39 pairs (alone: 250)
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 2, 85, 112),  # sqrt(2.3e5 x 1.5e6) = 5.87e5: 98 pairs
+    (EUCLIDEAN_ERROR, EST_RANSAC, 1157, 300, 3, 14, 26),     # 2.4e4: 20 pairs (hb - 1 = 4; alone: 50)
+])
+def test_cost_model_side_by_side_takes_the_staged_form_earlier(mode, est, H, kpts, sbs, below, above):
+    """Round 6: chains that run side by side hide one another's launch gaps, so the staged form's dependent launches cost throughput
+    little and it pays from 3 - 9 times smaller batches on (profiles/r06u/concurrent_crossover.txt).  The form taken just below /
+    just above the point is the predicted one, a lone context still takes complete scoring there, and the outputs are those of the
+    other form."""
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    prm = default_ransac_params(mode, lc=(H == 1157))
+    cfg, _ = make_config(est, H, seed=6160)
+    for P, expect_staged in ((below, False), (above, True)):
+        seq = synth.make_sequence(P + 1, kpts, config=3, index=9900 + P, inlier_frac=0.6, noise=0.005)
+        fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        c = api.Context(0)
+        c.set_option("side_by_side", sbs)
+        pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        g = pb.download()
+        assert (c.get_option("last_staged_pairs") > 0) == expect_staged, (P, c.get_option("last_staged_pairs"))
+        c.set_option("side_by_side", 0)
+        run_pairs(c, prm, cfg, TUM_FR1_K, fs, pb)
+        pb.download()
+        assert c.get_option("last_staged_pairs") == 0, P     # alone: complete scoring on either side of this point
+        c.close()
+        _same(g, _run(seq, prm, cfg, 0 if expect_staged else 2), P)
+
+
+def test_queue_chains_know_they_run_side_by_side():
+    """The chains of a PsBatchQueue carry side_by_side = their number (the parent's options otherwise), a queue of one chain does not."""
+    c = api.Context(0)
+    q = api.BatchQueue(c, 0)
+    assert q.chains == 4                                    # the library's default (profiles/r06u/small_batch_chains.txt)
+    assert [x.get_option("side_by_side") for x in q.contexts] == [4] * 4 and c.get_option("side_by_side") == 0
+    q.close()
+    q = api.BatchQueue(c, 1)
+    assert q.contexts[0].get_option("side_by_side") == 0
+    q.close()
+    c.close()
