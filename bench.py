@@ -530,7 +530,11 @@ def main():
         # ---- BASELINE configs[2] as written: the 500 frames STREAMED (frames start in pinned HOST memory, every step uploads
         # all of them and downloads every pair's matches / mask / pose / stats), ps_vo_stream_push_many + pop_many
         try:
-            other_modes.update(streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev))
+            # (a context of its own: c0 is a chain of the queue and carries the queue's side_by_side option, which the stream's
+            # lanes would inherit)
+            sctx = api.Context(dev.index)
+            other_modes.update(streamed_legs(args, api, sctx, seq, prm, est, cfg, res, dev))
+            sctx.close()
         except Exception as e:                                    # a leg must never cost the line its headline
             other_modes["streamed"] = {"error": repr(e)}
     if other_modes is not None and args.preset is None and not args.no_stress:

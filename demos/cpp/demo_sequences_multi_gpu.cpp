@@ -84,8 +84,9 @@ struct DeviceSide { // one member's resident frames and outputs
     uint8_t *desc = nullptr;
     float *pts = nullptr;
     int32_t *nk = nullptr, *pairs = nullptr;
-    PsPairResults out{}, out2{}; // consecutive steps run side by side on the member's two chains: an output block each, used in turn
-    void *block = nullptr, *block2 = nullptr;
+    static constexpr int kBlocks = 4; // consecutive steps run side by side on the member's four chains: an output block each, used in turn
+    PsPairResults out[kBlocks] = {};
+    void *block[kBlocks] = {};
 };
 
 #define HIPCHK(call)                                                                         \
@@ -116,26 +117,20 @@ int upload(const Sequence &s, int P, DeviceSide &d)
     if (P > 0) HIPCHK(hipMemcpy(d.pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t bytes = n * cap * sizeof(PsDMatch) + n * cap + n * 64 + n * sizeof(PsRansacStats) + n * 4 + 256;
-    HIPCHK(hipMalloc(&d.block, bytes));
-    HIPCHK(hipMemset(d.block, 0, bytes));
-    uint8_t *b = (uint8_t *)d.block;
-    d.out.matches = (PsDMatch *)b;
-    b += n * cap * sizeof(PsDMatch);
-    d.out.pose = (float *)b;
-    b += n * 64;
-    d.out.stats = (PsRansacStats *)b;
-    b += n * sizeof(PsRansacStats);
-    d.out.numMatches = (int32_t *)b;
-    b += n * 4;
-    d.out.inlierMask = b;
-    HIPCHK(hipMalloc(&d.block2, bytes));
-    HIPCHK(hipMemset(d.block2, 0, bytes));
-    const ptrdiff_t shift = (uint8_t *)d.block2 - (uint8_t *)d.block;
-    d.out2.matches = (PsDMatch *)((uint8_t *)d.out.matches + shift);
-    d.out2.pose = (float *)((uint8_t *)d.out.pose + shift);
-    d.out2.stats = (PsRansacStats *)((uint8_t *)d.out.stats + shift);
-    d.out2.numMatches = (int32_t *)((uint8_t *)d.out.numMatches + shift);
-    d.out2.inlierMask = d.out.inlierMask + shift;
+    for (int k = 0; k < DeviceSide::kBlocks; ++k) {
+        HIPCHK(hipMalloc(&d.block[k], bytes));
+        HIPCHK(hipMemset(d.block[k], 0, bytes));
+        uint8_t *b = (uint8_t *)d.block[k];
+        d.out[k].matches = (PsDMatch *)b;
+        b += n * cap * sizeof(PsDMatch);
+        d.out[k].pose = (float *)b;
+        b += n * 64;
+        d.out[k].stats = (PsRansacStats *)b;
+        b += n * sizeof(PsRansacStats);
+        d.out[k].numMatches = (int32_t *)b;
+        b += n * 4;
+        d.out[k].inlierMask = b;
+    }
     HIPCHK(hipDeviceSynchronize()); // (the clearing above was queued on the null stream; the member's chains are not ordered with it)
     return 0;
 }
@@ -263,9 +258,9 @@ int main(int argc, char **argv)
         dev[(size_t)i].device = ps_shard_device(g, i);
         if (upload(seq[(size_t)i], P, dev[(size_t)i])) return 2;
     }
-    // ---- the host loop: every step submits every member's batch (asynchronous: a PsBatchQueue of two chains per member, whole
+    // ---- the host loop: every step submits every member's batch (asynchronous: a PsBatchQueue of four chains per member, whole
     // batches in turn; the members on their own host threads) and starts the gather of its records; the records of step n are
-    // waited for after step n + 2 has been submitted, so nothing ever drains a GPU (at most PS_SHARD_GATHERS_IN_FLIGHT gathers are
+    // waited for after step n + 4 has been submitted, so nothing ever drains a GPU (at most PS_SHARD_GATHERS_IN_FLIGHT gathers are
     // outstanding)
     std::vector<PsRansacConfig> cfgs((size_t)L);
     std::vector<PsFrameSet> fsets((size_t)L);
@@ -291,10 +286,10 @@ int main(int argc, char **argv)
         j.frames = &fs;
         j.pairs = dev[(size_t)i].pairs;
         j.P = P;
-        j.out = &dev[(size_t)i].out;
+        j.out = &dev[(size_t)i].out[0];
     }
     std::vector<float> records(driveRoot ? (size_t)W * P * PS_SHARD_RECORD_FLOATS : 0);
-    std::vector<int64_t> inFlight; // gathers started and not read yet, oldest first (two are kept outstanding)
+    std::vector<int64_t> inFlight; // gathers started and not read yet, oldest first (four are kept outstanding)
     auto take = [&](int64_t t) -> int { // the records of gather t: complete, on the host
         const float *rec = nullptr;
         int rc2 = ps_shard_wait(g, t, &rec);
@@ -307,7 +302,7 @@ int main(int argc, char **argv)
     };
     long long stepNo = 0;
     std::function<int()> step = [&]() -> int {
-        for (int i = 0; i < L; ++i) jobs[(size_t)i].out = (stepNo & 1) ? &dev[(size_t)i].out2 : &dev[(size_t)i].out;
+        for (int i = 0; i < L; ++i) jobs[(size_t)i].out = &dev[(size_t)i].out[stepNo % DeviceSide::kBlocks];
         ++stepNo;
         int rc2 = ps_shard_submit_all(g, jobs.data());
         if (rc2 != PS_OK) {
@@ -322,10 +317,10 @@ int main(int argc, char **argv)
             return rc2;
         }
         inFlight.push_back(t);
-        // the records of the step before the previous one: with two chains per member two steps run side by side, and the host
-        // must not wait for the older of them before the next one is queued (of PS_SHARD_GATHERS_IN_FLIGHT = 4 record blocks
-        // three are in use)
-        while (inFlight.size() > 2) {
+        // the records of the step four steps back: with four chains per member four steps run side by side, and the host must
+        // not wait for the oldest of them before the next one is queued (of PS_SHARD_GATHERS_IN_FLIGHT = 8 record blocks five
+        // are in use)
+        while (inFlight.size() > 4) {
             if ((rc2 = take(inFlight.front())) != PS_OK) return rc2;
             inFlight.erase(inFlight.begin());
         }
@@ -344,7 +339,7 @@ int main(int argc, char **argv)
     if (blocking) {
         // rounds 1 - 5's host loop, kept for comparison: one context per member, the blocking gather every step
         std::vector<PsPairResults> results((size_t)L);
-        for (int i = 0; i < L; ++i) results[(size_t)i] = dev[(size_t)i].out;
+        for (int i = 0; i < L; ++i) results[(size_t)i] = dev[(size_t)i].out[0];
         step = [&, results]() -> int {
             for (int i = 0; i < L; ++i) {
                 const PsShardJob &j = jobs[(size_t)i];
@@ -429,8 +424,7 @@ int main(int argc, char **argv)
         (void)hipFree(d.pts);
         (void)hipFree(d.nk);
         (void)hipFree(d.pairs);
-        (void)hipFree(d.block);
-        (void)hipFree(d.block2);
+        for (void *b : d.block) (void)hipFree(b);
     }
     ps_shard_group_destroy(g);
     return bad ? 1 : 0;

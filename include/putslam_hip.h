@@ -164,7 +164,13 @@ int ps_context_device(const PsContext *ctx);
  *   "score_stats": 1 = count the evaluations the fast kernel hands to the value-exact code (ps_debug_score_stats).
  *   "stamps":  1 = kernels 2 and 4 record the shader clock at their phase boundaries (ps_debug_stamps); 0 (default) = they
  *              are passed a null pointer and record nothing.
- * Eleven options in all are the surface: "matcher", "matcher_fused", "score", "prune", "reorder", "bail", "model_room_mib",
+ *   "side_by_side": 0 (default) = the context's launches have the chip to themselves; n >= 2 = it is one of n launch chains
+ *              that run side by side (a PsBatchQueue sets it on its chains, the pipelined stream on its lanes from chunks of 48
+ *              frames on; a host that drives several contexts on streams of its own sets it itself).  The other chains fill the
+ *              gaps between the staged scoring's dependent launches, so "prune" = 1 takes the staged form from far smaller
+ *              batches on (E1 / fixed / H = 4096 / 2000 keypoints: from 16 pairs instead of 77; two chains: from 35).  Identical
+ *              outputs whatever the value  (PUTSLAM_HIP_SIDE_BY_SIDE).
+ * Twelve options in all are the surface: "matcher", "matcher_fused", "score", "prune", "side_by_side", "reorder", "bail", "model_room_mib",
  * "stream_copy_kernels", "stream_ahead" (places of the pipelined stream beyond one per lane, see below), "score_stats", "stamps",
  * and the read-only ones.
  * NOT part of it -- launch-shape and tuning knobs of the sweeps and of the staged scoring, every value of which gives the same
@@ -287,8 +293,8 @@ typedef struct PsPairResults {
  * 850 000, USAC_wrapper.cpp:70; touched only up to each pair's trip limit); the staged scoring's parked models take 48 bytes
  * per pair and LEADING hypothesis, 256 MB at most under the adaptive schedules (2 GiB under the fixed one): a hypothesis
  * beyond the slots is swept in one piece and, should it win, rebuilt (options "arena_mib", "last_model_slots", read only).
- * Throughput: a host that loops over batches gets 18 % more (499 pairs) to 47 % more (125 pairs) from a PsBatchQueue (below), which
- * hands the batches to two contexts on two streams in turn -- launch chains that are never joined. */
+ * Throughput: a host that loops over batches gets 18 % more (499 pairs) to 2.9 x (64 pairs) from a PsBatchQueue (below), which
+ * hands the batches to four contexts on four streams in turn -- launch chains that are never joined. */
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg,
                        const float *K, const PsFrameSet *frames,
                        const int32_t *pairs, int P, const PsPairResults *out);
@@ -296,10 +302,14 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
 /* ---- A2, for a host that loops over batches (the loop of src/PUTSLAM/PUTSLAM.cpp:677-740 around Matcher::match,
  * src/Matcher/matcher.cpp:470-515): ps_vo_pairs_device through launch chains that are never joined.
  * One context is one launch chain: a batch's matrix-core Hamming sweep, then its vector scoring stages, dependent launches with
- * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = 2; 1 .. PS_BATCH_QUEUE_MAX_CHAINS) on ctx's device, with ctx's
- * options, and hands batch n to chain n mod chains, WHOLE: consecutive batches run side by side, one in its Hamming sweep while
- * the other scores -- 608 k instead of 517 k frame-pairs/s on batches of 499 pairs, + 18 ... 47 % on smaller ones (round 6's
- * measurement; splitting every batch over the chains, rounds 3 - 5's recipe, gave 559 k: profiles/r06h/queue_split_vs_turns.txt).
+ * the chip partly idle between them.  A queue owns `chains` contexts + streams (0 = the default, 4; 1 .. PS_BATCH_QUEUE_MAX_CHAINS)
+ * on ctx's device, with ctx's options, and hands batch n to chain n mod chains, WHOLE: consecutive batches run side by side, one
+ * in its Hamming sweep while the others score -- 610 k instead of 517 k frame-pairs/s on batches of 499 pairs, 488 k instead of
+ * 274 k at 125 pairs, 408 k instead of 142 k at 64 (round 6's measurements: splitting every batch over two chains, rounds 3 - 5's
+ * recipe, gave 559 k at 499 pairs, profiles/r06h/queue_split_vs_turns.txt; FOUR chains are the best count at every batch size
+ * from 16 to 1000 pairs, two read 601 k / 406 k / 183 k, six are worse than four: profiles/r06u/small_batch_chains.txt).  The chains'
+ * contexts carry option "side_by_side" = chains: with other chains filling the gaps between its dependent launches the staged
+ * scoring pays from 2 - 5 times smaller batches on than it does for a lone context (profiles/r06u/bench_data_crossover.txt).
  * The chains are ordered only within themselves; nothing ever makes one wait for another.
  *   submit: arguments of ps_vo_pairs_device (device pointers); pair p draws from cfg->seed + p: the outputs are byte for byte
  *           those of ONE ps_vo_pairs_device call.  Returns at once; *ticket (may be NULL) names the batch.  Inputs and outputs

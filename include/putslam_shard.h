@@ -17,14 +17,14 @@
  *   ps_shard_group_create_rank  one process per GPU (the torch.distributed.run / mpirun shape): every process is one member;
  *                               the 128-byte id comes from ps_shard_unique_id on one rank and travels by whatever the host
  *                               has (a file, a socket, MPI).
- * Every member owns a PsBatchQueue of two launch chains (include/putslam_hip.h: batches go to the chains in turn, the chains are
- * never joined) and a communication stream.  A step of a looping host is
+ * Every member owns a PsBatchQueue of four launch chains (include/putslam_hip.h: batches go to the chains in turn, the chains are
+ * never joined; consecutive steps run side by side: give them output blocks of their own, four used in turn) and a communication stream.  A step of a looping host is
  *       ps_shard_submit_all(g, jobs)                          every member's batch, asynchronous
  *       ps_shard_gather_records_async(g, pairs, root, &t)     records packed on the chains, gathered on the comm streams
  *       ... the next step's submit ...
  *       ps_shard_wait(g, t, &records)                         when the host wants that step's records
  * and nothing in it makes a chain wait: the records of a batch are packed by a small kernel queued on each chain behind its
- * share of the batch, the comm stream waits for those two events, gathers (ncclGather), copies to pinned host memory on the
+ * share of the batch, the comm stream waits for those events, gathers (ncclGather), copies to pinned host memory on the
  * root and records the ticket's event.  All functions return PS_OK or a negative PsStatus; ps_shard_last_error gives the text
  * (RCCL's included).
  */
@@ -39,7 +39,7 @@ extern "C" {
 
 #define PS_SHARD_RECORD_FLOATS 18   /* pose[16] column-major + numInliers + numMatchesIn, as floats: 72 bytes per pair */
 #define PS_SHARD_ID_BYTES 128       /* NCCL_UNIQUE_ID_BYTES */
-#define PS_SHARD_GATHERS_IN_FLIGHT 4 /* tickets whose records stay readable: a record block is reused four gathers later */
+#define PS_SHARD_GATHERS_IN_FLIGHT 8 /* tickets whose records stay readable: a record block is reused eight gathers later */
 
 typedef struct PsShardGroup PsShardGroup;
 
@@ -74,7 +74,7 @@ int ps_shard_local_count(const PsShardGroup *g);         /* members this process
 int ps_shard_rank(const PsShardGroup *g, int local);     /* rank of local member `local` */
 int ps_shard_device(const PsShardGroup *g, int local);
 PsContext *ps_shard_context(PsShardGroup *g, int local); /* the member's context: options set on it before the first submit reach its chains */
-PsBatchQueue *ps_shard_queue(PsShardGroup *g, int local);/* the member's batch queue (two chains) */
+PsBatchQueue *ps_shard_queue(PsShardGroup *g, int local);/* the member's batch queue (four chains) */
 
 /* Contiguous share [*lo, *hi) of `total` units for `rank` of `world` (sizes differ by at most one). */
 void ps_shard_range(int64_t total, int world, int rank, int64_t *lo, int64_t *hi);
@@ -82,7 +82,7 @@ void ps_shard_range(int64_t total, int world, int rank, int64_t *lo, int64_t *hi
 /* perLocal[local]: in on the root's member, out on every member (bytes identical to the root's).  Blocks until done. */
 int ps_shard_broadcast_params(PsShardGroup *g, PsShardRunParams *perLocal, int root);
 
-/* jobs[local] for every local member: the batch goes to the member's queue (ps_batch_queue_submit: two chains, whole batches in
+/* jobs[local] for every local member: the batch goes to the member's queue (ps_batch_queue_submit: four chains, whole batches in
  * turn -- consecutive batches run side by side, so a host that keeps two steps in flight gives consecutive steps output
  * blocks of their own) and its 72-byte records are packed behind it on the chain it ran on.  Asynchronous: returns when every member's launches are queued (with
  * two or more local members the members' submissions run on their own host threads, side by side).  A member whose job has

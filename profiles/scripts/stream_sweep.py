@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--warm", type=float, default=0.5, help="seconds of untimed steps before every row")
     ap.add_argument("--results", type=int, default=0, help="0 = everything, 1 = inlier matches + pose + stats, 2 = pose + stats")
     ap.add_argument("--packed", type=int, default=0, help="1 = PS_FRAMES_PACKED: one block per frame, one upload per chunk (push_many_packed)")
+    ap.add_argument("--idle-contexts", type=int, default=0, help="contexts (stream + arena each) created before the sweep and left idle")
+    ap.add_argument("--idle-queue", type=int, default=0, help="a PsBatchQueue of that many chains, warmed with one batch, left idle")
     ap.add_argument("--grid", default="125x4,125x6,125x8,166x4,166x6,250x4,250x6,64x8,32x8")
     a = ap.parse_args()
     from putslam_amd import api, synth
@@ -43,6 +45,15 @@ def main():
     prm = default_ransac_params(a.ev)
     cfg, _ = make_config(est, a.hyp, seed=0xB0B0)
     ctx = api.Context(0)
+    idle = [api.Context(0) for _ in range(a.idle_contexts)]
+    if a.idle_queue:
+        from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs_queue
+        iq = api.BatchQueue(ctx, a.idle_queue)
+        ifs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+        ipb = [PairBatchDevice(seq["pairs"], ifs.max_kpts) for _ in range(a.idle_queue)]
+        for k in range(2 * a.idle_queue):
+            run_pairs_queue(iq, prm, cfg, TUM_FR1_K, ifs, ipb[k % a.idle_queue])
+        iq.synchronize()
     for item in a.grid.split(","):
         ahead = 2                                   # "125x4a0": chunk x lanes, upload-ahead depth (option stream_ahead)
         if "a" in item:

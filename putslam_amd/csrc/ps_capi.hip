@@ -41,9 +41,11 @@ constexpr StagedFrom kStagedFromEuclidFixed = {7.8e5, 250.0}, kStagedFromReprojF
 // ... and where it does when the context is one of several launch chains that run side by side (option "side_by_side": the
 // chains of a PsBatchQueue, the lanes of the pipelined stream): the other chains' kernels fill the gaps between the staged form's
 // dependent, chip-underfilling launches, so what is left of its price is the work of the extra launches -- the crossover lies
-// 3 - 9 times lower (profiles/r06u/concurrent_crossover.txt: four chains, 500 ... 4000 keypoints x H = 1024 ... 16384 x 2 ... 64
-// pairs; batches of 16 / 32 / 64 pairs of the bench workload's shape gain 1.25 / 1.65 / 2.0 x)
-constexpr StagedFrom kStagedFromEuclidFixedSbs = {2.5e5, 50.0}, kStagedFromReprojFixedSbs = {2.0e5, 75.0},
+// 2 - 5 times lower (profiles/r06u/concurrent_crossover.txt: four chains, 500 ... 4000 keypoints x H = 1024 ... 16384 x 2 ... 64
+// pairs on the C++ demo's frames, 73 % inliers; profiles/r06u/bench_data_crossover.txt: bench.py's kind of data with 70 % / 40 % true
+// correspondences, where the staged form abandons less -- the constants are set by the latter: batches of 32 / 64 pairs of the
+// bench workload's shape gain 1.26 / 1.58 x with the reprojection error, 1.27 / 1.58 x with the Euclidean one)
+constexpr StagedFrom kStagedFromEuclidFixedSbs = {4.5e5, 75.0}, kStagedFromReprojFixedSbs = {3.0e5, 90.0},
                      kStagedFromEuclidAdaptiveSbs = {2.4e4, 0.0}, kStagedFromReprojAdaptiveSbs = {2.4e4, 0.0};
 } // namespace
 

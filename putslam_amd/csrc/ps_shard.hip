@@ -4,9 +4,9 @@
 // block, one gather of 72-byte per-pair records to the rank that composes the trajectories (the reference's only sequential
 // step, src/PUTSLAM/PUTSLAM.cpp:735-740).
 //
-// Round 6: nothing on the data path joins.  Every member owns a PsBatchQueue (two launch chains) and a communication stream.
+// Round 6: nothing on the data path joins.  Every member owns a PsBatchQueue (four launch chains) and a communication stream.
 // A batch's records are packed by a small kernel queued on each chain right behind that chain's share of the batch (so the
-// chain's next batch cannot overwrite a pose before it has been packed); the communication stream waits for the two packing
+// chain's next batch cannot overwrite a pose before it has been packed); the communication stream waits for the packing
 // events, gathers, copies to pinned host memory on the root and records the ticket's event.  The chains never wait for the
 // communication stream: a record block is one of PS_SHARD_GATHERS_IN_FLIGHT, and it is the HOST that waits (in submit) when all
 // of them are outstanding.  Rounds 1 - 5 packed, gathered, copied and synchronised every member on the member's one chain,
@@ -240,7 +240,7 @@ int find_root(const PsShardGroup *g, int root)
 int ensure_queue(Member &mb)
 {
     if (mb.queue) return PS_OK;
-    int rc = ps_batch_queue_create(mb.ctx, 2, &mb.queue);
+    int rc = ps_batch_queue_create(mb.ctx, 0, &mb.queue); // (the library's default: four chains)
     if (rc != PS_OK) return mfail(mb, rc, "ps_batch_queue_create", ps_last_error(mb.ctx));
     return PS_OK;
 }

@@ -751,7 +751,9 @@ int async_build(PsVoStream *s)
         // Chunks on different lanes overlap, so the staged scoring pays from smaller batches on (prepare_score) -- from chunks of
         // 48 frames on: below, a chunk's extra launches cost more than its abandoned evaluations save (chunks of 32 / 64 frames on
         // three lanes, E1 / fixed / H = 4096: complete 204 k / 251 k, staged 156 k / 301 k frame-pairs/s, profiles/r06u/stream_small_chunks.txt)
-        if (a->lanes > 1 && B >= 48 && c->sideBySide < a->lanes) c->sideBySide = a->lanes;
+        // (the decision is the stream's own: below 48 frames per chunk the lanes run as lone contexts whatever the stream's context says)
+        if (B < 48) c->sideBySide = 0;
+        else if (a->lanes > 1 && c->sideBySide < a->lanes) c->sideBySide = a->lanes;
     }
     a->lane.resize((size_t)(a->lanes + a->ahead));
     const size_t metaBytes = std::max(((size_t)2 * B + a->ringFrames) * sizeof(int32_t), sizeof(psdev::MiniMeta));

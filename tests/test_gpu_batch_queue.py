@@ -193,7 +193,7 @@ def fuzz_queue(iters, seed, verbose=False):
         mode = int(rng.choice([0, 1, 2, 4]))
         est, H = [(EST_RANSAC, 487), (EST_USAC, int(rng.integers(300, 3000))), (EST_FIXED, int(rng.integers(257, 5000)))][int(rng.integers(0, 3))]
         prm = default_ransac_params(mode)
-        chains = int(rng.integers(1, 5))
+        chains = int(rng.choice([1, 2, 3, 4, 4, 4, 6, 8]))
         sf = rng.choice([None, 2, 20, 60])
         if sf is None:
             os.environ.pop("PUTSLAM_HIP_QUEUE_SPLIT_FROM", None)

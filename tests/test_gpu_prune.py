@@ -471,14 +471,14 @@ def test_cost_model_picks_the_form_by_batch_size_and_both_forms_agree(mode, est,
     # a context that shares the chip with other launch chains (option "side_by_side": the chains of a PsBatchQueue, the lanes of
     # the pipelined stream) takes the staged form from far smaller batches on (ps_capi.hip: kStagedFrom*Sbs); with TWO chains the
     # point lies half way, on the logarithmic scale
-    (EUCLIDEAN_ERROR, EST_FIXED, 4096, 500, 4, 30, 44),      # 2.5e5 + 50 x 500 = 2.75e5: 37 pairs (alone: 121)
-    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 4, 32, 46),   # 2.0e5 + 75 x 400 = 2.3e5: 39 pairs (alone: 250)
-    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 2, 85, 112),  # sqrt(2.3e5 x 1.5e6) = 5.87e5: 98 pairs
+    (EUCLIDEAN_ERROR, EST_FIXED, 4096, 500, 4, 56, 74),      # 4.5e5 + 75 x 500 = 4.875e5: 65 pairs (alone: 121)
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 4, 48, 64),   # 3.0e5 + 90 x 400 = 3.36e5: 56 pairs (alone: 250)
+    (REPROJECTION_ERROR, EST_FIXED, 4096, 400, 2, 104, 134), # sqrt(3.36e5 x 1.5e6) = 7.1e5: 119 pairs
     (EUCLIDEAN_ERROR, EST_RANSAC, 1157, 300, 3, 14, 26),     # 2.4e4: 20 pairs (hb - 1 = 4; alone: 50)
 ])
 def test_cost_model_side_by_side_takes_the_staged_form_earlier(mode, est, H, kpts, sbs, below, above):
     """Round 6: chains that run side by side hide one another's launch gaps, so the staged form's dependent launches cost throughput
-    little and it pays from 3 - 9 times smaller batches on (profiles/r06u/concurrent_crossover.txt).  The form taken just below /
+    little and it pays from 2 - 5 times smaller batches on (profiles/r06u/concurrent_crossover.txt, bench_data_crossover.txt).  The form taken just below /
     just above the point is the predicted one, a lone context still takes complete scoring there, and the outputs are those of the
     other form."""
     from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
