@@ -3,8 +3,9 @@
 # C++ demo's synthetic frames, so the staged form abandons less): PsBatchQueue, 4 chains, complete (0) / cost model (1) / staged (2).
 # Output: gpurun_out/r06u/bench_data_crossover.txt
 out=gpurun_out/r06u; mkdir -p $out /tmp/psq
-f=$out/bench_data_crossover.txt; : > $f
-for frames in 5 9 17 33 65; do
+f=$out/bench_data_crossover${TAG:-}.txt; : > $f
+SIZES=${SIZES:-"5 9 17 33 65"}; CHAINS=${CHAINS:-4}
+for frames in $SIZES; do
 python3 - $frames <<'P'
 import sys, numpy as np
 sys.path.insert(0, '.')
@@ -23,11 +24,11 @@ done
 for frac in 70 40; do
 for ev in "1 fixed 4096" "0 fixed 4096" "0 ransac 487" "1 ransac 487"; do
   set -- $ev
-  for frames in 5 9 17 33 65; do
+  for frames in $SIZES; do
     steps=$(( 6000 / frames )); [ $steps -gt 300 ] && steps=300
-    line="inliers $frac E$1 $2 $3 pairs $(( frames - 1 )):"
+    line="chains $CHAINS inliers $frac E$1 $2 $3 pairs $(( frames - 1 )):"
     for prune in 0 1 2; do
-      r=$(PUTSLAM_HIP_PRUNE=$prune timeout 120 ./demos/cpp/demo_batch_queue --sequence /tmp/psq/seq_${frames}_$frac.bin --chains 4 --error-version $1 --estimator $2 --hyp $3 --steps $steps --warmup 3 --warm-seconds 0.2 --repeats 3 | tail -1 | sed -e 's/.*median \([0-9]*\) .*/\1/')
+      r=$(PUTSLAM_HIP_PRUNE=$prune timeout 120 ./demos/cpp/demo_batch_queue --sequence /tmp/psq/seq_${frames}_$frac.bin --chains $CHAINS --error-version $1 --estimator $2 --hyp $3 --steps $steps --warmup 3 --warm-seconds 0.2 --repeats 3 | tail -1 | sed -e 's/.*median \([0-9]*\) .*/\1/')
       line="$line  prune$prune $r"
     done
     echo "$line" >> $f

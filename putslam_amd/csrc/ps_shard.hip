@@ -68,8 +68,8 @@ struct Member {
     hipStream_t commStream = nullptr;
     uint8_t *blob = nullptr; // device: parameter block
     Slot slot[kSlots];
-    hipEvent_t packed[kProducers] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool packedUsed[kProducers] = {false, false, false, false, false};
+    hipEvent_t packed[kProducers] = {};
+    bool packedUsed[kProducers] = {};
     int lastP = 0;           // pairs packed for the next gather
     std::string err;
     Worker *worker = nullptr;

@@ -1,4 +1,4 @@
-"""PsBatchQueue (include/putslam_hip.h): the two-chain submission inside the library.  Whatever chain a pair runs on, the outputs
+"""PsBatchQueue (include/putslam_hip.h): the multi-chain submission inside the library (four chains by default).  Whatever chain a pair runs on, the outputs
 are those of ONE ps_vo_pairs_device call -- checked against the oracle's Matcher::match data flow (reference
 src/Matcher/matcher.cpp:470-515) and against the single call, byte for byte."""
 import ctypes as C
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_batch import _compare  # noqa: E402
 
 
-@pytest.mark.parametrize("chains", [1, 2, 3])
+@pytest.mark.parametrize("chains", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("split_from", [None, 20])
 @pytest.mark.parametrize("mode,est,H,frames", [(REPROJECTION_ERROR, EST_FIXED, 1024, 41), (EUCLIDEAN_ERROR, EST_RANSAC, 487, 30),
                                                (EUCLIDEAN_ERROR, EST_USAC, 800, 9)])
@@ -35,7 +35,7 @@ def test_queue_equals_oracle(ctx, oracle, monkeypatch, chains, split_from, mode,
     prm = default_ransac_params(mode)
     cfg, _ = make_config(est, H, seed=777)
     fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
-    pbs = [PairBatchDevice(seq["pairs"], fs.max_kpts) for _ in range(3)]     # consecutive batches run side by side: a block each
+    pbs = [PairBatchDevice(seq["pairs"], fs.max_kpts) for _ in range(max(3, chains + 1))]     # consecutive batches run side by side: a block each
     q = api.BatchQueue(ctx, chains)
     assert q.chains == chains
     c = oracle.vo_pairs(prm, cfg, TUM_FR1_K, seq["desc"], seq["pts"], seq["nkpts"], seq["pairs"], threads=4)
