@@ -202,9 +202,14 @@ int main(int argc, char **argv)
         }
     }
     std::vector<double> rates;
+    double inSubmit = 0; // host seconds inside the submit calls of the timed regions
     for (int r = 0; r < repeats; ++r) {
         const auto t0 = clk::now();
-        for (int i = 0; i < steps; ++i) PSCHK(step());
+        for (int i = 0; i < steps; ++i) {
+            const auto s0 = clk::now();
+            PSCHK(step());
+            inSubmit += std::chrono::duration<double>(clk::now() - s0).count();
+        }
         PSCHK(fence());
         const double sec = std::chrono::duration<double>(clk::now() - t0).count();
         rates.push_back((double)P * steps / sec);
@@ -253,9 +258,10 @@ int main(int argc, char **argv)
     std::sort(rates.begin(), rates.end());
     const char *hq = std::getenv("GPU_MAX_HW_QUEUES");
     std::printf("batch_queue: chains %d, median %.0f frame-pairs/s, min %.0f, max %.0f, %d pairs x %d steps x %d regions, accepted %lld, mean inliers %.1f, "
-                "hw_queues_seen %d (GPU_MAX_HW_QUEUES=%s)\n",
+                "hw_queues_seen %d (GPU_MAX_HW_QUEUES=%s), host %.1f us per submit\n",
                 q ? ps_batch_queue_chains(q) : 1, rates[rates.size() / 2], rates.front(), rates.back(), P, steps, repeats, accepted,
-                (double)inliers / (double)(P > 0 ? P : 1), ps_context_get_option(ctx, "hw_queues_seen"), hq ? hq : "(unset)");
+                (double)inliers / (double)(P > 0 ? P : 1), ps_context_get_option(ctx, "hw_queues_seen"), hq ? hq : "(unset)",
+                1e6 * inSubmit / ((double)steps * repeats));
     if (q) ps_batch_queue_destroy(q);
     (void)hipFree(dDesc);
     (void)hipFree(dPts);
