@@ -15,6 +15,9 @@
 // drops below the staged scoring's cost-model threshold: 125 pairs split run complete scoring, twice the work) while the chains
 // still drift out of step.  So that is what the queue does: batch n runs on chain n mod chains, whole.  The split form is kept
 // behind PUTSLAM_HIP_QUEUE_SPLIT_FROM=<pairs> (batches of at least that many pairs are split, two chains: 45 % / 55 %) for A/B runs.
+// (The table is two chains'.  FOUR are the best count at every batch size from 16 to 1000 pairs and the default since late round 6 --
+// 499 pairs: 610 k on the bench sequence, 125: 490 k, 64: 416 k with the chains' side_by_side option, which moves the staged
+// scoring's crossover to where it lies when other chains fill the gaps between its launches: profiles/r06u, profiles/r06v.)
 //
 //   * chains are ordered only within themselves: submit never makes one chain wait for another, and a batch's completion is an
 //     event per chain it ran on, recorded behind its last launch -- waited for by the host (ps_batch_queue_wait) or by a stream of
@@ -119,7 +122,7 @@ int ps_batch_queue_create(PsContext *ctx, int chains, PsBatchQueue **out)
     if (!ctx) return PS_ERR_BAD_ARG;
     if (chains == 0) chains = kDefaultChains;
     if (chains < 1 || chains > kMaxChains) {
-        psi_set_error(ctx, "ps_batch_queue_create: chains 1 .. 8 (0 = 2)");
+        psi_set_error(ctx, "ps_batch_queue_create: chains 1 .. 8 (0 = 4)");
         return PS_ERR_BAD_ARG;
     }
     PsBatchQueue *q = new PsBatchQueue();
