@@ -526,6 +526,17 @@ def main():
                 torch.cuda.synchronize(dev)
                 ch_ms = (time.perf_counter() - tc0) / n_ch * 1e3
                 other_modes[name]["chains"] = {"streams": S, "ms_per_step": ch_ms, "pairs_per_s": P / (ch_ms * 1e-3), "steps": n_ch}
+    # (The C++ host legs run BEFORE the streamed legs: those leave this process holding all 16 of its hardware queues, and a child
+    # that wants ten more -- the shard demo: four chains, a communication stream, RCCL's own -- then shares the chip's queue slots with
+    # them: 544 - 550 k instead of 590 - 597 k, profiles/r06v/native_shard_ab.txt.  A host of its own has the slots to itself.)
+    if other_modes is not None and args.preset is None and not args.no_native_legs:
+        # ---- what a C / C++ host that links the library gets on THIS workload: (a) a loop of ps_batch_queue_submit calls
+        # (demos/cpp/demo_batch_queue), (b) the sharding layer with a world of one (demos/cpp/demo_sequences_multi_gpu: a queue per
+        # member, asynchronous RCCL gather of the records) -- child processes of their own, GPU_MAX_HW_QUEUES unset in their environment
+        try:
+            other_modes.update(native_legs(args, seq, cfg))
+        except Exception as e:
+            other_modes["native"] = {"error": repr(e)}
     if other_modes is not None and args.preset is None and not args.no_streamed:
         # ---- BASELINE configs[2] as written: the 500 frames STREAMED (frames start in pinned HOST memory, every step uploads
         # all of them and downloads every pair's matches / mask / pose / stats), ps_vo_stream_push_many + pop_many
@@ -558,14 +569,6 @@ def main():
             other_modes["latency"] = latency_leg()
         except Exception as e:
             other_modes["latency"] = {"error": repr(e)}
-    if other_modes is not None and args.preset is None and not args.no_native_legs:
-        # ---- what a C / C++ host that links the library gets on THIS workload: (a) a loop of ps_batch_queue_submit calls
-        # (demos/cpp/demo_batch_queue), (b) the sharding layer with a world of one (demos/cpp/demo_sequences_multi_gpu: a queue per
-        # member, asynchronous RCCL gather of the records) -- child processes of their own, GPU_MAX_HW_QUEUES unset in their environment
-        try:
-            other_modes.update(native_legs(args, seq, cfg))
-        except Exception as e:
-            other_modes["native"] = {"error": repr(e)}
     if args.dump_records:
         # test hook (tests/test_gpu_multirank.py): the 72-byte per-pair records rank 0 holds after the last step
         if dist_on and rank == 0:
@@ -914,6 +917,8 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
         return leg
 
     steps = max(10, min(40, 2 * args.steps))
+    only = os.environ.get("PUTSLAM_BENCH_STREAM_LEGS")       # (diagnostic: a comma-separated subset of the side legs below)
+    want = (lambda name: True) if not only else (lambda name: name in only.split(","))
     main = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=1.0, windows=5)   # the last step's poses against the batched call's
     main["roofline"] = {"bound": "pcie", "achieved": main["h2d_GBps"], "peak": PCIE_GEN5_X16_GBS, "unit": "GB/s",
                         "frac": main["h2d_GBps"] / PCIE_GEN5_X16_GBS, "measured_link_h2d_GBps": h2d,
@@ -926,19 +931,23 @@ def streamed_legs(args, api, c0, seq, prm, est, cfg, res, dev):
                         "parameters as the timed workload" % (F, args.stream_chunk, _stream_shape(args.stream_chunk, args.stream_lanes)[0]))
     out["streamed"] = main
     # rounds 4 - 5's form, kept beside it: descriptors and points as two host arrays, two uploads per chunk
-    out["streamed/two_arrays"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=0.5, windows=3, packed=False)
+    if want("two_arrays"):
+        out["streamed/two_arrays"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, warm_s=0.5, windows=3, packed=False)
     # what Matcher::match itself returns -- estimatedTransformation + inlierMatches (matcher.cpp:452-516) -- instead of every
     # cross-check match + mask: a third of the download, written by a kernel straight into the pinned block
-    out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
-    out["streamed/poses"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=2)   # (a host that only composes the trajectory)
+    if want("inliers"):
+        out["streamed/inliers"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=1)
+    if want("poses"):
+        out["streamed/poses"] = run(args.stream_chunk, args.stream_lanes, steps, check=1, results=2)   # (a host that only composes the trajectory)
     for other in (125, 250, 500):
-        if other != args.stream_chunk:
+        if other != args.stream_chunk and want("chunk%d" % other):
             out["streamed/chunk%d" % other] = run(other, args.stream_lanes, steps, check=0)
-    small = run(32, args.stream_lanes, max(5, steps // 2), check=0, warm_s=0.6, windows=3)
-    out["streamed/chunk32"] = small
-    one = run(1, args.stream_lanes, 3, check=1, warm_s=0.2)
-    out["streamed/chunk1"] = one
-    out["streamed/chunk4"] = run(4, args.stream_lanes, 3, check=0, warm_s=0.2)
+    if want("chunk32"):
+        out["streamed/chunk32"] = run(32, args.stream_lanes, max(5, steps // 2), check=0, warm_s=0.6, windows=3)
+    if want("chunk1"):
+        out["streamed/chunk1"] = run(1, args.stream_lanes, 3, check=1, warm_s=0.2)
+    if want("chunk4"):
+        out["streamed/chunk4"] = run(4, args.stream_lanes, 3, check=0, warm_s=0.2)
     hd.close()
     hp.close()
     hpk.close()

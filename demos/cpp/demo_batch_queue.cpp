@@ -72,8 +72,8 @@ int alloc_results(int P, int cap, Results &r)
 
 int main(int argc, char **argv)
 {
-    int frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 20, warmup = 5, repeats = 5, chains = 4;
-    bool check = false;
+    int frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 20, warmup = 5, repeats = 5, chains = 4, pendingWaits = 0, waitLag = 0;
+    bool check = false, recordOnly = false, waitOnly = false;
     double warmSeconds = 1.0;
     uint64_t seed = 0xB0B0;
     std::string estimator = "fixed", seqPath;
@@ -92,6 +92,10 @@ int main(int argc, char **argv)
         else if (a == "--repeats") repeats = std::atoi(next());
         else if (a == "--chains") chains = std::atoi(next());
         else if (a == "--check") check = true;
+        else if (a == "--pending-waits") pendingWaits = std::atoi(next());
+        else if (a == "--record-only") recordOnly = true;
+        else if (a == "--wait-lag") waitLag = std::atoi(next());
+        else if (a == "--wait-only") waitOnly = true;
         else if (a == "--warm-seconds") warmSeconds = std::atof(next());
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -201,6 +205,12 @@ int main(int argc, char **argv)
             PSCHK(fence());
         }
     }
+    std::vector<hipStream_t> aux((size_t)(pendingWaits > 0 ? (pendingWaits < 8 ? pendingWaits : 8) : 0));
+    std::vector<hipEvent_t> gates((size_t)(pendingWaits > 0 ? pendingWaits * steps : 0));
+    void *auxWord = nullptr;
+    for (hipStream_t &a : aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (hipEvent_t &e : gates) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (pendingWaits > 0) HIPCHK(hipMalloc(&auxWord, 256));
     std::vector<double> rates;
     double inSubmit = 0; // host seconds inside the submit calls of the timed regions
     for (int r = 0; r < repeats; ++r) {
@@ -209,8 +219,24 @@ int main(int argc, char **argv)
             const auto s0 = clk::now();
             PSCHK(step());
             inSubmit += std::chrono::duration<double>(clk::now() - s0).count();
+            // (diagnostic, --pending-waits K: K other streams each wait, device-side, for an event behind this step on its chain --
+            // cross-queue waits that stay pending while the chains run: what the pipelined stream's places and the shard layer's
+            // communication stream queue up, profiles/r06v/pending_waits.txt)
+            if (q && pendingWaits > 0) {
+                for (int k = 0; k < pendingWaits; ++k) {
+                    const int c = (int)((submitted - 1) % chains);
+                    hipEvent_t &ev = gates[(size_t)(i * pendingWaits + k) % gates.size()];
+                    HIPCHK(hipEventRecord(ev, (hipStream_t)ps_context_stream(ps_batch_queue_context(q, c))));
+                    if (recordOnly) continue; // (--record-only: the K event records alone)
+                    if (i < waitLag) continue; // (--wait-lag L: the wait is queued L steps after the event it waits for was recorded)
+                    hipEvent_t &evw = gates[(size_t)((i - waitLag) * pendingWaits + k) % gates.size()];
+                    HIPCHK(hipStreamWaitEvent(aux[(size_t)k % aux.size()], evw, 0));
+                    if (!waitOnly) HIPCHK(hipMemsetAsync(auxWord, 0, 4, aux[(size_t)k % aux.size()])); // (--wait-only: nothing behind the wait)
+                }
+            }
         }
         PSCHK(fence());
+        for (hipStream_t a : aux) HIPCHK(hipStreamSynchronize(a));
         const double sec = std::chrono::duration<double>(clk::now() - t0).count();
         rates.push_back((double)P * steps / sec);
         std::printf("region %d: %d steps of %d pairs, %.3f ms per step, %.0f frame-pairs/s\n", r, steps, P, 1e3 * sec / steps, rates.back());

@@ -141,6 +141,7 @@ int main(int argc, char **argv)
 {
     int gpus = 0, frames = 500, kpts = 2000, hyp = 4096, errorVersion = 1, steps = 5, rank = -1, world = 0, repeats = 1;
     bool blocking = false;
+    int outstanding = 4; // gathers the host keeps outstanding before it reads the oldest (--outstanding, 1 .. PS_SHARD_GATHERS_IN_FLIGHT - 1)
     double warmSeconds = 0.0;
     uint64_t seed = 0xB0B0;
     std::string estimator = "fixed", seqPrefix, dumpPath, trajPrefix, idFile;
@@ -158,6 +159,7 @@ int main(int argc, char **argv)
         else if (a == "--repeats") repeats = std::atoi(next());
         else if (a == "--warm-seconds") warmSeconds = std::atof(next());
         else if (a == "--blocking") blocking = true;
+        else if (a == "--outstanding") outstanding = std::atoi(next());
         else if (a == "--sequence-prefix") seqPrefix = next();
         else if (a == "--dump") dumpPath = next();
         else if (a == "--traj-prefix") trajPrefix = next();
@@ -320,7 +322,7 @@ int main(int argc, char **argv)
         // the records of the step four steps back: with four chains per member four steps run side by side, and the host must
         // not wait for the oldest of them before the next one is queued (of PS_SHARD_GATHERS_IN_FLIGHT = 8 record blocks five
         // are in use)
-        while (inFlight.size() > 4) {
+        while ((int)inFlight.size() > outstanding) {
             if ((rc2 = take(inFlight.front())) != PS_OK) return rc2;
             inFlight.erase(inFlight.begin());
         }

@@ -24,9 +24,12 @@
  *       ... the next step's submit ...
  *       ps_shard_wait(g, t, &records)                         when the host wants that step's records
  * and nothing in it makes a chain wait: the records of a batch are packed by a small kernel queued on each chain behind its
- * share of the batch, the comm stream waits for those events, gathers (ncclGather), copies to pinned host memory on the
- * root and records the ticket's event.  All functions return PS_OK or a negative PsStatus; ps_shard_last_error gives the text
- * (RCCL's included).
+ * share of the batch; once the HOST has seen that kernel's event complete -- at the next submit / gather call that finds it so, or
+ * in ps_shard_wait, which waits for it -- the gather goes onto the comm stream (ncclGather, the copy to pinned host memory on the
+ * root, the ticket's event), tickets in order.  No stream ever holds a wait for another one: a cross-queue wait that stays pending
+ * costs the chains 5 - 19 % of their rate (profiles/r06v/pending_waits.txt).  Every rank therefore has to come back -- ps_shard_wait
+ * on the ticket (or a later one), or ps_shard_synchronize -- for its share of a gather to be issued; a loop that submits, gathers
+ * and waits does.  All functions return PS_OK or a negative PsStatus; ps_shard_last_error gives the text (RCCL's included).
  */
 #ifndef PUTSLAM_SHARD_H_
 #define PUTSLAM_SHARD_H_
@@ -89,13 +92,15 @@ int ps_shard_broadcast_params(PsShardGroup *g, PsShardRunParams *perLocal, int r
  * P = 0 submits nothing. */
 int ps_shard_submit_all(PsShardGroup *g, const PsShardJob *jobs);
 
-/* The records of every member's LAST submitted batch -> rank `root`, asynchronously: on each member's communication stream, behind
- * the events of that batch's packing.  pairsPerRank >= every member's P (blocks are zero-filled up to it; it must be the same on
- * every rank).  *ticket names the gather.  At most PS_SHARD_GATHERS_IN_FLIGHT gathers are outstanding: a further submit waits
- * (on the host) for the oldest. */
+/* The records of every member's LAST submitted batch -> rank `root`, asynchronously: noted now, and queued on each member's
+ * communication stream as soon as the host has seen that batch's packing complete -- in this call, in a later submit / gather call
+ * or in ps_shard_wait (which waits for the packing), gathers in ticket order.  pairsPerRank >= every member's P (blocks are
+ * zero-filled up to it; it must be the same on every rank).  *ticket names the gather.  At most PS_SHARD_GATHERS_IN_FLIGHT gathers
+ * are outstanding: a further submit settles the oldest (on the host).  Every rank has to come back with ps_shard_wait (on this or a
+ * later ticket) or ps_shard_synchronize: a gather completes when every rank has issued its share. */
 int ps_shard_gather_records_async(PsShardGroup *g, int pairsPerRank, int root, int64_t *ticket);
 
-/* Blocks until gather `ticket` has completed on every local member.  In the process that drives the root, *hostRecords (may be
+/* Queues what is left to queue of the gathers up to `ticket`, then blocks until gather `ticket` has completed on every local member.  In the process that drives the root, *hostRecords (may be
  * NULL) points at [worldSize][pairsPerRank][18] floats in pinned host memory, valid until PS_SHARD_GATHERS_IN_FLIGHT - 1 further
  * gathers have been started; NULL elsewhere. */
 int ps_shard_wait(PsShardGroup *g, int64_t ticket, const float **hostRecords);

@@ -6,11 +6,15 @@
 //
 // Round 6: nothing on the data path joins.  Every member owns a PsBatchQueue (four launch chains) and a communication stream.
 // A batch's records are packed by a small kernel queued on each chain right behind that chain's share of the batch (so the
-// chain's next batch cannot overwrite a pose before it has been packed); the communication stream waits for the packing
-// events, gathers, copies to pinned host memory on the root and records the ticket's event.  The chains never wait for the
-// communication stream: a record block is one of PS_SHARD_GATHERS_IN_FLIGHT, and it is the HOST that waits (in submit) when all
-// of them are outstanding.  Rounds 1 - 5 packed, gathered, copied and synchronised every member on the member's one chain,
-// every call, from one host thread.
+// chain's next batch cannot overwrite a pose before it has been packed), with an event behind it.  The gather itself -- ncclGather,
+// the copy to pinned host memory on the root, the ticket's event -- goes onto the communication stream once the HOST has seen that
+// event complete: at the next submit / gather call that finds it so, or inside ps_shard_wait, which waits for it (member_flush;
+// tickets in order, every rank the same order).  The chains never wait for the communication stream, and the communication stream
+// never holds a wait for a chain: a cross-queue wait that stays pending while the chains run costs THEM 5 % at 499 pairs per batch
+// and 19 % at 125 (profiles/r06v/pending_waits.txt) -- round 6's first form queued the gather at once behind such a wait and lay
+// 4 - 5 % below the batch queue's rate; this form lies 1 - 2 % below it.  A record block is one of PS_SHARD_GATHERS_IN_FLIGHT, and
+// it is the HOST that waits (in submit) when all of them are outstanding.  Rounds 1 - 5 packed, gathered, copied and synchronised
+// every member on the member's one chain, every call, from one host thread.
 //
 // One process driving several GPUs: from two members on every member has a host thread of its own; a call that addresses all
 // members hands each thread its member's share and waits for all of them.  RCCL collectives are then issued one per thread on
@@ -50,6 +54,12 @@ struct Slot { // the buffers of one gather on one member
     long long ticket = -1;
     int pairsPerRank = 0;
     bool isRoot = false;
+    // the gather's request, kept until the records are packed (member_flush): who packs (an event behind every producer's packing
+    // kernel), how many pairs this member packed, where the records go
+    hipEvent_t packed[PS_BATCH_QUEUE_MAX_CHAINS + 1] = {};
+    bool packedUsed[PS_BATCH_QUEUE_MAX_CHAINS + 1] = {};
+    bool requested = false;    // ps_shard_gather_records_async has asked for this slot's gather; it has not been queued yet
+    int lastP = 0, root = 0;
 };
 
 struct Worker {
@@ -68,9 +78,7 @@ struct Member {
     hipStream_t commStream = nullptr;
     uint8_t *blob = nullptr; // device: parameter block
     Slot slot[kSlots];
-    hipEvent_t packed[kProducers] = {};
-    bool packedUsed[kProducers] = {};
-    int lastP = 0;           // pairs packed for the next gather
+    long long nextFlush = 0; // the oldest gather that has been asked for and not queued yet (tickets are queued in order)
     std::string err;
     Worker *worker = nullptr;
 };
@@ -96,7 +104,8 @@ struct PsShardGroup {
     int world = 0;
     std::vector<Member> m;
     std::string err;
-    long long nextGather = 0;
+    long long nextGather = 0;  // the next ticket
+    long long nextRequest = 0; // tickets below this have been asked for (member_flush queues them)
     bool threaded = false;
     // completion of a fan-out over the workers
     std::mutex jm;
@@ -211,8 +220,10 @@ int member_init(PsShardGroup *g, Member &mb)
     if (rc != PS_OK) return sfail(g, rc, "ps_context_create");
     SH_HIP(hipMalloc((void **)&mb.blob, sizeof(PsShardRunParams)));
     SH_HIP(hipStreamCreateWithFlags(&mb.commStream, hipStreamNonBlocking));
-    for (hipEvent_t &e : mb.packed) SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (Slot &s : mb.slot) SH_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    for (Slot &s : mb.slot) {
+        SH_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        for (hipEvent_t &e : s.packed) SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     return PS_OK;
 }
 
@@ -276,74 +287,16 @@ int ensure_rec(Member &mb, Slot &s, size_t floats, bool keep)
     return PS_OK;
 }
 
-int member_submit(PsShardGroup *g, Member &mb, const PsShardJob &job)
+// The gather of slot `s` goes onto the communication stream: its records are packed (the caller has seen every producer's event
+// complete), so nothing is queued that has to wait for another queue.
+int queue_gather(PsShardGroup *g, Member &mb, Slot &s)
 {
-    for (bool &u : mb.packedUsed) u = false;
-    mb.lastP = 0;
-    if (job.P <= 0) return PS_OK;
-    if (!job.params || !job.cfg || !job.frames || !job.pairs || !job.out || !job.out->pose || !job.out->stats)
-        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_submit_all: bad job");
-    int rc = ensure_queue(mb);
-    if (rc != PS_OK) return rc;
-    Slot &s = mb.slot[g->nextGather % kSlots];
-    rc = slot_free(mb, s);
-    if (rc != PS_OK) return rc;
-    rc = ensure_rec(mb, s, (size_t)job.P * PS_SHARD_RECORD_FLOATS, false);
-    if (rc != PS_OK) return rc;
-    rc = ps_batch_queue_submit(mb.queue, job.params, job.cfg, job.K, job.frames, job.pairs, job.P, job.out, nullptr);
-    if (rc != PS_OK) return mfail(mb, rc, "ps_batch_queue_submit", ps_last_error(mb.ctx));
-    int32_t bounds[kMaxChains + 1];
-    const int C = ps_batch_queue_last_split(mb.queue, bounds);
-    for (int i = 0; i < C; ++i) {
-        const int lo = bounds[i], n = bounds[i + 1] - bounds[i];
-        if (n <= 0) continue;
-        hipStream_t st = (hipStream_t)ps_context_stream(ps_batch_queue_context(mb.queue, i));
-        // behind this chain's share of the batch, before the chain's next batch can overwrite a pose
-        hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, job.out->pose + (size_t)lo * 16,
-                           job.out->stats + lo, n, n, s.rec + (size_t)lo * PS_SHARD_RECORD_FLOATS);
-        MB_HIP(hipGetLastError());
-        MB_HIP(hipEventRecord(mb.packed[i], st));
-        mb.packedUsed[i] = true;
-    }
-    mb.lastP = job.P;
-    return PS_OK;
-}
-
-// the blocking form's producer: results a host wrote with ps_vo_pairs_device on the member's own context
-int member_pack_from_context(PsShardGroup *g, Member &mb, const PsPairResults &res, int valid, int pairsPerRank)
-{
-    for (bool &u : mb.packedUsed) u = false;
-    mb.lastP = 0;
-    if (valid < 0 || valid > pairsPerRank || !res.pose || !res.stats)
-        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records: bad results / validPairs");
-    Slot &s = mb.slot[g->nextGather % kSlots];
-    int rc = slot_free(mb, s);
-    if (rc != PS_OK) return rc;
-    rc = ensure_rec(mb, s, (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS, false);
-    if (rc != PS_OK) return rc;
-    hipStream_t st = (hipStream_t)ps_context_stream(mb.ctx);
-    hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((pairsPerRank + 255) / 256)), dim3(256), 0, st, res.pose, res.stats, valid,
-                       pairsPerRank, s.rec);
-    MB_HIP(hipGetLastError());
-    MB_HIP(hipEventRecord(mb.packed[kMaxChains], st));
-    mb.packedUsed[kMaxChains] = true;
-    mb.lastP = pairsPerRank; // (zero-filled by the kernel itself)
-    return PS_OK;
-}
-
-int member_gather(PsShardGroup *g, Member &mb, long long ticket, int pairsPerRank, int root)
-{
-    Slot &s = mb.slot[ticket % kSlots];
-    int rc = slot_free(mb, s); // (a gather with no submit since this slot's last use)
-    if (rc != PS_OK) return rc;
-    if (mb.lastP > pairsPerRank) return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: pairsPerRank is smaller than the member's batch");
+    const int pairsPerRank = s.pairsPerRank, root = s.root;
     const size_t recFloats = (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS;
-    for (int i = 0; i < kProducers; ++i)
-        if (mb.packedUsed[i]) MB_HIP(hipStreamWaitEvent(mb.commStream, mb.packed[i], 0));
-    rc = ensure_rec(mb, s, recFloats, true);
+    int rc = ensure_rec(mb, s, recFloats, true);
     if (rc != PS_OK) return rc;
-    if (mb.lastP < pairsPerRank)
-        MB_HIP(hipMemsetAsync(s.rec + (size_t)mb.lastP * PS_SHARD_RECORD_FLOATS, 0, (size_t)(pairsPerRank - mb.lastP) * PS_SHARD_RECORD_FLOATS * sizeof(float),
+    if (s.lastP < pairsPerRank)
+        MB_HIP(hipMemsetAsync(s.rec + (size_t)s.lastP * PS_SHARD_RECORD_FLOATS, 0, (size_t)(pairsPerRank - s.lastP) * PS_SHARD_RECORD_FLOATS * sizeof(float),
                               mb.commStream));
     s.isRoot = mb.rank == root;
     if (s.isRoot) {
@@ -367,8 +320,128 @@ int member_gather(PsShardGroup *g, Member &mb, long long ticket, int pairsPerRan
         MB_HIP(hipMemcpyAsync(s.host, s.gathered, recFloats * (size_t)g->world * sizeof(float), hipMemcpyDeviceToHost, mb.commStream));
     MB_HIP(hipEventRecord(s.done, mb.commStream));
     s.pending = true;
+    s.requested = false;
+    for (bool &u : s.packedUsed) u = false; // (consumed: a later gather on this slot with no submit before it sends zeros)
+    s.lastP = 0;
+    return PS_OK;
+}
+
+// Gathers that have been asked for are queued IN TICKET ORDER (every rank issues its collectives in the same order), each one when
+// its records are packed: up to `upto`, waiting for the packing (force) or stopping at the first one that is not packed yet.
+//
+// Why the host mediates: a gather queued at once had to make the communication stream wait, on the device, for the packing event
+// of a batch that runs for milliseconds -- and a cross-queue wait that stays PENDING slows the launch chains themselves:
+// demos/cpp/demo_batch_queue --pending-waits 1 (one such wait per batch on a stream of its own) reads 545 k instead of 574 k
+// frame-pairs/s at 499 pairs per batch and 395 k instead of 484 k at 125 (profiles/r06v/pending_waits.txt) -- the 4 - 5 % the
+// native path lay below the batch queue's rate.  A wait for an event the host has SEEN complete is none.
+int member_flush(PsShardGroup *g, Member &mb, long long upto, bool force)
+{
+    for (;;) {
+        const long long t = mb.nextFlush;
+        if (t > upto || t >= g->nextRequest) return PS_OK;
+        Slot &s = mb.slot[t % kSlots];
+        if (!s.requested || s.ticket != t) { // (nothing to queue for this ticket on this member)
+            mb.nextFlush = t + 1;
+            continue;
+        }
+        for (int i = 0; i < kProducers; ++i) {
+            if (!s.packedUsed[i]) continue;
+            if (force) {
+                MB_HIP(hipEventSynchronize(s.packed[i]));
+            } else {
+                const hipError_t e = hipEventQuery(s.packed[i]);
+                if (e == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    return PS_OK; // not packed yet: this gather and the later ones stay where they are
+                }
+                if (e != hipSuccess) return mfail(mb, PS_ERR_HIP, "hipEventQuery", hipGetErrorString(e));
+            }
+        }
+        int rc = queue_gather(g, mb, s);
+        if (rc != PS_OK) return rc;
+        mb.nextFlush = t + 1;
+    }
+}
+
+// the slot's blocks are about to be written again: whatever the slot still owes is settled first
+int slot_retire(PsShardGroup *g, Member &mb, Slot &s)
+{
+    if (s.requested) { // (the host never waited for that ticket: its gather is queued now, after the older ones)
+        int rc = member_flush(g, mb, s.ticket, true);
+        if (rc != PS_OK) return rc;
+    }
+    return slot_free(mb, s);
+}
+
+int member_submit(PsShardGroup *g, Member &mb, const PsShardJob &job)
+{
+    int rc = member_flush(g, mb, g->nextRequest, false); // (whatever has been packed meanwhile)
+    if (rc != PS_OK) return rc;
+    Slot &s = mb.slot[g->nextGather % kSlots];
+    rc = slot_retire(g, mb, s);
+    if (rc != PS_OK) return rc;
+    for (bool &u : s.packedUsed) u = false;
+    s.lastP = 0;
+    if (job.P <= 0) return PS_OK;
+    if (!job.params || !job.cfg || !job.frames || !job.pairs || !job.out || !job.out->pose || !job.out->stats)
+        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_submit_all: bad job");
+    rc = ensure_queue(mb);
+    if (rc != PS_OK) return rc;
+    rc = ensure_rec(mb, s, (size_t)job.P * PS_SHARD_RECORD_FLOATS, false);
+    if (rc != PS_OK) return rc;
+    rc = ps_batch_queue_submit(mb.queue, job.params, job.cfg, job.K, job.frames, job.pairs, job.P, job.out, nullptr);
+    if (rc != PS_OK) return mfail(mb, rc, "ps_batch_queue_submit", ps_last_error(mb.ctx));
+    int32_t bounds[kMaxChains + 1];
+    const int C = ps_batch_queue_last_split(mb.queue, bounds);
+    for (int i = 0; i < C; ++i) {
+        const int lo = bounds[i], n = bounds[i + 1] - bounds[i];
+        if (n <= 0) continue;
+        hipStream_t st = (hipStream_t)ps_context_stream(ps_batch_queue_context(mb.queue, i));
+        // behind this chain's share of the batch, before the chain's next batch can overwrite a pose
+        hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, job.out->pose + (size_t)lo * 16,
+                           job.out->stats + lo, n, n, s.rec + (size_t)lo * PS_SHARD_RECORD_FLOATS);
+        MB_HIP(hipGetLastError());
+        MB_HIP(hipEventRecord(s.packed[i], st));
+        s.packedUsed[i] = true;
+    }
+    s.lastP = job.P;
+    return PS_OK;
+}
+
+// the blocking form's producer: results a host wrote with ps_vo_pairs_device on the member's own context
+int member_pack_from_context(PsShardGroup *g, Member &mb, const PsPairResults &res, int valid, int pairsPerRank)
+{
+    if (valid < 0 || valid > pairsPerRank || !res.pose || !res.stats)
+        return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records: bad results / validPairs");
+    Slot &s = mb.slot[g->nextGather % kSlots];
+    int rc = slot_retire(g, mb, s);
+    if (rc != PS_OK) return rc;
+    for (bool &u : s.packedUsed) u = false;
+    s.lastP = 0;
+    rc = ensure_rec(mb, s, (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS, false);
+    if (rc != PS_OK) return rc;
+    hipStream_t st = (hipStream_t)ps_context_stream(mb.ctx);
+    hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((pairsPerRank + 255) / 256)), dim3(256), 0, st, res.pose, res.stats, valid,
+                       pairsPerRank, s.rec);
+    MB_HIP(hipGetLastError());
+    MB_HIP(hipEventRecord(s.packed[kMaxChains], st));
+    s.packedUsed[kMaxChains] = true;
+    s.lastP = pairsPerRank; // (zero-filled by the kernel itself)
+    return PS_OK;
+}
+
+// ps_shard_gather_records_async on one member: the request is noted on the ticket's slot; the gather itself is queued by
+// member_flush once the records are packed
+int member_request(PsShardGroup *g, Member &mb, long long ticket, int pairsPerRank, int root)
+{
+    Slot &s = mb.slot[ticket % kSlots];
+    int rc = slot_retire(g, mb, s); // (a gather with no submit since this slot's last use; after a submit there is nothing left to settle)
+    if (rc != PS_OK) return rc;
+    if (s.lastP > pairsPerRank) return mfail(mb, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: pairsPerRank is smaller than the member's batch");
+    s.requested = true;
     s.ticket = ticket;
     s.pairsPerRank = pairsPerRank;
+    s.root = root;
     return PS_OK;
 }
 
@@ -485,9 +558,9 @@ void ps_shard_group_destroy(PsShardGroup *g)
             if (s.gathered) (void)hipFree(s.gathered);
             if (s.host) (void)hipHostFree(s.host);
             if (s.done) (void)hipEventDestroy(s.done);
+            for (hipEvent_t e : s.packed)
+                if (e) (void)hipEventDestroy(e);
         }
-        for (hipEvent_t e : mb.packed)
-            if (e) (void)hipEventDestroy(e);
         if (mb.blob) (void)hipFree(mb.blob);
         if (mb.commStream) (void)hipStreamDestroy(mb.commStream);
         if (mb.queue) ps_batch_queue_destroy(mb.queue);
@@ -552,17 +625,23 @@ int ps_shard_gather_records_async(PsShardGroup *g, int pairsPerRank, int root, i
     if (ticket) *ticket = -1;
     if (!g || pairsPerRank < 1 || root < 0 || root >= g->world) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: bad argument");
     const long long t = g->nextGather;
-    int rc = for_members(g, [g, t, pairsPerRank, root](int i) -> int { return member_gather(g, g->m[(size_t)i], t, pairsPerRank, root); });
+    int rc = for_members(g, [g, t, pairsPerRank, root](int i) -> int { return member_request(g, g->m[(size_t)i], t, pairsPerRank, root); });
     if (rc != PS_OK) return rc;
     g->nextGather = t + 1;
+    g->nextRequest = t + 1;
     if (ticket) *ticket = t;
-    return PS_OK;
+    // (whatever is packed already goes out now; the rest at the next submit, gather or wait)
+    return for_members(g, [g, t](int i) -> int { return member_flush(g, g->m[(size_t)i], t, false); });
 }
 
 int ps_shard_wait(PsShardGroup *g, int64_t ticket, const float **hostRecords)
 {
     if (hostRecords) *hostRecords = nullptr;
     if (!g || ticket < 0 || ticket >= g->nextGather) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_wait: no such ticket");
+    // the gathers up to this ticket that are not queued yet are queued now (the host waits for their records to be packed)
+    const long long upto = ticket;
+    int rc = for_members(g, [g, upto](int i) -> int { return member_flush(g, g->m[(size_t)i], upto, true); });
+    if (rc != PS_OK) return rc;
     for (Member &mb : g->m) {
         Slot &s = mb.slot[ticket % kSlots];
         if (s.ticket != ticket) continue; // the slot has moved on: that gather is complete, its records are gone
@@ -601,6 +680,11 @@ int ps_shard_gather_records(PsShardGroup *g, const PsPairResults *results, const
 int ps_shard_synchronize(PsShardGroup *g)
 {
     if (!g) return PS_ERR_BAD_ARG;
+    if (g->nextRequest > 0) { // (every gather that has been asked for is queued first)
+        const long long upto = g->nextRequest - 1;
+        int rc = for_members(g, [g, upto](int i) -> int { return member_flush(g, g->m[(size_t)i], upto, true); });
+        if (rc != PS_OK) return rc;
+    }
     for (Member &mb : g->m) {
         SH_HIP(hipSetDevice(mb.device));
         if (mb.queue && ps_batch_queue_synchronize(mb.queue) != PS_OK) return sfail(g, PS_ERR_HIP, "ps_batch_queue_synchronize", ps_last_error(mb.ctx));
