@@ -204,6 +204,12 @@ def main():
     # (round 5: 16 -- the streamed legs run up to six lanes + an upload and a download stream beside the chains' streams; with
     # eight queues two of those shared one and the leg dropped from 390 k to 130 k pairs/s; the headline is the same either way)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # Rank 0's stdout carries ONE line, the JSON line.  Libraries write to the C-level stdout on their own -- RCCL prints a block with
+    # its version and path when the process group is created, flushed when the process ends: five more lines behind the JSON line of
+    # every run with a process group --, so file descriptor 1 points at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -318,7 +324,9 @@ def main():
         bounds = [min(P, Pmax * i // S) for i in range(S)] + [P]
     gathered = ([[torch.zeros((gsize[i], sharding.RECORD_FLOATS), dtype=torch.float32, device=xdev)
                   for _ in range(world)] for i in range(S)] if (dist_on and rank == 0) else [None] * S)
-    pending = [None] * S     # per chain: (in-flight gather of the previous step, the record block it reads)
+    deferred = []            # steps whose records are being packed: (chain, record block, event behind the packing), in step order
+    works = []               # gathers issued and not known complete: (work, the record block it reads)
+    comm = torch.cuda.Stream(device=dev) if dist_on else None    # the gathers are issued here once their records are packed
     state = {"step": 0, "parts": [(i, bounds[i], bounds[i + 1]) for i in range(S)]}
 
     def step():
@@ -335,9 +343,12 @@ def main():
         else:
             run_pairs_split(ctxs, chains, prm, est, args.hyp, cfg.seed, TUM_FR1_K, fs, out, bounds=bounds, join=join)
         if dist_on:
-            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI -- one
-            # gather per chain the step ran on, queued behind that chain's kernels and issued asynchronously: it completes beside
-            # the next step's kernels and is waited for before the chain's next gather (or the closing fence)
+            # the only exchange of the path: 72 B per pair (pose + counts) to rank 0, RCCL gather over xGMI.  The records are packed
+            # on the chain the step ran on, right behind its kernels (before that chain's next batch can overwrite the block); the
+            # gather itself is issued -- on a communication stream of its own -- when the HOST has seen the packing complete, at a
+            # later step or at the fence, gathers in step order on every rank.  Nothing is queued behind a wait for a running batch:
+            # a cross-queue wait that stays pending costs the chains 5 % of their rate at this batch size and 19 % at 125 pairs
+            # (profiles/r06v/pending_waits.txt; rounds 3 - 6 issued the gather at once, behind torch.distributed's event wait).
             st32 = out.stats.view(torch.int32).view(P, -1)           # PsRansacStats: [5] numInliers, [0] numMatchesIn
             for i, lo, hi in state["parts"]:
                 with torch.cuda.stream(chains[i]):
@@ -345,19 +356,33 @@ def main():
                     if rec.shape[0] < gsize[i]:          # --shard sequence: pad to the common block size
                         rec = torch.cat([rec, torch.zeros((gsize[i] - rec.shape[0], sharding.RECORD_FLOATS),
                                                           dtype=rec.dtype, device=rec.device)])
-                    rec = rec.to(xdev)
-                    if pending[i] is not None:
-                        pending[i][0].wait()
-                    work, _ = sharding.gather_records(rec, dst=0, out=gathered[i], async_op=True)
-                    pending[i] = (work, rec)
+                    ev = torch.cuda.Event()
+                    ev.record(chains[i])
+                deferred.append((i, rec, ev))
+            issue_gathers(False)
+
+    def issue_gathers(force):
+        while deferred:
+            i, rec, ev = deferred[0]
+            if force:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            deferred.pop(0)
+            with torch.cuda.stream(comm):
+                rec = rec.to(xdev)
+                work, _ = sharding.gather_records(rec, dst=0, out=gathered[i], async_op=True)
+            works.append((work, rec))
+            while len(works) > 8 * S:                    # (an old gather: long complete; its record block may go)
+                works.pop(0)[0].wait()
 
     def fence():
         if dist_on:
-            for i in range(S):
-                if pending[i] is not None:
-                    with torch.cuda.stream(chains[i]):
-                        pending[i][0].wait()
-                    pending[i] = None
+            issue_gathers(True)
+            with torch.cuda.stream(comm):
+                for w, _ in works:
+                    w.wait()
+            del works[:]
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -776,7 +801,8 @@ def main():
         # rank waits in a collective while rank 0 computes (its peers have left; their GPUs are idle, the cores are rank 0's)
         if not args.no_cpu_baseline:
             out.update(cpu_baseline(args, seq, prm, cfg, est))
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 PCIE_GEN5_X16_GBS = 63.0        # PCIe 5.0 x16, one direction, after 128b/130b encoding (the MI355X host link)
