@@ -321,7 +321,10 @@ int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRan
  *           for whatever part of the batch was queued.
  *   wait / query: the host blocks until / asks whether that batch is complete (query: 1 complete, 0 not yet).
  *   wait_on_stream: the given hipStream_t waits for the batch instead (device-side; the host does not block): what a host
- *           that post-processes on a stream of its own, or gathers results with a collective, queues behind a batch.
+ *           that post-processes on a stream of its own queues behind a batch.  A device-side wait for a batch that is still
+ *           running is not free: while it is pending the chains themselves lose 5 % (499 pairs per batch) to 19 % (125) of
+ *           their rate (profiles/r06v/pending_waits.txt) -- a host that can, queues its dependent work once query / wait says
+ *           the batch is complete (the sharding layer and bench.py issue their gathers that way).
  *   context(q, i): chain i's context -- for ps_context_stream (work to be queued behind that chain's batch),
  *           ps_context_enable_timing, options; not for calls of its own while batches are in flight.
  *   last_split: bounds[0 .. chains] of the last submitted batch: pairs [bounds[i], bounds[i+1]) ran on chain i (all of them on
