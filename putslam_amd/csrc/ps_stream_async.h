@@ -261,6 +261,11 @@ int async_launch(PsVoStream *s, const AsyncChunk &c)
     up.n = 1;
     hipLaunchKernelGGL(ps_copy_segments, dim3(1), dim3(256), 0, lc->stream, up); // (a few KB: beside the previous chunk's kernels)
     PS_HIP(hipGetLastError());
+#ifdef PS_STREAM_DIAG
+    // (experiment, results meaningless: the chunk's kernels do not wait for its upload -- what the upload -> lane dependency costs)
+    static const bool diagNoUpWait = std::getenv("PUTSLAM_HIP_STREAM_DIAG_NO_UPWAIT") != nullptr;
+    if (!diagNoUpWait)
+#endif
     PS_HIP(hipStreamWaitEvent(lc->stream, c.up, 0));
     PsFrameSet fs;
     fs.desc = (const uint8_t *)a->ringDesc.p;
