@@ -625,13 +625,23 @@ int ps_shard_gather_records_async(PsShardGroup *g, int pairsPerRank, int root, i
     if (ticket) *ticket = -1;
     if (!g || pairsPerRank < 1 || root < 0 || root >= g->world) return sfail(g, PS_ERR_BAD_ARG, "ps_shard_gather_records_async: bad argument");
     const long long t = g->nextGather;
-    int rc = for_members(g, [g, t, pairsPerRank, root](int i) -> int { return member_request(g, g->m[(size_t)i], t, pairsPerRank, root); });
-    if (rc != PS_OK) return rc;
-    g->nextGather = t + 1;
-    g->nextRequest = t + 1;
-    if (ticket) *ticket = t;
+    g->nextRequest = t + 1; // (read by member_flush on the members' threads: set before they start)
     // (whatever is packed already goes out now; the rest at the next submit, gather or wait)
-    return for_members(g, [g, t](int i) -> int { return member_flush(g, g->m[(size_t)i], t, false); });
+    int rc = for_members(g, [g, t, pairsPerRank, root](int i) -> int {
+        int rc2 = member_request(g, g->m[(size_t)i], t, pairsPerRank, root);
+        return rc2 != PS_OK ? rc2 : member_flush(g, g->m[(size_t)i], t, false);
+    });
+    if (rc != PS_OK) {
+        g->nextRequest = t; // (the ticket was not given out; a member that did note the request forgets it at its slot's next use)
+        for (Member &mb : g->m) {
+            Slot &s = mb.slot[t % kSlots];
+            if (s.requested && s.ticket == t) s.requested = false;
+        }
+        return rc;
+    }
+    g->nextGather = t + 1;
+    if (ticket) *ticket = t;
+    return PS_OK;
 }
 
 int ps_shard_wait(PsShardGroup *g, int64_t ticket, const float **hostRecords)
