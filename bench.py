@@ -13,7 +13,8 @@ Workload (BASELINE.json configs[2], the 2000-keypoint throughput case of the met
 pairs per rank, 2000 keypoints per frame, 256-bit descriptors, H = 4096 hypotheses per pair
 (fixed, adaptive stop disabled), reprojection error (errorVersion 1, north_star), shipped
 thresholds.  Every rank owns its own sequence (weak scaling); per-pair records (pose + counts,
-72 B) are gathered to rank 0 with RCCL inside the step when N > 1.
+72 B) are gathered to rank 0 with RCCL when N > 1: packed on the chain behind the step's kernels, the gather issued on a
+communication stream once the host has seen them packed (all of a region's gathers are complete at its closing fence).
 
 Submission: every step is ONE ps_batch_queue_submit (include/putslam_hip.h): the library owns --streams launch chains (default 4:
 contexts + HIP streams; 2 read 601 k, 3 and 4 609 - 610 k, profiles/r06u) and hands the steps' batches to them in turn, whole -- consecutive steps run side by side (one chain's
@@ -135,7 +136,7 @@ def parse():
                          "sequence of --frames frames split over the ranks with a one-frame halo "
                          "(sharding.shard_sequence; strong scaling)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the N > 1 control flow (RCCL process group, parameter broadcast, per-chain asynchronous gather "
+                    help="run the N > 1 control flow (RCCL process group, parameter broadcast, per-step asynchronous gather "
                          "of device-resident records, fence) even with ONE rank: the only way to execute that branch on a "
                          "one-GPU box (also PUTSLAM_BENCH_FORCE_DIST=1)")
     ap.add_argument("--warm-seconds", type=float, default=1.0,
