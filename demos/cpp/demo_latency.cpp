@@ -8,7 +8,7 @@
 //       pose / stats out, one synchronisation inside;
 //   (d) the pipelined form at one frame per chunk: ps_vo_stream_push_async per frame, the result one or more calls late (every
 //       place replays its chunk from a captured hipGraph; six in flight).
-// usage: demo_latency [kpts=2000] [errorVersion=0] [calls=2000]
+// usage: demo_latency [kpts=2000] [errorVersion=0] [calls=2000] [frames per chunk of leg (d) = 1]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -48,6 +48,7 @@ int main(int argc, char **argv)
     const int N = argc > 1 ? std::atoi(argv[1]) : 2000;
     const int errorVersion = argc > 2 ? std::atoi(argv[2]) : 0;
     const int calls = argc > 3 ? std::atoi(argv[3]) : 2000;
+    const int chunkD = argc > 4 ? std::atoi(argv[4]) : 1; // frames per chunk of leg (d)
     const int frames = 16;
     using clk = std::chrono::steady_clock;
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -174,7 +175,7 @@ int main(int argc, char **argv)
         PSCHK(ps_vo_stream_create(ctx, N, &ps));
         cfg.seed = 3;
         PSCHK(ps_vo_stream_set_result_mode(ps, mode == 0 ? PS_RESULTS_FULL : PS_RESULTS_INLIERS));
-        PSCHK(ps_vo_stream_configure_async(ps, &prm, &cfg, K, 1, 0));
+        PSCHK(ps_vo_stream_configure_async(ps, &prm, &cfg, K, chunkD, 0));
         std::vector<clk::time_point> sent;
         std::vector<double> lag;
         long long popped = 0, acc = 0;
@@ -212,12 +213,13 @@ int main(int argc, char **argv)
             while (take(0) > 0) {
             }
         }
+        PSCHK(ps_vo_stream_flush(ps)); // (a partly filled last chunk)
         while (take(1) > 0) {
         }
         const double sec = std::chrono::duration<double>(clk::now() - tStart).count();
-        std::printf("(d%d) ps_vo_stream_push_async, one frame per chunk, %s: %.0f frames/s, result lag median %.1f us  p90 %.1f  "
+        std::printf("(d%d) ps_vo_stream_push_async, %d frame(s) per chunk, %s: %.0f frames/s, result lag median %.1f us  p90 %.1f  "
                     "(%lld chunks from graphs, %lld of %lld increments accepted)\n",
-                    mode, mode == 0 ? "every match + mask out" : "inlier matches out", (double)(popped - poppedAtStart) / sec, percentile(lag, 0.5),
+                    mode, chunkD, mode == 0 ? "every match + mask out" : "inlier matches out", (double)(popped - poppedAtStart) / sec, percentile(lag, 0.5),
                     percentile(lag, 0.9), ps_vo_stream_graph_launches(ps), acc, popped);
         if (popped != total - 1 || acc < popped - 2 * (total / frames) - 2) accepted = -1; // (every pair came back; turn-around frames aside, accepted)
         ps_vo_stream_destroy(ps);
