@@ -730,7 +730,9 @@ def main():
             step_ms = elapsed / args.steps * 1e3
             issue = {"bound": "issue (vector + matrix pipe, 1024 SIMDs x 2.4 GHz)", "busy_simd_cycles_per_step": busy,
                      "ms_per_step_at_full_issue": floor_ms, "ms_per_step": step_ms, "frac": floor_ms / step_ms,
-                     "source": os.path.relpath(sqp, ROOT) + " (profiled single-chain run of the same workload, not this one)"}
+                     "source": os.path.relpath(sqp, ROOT) + " (profiled single-chain run of the same workload, not this one)",
+                     "note": "the two pipes' busy cycles are SUMMED: the time they need if they never overlap; with four chains they "
+                             "overlap by a few per cent, so frac can read 1.00 - 1.03"}
         except Exception:
             pass
         out = {
