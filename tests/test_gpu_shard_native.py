@@ -87,3 +87,26 @@ def test_native_demo_on_synthetic_sequences(tmp_path):
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert "29 of 29 increments accepted" in p.stdout and "records gathered over RCCL" in p.stdout
+
+
+@pytest.mark.parametrize("outstanding,steps,threaded", [(99, 12, False), (99, 12, True), (1, 5, False), (7, 11, False)])
+def test_native_gathers_the_host_never_waits_for_are_issued_all_the_same(tmp_path, outstanding, steps, threaded):
+    """The gather of a step is issued once the host has seen its records packed (ps_shard.hip: member_flush) -- at a later submit /
+    gather call, or in ps_shard_wait.  A host that keeps more gathers outstanding than there are record blocks (--outstanding 99:
+    it never waits before the end) has them issued when their block is needed again (slot_retire), tickets in order; one that waits
+    at once (--outstanding 1) has them issued in the wait.  The last step's records are those of the default loop, byte for byte."""
+    seq = synth.make_sequence(14, 600, config=3, index=777)
+    _write_sequence(tmp_path / "seq0.bin", seq)
+    dumps = []
+    for tag, extra in (("default", []), ("probe", ["--outstanding", str(outstanding)])):
+        dump = tmp_path / (tag + ".bin")
+        cmd = [_exe(), "--gpus", "1", "--sequence-prefix", str(tmp_path / "seq"), "--estimator", "fixed", "--hyp", "512", "--error-version", "1",
+               "--seed", "4321", "--steps", str(steps), "--dump", str(dump)] + extra
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if threaded and tag == "probe":
+            env["PUTSLAM_SHARD_THREADS"] = "1"
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        dumps.append(np.fromfile(dump, np.float32))
+    assert dumps[0].size == 13 * 18 and dumps[0].tobytes() == dumps[1].tobytes()
+    assert np.abs(dumps[0].reshape(13, 18)[:, :16]).sum() > 0
