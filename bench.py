@@ -352,11 +352,10 @@ def main():
             # (profiles/r06v/pending_waits.txt; rounds 3 - 6 issued the gather at once, behind torch.distributed's event wait).
             st32 = out.stats.view(torch.int32).view(P, -1)           # PsRansacStats: [5] numInliers, [0] numMatchesIn
             for i, lo, hi in state["parts"]:
+                # (ONE launch of the library on the chain, padded to the common block size -- --shard sequence --; torch's slice
+                #  assignments were five launches between the chain's batches: 3 % of the step)
+                rec = sharding.pack_records_device(ctxs[i], out.pose[lo:hi], st32[lo:hi], pad_to=gsize[i], stream=chains[i])
                 with torch.cuda.stream(chains[i]):
-                    rec = sharding.pack_records(out.pose[lo:hi], st32[lo:hi, 5], st32[lo:hi, 0])
-                    if rec.shape[0] < gsize[i]:          # --shard sequence: pad to the common block size
-                        rec = torch.cat([rec, torch.zeros((gsize[i] - rec.shape[0], sharding.RECORD_FLOATS),
-                                                          dtype=rec.dtype, device=rec.device)])
                     ev = torch.cuda.Event()
                     ev.record(chains[i])
                 deferred.append((i, rec, ev))

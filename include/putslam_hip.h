@@ -349,6 +349,17 @@ int ps_batch_queue_chains(const PsBatchQueue *q);
 PsContext *ps_batch_queue_context(PsBatchQueue *q, int chain);
 int ps_batch_queue_last_split(const PsBatchQueue *q, int32_t *bounds);
 
+/* ---- The path's only exchange between GPUs: what travels to the rank that composes the trajectories -- the one
+ * sequential step of the reference, VO pose composition with the 0.1 m gate, src/PUTSLAM/PUTSLAM.cpp:735-740 -- is a 72-byte record
+ * per pair: pose[16] (column-major) + numInliers + numMatchesIn, as PS_RECORD_FLOATS floats.  ONE launch on hipStream (NULL: the
+ * context's stream) packs `pairs` records from a batch's device-resident results: rows [0, valid) from pose / stats, rows
+ * [valid, pairs) zero-filled (ranks of a gather send blocks of one size).  Queued behind a batch on the chain it ran on
+ * (ps_batch_queue_context(q, chain)), it reads the block before that chain's next batch can overwrite it.  include/putslam_shard.h
+ * and bench.py's multi-rank steps pack with it (torch's slice assignments were five launches on the chain). */
+#define PS_RECORD_FLOATS 18
+int ps_pack_records_device(PsContext *ctx, void *hipStream, const float *pose, const PsRansacStats *stats, int valid, int pairs,
+                           float *records);
+
 /* ---- A2, streaming form: Matcher::match (src/Matcher/matcher.cpp:452-516) with the previous frame's
  * descriptors and 3-D points resident in HBM (the prevDescriptors / prevFeatures3D state, matcher.h:379-384).
  * The first push only stores the frame (detectInitFeatures, matcher.cpp:17-64) and returns *nmatches = -1;

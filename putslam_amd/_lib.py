@@ -27,7 +27,7 @@ EXPORTED = [
     "ps_keypoints2Dto3D", "ps_points3Dto2D", "ps_vo_pairs_device",
     "ps_batch_queue_create", "ps_batch_queue_destroy", "ps_batch_queue_submit", "ps_batch_queue_wait", "ps_batch_queue_query",
     "ps_batch_queue_wait_on_stream", "ps_batch_queue_synchronize", "ps_batch_queue_chains", "ps_batch_queue_context",
-    "ps_batch_queue_last_split", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
+    "ps_batch_queue_last_split", "ps_pack_records_device", "ps_match_xyz", "ps_predicted_level", "ps_remove_image_distortion",
     "ps_vo_stream_create", "ps_vo_stream_destroy", "ps_vo_stream_reset", "ps_vo_stream_push",
     "ps_vo_stream_set_result_mode", "ps_vo_stream_set_frame_layout", "ps_vo_stream_packed_stride", "ps_vo_stream_push_many_packed", "ps_vo_stream_configure_async", "ps_vo_stream_push_async", "ps_vo_stream_push_many", "ps_vo_stream_flush",
     "ps_vo_stream_pop_many", "ps_vo_stream_pop", "ps_vo_stream_pending", "ps_vo_stream_graph_launches", "ps_host_alloc", "ps_host_free",
@@ -179,6 +179,7 @@ def load_path(path):
     L.ps_batch_queue_context.argtypes = [vp, i32]
     L.ps_batch_queue_context.restype = vp
     L.ps_batch_queue_last_split.argtypes = [vp, vp]
+    L.ps_pack_records_device.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.ps_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
     L.ps_algorithmic_bytes.restype = C.c_uint64
     L.ps_kernel_names.restype = C.POINTER(C.c_char)

@@ -53,6 +53,12 @@ class Context:
     def arch(self):
         return self._L.ps_device_arch(self._h).decode()
 
+    def pack_records(self, pose_ptr, stats_ptr, valid, pairs, records_ptr, stream_ptr=0):
+        """ps_pack_records_device: the 72-byte per-pair records of the multi-GPU gather (pose + numInliers + numMatchesIn as 18 floats),
+        one launch on `stream_ptr` (0: the context's stream); rows [valid, pairs) are zero-filled.  Device pointers."""
+        self._chk(self._L.ps_pack_records_device(self._h, C.c_void_p(stream_ptr), C.c_void_p(pose_ptr), C.c_void_p(stats_ptr),
+                                                 int(valid), int(pairs), C.c_void_p(records_ptr)))
+
     def set_stream(self, stream_ptr):
         self._chk(self._L.ps_context_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -1260,6 +1260,39 @@ int ps_points3Dto2D(PsContext *ctx, const float *xyz, int n, const float *K, flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// the 72-byte per-pair record of the multi-GPU gather (include/putslam_hip.h: ps_pack_records_device)
+namespace {
+__global__ void ps_pack_records_kernel(const float *__restrict__ pose, const PsRansacStats *__restrict__ stats, int valid, int pairs,
+                                       float *__restrict__ rec)
+{
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= pairs) return;
+    float *r = rec + (size_t)p * PS_RECORD_FLOATS;
+    if (p < valid) {
+        for (int i = 0; i < 16; ++i) r[i] = pose[(size_t)p * 16 + i];
+        r[16] = (float)stats[p].numInliers;
+        r[17] = (float)stats[p].numMatchesIn;
+    } else {
+        for (int i = 0; i < PS_RECORD_FLOATS; ++i) r[i] = 0.0f;
+    }
+}
+} // namespace
+
+int ps_pack_records_device(PsContext *ctx, void *hipStream, const float *pose, const PsRansacStats *stats, int valid, int pairs,
+                           float *records)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (pairs < 0 || valid < 0 || valid > pairs || (pairs > 0 && !records) || (valid > 0 && (!pose || !stats)))
+        return fail(ctx, PS_ERR_BAD_ARG, "ps_pack_records_device: bad argument");
+    if (pairs == 0) return PS_OK;
+    hipStream_t st = hipStream ? (hipStream_t)hipStream : ctx->stream;
+    hipLaunchKernelGGL(ps_pack_records_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, pose, stats, valid, pairs, records);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 int ps_vo_pairs_device(PsContext *ctx, const PsRansacParams *params, const PsRansacConfig *cfg, const float *K,
                        const PsFrameSet *frames, const int32_t *pairs, int P, const PsPairResults *out)
 {

@@ -35,6 +35,7 @@
 #include "putslam_shard.h"
 
 static_assert(PS_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+static_assert(PS_SHARD_RECORD_FLOATS == PS_RECORD_FLOATS, "record size");
 
 namespace {
 
@@ -82,21 +83,6 @@ struct Member {
     std::string err;
     Worker *worker = nullptr;
 };
-
-__global__ void ps_pack_records(const float *__restrict__ pose, const PsRansacStats *__restrict__ stats, int valid, int pairs,
-                                float *__restrict__ rec)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pairs) return;
-    float *r = rec + (size_t)p * PS_SHARD_RECORD_FLOATS;
-    if (p < valid) {
-        for (int i = 0; i < 16; ++i) r[i] = pose[(size_t)p * 16 + i];
-        r[16] = (float)stats[p].numInliers;
-        r[17] = (float)stats[p].numMatchesIn;
-    } else {
-        for (int i = 0; i < PS_SHARD_RECORD_FLOATS; ++i) r[i] = 0.0f;
-    }
-}
 
 } // namespace
 
@@ -396,11 +382,11 @@ int member_submit(PsShardGroup *g, Member &mb, const PsShardJob &job)
     for (int i = 0; i < C; ++i) {
         const int lo = bounds[i], n = bounds[i + 1] - bounds[i];
         if (n <= 0) continue;
-        hipStream_t st = (hipStream_t)ps_context_stream(ps_batch_queue_context(mb.queue, i));
+        PsContext *cc = ps_batch_queue_context(mb.queue, i);
+        hipStream_t st = (hipStream_t)ps_context_stream(cc);
         // behind this chain's share of the batch, before the chain's next batch can overwrite a pose
-        hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, job.out->pose + (size_t)lo * 16,
-                           job.out->stats + lo, n, n, s.rec + (size_t)lo * PS_SHARD_RECORD_FLOATS);
-        MB_HIP(hipGetLastError());
+        if (ps_pack_records_device(cc, nullptr, job.out->pose + (size_t)lo * 16, job.out->stats + lo, n, n, s.rec + (size_t)lo * PS_SHARD_RECORD_FLOATS) != PS_OK)
+            return mfail(mb, PS_ERR_HIP, "ps_pack_records_device", ps_last_error(cc));
         MB_HIP(hipEventRecord(s.packed[i], st));
         s.packedUsed[i] = true;
     }
@@ -421,9 +407,8 @@ int member_pack_from_context(PsShardGroup *g, Member &mb, const PsPairResults &r
     rc = ensure_rec(mb, s, (size_t)pairsPerRank * PS_SHARD_RECORD_FLOATS, false);
     if (rc != PS_OK) return rc;
     hipStream_t st = (hipStream_t)ps_context_stream(mb.ctx);
-    hipLaunchKernelGGL(ps_pack_records, dim3((unsigned)((pairsPerRank + 255) / 256)), dim3(256), 0, st, res.pose, res.stats, valid,
-                       pairsPerRank, s.rec);
-    MB_HIP(hipGetLastError());
+    if (ps_pack_records_device(mb.ctx, nullptr, res.pose, res.stats, valid, pairsPerRank, s.rec) != PS_OK)
+        return mfail(mb, PS_ERR_HIP, "ps_pack_records_device", ps_last_error(mb.ctx));
     MB_HIP(hipEventRecord(s.packed[kMaxChains], st));
     s.packedUsed[kMaxChains] = true;
     s.lastP = pairsPerRank; // (zero-filled by the kernel itself)

@@ -40,6 +40,20 @@ def pack_records(pose, num_inliers, num_matches):
     return rec
 
 
+def pack_records_device(ctx, pose, stats_i32, pad_to=None, stream=None):
+    """The same records from a batch's device-resident results in ONE launch of the library (ps_pack_records_device) on `stream`
+    (a torch stream; None: the current one): pose (n, 16) float32, stats_i32 (n, 10) int32 view of PsRansacStats, both torch CUDA
+    tensors (contiguous rows); rows [n, pad_to) are zero-filled.  Returns the (pad_to or n, 18) float32 record block."""
+    import torch
+    n = int(pose.shape[0])
+    rows = n if pad_to is None else int(pad_to)
+    st = stream if stream is not None else torch.cuda.current_stream(pose.device)
+    with torch.cuda.stream(st):
+        rec = torch.empty((rows, RECORD_FLOATS), dtype=torch.float32, device=pose.device)
+        ctx.pack_records(pose.data_ptr() if n else 0, stats_i32.data_ptr() if n else 0, n, rows, rec.data_ptr(), st.cuda_stream)
+    return rec
+
+
 def gather_records(rec, dst=0, group=None, out=None, async_op=False):
     """Gather equally sized per-rank record blocks on `dst` (RCCL/gloo gather).
     Blocking form: returns the list on dst, else None.  async_op=True: returns (work, list-or-None); the caller

@@ -207,3 +207,28 @@ def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
     assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["pairs_per_step"] == 26 and j["value"] > 0
     got = np.load(multi)
     assert got.shape == (2, 13, 18) and got[0].tobytes() != got[1].tobytes()
+
+
+def test_pack_records_device_equals_the_torch_packing(ctx):
+    """ps_pack_records_device (include/putslam_hip.h): the 72-byte per-pair records of the gather in one launch -- the bytes of
+    sharding.pack_records, rows beyond `valid` zero-filled."""
+    import torch
+    from putslam_amd import sharding, synth
+    from putslam_amd._abi import EST_FIXED, REPROJECTION_ERROR, TUM_FR1_K, default_ransac_params, make_config
+    from putslam_amd.device_batch import FrameSetDevice, PairBatchDevice, run_pairs
+    seq = synth.make_sequence(12, 500, config=3, index=31337)
+    fs = FrameSetDevice(seq["desc"], seq["pts"], seq["nkpts"])
+    pb = PairBatchDevice(seq["pairs"], fs.max_kpts)
+    cfg, _ = make_config(EST_FIXED, 512, seed=9)
+    run_pairs(ctx, default_ransac_params(REPROJECTION_ERROR), cfg, TUM_FR1_K, fs, pb)
+    torch.cuda.synchronize()
+    P = len(seq["pairs"])
+    st32 = pb.stats.view(torch.int32).view(P, -1)
+    want = sharding.pack_records(pb.pose, st32[:, 5], st32[:, 0])
+    got = sharding.pack_records_device(ctx, pb.pose, st32, pad_to=P + 3)
+    torch.cuda.synchronize()
+    assert got.shape == (P + 3, 18) and got[:P].cpu().numpy().tobytes() == want.cpu().numpy().tobytes()
+    assert float(got[P:].abs().sum()) == 0.0 and float(got[:P, :16].abs().sum()) > 0
+    part = sharding.pack_records_device(ctx, pb.pose[2:7], st32[2:7])
+    torch.cuda.synchronize()
+    assert part.cpu().numpy().tobytes() == want[2:7].cpu().numpy().tobytes()
